@@ -1,0 +1,267 @@
+"""ctypes mirror of include/restir_rt.h (librestir_rt.so).
+
+`Renderer` keeps the reference example's host API — camera, options, accumulation, one call per
+kernel with the reference's kernel names (examples/10_restir_di/10_restir_di.cpp:231-383) — on
+top of the C-ABI. There is NO CPU fallback: if the HIP library is missing or no GPU is visible
+the constructor raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .types import OPTIONS, RAYGEN, RESERVOIR, TRIANGLE, VISIBILITY, default_options
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librestir_rt.so")
+
+RT_RES_0, RT_RES_1, RT_RES_TEMPORAL = 0, 1, 2
+RT_BUF_VISIBILITY, RT_BUF_RES_0, RT_BUF_RES_1, RT_BUF_RES_TEMPORAL, RT_BUF_ACCUMULATION, RT_BUF_PIXELS = range(6)
+
+EXPORTS = [
+    "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_sync", "rt_scene_set", "rt_scene_info",
+    "rt_camera_lookat", "rt_camera_set", "rt_camera_get", "rt_options_set", "rt_options_get", "rt_clear",
+    "rt_raycast", "rt_generate_candidate", "rt_temporal_resampling", "rt_save_temporal_reservoir",
+    "rt_spatial_resampling", "rt_resolve", "rt_tone_mapping", "rt_frame", "rt_local_rows", "rt_download",
+    "rt_upload", "rt_halo_bytes", "rt_halo_pack", "rt_halo_unpack", "rt_ray_count", "rt_timing_enable",
+    "rt_timing", "rt_trace_closest", "rt_math_eval",
+]
+
+
+class RtError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """Load librestir_rt.so and declare prototypes. Raises if the library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RtError(f"{LIB_PATH} not built: run __graft_entry__.build() (make -C cedec_2024_rt_amd/csrc)")
+    L = C.CDLL(LIB_PATH)
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    L.rt_create.argtypes = [ci, ci, ci, ci, ci, ci, C.POINTER(vp)]
+    L.rt_destroy.argtypes = [vp]
+    L.rt_last_error.argtypes = [vp]
+    L.rt_last_error.restype = C.c_char_p
+    L.rt_set_stream.argtypes = [vp, vp]
+    L.rt_sync.argtypes = [vp]
+    L.rt_scene_set.argtypes = [vp, vp, C.c_uint32]
+    L.rt_scene_info.argtypes = [vp, vp, vp, vp]
+    L.rt_camera_lookat.argtypes = [vp, vp, vp, vp, cf]
+    L.rt_camera_set.argtypes = [vp, vp, vp]
+    L.rt_camera_get.argtypes = [vp, vp]
+    L.rt_options_set.argtypes = [vp, vp]
+    L.rt_options_get.argtypes = [vp, vp]
+    L.rt_clear.argtypes = [vp]
+    L.rt_raycast.argtypes = [vp]
+    L.rt_generate_candidate.argtypes = [vp, ci, ci]
+    L.rt_temporal_resampling.argtypes = [vp, ci, ci, ci]
+    L.rt_save_temporal_reservoir.argtypes = [vp, ci, ci]
+    L.rt_spatial_resampling.argtypes = [vp, ci, ci, ci, ci]
+    L.rt_resolve.argtypes = [vp, ci]
+    L.rt_tone_mapping.argtypes = [vp]
+    L.rt_frame.argtypes = [vp, ci, ci, vp]
+    L.rt_local_rows.argtypes = [vp, vp, vp]
+    L.rt_download.argtypes = [vp, ci, vp, C.c_size_t]
+    L.rt_upload.argtypes = [vp, ci, vp, C.c_size_t]
+    L.rt_halo_bytes.argtypes = [vp, ci]
+    L.rt_halo_bytes.restype = C.c_size_t
+    L.rt_halo_pack.argtypes = [vp, ci, ci, ci, vp]
+    L.rt_halo_unpack.argtypes = [vp, ci, ci, ci, vp]
+    L.rt_ray_count.argtypes = [vp, vp, vp]
+    L.rt_timing_enable.argtypes = [vp, ci]
+    L.rt_timing.argtypes = [vp, vp]
+    L.rt_trace_closest.argtypes = [vp, vp, C.c_uint32, vp]
+    L.rt_math_eval.argtypes = [vp, ci, vp, C.c_uint32, vp]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+_BUF_DTYPE = {
+    RT_BUF_VISIBILITY: VISIBILITY, RT_BUF_RES_0: RESERVOIR, RT_BUF_RES_1: RESERVOIR,
+    RT_BUF_RES_TEMPORAL: RESERVOIR, RT_BUF_ACCUMULATION: np.dtype(("<f4", 4)), RT_BUF_PIXELS: np.dtype(("u1", 4)),
+}
+
+
+class Renderer:
+    """One HIP context = one GPU = one row strip of the image (the whole image by default)."""
+
+    def __init__(self, width, height, device=0, rows=None, halo=0, stream=None):
+        self.L = load_library()
+        self.W, self.H = int(width), int(height)
+        r0, r1 = rows if rows is not None else (0, self.H)
+        self.rows = (int(r0), int(r1))
+        self.halo = int(halo)
+        h = C.c_void_p()
+        rc = self.L.rt_create(int(device), self.W, self.H, int(r0), int(r1), int(halo), C.byref(h))
+        self.h = h
+        if rc != 0:
+            msg = self.L.rt_last_error(h).decode() if h else "rt_create failed"
+            raise RtError(f"rt_create -> {rc}: {msg} (no GPU visible? the HIP path has no CPU fallback)")
+        if stream is not None:
+            self._ck(self.L.rt_set_stream(self.h, C.c_void_p(int(stream))))
+        a, b = C.c_int(), C.c_int()
+        self._ck(self.L.rt_local_rows(self.h, C.byref(a), C.byref(b)))
+        self.local_row0, self.local_rows = a.value, b.value
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RtError(f"librestir_rt error {rc}: {self.L.rt_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- scene / camera / options
+    def set_scene(self, triangles):
+        t = np.ascontiguousarray(triangles, dtype=TRIANGLE)
+        self._ck(self.L.rt_scene_set(self.h, _p(t), len(t)))
+
+    def scene_info(self):
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._ck(self.L.rt_scene_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(triangles=a.value, lights=b.value, bvh_height=c.value)
+
+    def lookat(self, eye, center, up=(0.0, 1.0, 0.0), fovy=None):
+        fovy = np.float32(np.pi) / np.float32(4.0) if fovy is None else np.float32(fovy)  # 10_restir_di.cpp:242
+        e, c, u = (np.asarray(v, dtype=np.float32) for v in (eye, center, up))
+        self._ck(self.L.rt_camera_lookat(self.h, _p(e), _p(c), _p(u), C.c_float(fovy)))
+
+    def set_raygen(self, raygen, eye):
+        rg = np.ascontiguousarray(raygen, dtype=RAYGEN)
+        e = np.asarray(eye, dtype=np.float32)
+        self._ck(self.L.rt_camera_set(self.h, _p(rg), _p(e)))
+
+    def raygen(self):
+        rg = np.zeros(1, dtype=RAYGEN)
+        self._ck(self.L.rt_camera_get(self.h, _p(rg)))
+        return rg
+
+    def set_options(self, options=None, **kw):
+        o = default_options() if options is None else np.array(options, dtype=OPTIONS, copy=True)
+        for k, v in kw.items():
+            o[k] = v
+        self._ck(self.L.rt_options_set(self.h, _p(o)))
+
+    def options(self):
+        o = np.zeros(1, dtype=OPTIONS)
+        self._ck(self.L.rt_options_get(self.h, _p(o)))
+        return o
+
+    # ---- kernels, named as in examples/10_restir_di/10_restir_di.cu
+    def clear(self):
+        self._ck(self.L.rt_clear(self.h))
+
+    def raycast(self):
+        self._ck(self.L.rt_raycast(self.h))
+
+    def generate_candidate(self, frame, dst=RT_RES_0):
+        self._ck(self.L.rt_generate_candidate(self.h, frame, dst))
+
+    def temporal_resampling(self, frame, prev=RT_RES_TEMPORAL, inout=RT_RES_0):
+        self._ck(self.L.rt_temporal_resampling(self.h, frame, prev, inout))
+
+    def save_temporal_reservoir(self, src=RT_RES_0, dst=RT_RES_TEMPORAL):
+        self._ck(self.L.rt_save_temporal_reservoir(self.h, src, dst))
+
+    def spatial_resampling(self, frame, pas, src, dst):
+        self._ck(self.L.rt_spatial_resampling(self.h, frame, pas, src, dst))
+
+    def resolve(self, res):
+        self._ck(self.L.rt_resolve(self.h, res))
+
+    def tone_mapping(self):
+        self._ck(self.L.rt_tone_mapping(self.h))
+
+    def frame_by_kernels(self, frame, clear_first=False):
+        """The launch sequence of 10_restir_di.cpp:257-379, kernel by kernel."""
+        if clear_first:
+            self.clear()
+        self.raycast()
+        self.generate_candidate(frame, RT_RES_0)
+        self.temporal_resampling(frame, RT_RES_TEMPORAL, RT_RES_0)
+        self.save_temporal_reservoir(RT_RES_0, RT_RES_TEMPORAL)
+        src, dst = RT_RES_0, RT_RES_1
+        passes = int(self.options()["spatial_resampling_passes"][0])
+        for k in range(passes):
+            if k != 0:
+                src, dst = dst, src
+            self.spatial_resampling(frame, k, src, dst)
+        self.resolve(dst)
+        self.tone_mapping()
+        return dst
+
+    def frame(self, frame, clear_first=False):
+        """Fused fast path (rt_frame). Returns the logical buffer resolve read."""
+        out = C.c_int(-1)
+        self._ck(self.L.rt_frame(self.h, int(frame), int(bool(clear_first)), C.byref(out)))
+        return out.value
+
+    def sync(self):
+        self._ck(self.L.rt_sync(self.h))
+
+    # ---- data movement
+    def download(self, buf):
+        dt = _BUF_DTYPE[buf]
+        n = self.W * self.local_rows
+        out = np.zeros(n, dtype=dt)
+        self._ck(self.L.rt_download(self.h, buf, _p(out), out.nbytes))
+        return out
+
+    def upload(self, buf, arr):
+        a = np.ascontiguousarray(arr, dtype=_BUF_DTYPE[buf])
+        self._ck(self.L.rt_upload(self.h, buf, _p(a), a.nbytes))
+
+    def halo_bytes(self, n_rows):
+        return int(self.L.rt_halo_bytes(self.h, int(n_rows)))
+
+    def halo_pack(self, res, row0, n_rows, device_ptr):
+        self._ck(self.L.rt_halo_pack(self.h, res, row0, n_rows, C.c_void_p(int(device_ptr))))
+
+    def halo_unpack(self, res, row0, n_rows, device_ptr):
+        self._ck(self.L.rt_halo_unpack(self.h, res, row0, n_rows, C.c_void_p(int(device_ptr))))
+
+    # ---- measurement / utilities
+    def ray_count(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self._ck(self.L.rt_ray_count(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def timing_enable(self, on=True):
+        self._ck(self.L.rt_timing_enable(self.h, int(on)))
+
+    def timing(self):
+        ms = np.zeros(9, dtype=np.float32)
+        self._ck(self.L.rt_timing(self.h, _p(ms)))
+        names = ["clear", "raycast", "generate_candidate", "spatial0", "spatial1", "spatial2", "resolve",
+                 "tone_mapping", "frame"]
+        return dict(zip(names, (float(x) for x in ms)))
+
+    def trace_closest(self, rays):
+        r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        hits = np.zeros((len(r), 4), dtype=np.float32)
+        self._ck(self.L.rt_trace_closest(self.h, _p(r), len(r), _p(hits)))
+        return hits
+
+    def math_eval(self, fn, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n = x.size // (2 if fn == 26 else 1)
+        out = np.zeros(n, dtype=np.float32)
+        self._ck(self.L.rt_math_eval(self.h, int(fn), _p(x), n, _p(out)))
+        return out

@@ -1,0 +1,1328 @@
+/*
+ * restir_rt.hip — gfx950 kernels and C-ABI (include/restir_rt.h) of the ReSTIR DI hot path.
+ *
+ * Kernels restate, per pixel, examples/10_restir_di/10_restir_di.cu and
+ * common/kernels/common.cu of the reference (file:line cited at each kernel) over the
+ * MI355X-native data layout of rt_device.h (32-B G-buffer, 64-B aligned reservoir records)
+ * and the software LBVH of bvh.h. Compile with -ffp-contract=off (parity, rt_device.h).
+ *
+ * Launch shape: one thread per pixel, 256-thread workgroups covering 32 x 8 pixel tiles
+ * (a wave = two 32-pixel row segments => own-pixel record traffic is 2-KiB contiguous runs).
+ * Workgroup -> tile mapping is XCD-aware: workgroups are dealt round-robin over the 8 XCDs
+ * (MI355X_MICROARCH "Workgroup dispatch"), so workgroup b works on tile
+ * (b % 8) * ceil(T/8) + b / 8: every XCD owns one horizontal band of the image and the
+ * spatial pass's neighbour gathers (sigma = 15 px) stay in that XCD's L2.
+ */
+#include <cmath>
+#include <cstddef>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "../../include/restir_rt.h"
+#include "bvh.h"
+#include "rt_device.h"
+
+using namespace rt;
+
+static_assert(sizeof(rt_triangle) == 60, "Triangle layout (common/core.hpp:38-43)");
+static_assert(sizeof(rt_visibility) == 16, "Visibility layout (common/core.hpp:167-172)");
+static_assert(sizeof(rt_reservoir) == 76, "Reservoir layout (common/reservoir.hpp:5-38)");
+static_assert(sizeof(rt_options) == 48, "Options layout (common/options.hpp:4-22)");
+static_assert(offsetof(rt_options, use_shadowed_target_function) == 44, "Options layout");
+static_assert(sizeof(rt_raygen) == 36, "RayGenerator layout (common/camera.hpp:5-9)");
+static_assert(sizeof(BvhNode) == 64, "BVH node");
+
+/* ------------------------------------------------------------------ params */
+
+struct FrameParams
+{
+    int W, H;           /* full image */
+    int row0, row1;     /* global storage rows processed by this launch */
+    int lrow0, lrows;   /* global row of local buffer row 0, local rows held */
+    int frame, pass;
+    f3 eye;
+    f3 rg_origin, rg_right, rg_up;
+    int n_lights;
+    /* options (common/options.hpp) */
+    int accumulate, ris_sample_count, use_temporal, use_spatial, spatial_count, vis_reuse;
+    float spatial_radius;
+};
+
+struct SceneView
+{
+    BvhView bvh;
+    const float4* __restrict__ trimat; /* 2 per triangle: {Kd.xyz, bits(emissive?)}, {Ke.xyz, 0} */
+    const float4* __restrict__ lights; /* 5 per light, see k_light_table */
+};
+
+constexpr int TILE_W = 32, TILE_H = 8, BLOCK = 256;
+
+/* XCD-aware workgroup -> tile -> pixel. Returns false for threads outside the row range. */
+RT_DEV bool tile_pixel(const FrameParams& P, int& x, int& row)
+{
+    const int tiles_x = (P.W + TILE_W - 1) / TILE_W;
+    const int tiles_y = (P.row1 - P.row0 + TILE_H - 1) / TILE_H;
+    const int n_tiles = tiles_x * tiles_y;
+    const int per_xcd = (n_tiles + 7) / 8;
+    const int b = blockIdx.x;
+    const int tile = (b & 7) * per_xcd + (b >> 3);
+    if (tile >= n_tiles) return false;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    x = tx * TILE_W + (threadIdx.x & (TILE_W - 1));
+    row = P.row0 + ty * TILE_H + (threadIdx.x >> 5);
+    return x < P.W && row < P.row1;
+}
+static inline int tile_grid(int W, int rows)
+{
+    const int tiles = ((W + TILE_W - 1) / TILE_W) * ((rows + TILE_H - 1) / TILE_H);
+    return ((tiles + 7) / 8) * 8;
+}
+
+/* common/core.hpp:189-207: surface point + normal flipped toward the eye [parity] */
+RT_DEV void surface_info(const BvhView& bvh, int tri, float u, float v, f3 eye, f3& p, f3& n)
+{
+    f3 v0, v1, v2;
+    load_tri(bvh.tv, tri, v0, v1, v2);
+    p = (1.0f - u - v) * v0 + u * v1 + v * v2;
+    n = tri_normal(v0, v1, v2);
+    const f3 view = normalize(eye - p);
+    if (dot(view, n) < 0.0f) n = -n;
+}
+
+/* G-buffer entry from a Visibility record */
+RT_DEV void gbuffer_write(const SceneView& S, const FrameParams& P, float4* __restrict__ g0,
+                          float4* __restrict__ g1, size_t li, float u, float v, int index)
+{
+    if (index < 0)
+    {
+        g0[li] = make_float4(0.0f, 0.0f, 0.0f, as_float(-1));
+        g1[li] = make_float4(0.0f, 0.0f, 0.0f, as_float(0u));
+        return;
+    }
+    const bool emissive = as_uint(S.trimat[2 * (size_t)index].w) != 0u;
+    f3 p, n;
+    surface_info(S.bvh, index, u, v, P.eye, p, n);
+    g0[li] = make_float4(p.x, p.y, p.z, as_float(index));
+    g1[li] = make_float4(n.x, n.y, n.z, as_float(emissive ? GB_EMISSIVE : GB_SHADED));
+}
+
+/* -------------------------------------------------------------------- raycast */
+/* examples/10_restir_di/10_restir_di.cu:9-34 (+ common/camera.hpp:27-35) */
+__global__ __launch_bounds__(BLOCK) void k_raycast(SceneView S, FrameParams P, float4* __restrict__ vis,
+                                                    float4* __restrict__ g0, float4* __restrict__ g1)
+{
+    int x, row;
+    if (!tile_pixel(P, x, row)) return;
+    const int yi = P.H - 1 - row;
+    const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
+
+    const float u = (float)x / (float)P.W, v = (float)yi / (float)P.H;
+    const f3 forward = normalize(cross(P.rg_up, P.rg_right));
+    const f3 to = P.rg_origin + forward + mix(-P.rg_right, P.rg_right, u) + mix(P.rg_up, -P.rg_up, v);
+    const f3 rd = normalize(to - P.rg_origin);
+
+    Hit h;
+    h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.prim = -1;
+    trace<false>(S.bvh, P.rg_origin, rd, 0.0f, kFltMax, h);
+    vis[li] = make_float4(h.u, h.v, as_float(h.prim), as_float(0));
+    gbuffer_write(S, P, g0, g1, li, h.u, h.v, h.prim);
+}
+
+/* rebuild the G-buffer from an uploaded Visibility buffer */
+__global__ __launch_bounds__(BLOCK) void k_gbuffer_from_vis(SceneView S, FrameParams P,
+                                                             const float4* __restrict__ vis,
+                                                             float4* __restrict__ g0, float4* __restrict__ g1)
+{
+    int x, row;
+    if (!tile_pixel(P, x, row)) return;
+    const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
+    const float4 vv = vis[li];
+    gbuffer_write(S, P, g0, g1, li, vv.x, vv.y, as_int(vv.z));
+}
+
+/* ------------------------------------------------------- target function helper */
+/* common/reservoir.hpp:42-59 */
+template <bool SHADOWED>
+RT_DEV float target_function(const SceneView& S, f3 op, f3 on, f3 hp, f3 hn, float lum)
+{
+    if (SHADOWED)
+    {
+        const float brdf = 1.0f / kPI;
+        const float G = geometry_term(op, on, hp, hn);
+        const float V = check_visibility(S.bvh, op, on, hp) ? 1.0f : 0.0f;
+        return brdf * G * V * lum;
+    }
+    return target_unshadowed(op, on, hp, hn, lum);
+}
+
+RT_DEV void res_take_sample(Res& r, const Res& o)
+{
+    r.hit_p = o.hit_p; r.hit_n = o.hit_n; r.org_p = o.org_p; r.org_n = o.org_n;
+    r.rad = o.rad; r.lum = o.lum; r.vis = o.vis;
+}
+
+/* temporal merge of 10_restir_di.cu:177-233; r = current, pr = previous frame, same pixel */
+template <bool SHADOWED>
+RT_DEV void temporal_merge(const SceneView& S, const FrameParams& P, int x, int yi, f3 sp, f3 sn, Res& r, Res pr)
+{
+    PCG rng = pcg_init(hashPCG4((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame, 1u), 0);
+    const int cap = 20 * P.ris_sample_count;
+    pr.M = pr.M < cap ? pr.M : cap;
+    float p_hat_y = target_function<SHADOWED>(S, sp, sn, pr.hit_p, pr.hit_n, pr.lum);
+    if (P.vis_reuse) p_hat_y *= pr.vis ? 1.0f : 0.0f;
+    pr.M = scale_M(pr.M, rejection_heuristics(r.org_p, r.org_n, pr.org_p, pr.org_n, P.eye));
+    const float weight = p_hat_y * pr.ucw * (float)pr.M;
+    const float u = rng.uniformf();
+    r.w_sum += weight;
+    r.M += pr.M;
+    if (u < weight / r.w_sum) res_take_sample(r, pr);
+    const float p_hat = target_function<SHADOWED>(S, sp, sn, r.hit_p, r.hit_n, r.lum);
+    r.ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
+}
+
+/* --------------------------------------------------------- generate_candidate */
+/* examples/10_restir_di/10_restir_di.cu:36-135; with FUSE_TEMPORAL also :137-237 on the
+ * value still in registers (the reference round-trips it through reservoir_buffer0). */
+template <bool FUSE_TEMPORAL, bool SHADOWED>
+__global__ __launch_bounds__(BLOCK) void k_generate_candidate(
+    SceneView S, FrameParams P, const float4* __restrict__ g0, const float4* __restrict__ g1,
+    const float4* __restrict__ prev_rec, const float4* __restrict__ prev_rad, float4* __restrict__ out_rec,
+    float4* __restrict__ out_rad)
+{
+    int x, row;
+    if (!tile_pixel(P, x, row)) return;
+    const int yi = P.H - 1 - row;
+    const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
+
+    const float4 G0 = g0[li], G1 = g1[li];
+    const uint32_t flags = as_uint(G1.w);
+    Res r = res_zero();
+    if (!(flags & GB_SHADED))
+    {
+        res_store(out_rec, out_rad, li, r, false); /* Reservoir{} (:56-70) */
+        return;
+    }
+    const f3 sp = F3(G0.x, G0.y, G0.z), sn = F3(G1.x, G1.y, G1.z);
+
+    PCG rng = pcg_init(hashPCG4((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame, 0u), 0);
+    const float fL = (float)(size_t)P.n_lights;
+    for (int i = 0; i < P.ris_sample_count; ++i)
+    {
+        /* draw order rv0, rv1, rv2, u: left-to-right argument evaluation (hipcc) */
+        const float rv0 = rng.uniformf();
+        float bx = rng.uniformf();
+        float by = rng.uniformf();
+        /* common/core.hpp:261-285 */
+        uint32_t nth = (uint32_t)(rv0 * fL);
+        if (nth == (uint32_t)P.n_lights) nth = (uint32_t)P.n_lights - 1u;
+        const float4* L = S.lights + 5 * (size_t)nth;
+        const float4 L0 = L[0], L1 = L[1], L2 = L[2], L3 = L[3], L4 = L[4];
+        const f3 v0 = F3(L0.x, L0.y, L0.z), v1 = F3(L0.w, L1.x, L1.y), v2 = F3(L1.z, L1.w, L2.x);
+        warp_unit_triangle(bx, by);
+        const f3 lp = (1.0f - bx - by) * v0 + bx * v1 + by * v2;
+        const f3 ln = F3(L2.y, L2.z, L2.w);
+        const float lum = L3.w;
+        const float light_pdf = L4.x; /* 1/L * 1/area (:98-99) */
+        const float p_hat = target_unshadowed(sp, sn, lp, ln, lum); /* unshadowed always (:104) */
+        const float weight = p_hat / light_pdf;
+        const float u = rng.uniformf();
+        /* common/reservoir.hpp:22-29 */
+        r.w_sum += weight;
+        r.M += 1;
+        if (u < weight / r.w_sum)
+        {
+            r.hit_p = lp; r.hit_n = ln; r.rad = F3(L3.x, L3.y, L3.z); r.lum = lum;
+            r.org_p = sp; r.org_n = sn; r.vis = false;
+        }
+    }
+    {
+        const float p_hat = target_function<SHADOWED>(S, sp, sn, r.hit_p, r.hit_n, r.lum);
+        r.ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
+    }
+    if (P.vis_reuse) r.vis = check_visibility(S.bvh, sp, sn, r.hit_p);
+
+    if (FUSE_TEMPORAL)
+    {
+        bool dummy;
+        Res pr = res_load(prev_rec, li, dummy);
+        const float4 pq = prev_rad[li];
+        pr.rad = F3(pq.x, pq.y, pq.z);
+        temporal_merge<SHADOWED>(S, P, x, yi, sp, sn, r, pr);
+    }
+    res_store(out_rec, out_rad, li, r, true);
+}
+
+/* -------------------------------------------------------- temporal_resampling */
+/* examples/10_restir_di/10_restir_di.cu:137-237 (stand-alone entry point) */
+template <bool SHADOWED>
+__global__ __launch_bounds__(BLOCK) void k_temporal(SceneView S, FrameParams P, const float4* __restrict__ g0,
+                                                     const float4* __restrict__ g1,
+                                                     const float4* __restrict__ prev_rec,
+                                                     const float4* __restrict__ prev_rad,
+                                                     float4* __restrict__ rec, float4* __restrict__ radb)
+{
+    int x, row;
+    if (!tile_pixel(P, x, row)) return;
+    const int yi = P.H - 1 - row;
+    const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
+    const float4 G0 = g0[li], G1 = g1[li];
+    if (!(as_uint(G1.w) & GB_SHADED)) return;
+    if (!P.use_temporal) return;
+    const f3 sp = F3(G0.x, G0.y, G0.z), sn = F3(G1.x, G1.y, G1.z);
+    bool dummy;
+    Res r = res_load(rec, li, dummy);
+    const float4 rq = radb[li];
+    r.rad = F3(rq.x, rq.y, rq.z);
+    Res pr = res_load(prev_rec, li, dummy);
+    const float4 pq = prev_rad[li];
+    pr.rad = F3(pq.x, pq.y, pq.z);
+    temporal_merge<SHADOWED>(S, P, x, yi, sp, sn, r, pr);
+    res_store(rec, radb, li, r, true);
+}
+
+/* --------------------------------------------------------- spatial_resampling */
+/* examples/10_restir_di/10_restir_di.cu:256-388 — the roofline kernel.
+ * Per neighbour ONE 64-B aligned record is gathered (the reference gathers a 16-B Visibility,
+ * a Triangle and a 76-B Reservoir); the "sky / emissive neighbour" test of :326-338 reads the
+ * shaded bit kept inside the record; radiance (side record) is fetched once, for the sample
+ * that survived. */
+template <bool SHADOWED>
+__global__ __launch_bounds__(BLOCK) void k_spatial(SceneView S, FrameParams P, const float4* __restrict__ g0,
+                                                    const float4* __restrict__ g1,
+                                                    const float4* __restrict__ in_rec,
+                                                    const float4* __restrict__ in_rad,
+                                                    float4* __restrict__ out_rec, float4* __restrict__ out_rad)
+{
+    int x, row;
+    if (!tile_pixel(P, x, row)) return;
+    const int yi = P.H - 1 - row;
+    const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
+    const float4 G0 = g0[li], G1 = g1[li];
+    if (!(as_uint(G1.w) & GB_SHADED))
+    {
+        /* the reference stores nothing here (:275-287); we keep the shaded bit valid */
+        res_store(out_rec, out_rad, li, res_zero(), false);
+        return;
+    }
+    const f3 sp = F3(G0.x, G0.y, G0.z), sn = F3(G1.x, G1.y, G1.z);
+    PCG rng = pcg_init(hashPCG4((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame, (uint32_t)(2 + P.pass)), 0);
+
+    bool own_shaded;
+    Res r = res_load(in_rec, li, own_shaded);
+    size_t rad_from = li;
+
+    if (P.use_spatial)
+    {
+        const float scale = P.spatial_radius / 1.96f;
+        for (int k = 0; k < P.spatial_count; ++k)
+        {
+            const float rv0 = rng.uniformf();
+            const float rv1 = rng.uniformf();
+            /* common/reservoir.hpp:89-95 with portable log/cos/sin */
+            const float radius = sqrtf(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
+            const float phi = 2.0f * kPI * rv1;
+            const float gx = radius * pm_cosf(phi), gy = radius * pm_sinf(phi);
+            const int nx = f2i_sat((float)x + scale * gx);
+            const int ny = f2i_sat((float)yi + scale * gy);
+            if (nx < 0 || nx >= P.W || ny < 0 || ny >= P.H) continue;
+            if (nx == x && ny == yi) continue;
+            const int nrow = P.H - 1 - ny;
+            const int lr = nrow - P.lrow0;
+            if (lr < 0 || lr >= P.lrows) continue; /* only when halo < 87: outside the contract */
+            const size_t pid = (size_t)nx + (size_t)lr * P.W;
+            bool n_shaded;
+            Res nr = res_load(in_rec, pid, n_shaded);
+            if (!n_shaded) continue; /* sky or emissive neighbour (:326-338) */
+
+            float p_hat_y = target_function<SHADOWED>(S, sp, sn, nr.hit_p, nr.hit_n, nr.lum);
+            if (P.vis_reuse) p_hat_y *= nr.vis ? 1.0f : 0.0f;
+            nr.M = scale_M(nr.M, rejection_heuristics(r.org_p, r.org_n, nr.org_p, nr.org_n, P.eye));
+            const float weight = p_hat_y * nr.ucw * (float)nr.M;
+            const float u = rng.uniformf();
+            r.w_sum += weight;
+            r.M += nr.M;
+            if (u < weight / r.w_sum)
+            {
+                res_take_sample(r, nr);
+                rad_from = pid;
+            }
+        }
+        const float p_hat = target_function<SHADOWED>(S, sp, sn, r.hit_p, r.hit_n, r.lum);
+        r.ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
+    }
+    const float4 rq = in_rad[rad_from];
+    r.rad = F3(rq.x, rq.y, rq.z);
+    res_store(out_rec, out_rad, li, r, true);
+}
+
+/* -------------------------------------------------------------------- resolve */
+/* examples/10_restir_di/10_restir_di.cu:390-459 */
+__global__ __launch_bounds__(BLOCK) void k_resolve(SceneView S, FrameParams P, const float4* __restrict__ g0,
+                                                    const float4* __restrict__ g1,
+                                                    const float4* __restrict__ rec,
+                                                    const float4* __restrict__ radb, float4* __restrict__ accum)
+{
+    int x, row;
+    if (!tile_pixel(P, x, row)) return;
+    const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
+    const float4 G0 = g0[li], G1 = g1[li];
+    const int tri = as_int(G0.w);
+    const uint32_t flags = as_uint(G1.w);
+    if (tri < 0) { accum[li] = make_float4(0.0f, 0.0f, 0.0f, 1.0f); return; }
+    if (flags & GB_EMISSIVE)
+    {
+        const float4 ke = S.trimat[2 * (size_t)tri + 1];
+        accum[li] = make_float4(ke.x, ke.y, ke.z, 1.0f);
+        return;
+    }
+    const f3 sp = F3(G0.x, G0.y, G0.z), sn = F3(G1.x, G1.y, G1.z);
+    const float4 q0 = rec[4 * li + 0], q1 = rec[4 * li + 1];
+    const float4 rq = radb[li];
+    const float4 kd = S.trimat[2 * (size_t)tri];
+    const f3 hp = F3(q0.x, q0.y, q0.z), hn = F3(q1.x, q1.y, q1.z);
+    const f3 brdf = (1.0f / kPI) * F3(kd.x, kd.y, kd.z);
+    const float G = geometry_term(sp, sn, hp, hn);
+    const float V = check_visibility(S.bvh, sp, sn, hp) ? 1.0f : 0.0f;
+    const f3 radiance = brdf * G * V * F3(rq.x, rq.y, rq.z) * q0.w;
+    if (P.accumulate)
+    {
+        const float4 a = accum[li];
+        accum[li] = make_float4(a.x + radiance.x, a.y + radiance.y, a.z + radiance.z, a.w + 1.0f);
+    }
+    else { accum[li] = make_float4(radiance.x, radiance.y, radiance.z, 1.0f); }
+}
+
+/* --------------------------------------------------------- clear / tone_mapping */
+/* common/kernels/common.cu:4-17 */
+__global__ __launch_bounds__(BLOCK) void k_clear(FrameParams P, float4* __restrict__ accum)
+{
+    int x, row;
+    if (!tile_pixel(P, x, row)) return;
+    accum[(size_t)x + (size_t)(row - P.lrow0) * P.W] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+RT_DEV float aces(float x)
+{
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    return (x * (a * x + b)) / (x * (c * x + d) + e);
+}
+RT_DEV uint32_t to_u8(float v)
+{
+    const float c = fminf(fmax_dev(v, 0.0f), 255.0f);
+    return (uint32_t)(int)c;
+}
+/* common/kernels/common.cu:30-74 (display only; powf = portable exp(y*log(x))) */
+__global__ __launch_bounds__(BLOCK) void k_tone_mapping(FrameParams P, const float4* __restrict__ accum,
+                                                         uint32_t* __restrict__ pixels)
+{
+    int x, row;
+    if (!tile_pixel(P, x, row)) return;
+    const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
+    const float4 a = accum[li];
+    const float gamma = 1.0f / 2.2f;
+    const float r = pm_powf_pos(aces(a.x / a.w * 1.0f), gamma);
+    const float g = pm_powf_pos(aces(a.y / a.w * 1.0f), gamma);
+    const float b = pm_powf_pos(aces(a.z / a.w * 1.0f), gamma);
+    pixels[li] = to_u8(r * 255.0f) | (to_u8(g * 255.0f) << 8) | (to_u8(b * 255.0f) << 16) | 0xff000000u;
+}
+
+/* ------------------------------------------------ layout conversion (upload/download) */
+__global__ void k_res_to_ref(int n, const float4* __restrict__ rec, const float4* __restrict__ radb,
+                             uint32_t* __restrict__ out /* 19 words per pixel */)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool shaded;
+    Res r = res_load(rec, (size_t)i, shaded);
+    const float4 rq = radb[i];
+    uint32_t* o = out + 19 * (size_t)i;
+    const float f[15] = {r.org_p.x, r.org_p.y, r.org_p.z, r.org_n.x, r.org_n.y, r.org_n.z, r.hit_p.x, r.hit_p.y,
+                         r.hit_p.z, r.hit_n.x, r.hit_n.y, r.hit_n.z, rq.x, rq.y, rq.z};
+    for (int k = 0; k < 15; ++k) o[k] = as_uint(f[k]);
+    o[15] = r.vis ? 1u : 0u;
+    o[16] = as_uint(r.w_sum);
+    o[17] = as_uint(r.ucw);
+    o[18] = (uint32_t)r.M;
+}
+__global__ void k_res_from_ref(int n, const uint32_t* __restrict__ in, const float4* __restrict__ g1,
+                               float4* __restrict__ rec, float4* __restrict__ radb)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* s = in + 19 * (size_t)i;
+    Res r;
+    r.org_p = F3(as_float(s[0]), as_float(s[1]), as_float(s[2]));
+    r.org_n = F3(as_float(s[3]), as_float(s[4]), as_float(s[5]));
+    r.hit_p = F3(as_float(s[6]), as_float(s[7]), as_float(s[8]));
+    r.hit_n = F3(as_float(s[9]), as_float(s[10]), as_float(s[11]));
+    r.rad = F3(as_float(s[12]), as_float(s[13]), as_float(s[14]));
+    r.vis = (s[15] & 0xffu) != 0u;
+    r.w_sum = as_float(s[16]);
+    r.ucw = as_float(s[17]);
+    r.M = (int)s[18];
+    r.lum = luminance(r.rad);
+    const bool shaded = (as_uint(g1[i].w) & GB_SHADED) != 0u;
+    res_store(rec, radb, (size_t)i, r, shaded);
+}
+
+/* ------------------------------------------------------------- scene tables */
+/* per emissive triangle (index order, 10_restir_di.cpp:196-205), 5 x float4:
+ *   {v0.xyz, v1.x} {v1.yz, v2.xy} {v2.z, n.xyz} {Ke.xyz, luminance(Ke)} {pdf, bits(tri), 0, 0}
+ * n = normal_of, pdf = 1/L * 1/area_of — the exact expressions of common/core.hpp:45-62 and
+ * 10_restir_di.cu:98-99, evaluated once instead of once per candidate. */
+__global__ void k_light_table(int n_lights, const uint32_t* __restrict__ light_ids, const float* __restrict__ tris,
+                              float4* __restrict__ lights)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_lights) return;
+    const int ti = (int)light_ids[i];
+    const float* t = tris + 15 * (size_t)ti;
+    const f3 v0 = F3(t[0], t[1], t[2]), v1 = F3(t[3], t[4], t[5]), v2 = F3(t[6], t[7], t[8]);
+    const f3 ke = F3(t[12], t[13], t[14]);
+    const f3 n = tri_normal(v0, v1, v2);
+    const float pdf = 1.0f / (float)(size_t)n_lights * 1.0f / tri_area(v0, v1, v2);
+    float4* L = lights + 5 * (size_t)i;
+    L[0] = make_float4(v0.x, v0.y, v0.z, v1.x);
+    L[1] = make_float4(v1.y, v1.z, v2.x, v2.y);
+    L[2] = make_float4(v2.z, n.x, n.y, n.z);
+    L[3] = make_float4(ke.x, ke.y, ke.z, luminance(ke));
+    L[4] = make_float4(pdf, as_float(ti), 0.0f, 0.0f);
+}
+__global__ void k_trimat(int n, const float* __restrict__ tris, float4* __restrict__ trimat)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* t = tris + 15 * (size_t)i;
+    /* has_emission, common/core.hpp:64-68 */
+    const bool e = t[12] > 0.0f || t[13] > 0.0f || t[14] > 0.0f;
+    trimat[2 * (size_t)i] = make_float4(t[9], t[10], t[11], as_float(e ? 1u : 0u));
+    trimat[2 * (size_t)i + 1] = make_float4(t[12], t[13], t[14], 0.0f);
+}
+
+/* ------------------------------------------------------------------ utilities */
+__global__ void k_count_shaded(FrameParams P, const float4* __restrict__ g1, unsigned long long* __restrict__ out)
+{
+    int x, row;
+    const bool ok = tile_pixel(P, x, row);
+    bool shaded = false;
+    if (ok) shaded = (as_uint(g1[(size_t)x + (size_t)(row - P.lrow0) * P.W].w) & GB_SHADED) != 0u;
+    const unsigned long long m = __ballot(shaded);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
+}
+__global__ void k_trace_closest(BvhView bvh, const float* __restrict__ rays, int n, float* __restrict__ hits)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rays + 8 * (size_t)i;
+    Hit h;
+    h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.prim = -1;
+    trace<false>(bvh, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7], h);
+    float* o = hits + 4 * (size_t)i;
+    o[0] = h.t; o[1] = h.u; o[2] = h.v; o[3] = as_float(h.prim);
+}
+__global__ void k_math_eval(int fn, const float* __restrict__ in, int n, float* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r = 0.0f;
+    switch (fn)
+    {
+        case 20: r = pm_logf(in[i]); break;
+        case 21: r = pm_cosf(in[i]); break;
+        case 22: r = pm_sinf(in[i]); break;
+        case 23: r = pm_expf(in[i]); break;
+        case 24: r = pm_pow8f(in[i]); break;
+        case 25: r = pm_powf_pos(in[i], 1.0f / 2.2f); break;
+        case 26: r = in[2 * (size_t)i] / in[2 * (size_t)i + 1]; break;
+        case 27: r = sqrtf(in[i]); break;
+        default: break;
+    }
+    out[i] = r;
+}
+
+/* ======================================================================= host */
+
+struct rt_ctx
+{
+    int device = 0, W = 0, H = 0, row_begin = 0, row_end = 0, halo = 0;
+    int lrow0 = 0, lrows = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err;
+
+    int n_tris = 0, n_lights = 0, bvh_height = 0;
+    float* d_tris = nullptr;
+    float4* d_tv = nullptr;
+    BvhNode* d_nodes = nullptr;
+    float4* d_trimat = nullptr;
+    float4* d_lights = nullptr;
+
+    float4 *d_vis = nullptr, *d_g0 = nullptr, *d_g1 = nullptr, *d_accum = nullptr;
+    uint32_t* d_pixels = nullptr;
+    float4* d_rec[3] = {nullptr, nullptr, nullptr};
+    float4* d_rad[3] = {nullptr, nullptr, nullptr};
+    int res_map[3] = {0, 1, 2};
+    unsigned long long* d_counter = nullptr;
+    void* d_stage = nullptr;
+    size_t stage_bytes = 0;
+
+    rt_options opt;
+    rt_raygen rg;
+    float eye[3] = {0, 0, 0};
+    bool has_camera = false, has_scene = false, has_gbuffer = false;
+
+    bool timing = false;
+    hipEvent_t ev[10] = {};
+    bool ev_created = false;
+    float last_ms[9] = {};
+    bool last_valid = false;
+};
+
+#define RT_CHECK_CTX(ctx) \
+    if (!(ctx)) return RT_ERR_ARG;
+#define RT_FAIL(ctx, code, ...)                       \
+    do                                                \
+    {                                                 \
+        char _b[512];                                 \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);        \
+        (ctx)->err = _b;                              \
+        return (code);                                \
+    } while (0)
+#define RT_HIP(ctx, call)                                                                      \
+    do                                                                                         \
+    {                                                                                          \
+        hipError_t _e = (call);                                                                \
+        if (_e != hipSuccess) RT_FAIL(ctx, RT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(_e)); \
+    } while (0)
+
+static rt_options default_options()
+{
+    rt_options o;
+    memset(&o, 0, sizeof(o));
+    o.accumulate = 0; o.max_depth = 6;
+    o.ris_sample_count = 32; o.rejection_heuristics_threshold = 0.2f;
+    o.use_temporal_resampling = 0; o.use_spatial_resampling = 0;
+    o.spatial_resampling_sample_count = 5; o.spatial_resampling_radius = 30.0f;
+    o.spatial_resampling_passes = 3; o.use_shadowed_target_function = 0; o.use_visibility_reuse = 1;
+    return o;
+}
+
+static FrameParams make_params(const rt_ctx* c, int frame, int pass)
+{
+    FrameParams P;
+    P.W = c->W; P.H = c->H;
+    P.row0 = c->row_begin; P.row1 = c->row_end;
+    P.lrow0 = c->lrow0; P.lrows = c->lrows;
+    P.frame = frame; P.pass = pass;
+    P.eye = F3(c->eye[0], c->eye[1], c->eye[2]);
+    P.rg_origin = F3(c->rg.origin[0], c->rg.origin[1], c->rg.origin[2]);
+    P.rg_right = F3(c->rg.right[0], c->rg.right[1], c->rg.right[2]);
+    P.rg_up = F3(c->rg.up[0], c->rg.up[1], c->rg.up[2]);
+    P.n_lights = c->n_lights;
+    P.accumulate = c->opt.accumulate; P.ris_sample_count = c->opt.ris_sample_count;
+    P.use_temporal = c->opt.use_temporal_resampling; P.use_spatial = c->opt.use_spatial_resampling;
+    P.spatial_count = c->opt.spatial_resampling_sample_count; P.vis_reuse = c->opt.use_visibility_reuse;
+    P.spatial_radius = c->opt.spatial_resampling_radius;
+    return P;
+}
+static SceneView make_scene(const rt_ctx* c)
+{
+    SceneView S;
+    S.bvh.nodes = c->d_nodes; S.bvh.tv = c->d_tv; S.bvh.n_tris = c->n_tris;
+    S.trimat = c->d_trimat; S.lights = c->d_lights;
+    return S;
+}
+static size_t local_pixels(const rt_ctx* c) { return (size_t)c->W * (size_t)c->lrows; }
+
+extern "C" {
+
+int rt_create(int device, int width, int height, int row_begin, int row_end, int halo, rt_ctx** out)
+{
+    if (!out || width <= 0 || height <= 0 || row_begin < 0 || row_end > height || row_begin >= row_end || halo < 0)
+        return RT_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device >= ndev) return RT_ERR_NO_DEVICE;
+    rt_ctx* c = new rt_ctx();
+    *out = c;
+    c->device = device; c->W = width; c->H = height;
+    c->row_begin = row_begin; c->row_end = row_end; c->halo = halo;
+    c->lrow0 = row_begin - halo < 0 ? 0 : row_begin - halo;
+    const int lend = row_end + halo > height ? height : row_end + halo;
+    c->lrows = lend - c->lrow0;
+    c->opt = default_options();
+    memset(&c->rg, 0, sizeof(c->rg));
+    RT_HIP(c, hipSetDevice(device));
+    RT_HIP(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    const size_t n = local_pixels(c);
+    RT_HIP(c, hipMalloc(&c->d_vis, n * 16));
+    RT_HIP(c, hipMalloc(&c->d_g0, n * 16));
+    RT_HIP(c, hipMalloc(&c->d_g1, n * 16));
+    RT_HIP(c, hipMalloc(&c->d_accum, n * 16));
+    RT_HIP(c, hipMalloc(&c->d_pixels, n * 4));
+    for (int k = 0; k < 3; ++k)
+    {
+        RT_HIP(c, hipMalloc(&c->d_rec[k], n * 64));
+        RT_HIP(c, hipMalloc(&c->d_rad[k], n * 16));
+        /* temporal history is defined as Reservoir{} before frame 1 */
+        RT_HIP(c, hipMemsetAsync(c->d_rec[k], 0, n * 64, c->stream));
+        RT_HIP(c, hipMemsetAsync(c->d_rad[k], 0, n * 16, c->stream));
+    }
+    RT_HIP(c, hipMemsetAsync(c->d_vis, 0, n * 16, c->stream));
+    RT_HIP(c, hipMemsetAsync(c->d_g0, 0, n * 16, c->stream));
+    RT_HIP(c, hipMemsetAsync(c->d_g1, 0, n * 16, c->stream));
+    RT_HIP(c, hipMemsetAsync(c->d_accum, 0, n * 16, c->stream));
+    RT_HIP(c, hipMemsetAsync(c->d_pixels, 0, n * 4, c->stream));
+    RT_HIP(c, hipMalloc(&c->d_counter, 8));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+static void free_scene(rt_ctx* c)
+{
+    hipFree(c->d_tris); hipFree(c->d_tv); hipFree(c->d_nodes); hipFree(c->d_trimat); hipFree(c->d_lights);
+    c->d_tris = nullptr; c->d_tv = nullptr; c->d_nodes = nullptr; c->d_trimat = nullptr; c->d_lights = nullptr;
+    c->has_scene = false;
+}
+
+int rt_destroy(rt_ctx* c)
+{
+    RT_CHECK_CTX(c);
+    hipSetDevice(c->device);
+    if (c->own_stream) hipStreamSynchronize(c->own_stream);
+    free_scene(c);
+    hipFree(c->d_vis); hipFree(c->d_g0); hipFree(c->d_g1); hipFree(c->d_accum); hipFree(c->d_pixels);
+    for (int k = 0; k < 3; ++k) { hipFree(c->d_rec[k]); hipFree(c->d_rad[k]); }
+    hipFree(c->d_counter); hipFree(c->d_stage);
+    if (c->ev_created) for (auto& e : c->ev) hipEventDestroy(e);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    delete c;
+    return RT_OK;
+}
+
+const char* rt_last_error(rt_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int rt_set_stream(rt_ctx* c, void* s)
+{
+    RT_CHECK_CTX(c);
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return RT_OK;
+}
+int rt_sync(rt_ctx* c)
+{
+    RT_CHECK_CTX(c);
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+static int ensure_stage(rt_ctx* c, size_t bytes)
+{
+    if (c->stage_bytes >= bytes) return RT_OK;
+    if (c->d_stage) { RT_HIP(c, hipStreamSynchronize(c->stream)); hipFree(c->d_stage); c->d_stage = nullptr; }
+    RT_HIP(c, hipMalloc(&c->d_stage, bytes));
+    c->stage_bytes = bytes;
+    return RT_OK;
+}
+
+/* LBVH build, see bvh.h */
+static int build_bvh(rt_ctx* c, const rt_triangle* tris, int n)
+{
+    hipStream_t st = c->stream;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k)
+            for (int a = 0; a < 3; ++a)
+            {
+                const float v = tris[i].v[k][a];
+                if (v < lo[a]) lo[a] = v;
+                if (v > hi[a]) hi[a] = v;
+            }
+    float ext = 0.0f;
+    for (int a = 0; a < 3; ++a) ext = fmaxf(ext, fmaxf(fabsf(lo[a]), fabsf(hi[a])));
+    const float pad = 4e-5f * (ext > 1.0f ? ext : 1.0f);
+    float3 slo = make_float3(lo[0], lo[1], lo[2]);
+    float3 sext = make_float3(fmaxf(hi[0] - lo[0], 1e-20f), fmaxf(hi[1] - lo[1], 1e-20f), fmaxf(hi[2] - lo[2], 1e-20f));
+
+    RT_HIP(c, hipMalloc(&c->d_tv, (size_t)n * 48));
+    RT_HIP(c, hipMalloc(&c->d_nodes, (size_t)(n > 1 ? n - 1 : 1) * sizeof(BvhNode)));
+    float* d_boxes = nullptr; float* d_node_boxes = nullptr;
+    uint64_t *d_keys = nullptr, *d_keys2 = nullptr;
+    uint32_t *d_ids = nullptr, *d_ids2 = nullptr;
+    int2* d_children = nullptr; int *d_parent_inner = nullptr, *d_parent_leaf = nullptr, *d_level = nullptr, *d_remaining = nullptr;
+    void* d_temp = nullptr;
+    int rc = RT_OK;
+    auto cleanup = [&]() {
+        hipFree(d_boxes); hipFree(d_node_boxes); hipFree(d_keys); hipFree(d_keys2); hipFree(d_ids); hipFree(d_ids2);
+        hipFree(d_children); hipFree(d_parent_inner); hipFree(d_parent_leaf); hipFree(d_level); hipFree(d_remaining);
+        hipFree(d_temp);
+    };
+#define BV_HIP(call)                                                                               \
+    do                                                                                             \
+    {                                                                                              \
+        hipError_t _e = (call);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+        {                                                                                          \
+            char _b[512];                                                                          \
+            snprintf(_b, sizeof(_b), "%s failed: %s", #call, hipGetErrorString(_e));               \
+            c->err = _b; cleanup(); return RT_ERR_HIP;                                             \
+        }                                                                                          \
+    } while (0)
+    BV_HIP(hipMalloc(&d_boxes, (size_t)n * 24));
+    BV_HIP(hipMalloc(&d_node_boxes, (size_t)n * 24));
+    BV_HIP(hipMalloc(&d_keys, (size_t)n * 8));
+    BV_HIP(hipMalloc(&d_keys2, (size_t)n * 8));
+    BV_HIP(hipMalloc(&d_ids, (size_t)n * 4));
+    BV_HIP(hipMalloc(&d_ids2, (size_t)n * 4));
+    BV_HIP(hipMalloc(&d_children, (size_t)n * 8));
+    BV_HIP(hipMalloc(&d_parent_inner, (size_t)n * 4));
+    BV_HIP(hipMalloc(&d_parent_leaf, (size_t)n * 4));
+    BV_HIP(hipMalloc(&d_level, (size_t)n * 4));
+    BV_HIP(hipMalloc(&d_remaining, 4));
+
+    const int grid = (n + 255) / 256;
+    k_bvh_prims<<<grid, 256, 0, st>>>(c->d_tris, n, slo, sext, pad, c->d_tv, d_boxes, d_keys, d_ids);
+    BV_HIP(hipGetLastError());
+    size_t temp_bytes = 0;
+    BV_HIP(rocprim::radix_sort_pairs(nullptr, temp_bytes, d_keys, d_keys2, d_ids, d_ids2, (size_t)n, 0, 64, st));
+    BV_HIP(hipMalloc(&d_temp, temp_bytes > 0 ? temp_bytes : 16));
+    BV_HIP(rocprim::radix_sort_pairs(d_temp, temp_bytes, d_keys, d_keys2, d_ids, d_ids2, (size_t)n, 0, 64, st));
+
+    if (n == 1)
+    {
+        /* one triangle: both children are the same leaf (the second test is rejected by the tie rule) */
+        BvhNode nd;
+        float hb[6];
+        BV_HIP(hipMemcpyAsync(hb, d_boxes, 24, hipMemcpyDeviceToHost, st));
+        BV_HIP(hipStreamSynchronize(st));
+        nd.a = make_float4(hb[0], hb[1], hb[2], hb[0]);
+        nd.b = make_float4(hb[3], hb[4], hb[5], hb[1]);
+        nd.c = make_float4(hb[3], hb[4], hb[5], hb[2]);
+        nd.d = make_int4(~0, ~0, -1, -1);
+        BV_HIP(hipMemcpyAsync(c->d_nodes, &nd, sizeof(nd), hipMemcpyHostToDevice, st));
+        BV_HIP(hipStreamSynchronize(st));
+        c->bvh_height = 1;
+        cleanup();
+        return RT_OK;
+    }
+
+    k_bvh_hierarchy<<<grid, 256, 0, st>>>(d_keys2, n, d_children, d_parent_inner, d_parent_leaf);
+    BV_HIP(hipGetLastError());
+    BV_HIP(hipMemsetAsync(d_level, 0, (size_t)n * 4, st));
+    int height = 0;
+    for (int pass = 1; pass <= 4096; ++pass)
+    {
+        BV_HIP(hipMemsetAsync(d_remaining, 0, 4, st));
+        k_bvh_refit_pass<<<grid, 256, 0, st>>>(n, pass, d_ids2, d_boxes, d_children, d_node_boxes, d_level, d_remaining);
+        BV_HIP(hipGetLastError());
+        int remaining = 0;
+        BV_HIP(hipMemcpyAsync(&remaining, d_remaining, 4, hipMemcpyDeviceToHost, st));
+        BV_HIP(hipStreamSynchronize(st));
+        if (remaining == 0) { height = pass; break; }
+    }
+    if (height == 0) { c->err = "LBVH refit did not converge"; cleanup(); return RT_ERR_BVH_DEPTH; }
+    c->bvh_height = height;
+    if (height > 62)
+    {
+        char b[128];
+        snprintf(b, sizeof(b), "LBVH height %d exceeds the 63-level trail word", height);
+        c->err = b; cleanup();
+        return RT_ERR_BVH_DEPTH;
+    }
+    k_bvh_emit<<<grid, 256, 0, st>>>(n, d_ids2, d_boxes, d_children, d_parent_inner, d_node_boxes, c->d_nodes);
+    BV_HIP(hipGetLastError());
+    BV_HIP(hipStreamSynchronize(st));
+    cleanup();
+#undef BV_HIP
+    return rc;
+}
+
+int rt_scene_set(rt_ctx* c, const rt_triangle* triangles, uint32_t count)
+{
+    RT_CHECK_CTX(c);
+    if (!triangles && count) RT_FAIL(c, RT_ERR_ARG, "null triangles");
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    free_scene(c);
+    const int n = (int)count;
+    c->n_tris = n;
+    /* light list in index order (10_restir_di.cpp:196-205) */
+    std::vector<uint32_t> lights;
+    for (int i = 0; i < n; ++i)
+        if (triangles[i].emissive[0] > 0.0f || triangles[i].emissive[1] > 0.0f || triangles[i].emissive[2] > 0.0f)
+            lights.push_back((uint32_t)i);
+    c->n_lights = (int)lights.size();
+    c->bvh_height = 0;
+    if (n == 0) { c->has_scene = true; return RT_OK; }
+    RT_HIP(c, hipMalloc(&c->d_tris, (size_t)n * 60));
+    RT_HIP(c, hipMemcpyAsync(c->d_tris, triangles, (size_t)n * 60, hipMemcpyHostToDevice, c->stream));
+    RT_HIP(c, hipMalloc(&c->d_trimat, (size_t)n * 32));
+    k_trimat<<<(n + 255) / 256, 256, 0, c->stream>>>(n, c->d_tris, c->d_trimat);
+    RT_HIP(c, hipGetLastError());
+    if (c->n_lights > 0)
+    {
+        uint32_t* d_ids = nullptr;
+        RT_HIP(c, hipMalloc(&d_ids, lights.size() * 4));
+        RT_HIP(c, hipMemcpyAsync(d_ids, lights.data(), lights.size() * 4, hipMemcpyHostToDevice, c->stream));
+        RT_HIP(c, hipMalloc(&c->d_lights, lights.size() * 80));
+        k_light_table<<<(c->n_lights + 255) / 256, 256, 0, c->stream>>>(c->n_lights, d_ids, c->d_tris, c->d_lights);
+        RT_HIP(c, hipGetLastError());
+        RT_HIP(c, hipStreamSynchronize(c->stream));
+        hipFree(d_ids);
+    }
+    const int rc = build_bvh(c, triangles, n);
+    if (rc != RT_OK) return rc;
+    c->has_scene = true;
+    return RT_OK;
+}
+
+int rt_scene_info(rt_ctx* c, uint32_t* n_triangles, uint32_t* n_lights, uint32_t* bvh_height)
+{
+    RT_CHECK_CTX(c);
+    if (n_triangles) *n_triangles = (uint32_t)c->n_tris;
+    if (n_lights) *n_lights = (uint32_t)c->n_lights;
+    if (bvh_height) *bvh_height = (uint32_t)c->bvh_height;
+    return RT_OK;
+}
+
+/* common/camera.hpp:11-25 (host; tan of a float argument = tanf) */
+int rt_camera_lookat(rt_ctx* c, const float eye[3], const float center[3], const float up[3], float fovy)
+{
+    RT_CHECK_CTX(c);
+    if (!eye || !center || !up) RT_FAIL(c, RT_ERR_ARG, "null camera vector");
+    const f3 e = F3(eye[0], eye[1], eye[2]), ce = F3(center[0], center[1], center[2]), u0 = F3(up[0], up[1], up[2]);
+    const f3 f = normalize(ce - e);
+    const f3 s = normalize(cross(f, u0));
+    const f3 u = cross(s, f);
+    const float tanThetaY = tanf(fovy * 0.5f);
+    const float tanThetaX = tanThetaY / (float)c->H * (float)c->W;
+    const f3 r = s * tanThetaX, uu = u * tanThetaY;
+    c->rg.origin[0] = e.x; c->rg.origin[1] = e.y; c->rg.origin[2] = e.z;
+    c->rg.right[0] = r.x; c->rg.right[1] = r.y; c->rg.right[2] = r.z;
+    c->rg.up[0] = uu.x; c->rg.up[1] = uu.y; c->rg.up[2] = uu.z;
+    c->eye[0] = e.x; c->eye[1] = e.y; c->eye[2] = e.z;
+    c->has_camera = true;
+    return RT_OK;
+}
+int rt_camera_set(rt_ctx* c, const rt_raygen* rg, const float eye[3])
+{
+    RT_CHECK_CTX(c);
+    if (!rg || !eye) RT_FAIL(c, RT_ERR_ARG, "null raygen/eye");
+    c->rg = *rg;
+    c->eye[0] = eye[0]; c->eye[1] = eye[1]; c->eye[2] = eye[2];
+    c->has_camera = true;
+    return RT_OK;
+}
+int rt_camera_get(rt_ctx* c, rt_raygen* rg)
+{
+    RT_CHECK_CTX(c);
+    if (!rg) return RT_ERR_ARG;
+    *rg = c->rg;
+    return RT_OK;
+}
+int rt_options_set(rt_ctx* c, const rt_options* o)
+{
+    RT_CHECK_CTX(c);
+    if (!o) RT_FAIL(c, RT_ERR_ARG, "null options");
+    if (o->ris_sample_count < 0 || o->spatial_resampling_sample_count < 0 || o->spatial_resampling_passes < 0)
+        RT_FAIL(c, RT_ERR_ARG, "negative counts in options");
+    c->opt = *o;
+    return RT_OK;
+}
+int rt_options_get(rt_ctx* c, rt_options* o)
+{
+    RT_CHECK_CTX(c);
+    if (!o) return RT_ERR_ARG;
+    *o = c->opt;
+    return RT_OK;
+}
+
+#define NEED_SCENE(c)                                                               \
+    if (!(c)->has_scene || !(c)->has_camera) RT_FAIL(c, RT_ERR_STATE, "scene and camera must be set first");
+#define NEED_RES(c, id) \
+    if ((id) < 0 || (id) > 2) RT_FAIL(c, RT_ERR_ARG, "bad reservoir buffer id %d", (id));
+
+static int launch_grid(const rt_ctx* c) { return tile_grid(c->W, c->row_end - c->row_begin); }
+
+int rt_clear(rt_ctx* c)
+{
+    RT_CHECK_CTX(c);
+    k_clear<<<launch_grid(c), BLOCK, 0, c->stream>>>(make_params(c, 0, 0), c->d_accum);
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+
+int rt_raycast(rt_ctx* c)
+{
+    RT_CHECK_CTX(c);
+    NEED_SCENE(c);
+    k_raycast<<<launch_grid(c), BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0), c->d_vis, c->d_g0, c->d_g1);
+    RT_HIP(c, hipGetLastError());
+    c->has_gbuffer = true;
+    return RT_OK;
+}
+
+static int launch_generate(rt_ctx* c, int frame, int dst_phys, int prev_phys, bool fuse)
+{
+    if (c->n_lights == 0 && c->opt.ris_sample_count > 0)
+        RT_FAIL(c, RT_ERR_STATE, "scene has no emissive triangle (the reference divides by zero here)");
+    const SceneView S = make_scene(c);
+    const FrameParams P = make_params(c, frame, 0);
+    const bool sh = c->opt.use_shadowed_target_function;
+    float4 *orec = c->d_rec[dst_phys], *orad = c->d_rad[dst_phys];
+    const float4 *prec = fuse ? c->d_rec[prev_phys] : nullptr, *prad = fuse ? c->d_rad[prev_phys] : nullptr;
+    const int g = launch_grid(c);
+    if (fuse && sh) k_generate_candidate<true, true><<<g, BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
+    else if (fuse) k_generate_candidate<true, false><<<g, BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
+    else if (sh) k_generate_candidate<false, true><<<g, BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
+    else k_generate_candidate<false, false><<<g, BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+
+int rt_generate_candidate(rt_ctx* c, int frame, int dst)
+{
+    RT_CHECK_CTX(c);
+    NEED_SCENE(c);
+    NEED_RES(c, dst);
+    if (!c->has_gbuffer) RT_FAIL(c, RT_ERR_STATE, "no G-buffer: call rt_raycast or upload RT_BUF_VISIBILITY first");
+    return launch_generate(c, frame, c->res_map[dst], 0, false);
+}
+
+int rt_temporal_resampling(rt_ctx* c, int frame, int prev, int inout)
+{
+    RT_CHECK_CTX(c);
+    NEED_SCENE(c);
+    NEED_RES(c, prev);
+    NEED_RES(c, inout);
+    if (prev == inout) RT_FAIL(c, RT_ERR_ARG, "prev and inout must differ");
+    const SceneView S = make_scene(c);
+    const FrameParams P = make_params(c, frame, 0);
+    const int pp = c->res_map[prev], pi = c->res_map[inout];
+    if (c->opt.use_shadowed_target_function)
+        k_temporal<true><<<launch_grid(c), BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, c->d_rec[pp], c->d_rad[pp], c->d_rec[pi], c->d_rad[pi]);
+    else
+        k_temporal<false><<<launch_grid(c), BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, c->d_rec[pp], c->d_rad[pp], c->d_rec[pi], c->d_rad[pi]);
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+
+/* examples/10_restir_di/10_restir_di.cu:239-254: a plain copy of the owned rows */
+int rt_save_temporal_reservoir(rt_ctx* c, int src, int dst)
+{
+    RT_CHECK_CTX(c);
+    NEED_RES(c, src);
+    NEED_RES(c, dst);
+    if (src == dst) return RT_OK;
+    const size_t off = (size_t)(c->row_begin - c->lrow0) * c->W;
+    const size_t n = (size_t)(c->row_end - c->row_begin) * c->W;
+    const int ps = c->res_map[src], pd = c->res_map[dst];
+    RT_HIP(c, hipMemcpyAsync(c->d_rec[pd] + 4 * off, c->d_rec[ps] + 4 * off, n * 64, hipMemcpyDeviceToDevice, c->stream));
+    RT_HIP(c, hipMemcpyAsync(c->d_rad[pd] + off, c->d_rad[ps] + off, n * 16, hipMemcpyDeviceToDevice, c->stream));
+    return RT_OK;
+}
+
+static int launch_spatial(rt_ctx* c, int frame, int pass, int in_phys, int out_phys)
+{
+    const SceneView S = make_scene(c);
+    const FrameParams P = make_params(c, frame, pass);
+    if (c->opt.use_shadowed_target_function)
+        k_spatial<true><<<launch_grid(c), BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys]);
+    else
+        k_spatial<false><<<launch_grid(c), BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys]);
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+
+int rt_spatial_resampling(rt_ctx* c, int frame, int pass, int in, int out)
+{
+    RT_CHECK_CTX(c);
+    NEED_SCENE(c);
+    NEED_RES(c, in);
+    NEED_RES(c, out);
+    if (in == out) RT_FAIL(c, RT_ERR_ARG, "in and out must differ");
+    return launch_spatial(c, frame, pass, c->res_map[in], c->res_map[out]);
+}
+
+static int launch_resolve(rt_ctx* c, int phys)
+{
+    k_resolve<<<launch_grid(c), BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0), c->d_g0, c->d_g1,
+                                                        c->d_rec[phys], c->d_rad[phys], c->d_accum);
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+int rt_resolve(rt_ctx* c, int res)
+{
+    RT_CHECK_CTX(c);
+    NEED_SCENE(c);
+    NEED_RES(c, res);
+    return launch_resolve(c, c->res_map[res]);
+}
+
+int rt_tone_mapping(rt_ctx* c)
+{
+    RT_CHECK_CTX(c);
+    k_tone_mapping<<<launch_grid(c), BLOCK, 0, c->stream>>>(make_params(c, 0, 0), c->d_accum, c->d_pixels);
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+
+int rt_timing_enable(rt_ctx* c, int on)
+{
+    RT_CHECK_CTX(c);
+    if (on && !c->ev_created)
+    {
+        for (auto& e : c->ev) RT_HIP(c, hipEventCreate(&e));
+        c->ev_created = true;
+    }
+    c->timing = on != 0;
+    c->last_valid = false;
+    return RT_OK;
+}
+
+int rt_frame(rt_ctx* c, int frame, int clear_first, int* final_res)
+{
+    RT_CHECK_CTX(c);
+    NEED_SCENE(c);
+    if (c->row_begin != 0 || c->row_end != c->H)
+        RT_FAIL(c, RT_ERR_STATE, "rt_frame is for single-strip contexts; strips run the passes and exchange halos");
+    const bool T = c->timing;
+    int ei = 0;
+    auto mark = [&]() { if (T) hipEventRecord(c->ev[ei], c->stream); ++ei; };
+    int rc;
+    mark(); /* 0 */
+    if (clear_first) { if ((rc = rt_clear(c)) != RT_OK) return rc; }
+    mark(); /* 1 */
+    if ((rc = rt_raycast(c)) != RT_OK) return rc;
+    mark(); /* 2 */
+    /* X = history, Y = candidates(+temporal) -> next history, Z = spatial ping-pong partner */
+    const int X = c->res_map[RT_RES_TEMPORAL], Y = c->res_map[RT_RES_0], Z = c->res_map[RT_RES_1];
+    if ((rc = launch_generate(c, frame, Y, X, c->opt.use_temporal_resampling != 0)) != RT_OK) return rc;
+    mark(); /* 3 */
+    const int passes = c->opt.spatial_resampling_passes;
+    int in = Y, out = Z;
+    for (int k = 0; k < passes; ++k)
+    {
+        if (k != 0) { in = out; out = (in == Z) ? X : Z; }
+        if ((rc = launch_spatial(c, frame, k, in, out)) != RT_OK) return rc;
+        if (k < 3) mark(); /* 4,5,6 */
+    }
+    for (int k = passes; k < 3; ++k) mark();
+    if (passes < 2)
+    {
+        /* logical RT_RES_0 still equals the post-temporal reservoirs: materialise the copy the
+         * reference's save_temporal_reservoir makes (10_restir_di.cpp:314-321) */
+        const size_t n = local_pixels(c);
+        RT_HIP(c, hipMemcpyAsync(c->d_rec[X], c->d_rec[Y], n * 64, hipMemcpyDeviceToDevice, c->stream));
+        RT_HIP(c, hipMemcpyAsync(c->d_rad[X], c->d_rad[Y], n * 16, hipMemcpyDeviceToDevice, c->stream));
+    }
+    const int final_phys = passes > 0 ? out : Z;
+    if ((rc = launch_resolve(c, final_phys)) != RT_OK) return rc;
+    mark(); /* 7 */
+    if ((rc = rt_tone_mapping(c)) != RT_OK) return rc;
+    mark(); /* 8 */
+    /* new logical names: TEMPORAL = Y; RES_1 = Z; RES_0 = X (pass-1 output / copy) */
+    c->res_map[RT_RES_TEMPORAL] = Y;
+    c->res_map[RT_RES_0] = X;
+    c->res_map[RT_RES_1] = Z;
+    if (final_res) *final_res = (final_phys == Z) ? RT_RES_1 : RT_RES_0;
+    c->last_valid = T;
+    return RT_OK;
+}
+
+int rt_timing(rt_ctx* c, float ms[9])
+{
+    RT_CHECK_CTX(c);
+    if (!ms) return RT_ERR_ARG;
+    if (!c->last_valid) RT_FAIL(c, RT_ERR_STATE, "no timed frame (rt_timing_enable + rt_frame first)");
+    RT_HIP(c, hipEventSynchronize(c->ev[8]));
+    for (int k = 0; k < 8; ++k) RT_HIP(c, hipEventElapsedTime(&ms[k], c->ev[k], c->ev[k + 1]));
+    RT_HIP(c, hipEventElapsedTime(&ms[8], c->ev[0], c->ev[8]));
+    return RT_OK;
+}
+
+int rt_local_rows(rt_ctx* c, int* first_row, int* n_rows)
+{
+    RT_CHECK_CTX(c);
+    if (first_row) *first_row = c->lrow0;
+    if (n_rows) *n_rows = c->lrows;
+    return RT_OK;
+}
+
+int rt_download(rt_ctx* c, int buf, void* dst, size_t bytes)
+{
+    RT_CHECK_CTX(c);
+    if (!dst) RT_FAIL(c, RT_ERR_ARG, "null dst");
+    const size_t n = local_pixels(c);
+    switch (buf)
+    {
+        case RT_BUF_VISIBILITY:
+            if (bytes != n * 16) RT_FAIL(c, RT_ERR_ARG, "size mismatch: want %zu", n * 16);
+            RT_HIP(c, hipMemcpyAsync(dst, c->d_vis, bytes, hipMemcpyDeviceToHost, c->stream));
+            break;
+        case RT_BUF_ACCUMULATION:
+            if (bytes != n * 16) RT_FAIL(c, RT_ERR_ARG, "size mismatch: want %zu", n * 16);
+            RT_HIP(c, hipMemcpyAsync(dst, c->d_accum, bytes, hipMemcpyDeviceToHost, c->stream));
+            break;
+        case RT_BUF_PIXELS:
+            if (bytes != n * 4) RT_FAIL(c, RT_ERR_ARG, "size mismatch: want %zu", n * 4);
+            RT_HIP(c, hipMemcpyAsync(dst, c->d_pixels, bytes, hipMemcpyDeviceToHost, c->stream));
+            break;
+        case RT_BUF_RES_0:
+        case RT_BUF_RES_1:
+        case RT_BUF_RES_TEMPORAL:
+        {
+            if (bytes != n * 76) RT_FAIL(c, RT_ERR_ARG, "size mismatch: want %zu", n * 76);
+            const int phys = c->res_map[buf - RT_BUF_RES_0];
+            int rc = ensure_stage(c, n * 76);
+            if (rc != RT_OK) return rc;
+            k_res_to_ref<<<(int)((n + 255) / 256), 256, 0, c->stream>>>((int)n, c->d_rec[phys], c->d_rad[phys], (uint32_t*)c->d_stage);
+            RT_HIP(c, hipGetLastError());
+            RT_HIP(c, hipMemcpyAsync(dst, c->d_stage, bytes, hipMemcpyDeviceToHost, c->stream));
+            break;
+        }
+        default: RT_FAIL(c, RT_ERR_ARG, "unknown buffer %d", buf);
+    }
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_upload(rt_ctx* c, int buf, const void* src, size_t bytes)
+{
+    RT_CHECK_CTX(c);
+    if (!src) RT_FAIL(c, RT_ERR_ARG, "null src");
+    const size_t n = local_pixels(c);
+    switch (buf)
+    {
+        case RT_BUF_VISIBILITY:
+        {
+            if (bytes != n * 16) RT_FAIL(c, RT_ERR_ARG, "size mismatch: want %zu", n * 16);
+            NEED_SCENE(c);
+            RT_HIP(c, hipMemcpyAsync(c->d_vis, src, bytes, hipMemcpyHostToDevice, c->stream));
+            FrameParams P = make_params(c, 0, 0);
+            P.row0 = c->lrow0; P.row1 = c->lrow0 + c->lrows; /* all rows held, halos included */
+            k_gbuffer_from_vis<<<tile_grid(c->W, c->lrows), BLOCK, 0, c->stream>>>(make_scene(c), P, c->d_vis, c->d_g0, c->d_g1);
+            RT_HIP(c, hipGetLastError());
+            c->has_gbuffer = true;
+            break;
+        }
+        case RT_BUF_ACCUMULATION:
+            if (bytes != n * 16) RT_FAIL(c, RT_ERR_ARG, "size mismatch: want %zu", n * 16);
+            RT_HIP(c, hipMemcpyAsync(c->d_accum, src, bytes, hipMemcpyHostToDevice, c->stream));
+            break;
+        case RT_BUF_RES_0:
+        case RT_BUF_RES_1:
+        case RT_BUF_RES_TEMPORAL:
+        {
+            if (bytes != n * 76) RT_FAIL(c, RT_ERR_ARG, "size mismatch: want %zu", n * 76);
+            if (!c->has_gbuffer) RT_FAIL(c, RT_ERR_STATE, "upload RT_BUF_VISIBILITY (or rt_raycast) before reservoirs");
+            const int phys = c->res_map[buf - RT_BUF_RES_0];
+            int rc = ensure_stage(c, n * 76);
+            if (rc != RT_OK) return rc;
+            RT_HIP(c, hipMemcpyAsync(c->d_stage, src, bytes, hipMemcpyHostToDevice, c->stream));
+            k_res_from_ref<<<(int)((n + 255) / 256), 256, 0, c->stream>>>((int)n, (const uint32_t*)c->d_stage, c->d_g1, c->d_rec[phys], c->d_rad[phys]);
+            RT_HIP(c, hipGetLastError());
+            break;
+        }
+        default: RT_FAIL(c, RT_ERR_ARG, "buffer %d cannot be uploaded", buf);
+    }
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+size_t rt_halo_bytes(rt_ctx* c, int n_rows) { return c ? (size_t)n_rows * (size_t)c->W * 80 : 0; }
+
+static int halo_range(rt_ctx* c, int row0, int n_rows)
+{
+    if (n_rows <= 0 || row0 < c->lrow0 || row0 + n_rows > c->lrow0 + c->lrows)
+        RT_FAIL(c, RT_ERR_ARG, "rows [%d,%d) outside the rows held [%d,%d)", row0, row0 + n_rows, c->lrow0, c->lrow0 + c->lrows);
+    return RT_OK;
+}
+int rt_halo_pack(rt_ctx* c, int res, int row0, int n_rows, void* device_dst)
+{
+    RT_CHECK_CTX(c);
+    NEED_RES(c, res);
+    int rc = halo_range(c, row0, n_rows);
+    if (rc != RT_OK) return rc;
+    const int phys = c->res_map[res];
+    const size_t off = (size_t)(row0 - c->lrow0) * c->W, n = (size_t)n_rows * c->W;
+    RT_HIP(c, hipMemcpyAsync(device_dst, c->d_rec[phys] + 4 * off, n * 64, hipMemcpyDeviceToDevice, c->stream));
+    RT_HIP(c, hipMemcpyAsync((char*)device_dst + n * 64, c->d_rad[phys] + off, n * 16, hipMemcpyDeviceToDevice, c->stream));
+    return RT_OK;
+}
+int rt_halo_unpack(rt_ctx* c, int res, int row0, int n_rows, const void* device_src)
+{
+    RT_CHECK_CTX(c);
+    NEED_RES(c, res);
+    int rc = halo_range(c, row0, n_rows);
+    if (rc != RT_OK) return rc;
+    const int phys = c->res_map[res];
+    const size_t off = (size_t)(row0 - c->lrow0) * c->W, n = (size_t)n_rows * c->W;
+    RT_HIP(c, hipMemcpyAsync(c->d_rec[phys] + 4 * off, device_src, n * 64, hipMemcpyDeviceToDevice, c->stream));
+    RT_HIP(c, hipMemcpyAsync(c->d_rad[phys] + off, (const char*)device_src + n * 64, n * 16, hipMemcpyDeviceToDevice, c->stream));
+    return RT_OK;
+}
+
+int rt_ray_count(rt_ctx* c, uint64_t* rays, uint64_t* shaded_pixels)
+{
+    RT_CHECK_CTX(c);
+    if (!c->has_gbuffer) RT_FAIL(c, RT_ERR_STATE, "no G-buffer yet");
+    RT_HIP(c, hipMemsetAsync(c->d_counter, 0, 8, c->stream));
+    k_count_shaded<<<launch_grid(c), BLOCK, 0, c->stream>>>(make_params(c, 0, 0), c->d_g1, c->d_counter);
+    RT_HIP(c, hipGetLastError());
+    unsigned long long shaded = 0;
+    RT_HIP(c, hipMemcpyAsync(&shaded, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    const uint64_t n = (uint64_t)c->W * (uint64_t)(c->row_end - c->row_begin);
+    uint64_t per_shaded = 1; /* resolve (10_restir_di.cu:443-444) */
+    if (c->opt.use_visibility_reuse) per_shaded += 1; /* :129-130 */
+    if (c->opt.use_shadowed_target_function)
+    {
+        /* upper bound only: :115-118 (1), temporal :195-199,:224-227 (2), spatial per pass
+         * count+1 (:346-350, :375-378); exact counts come from the oracle's counters */
+        per_shaded += 1 + (c->opt.use_temporal_resampling ? 2 : 0) +
+                      (uint64_t)c->opt.spatial_resampling_passes * (c->opt.use_spatial_resampling ? (uint64_t)c->opt.spatial_resampling_sample_count + 1 : 0);
+    }
+    if (rays) *rays = n + per_shaded * shaded;
+    if (shaded_pixels) *shaded_pixels = shaded;
+    return RT_OK;
+}
+
+int rt_trace_closest(rt_ctx* c, const float* rays, uint32_t n, float* hits)
+{
+    RT_CHECK_CTX(c);
+    if (!c->has_scene) RT_FAIL(c, RT_ERR_STATE, "no scene");
+    if (n == 0) return RT_OK;
+    float *d_r = nullptr, *d_h = nullptr;
+    RT_HIP(c, hipMalloc(&d_r, (size_t)n * 32));
+    RT_HIP(c, hipMalloc(&d_h, (size_t)n * 16));
+    RT_HIP(c, hipMemcpyAsync(d_r, rays, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
+    BvhView b = make_scene(c).bvh;
+    k_trace_closest<<<(n + 255) / 256, 256, 0, c->stream>>>(b, d_r, (int)n, d_h);
+    RT_HIP(c, hipGetLastError());
+    RT_HIP(c, hipMemcpyAsync(hits, d_h, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    hipFree(d_r); hipFree(d_h);
+    return RT_OK;
+}
+
+int rt_math_eval(rt_ctx* c, int fn, const float* in, uint32_t n, float* out)
+{
+    RT_CHECK_CTX(c);
+    if (n == 0) return RT_OK;
+    const size_t nin = (fn == 26) ? 2 : 1;
+    float *d_i = nullptr, *d_o = nullptr;
+    RT_HIP(c, hipMalloc(&d_i, (size_t)n * 4 * nin));
+    RT_HIP(c, hipMalloc(&d_o, (size_t)n * 4));
+    RT_HIP(c, hipMemcpyAsync(d_i, in, (size_t)n * 4 * nin, hipMemcpyHostToDevice, c->stream));
+    k_math_eval<<<(n + 255) / 256, 256, 0, c->stream>>>(fn, d_i, (int)n, d_o);
+    RT_HIP(c, hipGetLastError());
+    RT_HIP(c, hipMemcpyAsync(out, d_o, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    hipFree(d_i); hipFree(d_o);
+    return RT_OK;
+}
+
+} /* extern "C" */

@@ -1,0 +1,242 @@
+/*
+ * rt_device.h — device-side vocabulary of the MI355X ReSTIR DI path: vector math, PCG,
+ * the reference's small pure functions, and the HBM record layouts.
+ *
+ * Parity rule: every function marked [parity] must produce bit-identical results to the
+ * reference's arithmetic (IEEE binary32, the reference's operation order, no FMA
+ * contraction; the translation unit is compiled with -ffp-contract=off). Code that only
+ * has to be conservative (BVH box tests) may use explicit __builtin_fmaf.
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "portable_math.h"
+
+#define RT_DEV __device__ __forceinline__
+#define RT_HD __host__ __device__ __forceinline__
+
+namespace rt
+{
+
+struct f3
+{
+    float x, y, z;
+};
+RT_HD f3 F3(float x, float y, float z) { return f3{x, y, z}; }
+RT_HD f3 operator+(f3 a, f3 b) { return F3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_HD f3 operator-(f3 a, f3 b) { return F3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_HD f3 operator*(f3 a, f3 b) { return F3(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_HD f3 operator*(f3 a, float s) { return F3(a.x * s, a.y * s, a.z * s); }
+RT_HD f3 operator*(float s, f3 a) { return F3(a.x * s, a.y * s, a.z * s); }
+RT_HD f3 operator/(f3 a, float s) { return F3(a.x / s, a.y / s, a.z / s); }
+RT_HD f3 operator-(f3 a) { return F3(-a.x, -a.y, -a.z); }
+
+/* common/math.hpp:109-130 [parity] */
+RT_HD f3 cross(f3 a, f3 b)
+{
+    return F3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+RT_HD float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_HD float length(f3 a) { return sqrtf(dot(a, a)); }
+RT_HD f3 normalize(f3 a) { return a / length(a); }
+RT_HD f3 mix(f3 a, f3 b, float t) { return a + (b - a) * t; }
+RT_HD float luminance(f3 a) { return dot(a, F3(0.1762044f, 0.8129847f, 0.0108109f)); }
+
+constexpr float kPI = 3.14159265358979323846f;
+constexpr float kFltMax = 3.402823466e+38f;
+
+RT_HD float as_float(int i) { return pm_u2f((uint32_t)i); }
+RT_HD float as_float(uint32_t i) { return pm_u2f(i); }
+RT_HD int as_int(float f) { return (int)pm_f2u(f); }
+RT_HD uint32_t as_uint(float f) { return pm_f2u(f); }
+
+/* device max(float,float): NaN operand yields the other one (v_max_f32 semantics) */
+RT_HD float fmax_dev(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a < b ? b : a)); }
+
+/* ------------------------------------------------------------------ RNG */
+/* common/rng.hpp:8-58 [parity, integer] */
+struct PCG
+{
+    uint64_t state, inc;
+    RT_HD uint32_t uniform()
+    {
+        const uint64_t old = state;
+        state = old * 6364136223846793005ULL + inc;
+        const uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+        const uint32_t rot = (uint32_t)(old >> 59u);
+        return (xorshifted >> rot) | (xorshifted << ((0u - rot) & 31u));
+    }
+    RT_HD float uniformf()
+    {
+        const uint32_t bits = (uniform() >> 9) | 0x3f800000u;
+        return pm_u2f(bits) - 1.0f;
+    }
+};
+RT_HD PCG pcg_init(uint64_t seed, uint64_t sequence)
+{
+    PCG r;
+    r.state = 0u;
+    r.inc = (sequence << 1u) | 1u;
+    r.uniform();
+    r.state += seed;
+    r.uniform();
+    return r;
+}
+RT_HD uint32_t hashPCG(uint32_t v)
+{
+    const uint32_t state = v * 747796405u + 2891336453u;
+    const uint32_t word = ((state >> ((state >> 28) + 4)) ^ state) * 277803737u;
+    return (word >> 22) ^ word;
+}
+RT_HD uint32_t hashPCG3(uint32_t x, uint32_t y, uint32_t z) { return hashPCG(hashPCG(hashPCG(x) + y) + z); }
+RT_HD uint32_t hashPCG4(uint32_t x, uint32_t y, uint32_t z, uint32_t w)
+{
+    return hashPCG(hashPCG(hashPCG(hashPCG(x) + y) + z) + w);
+}
+
+/* ------------------------------------------------ reference pure functions */
+/* common/core.hpp:237-252 [parity] */
+RT_HD void warp_unit_triangle(float& x, float& y)
+{
+    if (y > x) { x *= 0.5f; y -= x; }
+    else { y *= 0.5f; x -= y; }
+}
+/* common/core.hpp:287-295 [parity] */
+RT_HD float geometry_term(f3 p0, f3 n0, f3 p1, f3 n1)
+{
+    f3 v = p1 - p0;
+    const float sqr_dist = dot(v, v);
+    v = normalize(v);
+    return fabsf(dot(v, n0)) * fabsf(dot(-v, n1)) / sqr_dist;
+}
+/* common/reservoir.hpp:42-59, unshadowed branch; `lum` = luminance(radiance) [parity] */
+RT_HD float target_unshadowed(f3 op, f3 on, f3 hp, f3 hn, float lum)
+{
+    const float brdf = 1.0f / kPI;
+    const float G = geometry_term(op, on, hp, hn);
+    return brdf * G * lum;
+}
+/* common/reservoir.hpp:61-87 with the portable expf / x^8 [parity] */
+RT_HD float rejection_heuristics(f3 p0, f3 n0, f3 p1, f3 n1, f3 eye)
+{
+    const float d0 = length(p0 - eye);
+    const float d1 = length(p1 - eye);
+    const float diff = (d1 - d0) * (d1 - d0) / d0;
+    float w = 1.0f;
+    w *= pm_expf(-32.0f * diff);
+    w *= pm_pow8f(fmax_dev(dot(n0, n1), 0.0f));
+    return w;
+}
+/* float -> int as v_cvt_i32_f32 does it (NaN -> 0, saturating); C++ leaves it undefined */
+RT_HD int f2i_sat(float f)
+{
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)f;
+}
+/* `M *= w` for int M, float w (10_restir_di.cu:211-212, 362-363) [parity] */
+RT_HD int scale_M(int M, float w) { return f2i_sat((float)M * w); }
+
+/* common/core.hpp:45-68 on raw vertices [parity] */
+RT_HD f3 tri_normal(f3 v0, f3 v1, f3 v2) { return normalize(cross(v1 - v0, v2 - v0)); }
+RT_HD float tri_area(f3 v0, f3 v1, f3 v2) { return 0.5f * length(cross(v1 - v0, v2 - v0)); }
+
+/* common/core.hpp:91-136 [parity]: the canonical leaf test */
+RT_HD bool intersect_ray_triangle(float& tOut, float& uOut, float& vOut, f3 ro, f3 rd, float tmin,
+                                  float tmax, f3 v0, f3 v1, f3 v2)
+{
+    const f3 e0 = v1 - v0;
+    const f3 e1 = v2 - v1;
+    const f3 e2 = v0 - v2;
+    const f3 n = cross(e0, e1);
+    const float t = dot(v0 - ro, n) / dot(n, rd);
+    if (tmin <= t && t <= tmax)
+    {
+        const f3 p = ro + rd * t;
+        const float a0 = dot(n, cross(e0, p - v0));
+        const float a1 = dot(n, cross(e1, p - v1));
+        const float a2 = dot(n, cross(e2, p - v2));
+        if (a0 < 0.0f || a1 < 0.0f || a2 < 0.0f) return false;
+        const float a = a0 + a1 + a2;
+        tOut = t;
+        uOut = a2 / a; /* bV */
+        vOut = a0 / a; /* bW */
+        return true;
+    }
+    return false;
+}
+
+/* --------------------------------------------------------- HBM record layouts
+ *
+ * G-buffer (written once per frame by raycast, read by every later pass), 32 B / pixel:
+ *   g0 = { p.x, p.y, p.z, bits(triangle index, -1 = sky) }
+ *   g1 = { n.x, n.y, n.z, bits(flags) }          flags: GB_SHADED | GB_EMISSIVE
+ * p, n = make_surface_info(vis, triangles, eye) (common/core.hpp:189-207).
+ *
+ * Reservoir record, 64 B aligned (one gather = 4 x dwordx4 from one 64-B segment):
+ *   q0 = { hit_position.xyz, ucw }
+ *   q1 = { hit_normal.xyz,   bits(M | visibility << 31 | shaded << 30) }
+ *   q2 = { origin_position.xyz, luminance(radiance) }
+ *   q3 = { origin_normal.xyz,   w_sum }
+ * plus a 16-B side record { radiance.xyz, 0 } that only moves with the finally selected
+ * sample. Together they hold every field of the reference's 76-B Reservoir
+ * (common/reservoir.hpp:5-38) losslessly for 0 <= M < 2^30.
+ */
+constexpr uint32_t GB_SHADED = 1u;
+constexpr uint32_t GB_EMISSIVE = 2u;
+constexpr uint32_t RES_VIS_BIT = 0x80000000u;
+constexpr uint32_t RES_SHADED_BIT = 0x40000000u;
+constexpr uint32_t RES_M_MASK = 0x3fffffffu;
+
+struct Res
+{
+    f3 hit_p, hit_n, org_p, org_n, rad;
+    float ucw, lum, w_sum;
+    int M;
+    bool vis;
+};
+RT_HD Res res_zero()
+{
+    Res r;
+    r.hit_p = r.hit_n = r.org_p = r.org_n = r.rad = F3(0.0f, 0.0f, 0.0f);
+    r.ucw = r.lum = r.w_sum = 0.0f;
+    r.M = 0;
+    r.vis = false;
+    return r;
+}
+
+RT_DEV void res_store(float4* __restrict__ rec, float4* __restrict__ radb, size_t i, const Res& r, bool shaded)
+{
+    const uint32_t mbits = ((uint32_t)r.M & RES_M_MASK) | (r.vis ? RES_VIS_BIT : 0u) | (shaded ? RES_SHADED_BIT : 0u);
+    rec[4 * i + 0] = make_float4(r.hit_p.x, r.hit_p.y, r.hit_p.z, r.ucw);
+    rec[4 * i + 1] = make_float4(r.hit_n.x, r.hit_n.y, r.hit_n.z, as_float(mbits));
+    rec[4 * i + 2] = make_float4(r.org_p.x, r.org_p.y, r.org_p.z, r.lum);
+    rec[4 * i + 3] = make_float4(r.org_n.x, r.org_n.y, r.org_n.z, r.w_sum);
+    radb[i] = make_float4(r.rad.x, r.rad.y, r.rad.z, 0.0f);
+}
+/* loads everything except radiance */
+RT_DEV Res res_load(const float4* __restrict__ rec, size_t i, bool& shaded)
+{
+    const float4 q0 = rec[4 * i + 0];
+    const float4 q1 = rec[4 * i + 1];
+    const float4 q2 = rec[4 * i + 2];
+    const float4 q3 = rec[4 * i + 3];
+    Res r;
+    r.hit_p = F3(q0.x, q0.y, q0.z);
+    r.ucw = q0.w;
+    r.hit_n = F3(q1.x, q1.y, q1.z);
+    const uint32_t mb = as_uint(q1.w);
+    r.M = (int)(mb & RES_M_MASK);
+    r.vis = (mb & RES_VIS_BIT) != 0u;
+    shaded = (mb & RES_SHADED_BIT) != 0u;
+    r.org_p = F3(q2.x, q2.y, q2.z);
+    r.lum = q2.w;
+    r.org_n = F3(q3.x, q3.y, q3.z);
+    r.w_sum = q3.w;
+    r.rad = F3(0.0f, 0.0f, 0.0f);
+    return r;
+}
+
+}  // namespace rt

@@ -250,11 +250,11 @@ def make_blocks_restir(detail=1.0):
     # weak ceiling light
     b.patch(lambda i, j: (-40.0 + 80.0 * i / 8.0, 75.0, 0.0 + 80.0 * j / 8.0), 8, 8, M["WeakLight"])
 
-    # two stud panels at z = 40 facing the camera (-z)
+    # two stud panels at z = 70 facing the camera (-z); stud pitch 1.5
     def panel(x_left, text, mats_for_glyph, plate_mat, stud_mat):
-        cols, rows = 30, 12
-        y0 = 18.0
-        b.box((x_left - cols, y0, 40.0), (x_left, y0 + rows, 41.0), plate_mat)
+        cols, rows, pitch, zf = 30, 12, 1.5, 70.0
+        y0 = 16.0
+        b.box((x_left - cols * pitch, y0, zf), (x_left, y0 + rows * pitch, zf + 1.5), plate_mat)
         lit = {}
         col = 1
         for gi, ch in enumerate(text):
@@ -264,36 +264,37 @@ def make_blocks_restir(detail=1.0):
                     if glyph[r][c] == "1":
                         lit[(col + c, rows - 3 - r)] = mats_for_glyph(gi, c, r)
             col += 6
+        hp = 0.5 * pitch
         for i in range(cols):  # i grows towards -x = camera right, so the text reads correctly
             for j in range(rows):
-                cx = x_left - i - 0.5
-                cy = y0 + j + 0.5
+                cx = x_left - (i + 0.5) * pitch
+                cy = y0 + (j + 0.5) * pitch
                 m = lit.get((i, j))
                 if m is None:
-                    b.stud((cx, cy, 40.0), "z", 0.3, 0.2, stud_mat)
+                    b.stud((cx, cy, zf), "z", 0.45, 0.3, stud_mat)
                 else:
-                    b.quad((cx - 0.5, cy - 0.5, 39.99), (cx + 0.5, cy - 0.5, 39.99),
-                           (cx + 0.5, cy + 0.5, 39.99), (cx - 0.5, cy + 0.5, 39.99), m)
-                    b.stud((cx, cy, 39.99), "z", 0.3, 0.2, m)
+                    zt = zf - 0.015
+                    b.quad((cx - hp, cy - hp, zt), (cx + hp, cy - hp, zt), (cx + hp, cy + hp, zt), (cx - hp, cy + hp, zt), m)
+                    b.stud((cx, cy, zt), "z", 0.45, 0.3, m)
 
     rainbow = lambda gi, c, r: _EMISSIVE_IDS[(gi * 7 + c * 3 + r * 5) % 40]
     digits = [M["Emmisive"], M["Emmisive.021"], M["Emmisive.036"], M["Emmisive.045"]]
-    panel(31.0, "CEDEC", rainbow, M["Black"], M["Black"])
-    panel(-1.0, "2024", lambda gi, c, r: digits[gi], M["white"], M["white"])
+    panel(49.5, "CEDEC", rainbow, M["Black"], M["Black"])
+    panel(-4.5, "2024", lambda gi, c, r: digits[gi], M["white"], M["white"])
 
-    # bonsai: pot, trunk, foliage pads
+    # bonsai: pot, trunk, foliage pads (the camera looks over the crown towards the panels)
     for i in range(-3, 3):
         for j in range(0, 3):
-            b.brick(2.0 * i * 2, 0.0 + 1.2 * (j % 2), 13.0 + 4.0 * j, 4, 4, M["Black"])
-    tx, tz = 0, 16
-    for k in range(14):
+            b.brick(4 * i, 0.0 + 1.2 * (j % 2), 15.0 + 4.0 * j, 4, 4, M["Black"])
+    tx, tz = 0, 20
+    for k in range(9):
         b.brick(tx - 1, 2.4 + 1.2 * k, tz - 1, 2, 2, M["Brown"])
         tx += rng.below(3) - 1
         tz += rng.below(3) - 1
         tx = max(-3, min(3, tx))
-        tz = max(13, min(19, tz))
-    pads = [(-5, 13.2, 14, 7), (5, 14.4, 20, 7), (-2, 16.8, 22, 6), (4, 18.0, 13, 6),
-            (-6, 19.2, 18, 6), (1, 20.4, 17, 7), (7, 21.6, 24, 5), (-3, 22.8, 12, 5)]
+        tz = max(17, min(23, tz))
+    pads = [(-6, 6.0, 16, 8), (6, 7.2, 24, 8), (-2, 8.4, 27, 7), (5, 9.6, 15, 7), (-7, 10.8, 22, 7),
+            (1, 12.0, 20, 8), (8, 13.2, 28, 6), (-4, 14.4, 14, 6), (3, 15.6, 24, 6), (-1, 16.8, 18, 5)]
     keep = int(256 * min(1.0, max(0.0, detail)))
     for (cx, cy, cz, rad) in pads:
         for layer in range(3):
@@ -305,7 +306,7 @@ def make_blocks_restir(detail=1.0):
                     u = rng.below(256)
                     if mx * mx + mz * mz > r * r:
                         continue
-                    if u >= keep or u >= 224:
+                    if u >= keep or u >= 232:
                         continue
                     mat = M["Green"] if rng.below(16) else M["Yellow"]
                     b.brick(cx + ix, cy + 1.2 * layer, cz + iz, nx, nz, mat)

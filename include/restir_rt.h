@@ -1,0 +1,165 @@
+/*
+ * restir_rt.h — C-ABI of the MI355X-native ReSTIR DI hot path (librestir_rt.so).
+ *
+ * Drop-in boundary. The reference has no plugin/FFI layer; its de-facto
+ * boundary is the kernel-launch ABI `Shader::launch(name, args, grid, block, stream)`
+ * (common/shader.hpp:179-199) used by the frame loop of
+ * examples/10_restir_di/10_restir_di.cpp:257-379. This header exports one entry point per
+ * reference kernel — same names, same argument meaning — plus context/scene/camera calls that
+ * replace the Orochi/HIPRT setup of 10_restir_di.cpp:30-122,183-220, and a fused per-frame
+ * call. Plain pointers and sizes only; every call returns 0 on success or an RT_ERR_* code
+ * (rt_last_error() gives the text); nothing aborts (the reference SIGTRAPs,
+ * common/shader.hpp:10-16).
+ *
+ * PODs are byte-for-byte the reference's (sizes checked by static_assert in the library and
+ * by tests): rt_triangle = Triangle (common/core.hpp:38-43), rt_visibility = Visibility
+ * (core.hpp:167-172), rt_reservoir = Reservoir (common/reservoir.hpp:5-38), rt_options =
+ * Options (common/options.hpp:4-22), rt_raygen = RayGenerator (common/camera.hpp:5-9).
+ *
+ * Threading: a context is used by one host thread; all work is enqueued on the context's HIP
+ * stream (own stream, or the caller's via rt_set_stream) and is asynchronous until
+ * rt_sync / rt_download.
+ */
+#ifndef RESTIR_RT_H
+#define RESTIR_RT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float v[3][3]; float color[3]; float emissive[3]; } rt_triangle;      /* 60 B */
+typedef struct { float uv[2]; int32_t index; int32_t _pad; } rt_visibility;           /* 16 B */
+typedef struct
+{
+    float origin_position[3], origin_normal[3], hit_position[3], hit_normal[3], radiance[3];
+    uint8_t visibility;
+    uint8_t _pad[3];
+    float w_sum, ucw;
+    int32_t M;
+} rt_reservoir;                                                                        /* 76 B */
+typedef struct
+{
+    uint8_t accumulate;
+    int32_t max_depth;
+    float sky_color[3];
+    int32_t ris_sample_count;
+    float rejection_heuristics_threshold;
+    uint8_t use_temporal_resampling;
+    uint8_t use_spatial_resampling;
+    int32_t spatial_resampling_sample_count;
+    float spatial_resampling_radius;
+    int32_t spatial_resampling_passes;
+    uint8_t use_shadowed_target_function;
+    uint8_t use_visibility_reuse;
+} rt_options;                                                                          /* 48 B */
+typedef struct { float origin[3], right[3], up[3]; } rt_raygen;                        /* 36 B */
+
+typedef struct rt_ctx rt_ctx;
+
+enum
+{
+    RT_OK = 0,
+    RT_ERR_ARG = 1,         /* bad argument / size mismatch */
+    RT_ERR_HIP = 2,         /* a HIP call failed */
+    RT_ERR_STATE = 3,       /* call order (e.g. no scene) */
+    RT_ERR_BVH_DEPTH = 4,   /* LBVH deeper than the 63-level trail word */
+    RT_ERR_UNSUPPORTED = 5, /* option combination not built yet */
+    RT_ERR_NO_DEVICE = 6
+};
+
+/* reservoir buffers of 10_restir_di.cpp:113-122 */
+enum { RT_RES_0 = 0, RT_RES_1 = 1, RT_RES_TEMPORAL = 2 };
+/* rt_download / rt_upload targets (reference layouts) */
+enum
+{
+    RT_BUF_VISIBILITY = 0,   /* rt_visibility[W*H]            10_restir_di.cpp:108-109 */
+    RT_BUF_RES_0 = 1,        /* rt_reservoir[W*H]             :113-114 */
+    RT_BUF_RES_1 = 2,        /*                               :117-118 */
+    RT_BUF_RES_TEMPORAL = 3, /*                               :121-122 */
+    RT_BUF_ACCUMULATION = 4, /* float4[W*H] {R,G,B,spp}       :102-103 */
+    RT_BUF_PIXELS = 5        /* RGBA8[W*H]                    :96-97   */
+};
+
+/* ---- context (replaces oroInitialize..oroStreamCreate + hiprtCreateContext, :30-79) ---- */
+/* Full image W x H. The context owns storage rows [row_begin,row_end) of it (pass 0,H for a
+ * single GPU) plus `halo` rows on each side for the spatial pass (multi-GPU row strips,
+ * SURVEY.md §8e; halo >= 87 makes N-rank results bit-identical to 1 rank). Rows are STORAGE
+ * rows: row r holds the reference's pixel_idx range [r*W, (r+1)*W). */
+int rt_create(int device, int width, int height, int row_begin, int row_end, int halo, rt_ctx** out);
+int rt_destroy(rt_ctx* ctx);
+const char* rt_last_error(rt_ctx* ctx);
+int rt_set_stream(rt_ctx* ctx, void* hip_stream); /* NULL = context's own stream */
+int rt_sync(rt_ctx* ctx);
+
+/* ---- scene (replaces loadTrianglesFromObj + light list + buildHiprtGeometry, :184-220) ---- */
+/* Uploads the triangles, extracts the emissive-triangle list in index order (:196-205) and
+ * builds the LBVH on the device. */
+int rt_scene_set(rt_ctx* ctx, const rt_triangle* triangles, uint32_t count);
+int rt_scene_info(rt_ctx* ctx, uint32_t* n_triangles, uint32_t* n_lights, uint32_t* bvh_height);
+
+/* ---- camera / options (:240-251, :129) ---- */
+/* RayGenerator::lookat evaluated on the host (common/camera.hpp:11-25); eye is also the
+ * `eye`/cameraOrig kernel argument. */
+int rt_camera_lookat(rt_ctx* ctx, const float eye[3], const float center[3], const float up[3], float fovy);
+int rt_camera_set(rt_ctx* ctx, const rt_raygen* raygen, const float eye[3]);
+int rt_camera_get(rt_ctx* ctx, rt_raygen* raygen);
+int rt_options_set(rt_ctx* ctx, const rt_options* options);
+int rt_options_get(rt_ctx* ctx, rt_options* options);
+
+/* ---- one entry point per reference kernel (examples/10_restir_di/10_restir_di.cu, common/kernels/common.cu) ---- */
+int rt_clear(rt_ctx* ctx);                                   /* clear               common.cu:4-17   */
+int rt_raycast(rt_ctx* ctx);                                 /* raycast             .cu:9-34         */
+int rt_generate_candidate(rt_ctx* ctx, int frame, int dst);  /* generate_candidate  .cu:36-135       */
+int rt_temporal_resampling(rt_ctx* ctx, int frame, int prev, int inout); /* .cu:137-237              */
+int rt_save_temporal_reservoir(rt_ctx* ctx, int src, int dst);           /* .cu:239-254              */
+int rt_spatial_resampling(rt_ctx* ctx, int frame, int pass, int in, int out); /* .cu:256-388         */
+int rt_resolve(rt_ctx* ctx, int res);                        /* resolve             .cu:390-459      */
+int rt_tone_mapping(rt_ctx* ctx);                            /* tone_mapping        common.cu:30-74  */
+
+/* ---- one frame = 10_restir_di.cpp:257-379 (clear_first = camera.is_updated()) ----
+ * Same results as the per-kernel sequence; internally generate_candidate+temporal_resampling
+ * run as one kernel and save_temporal_reservoir is replaced by rotating three buffers. After
+ * the call RT_RES_TEMPORAL names the temporal history and `*final_res` (if not NULL) the buffer
+ * resolve read. Single-strip contexts only; strips drive the passes themselves and exchange
+ * halos between spatial passes (rt_halo_*). */
+int rt_frame(rt_ctx* ctx, int frame, int clear_first, int* final_res);
+
+/* ---- host <-> device in the reference's layouts (fixture injection, result read-back) ----
+ * Element counts are W * (rows held) where rows held = owned rows + halos clipped to the
+ * image; `bytes` must match exactly. RT_BUF_RES_* uploads need the G-buffer of the same
+ * frame (rt_raycast or an RT_BUF_VISIBILITY upload first). */
+int rt_local_rows(rt_ctx* ctx, int* first_row, int* n_rows);
+int rt_download(rt_ctx* ctx, int buf, void* dst, size_t bytes);
+int rt_upload(rt_ctx* ctx, int buf, const void* src, size_t bytes);
+
+/* ---- multi-GPU halo rows: pack/unpack `n_rows` storage rows starting at
+ * global row `row0` of reservoir buffer `res` to/from a caller-provided DEVICE buffer of
+ * rt_halo_bytes(ctx, n_rows) bytes (exchanged by the caller, e.g. RCCL send/recv). ---- */
+size_t rt_halo_bytes(rt_ctx* ctx, int n_rows);
+int rt_halo_pack(rt_ctx* ctx, int res, int row0, int n_rows, void* device_dst);
+int rt_halo_unpack(rt_ctx* ctx, int res, int row0, int n_rows, const void* device_src);
+
+/* ---- measurement ---- */
+/* rays per frame for the current G-buffer and options: N primary + per shaded pixel the
+ * visibility-reuse and resolve shadow rays; shaded = hit & not emissive. */
+int rt_ray_count(rt_ctx* ctx, uint64_t* rays, uint64_t* shaded_pixels);
+/* time spent by the last `rt_frame` per kernel, HIP events on the context's stream.
+ * ms[0..7] = clear, raycast, generate(+temporal), spatial pass 0,1,2, resolve, tone_mapping;
+ * ms[8] = whole frame. Enabled by rt_timing_enable(ctx, 1). */
+int rt_timing_enable(rt_ctx* ctx, int on);
+int rt_timing(rt_ctx* ctx, float ms[9]);
+
+/* ---- BVH utilities (parity tests: LBVH == brute force) ----
+ * rays: n x {ox,oy,oz, dx,dy,dz, tmin,tmax}; hits: n x {t,u,v, bits(index)}; host pointers. */
+int rt_trace_closest(rt_ctx* ctx, const float* rays, uint32_t n, float* hits);
+/* elementwise device evaluation of the portable math / IEEE div & sqrt (parity tests);
+ * fn ids as in tests/test_portable_math.py */
+int rt_math_eval(rt_ctx* ctx, int fn, const float* in, uint32_t n, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RESTIR_RT_H */

@@ -1,0 +1,315 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI) against the oracle, bit for bit.
+
+Integer / index / decision data must be identical; float data is compared as raw bits (the
+portable math + -ffp-contract=off contract, DESIGN.md "Parity") — no tolerance anywhere except
+the north-star's 1e-4 relative L2 that is asserted on top for the radiance.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FOVY = np.float32(np.pi) / np.float32(4)
+
+
+def _bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint8)
+
+
+def _eq_bits(a, b):
+    return np.array_equal(_bits(a), _bits(b))
+
+
+def _res_fields_equal(a, b, mask=None):
+    """Compare reservoir arrays field by field (padding excluded); returns list of bad fields."""
+    bad = []
+    for f in a.dtype.names:
+        if f == "pad":
+            continue
+        x, y = a[f], b[f]
+        if mask is not None:
+            x, y = x[mask], y[mask]
+        if not _eq_bits(np.ascontiguousarray(x), np.ascontiguousarray(y)):
+            bad.append((f, int((np.ascontiguousarray(x).reshape(len(x), -1) != np.ascontiguousarray(y).reshape(len(y), -1)).any(axis=1).sum())))
+    return bad
+
+
+def _rel_l2(a, b):
+    a = a.astype(np.float64)
+    b = b.astype(np.float64)
+    return float(np.sqrt(((a - b) ** 2).sum()) / max(np.sqrt((b ** 2).sum()), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def api():
+    from cedec_2024_rt_amd import api as _api
+
+    return _api
+
+
+@pytest.fixture(scope="module")
+def scenes():
+    from cedec_2024_rt_amd import scenes as s
+
+    return s
+
+
+@pytest.fixture(scope="module")
+def golden_scenes(golden_dir):
+    import os
+
+    return np.load(os.path.join(golden_dir, "scenes.npz"))
+
+
+def test_portable_math_and_ieee_on_device(api, oracle):
+    """Device portable_math.h == host portable_math.h; device fp32 divide / sqrt are IEEE
+    (correctly rounded, denormals kept)."""
+    oracle.set_math_mode(oracle.MATH_PORTABLE)
+    r = api.Renderer(8, 8)
+    rng = np.random.default_rng(5)
+    n = 200000
+    u = rng.random(n, dtype=np.float32)
+    cases = {
+        "logf": np.concatenate([u, (u * 2.0 ** -20).astype(np.float32), np.float32([0.0, 1.0, 2.0 ** -23, 1e-38, 1e-45])]),
+        "cosf": np.concatenate([(u * 6.2831855).astype(np.float32), (u * 40 - 20).astype(np.float32)]),
+        "sinf": np.concatenate([(u * 6.2831855).astype(np.float32), (u * 40 - 20).astype(np.float32)]),
+        "expf": np.concatenate([(-u * 100).astype(np.float32), (u * 4 - 2).astype(np.float32), np.float32([-103.0, -104.5, 0.0, 88.0, 89.0])]),
+        "pow8": np.concatenate([u, np.float32([0.0, 1.0, 1.0000001])]),
+        "pow_gamma": np.concatenate([u, (u * 8).astype(np.float32), np.float32([0.0, 1.0])]),
+        "sqrt": np.concatenate([u, (u * 1e-38).astype(np.float32), (u * 1e30).astype(np.float32)]),
+    }
+    for name, x in cases.items():
+        fid = oracle.FN[name][0]
+        dev = r.math_eval(fid, x)
+        host = oracle.fn_bulk(name, x).reshape(-1)
+        assert _eq_bits(dev, host), f"{name}: {(dev.view(np.uint32) != host.view(np.uint32)).sum()} of {len(x)} differ"
+    a = np.concatenate([u, (u * 1e-30).astype(np.float32), (u * 1e-39).astype(np.float32)])
+    b = np.concatenate([rng.random(n, dtype=np.float32) + np.float32(1e-3), (rng.random(n, dtype=np.float32) * 1e10).astype(np.float32) + np.float32(1), rng.random(n, dtype=np.float32) + np.float32(0.5)])
+    x = np.stack([a, b], axis=1).astype(np.float32)
+    dev = r.math_eval(26, x)
+    host = (a / b).astype(np.float32)
+    assert _eq_bits(dev, host), "fp32 division differs from IEEE"
+    r.close()
+
+
+def _random_rays(rng, n, lo, hi):
+    o = (rng.random((n, 3), dtype=np.float32) * (hi - lo) + lo).astype(np.float32)
+    d = (rng.random((n, 3), dtype=np.float32) * 2 - 1).astype(np.float32)
+    rays = np.zeros((n, 8), dtype=np.float32)
+    rays[:, 0:3] = o
+    rays[:, 3:6] = d
+    rays[:, 6] = 0.0
+    rays[:, 7] = 3.402823466e38
+    # some axis-parallel and some short (shadow-style) rays
+    rays[: n // 16, 3] = 0.0
+    rays[n // 16: n // 8, 4] = 0.0
+    rays[n // 8: n // 4, 7] = 0.99
+    return rays
+
+
+def test_lbvh_equals_brute_force(api, oracle, scenes, golden_scenes):
+    """LBVH closest hit == brute force over all triangles (t, u, v, index incl. the tie rule)."""
+    rng = np.random.default_rng(11)
+    for name, tris in (("cornellbox1", golden_scenes["cornellbox1"]), ("cornellbox2", golden_scenes["cornellbox2"]),
+                       ("quad_room", scenes.make_quad_room())):
+        r = api.Renderer(8, 8)
+        r.set_scene(tris)
+        v = tris["v"].reshape(-1, 3)
+        lo, hi = v.min(0), v.max(0)
+        rays = _random_rays(rng, 60000 if len(tris) < 1000 else 20000, lo - 0.5, hi + 0.5)
+        dev = r.trace_closest(rays)
+        sc = oracle.Scene(tris, use_bvh=False)
+        ref = sc.trace_closest(rays, force_brute=True)
+        assert _eq_bits(dev, ref), f"{name}: {(dev.view(np.uint32) != ref.view(np.uint32)).any(axis=1).sum()} rays differ"
+        assert (ref[:, 3].view(np.int32) >= 0).mean() > 0.2
+        r.close()
+
+
+def test_lbvh_blocks_scene_vs_oracle_bvh(api, oracle, scenes):
+    """On the benchmark stand-in (212k triangles) the oracle's own BVH (itself == brute force on
+    the small scenes, tests/test_oracle_bvh.py) and the device LBVH agree on 200k rays."""
+    tris = scenes.make_blocks_restir()
+    r = api.Renderer(8, 8)
+    r.set_scene(tris)
+    info = r.scene_info()
+    assert info["triangles"] == len(tris) and info["lights"] == len(scenes.light_indices(tris))
+    rng = np.random.default_rng(3)
+    v = tris["v"].reshape(-1, 3)
+    rays = _random_rays(rng, 200000, np.float32([-20, 0, -10]), np.float32([40, 40, 60]))
+    dev = r.trace_closest(rays)
+    sc = oracle.Scene(tris, use_bvh=True)
+    ref = sc.trace_closest(rays)
+    assert _eq_bits(dev, ref), f"{(dev.view(np.uint32) != ref.view(np.uint32)).any(axis=1).sum()} rays differ"
+    # a 2000-ray subset against true brute force
+    sub = rays[:2000]
+    assert _eq_bits(r.trace_closest(sub), sc.trace_closest(sub, force_brute=True))
+    r.close()
+
+
+def _setup(api, oracle, tris, W, H, eye, center, **optkw):
+    oracle.set_math_mode(oracle.MATH_PORTABLE)
+    r = api.Renderer(W, H)
+    r.set_scene(tris)
+    r.lookat(eye, center)
+    from cedec_2024_rt_amd.types import bench_options
+
+    r.set_options(bench_options(**optkw))
+    sc = oracle.Scene(tris, use_bvh=True)
+    rg = oracle.raygen_lookat(eye, center, (0, 1, 0), FOVY, W, H)
+    assert rg.tobytes() == r.raygen().tobytes()
+    return r, sc, rg, oracle.bench_options(**optkw), np.asarray(eye, np.float32)
+
+
+@pytest.mark.parametrize("scene_name", ["cornellbox1", "quad_room", "cornellbox2"])
+def test_kernel_by_kernel_parity(api, oracle, scenes, golden_scenes, scene_name):
+    """Every reference kernel, one at a time through its own entry point, two frames."""
+    if scene_name == "quad_room":
+        tris, eye, center = scenes.make_quad_room(), (0.5, 2.5, 6.0), (0.0, 1.5, -1.0)
+    elif scene_name == "cornellbox1":
+        tris, eye, center = golden_scenes["cornellbox1"], scenes.DEFAULT_EYE, scenes.DEFAULT_LOOKAT
+    else:
+        tris, eye, center = golden_scenes["cornellbox2"], scenes.CORNELLBOX_EYE, scenes.CORNELLBOX_LOOKAT
+    W, H = 96, 54
+    r, sc, rg, opt, eyev = _setup(api, oracle, tris, W, H, eye, center)
+    st = oracle.new_state(W, H)
+    lights = set(sc.lights.tolist())
+    for frame in (1, 2):
+        # raycast
+        r.raycast()
+        sc.raycast(W, H, rg, st["vis"])
+        vis = r.download(api.RT_BUF_VISIBILITY)
+        for f in ("uv", "index"):
+            assert _eq_bits(vis[f], st["vis"][f]), f"raycast {f} frame {frame}"
+        shaded = (st["vis"]["index"] >= 0) & ~np.isin(st["vis"]["index"], list(lights))
+        assert shaded.mean() > 0.1
+        # generate_candidate
+        r.generate_candidate(frame, api.RT_RES_0)
+        sc.generate_candidate(W, H, frame, st["vis"], eyev, opt, st["r0"])
+        got = r.download(api.RT_BUF_RES_0)
+        assert not _res_fields_equal(got, st["r0"]), f"generate_candidate frame {frame}: {_res_fields_equal(got, st['r0'])}"
+        # temporal_resampling
+        r.temporal_resampling(frame, api.RT_RES_TEMPORAL, api.RT_RES_0)
+        sc.temporal_resampling(W, H, frame, st["vis"], eyev, opt, st["temporal"], st["r0"])
+        got = r.download(api.RT_BUF_RES_0)
+        assert not _res_fields_equal(got, st["r0"]), f"temporal frame {frame}: {_res_fields_equal(got, st['r0'])}"
+        # save_temporal_reservoir
+        r.save_temporal_reservoir(api.RT_RES_0, api.RT_RES_TEMPORAL)
+        oracle.save_temporal_reservoir(W, H, st["r0"], st["temporal"])
+        assert not _res_fields_equal(r.download(api.RT_BUF_RES_TEMPORAL), st["temporal"])
+        # spatial x3 (the reference writes only shaded pixels of `out`)
+        src, dst = api.RT_RES_0, api.RT_RES_1
+        osrc, odst = st["r0"], st["r1"]
+        for k in range(3):
+            if k:
+                src, dst = dst, src
+                osrc, odst = odst, osrc
+            r.spatial_resampling(frame, k, src, dst)
+            sc.spatial_resampling(W, H, frame, k, st["vis"], eyev, opt, osrc, odst)
+            got = r.download(api.RT_BUF_RES_0 + dst)
+            bad = _res_fields_equal(got, odst, mask=shaded)
+            assert not bad, f"spatial pass {k} frame {frame}: {bad}"
+        # resolve + tone mapping
+        r.resolve(dst)
+        sc.resolve(st["accum"], W, H, st["vis"], eyev, opt, odst)
+        acc = r.download(api.RT_BUF_ACCUMULATION)
+        assert _eq_bits(acc, st["accum"].reshape(acc.shape)), f"resolve frame {frame}"
+        assert _rel_l2(acc[:, :3], st["accum"].reshape(acc.shape)[:, :3]) <= 1e-4
+        r.tone_mapping()
+        px = r.download(api.RT_BUF_PIXELS).reshape(H, W, 4)
+        opx = oracle.tone_mapping(st["accum"], W, H)
+        assert np.array_equal(px, opx), "tone_mapping"
+    r.close()
+
+
+@pytest.mark.parametrize("optkw", [
+    dict(),
+    dict(use_temporal_resampling=0),
+    dict(use_spatial_resampling=0),
+    dict(use_visibility_reuse=0),
+    dict(accumulate=1),
+    dict(spatial_resampling_passes=2),
+    dict(spatial_resampling_passes=1, spatial_resampling_sample_count=3, ris_sample_count=8),
+    dict(use_shadowed_target_function=1),
+])
+def test_fused_frame_equals_oracle_frame(api, oracle, scenes, optkw):
+    """rt_frame (fused generate+temporal, rotating buffers) == the reference's 8-launch frame,
+    over 3 frames and for every option toggle of the example (keys 1,2,3,4,A)."""
+    tris = scenes.make_quad_room()
+    W, H = 80, 45
+    r, sc, rg, opt, eyev = _setup(api, oracle, tris, W, H, (0.5, 2.5, 6.0), (0.0, 1.5, -1.0), **optkw)
+    st = oracle.new_state(W, H)
+    for frame in (1, 2, 3):
+        final = r.frame(frame)
+        sc.frame(W, H, frame, rg, eyev, opt, st)
+        acc = r.download(api.RT_BUF_ACCUMULATION)
+        assert _eq_bits(acc, st["accum"].reshape(acc.shape)), f"{optkw} frame {frame}: {(acc != st['accum'].reshape(acc.shape)).any(axis=1).sum()} pixels"
+        # temporal history handed to the next frame
+        shaded = (st["vis"]["index"] >= 0) & ~np.isin(st["vis"]["index"], sc.lights)
+        bad = _res_fields_equal(r.download(api.RT_BUF_RES_TEMPORAL), st["temporal"], mask=shaded)
+        assert not bad, f"{optkw} temporal history frame {frame}: {bad}"
+        passes = int(opt["spatial_resampling_passes"][0])
+        assert final == (api.RT_RES_1 if passes % 2 == 1 else api.RT_RES_0)
+        px = r.download(api.RT_BUF_PIXELS).reshape(H, W, 4)
+        assert np.array_equal(px, st["pixels"])
+    rays, shaded_n = r.ray_count()
+    assert shaded_n == int(shaded.sum())
+    r.close()
+
+
+def test_frame_parity_blocks_restir_quarter_res(api, oracle, scenes):
+    """The benchmark stand-in at 480x270, benchmark options, 2 frames: bit-identical radiance,
+    identical ray count (rays counted by the CPU restatement)."""
+    tris = scenes.make_blocks_restir()
+    W, H = 480, 270
+    r, sc, rg, opt, eyev = _setup(api, oracle, tris, W, H, scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)
+    st = oracle.new_state(W, H)
+    for frame in (1, 2):
+        cnt = oracle.new_counters()
+        r.frame(frame)
+        sc.frame(W, H, frame, rg, eyev, opt, st, cnt)
+        acc = r.download(api.RT_BUF_ACCUMULATION)
+        ref = st["accum"].reshape(acc.shape)
+        nbad = int((acc.view(np.uint32) != ref.view(np.uint32)).any(axis=1).sum())
+        assert nbad == 0, f"frame {frame}: {nbad} pixels differ, rel-L2 {_rel_l2(acc[:, :3], ref[:, :3])}"
+        rays, shaded_n = r.ray_count()
+        assert rays == int(cnt["rays"][0]) and shaded_n == int(cnt["shaded_pixels"][0])
+    r.close()
+
+
+def test_strip_contexts_match_full_frame(api, oracle, scenes):
+    """Two row-strip contexts on one GPU with an 87-row halo exchanged through the C-ABI halo
+    calls reproduce the single-context frame bit for bit."""
+    import ctypes as C
+
+    tris = scenes.make_quad_room()
+    W, H = 64, 240
+    from cedec_2024_rt_amd.types import bench_options
+    from cedec_2024_rt_amd import strips
+
+    full = api.Renderer(W, H)
+    full.set_scene(tris)
+    full.lookat((0.5, 2.5, 6.0), (0.0, 1.5, -1.0))
+    full.set_options(bench_options())
+    ctxs = []
+    bounds = strips.partition_rows(H, 2)
+    for (a, b) in bounds:
+        c = api.Renderer(W, H, rows=(a, b), halo=strips.HALO_ROWS)
+        c.set_scene(tris)
+        c.lookat((0.5, 2.5, 6.0), (0.0, 1.5, -1.0))
+        c.set_options(bench_options())
+        ctxs.append(c)
+    lib = api.load_library()
+    import torch
+
+    for frame in (1, 2):
+        full.frame(frame)
+        ref = full.download(api.RT_BUF_ACCUMULATION).reshape(H, W, 4)
+        strips.run_frame_local(ctxs, bounds, frame, torch.device("cuda:0"))
+        for c, (a, b) in zip(ctxs, bounds):
+            acc = c.download(api.RT_BUF_ACCUMULATION).reshape(c.local_rows, W, 4)
+            mine = acc[a - c.local_row0: b - c.local_row0]
+            assert _eq_bits(mine, ref[a:b]), f"strip rows {a}:{b} frame {frame}"
+    for c in ctxs:
+        c.close()
+    full.close()
