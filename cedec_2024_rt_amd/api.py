@@ -24,7 +24,7 @@ EXPORTS = [
     "rt_raycast", "rt_generate_candidate", "rt_temporal_resampling", "rt_save_temporal_reservoir",
     "rt_spatial_resampling", "rt_resolve", "rt_tone_mapping", "rt_frame", "rt_local_rows", "rt_download",
     "rt_upload", "rt_halo_bytes", "rt_halo_pack", "rt_halo_unpack", "rt_ray_count", "rt_timing_enable",
-    "rt_timing", "rt_trace_closest", "rt_math_eval",
+    "rt_timing", "rt_spatial_bytes", "rt_trace_closest", "rt_math_eval",
 ]
 
 
@@ -42,6 +42,15 @@ def load_library():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RtError(f"{LIB_PATH} not built: run __graft_entry__.build() (make -C cedec_2024_rt_amd/csrc)")
+    # One HIP runtime per process: the torch wheel bundles its own libamdhip64 (same SONAME as
+    # /opt/rocm's). If librestir_rt.so pulled in the system copy first and torch loaded its own
+    # afterwards (torch.distributed / RCCL for the strips), the second runtime finds no GPU.
+    # Importing torch first makes the loader resolve our NEEDED libamdhip64.so.7 to the copy that
+    # is already mapped. Without torch installed the system runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, ci, cf = C.c_void_p, C.c_int, C.c_float
     L.rt_create.argtypes = [ci, ci, ci, ci, ci, ci, C.POINTER(vp)]
@@ -76,6 +85,7 @@ def load_library():
     L.rt_ray_count.argtypes = [vp, vp, vp]
     L.rt_timing_enable.argtypes = [vp, ci]
     L.rt_timing.argtypes = [vp, vp]
+    L.rt_spatial_bytes.argtypes = [vp, ci, ci, ci, vp, vp]
     L.rt_trace_closest.argtypes = [vp, vp, C.c_uint32, vp]
     L.rt_math_eval.argtypes = [vp, ci, vp, C.c_uint32, vp]
     _lib = L
@@ -252,6 +262,11 @@ class Renderer:
         names = ["clear", "raycast", "generate_candidate", "spatial0", "spatial1", "spatial2", "resolve",
                  "tone_mapping", "frame"]
         return dict(zip(names, (float(x) for x in ms)))
+
+    def spatial_bytes(self, frame, pas, src):
+        a, b = C.c_uint64(), C.c_uint64()
+        self._ck(self.L.rt_spatial_bytes(self.h, frame, pas, src, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def trace_closest(self, rays):
         r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)

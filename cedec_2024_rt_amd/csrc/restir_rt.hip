@@ -360,6 +360,65 @@ __global__ __launch_bounds__(BLOCK) void k_spatial(SceneView S, FrameParams P, c
     res_store(out_rec, out_rad, li, r, true);
 }
 
+
+/* SURVEY.md §8(d) ALGORITHMIC bytes of one spatial_resampling launch, counted with the
+ * reference's record sizes (Visibility 16 B, Reservoir 76 B): per pixel 16; per shaded pixel
+ * +76 in +76 out; per neighbour that passed the on-screen / not-self tests +16, and +76 more if
+ * it is shaded. Replays exactly the RNG draws of k_spatial (the accept decisions depend only on
+ * the RNG and the shaded bits, not on reservoir contents). Measurement aid, not on the hot path. */
+__global__ __launch_bounds__(BLOCK) void k_spatial_bytes(FrameParams P, const float4* __restrict__ g1,
+                                                          const float4* __restrict__ in_rec,
+                                                          unsigned long long* __restrict__ out)
+{
+    int x, row;
+    const bool ok = tile_pixel(P, x, row);
+    unsigned long long bytes = 0, accepted = 0;
+    if (ok)
+    {
+        const int yi = P.H - 1 - row;
+        const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
+        bytes = 16;
+        if (as_uint(g1[li].w) & GB_SHADED)
+        {
+            bytes += 152;
+            if (P.use_spatial)
+            {
+                PCG rng = pcg_init(hashPCG4((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame, (uint32_t)(2 + P.pass)), 0);
+                const float scale = P.spatial_radius / 1.96f;
+                for (int k = 0; k < P.spatial_count; ++k)
+                {
+                    const float rv0 = rng.uniformf();
+                    const float rv1 = rng.uniformf();
+                    const float radius = sqrtf(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
+                    const float phi = 2.0f * kPI * rv1;
+                    const int nx = f2i_sat((float)x + scale * (radius * pm_cosf(phi)));
+                    const int ny = f2i_sat((float)yi + scale * (radius * pm_sinf(phi)));
+                    if (nx < 0 || nx >= P.W || ny < 0 || ny >= P.H) continue;
+                    if (nx == x && ny == yi) continue;
+                    const int lr = P.H - 1 - ny - P.lrow0;
+                    if (lr < 0 || lr >= P.lrows) continue;
+                    bytes += 16;
+                    accepted += 1;
+                    const uint32_t mb = as_uint(in_rec[4 * ((size_t)nx + (size_t)lr * P.W) + 1].w);
+                    if (!(mb & RES_SHADED_BIT)) continue;
+                    bytes += 76;
+                    rng.uniformf();
+                }
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        bytes += __shfl_down(bytes, off);
+        accepted += __shfl_down(accepted, off);
+    }
+    if ((threadIdx.x & 63) == 0)
+    {
+        atomicAdd(&out[0], bytes);
+        atomicAdd(&out[1], accepted);
+    }
+}
+
 /* -------------------------------------------------------------------- resolve */
 /* examples/10_restir_di/10_restir_di.cu:390-459 */
 __global__ __launch_bounds__(BLOCK) void k_resolve(SceneView S, FrameParams P, const float4* __restrict__ g0,
@@ -1287,6 +1346,25 @@ int rt_ray_count(rt_ctx* c, uint64_t* rays, uint64_t* shaded_pixels)
     }
     if (rays) *rays = n + per_shaded * shaded;
     if (shaded_pixels) *shaded_pixels = shaded;
+    return RT_OK;
+}
+
+int rt_spatial_bytes(rt_ctx* c, int frame, int pass, int in, uint64_t* bytes, uint64_t* accepted)
+{
+    RT_CHECK_CTX(c);
+    NEED_RES(c, in);
+    if (!c->has_gbuffer) RT_FAIL(c, RT_ERR_STATE, "no G-buffer yet");
+    unsigned long long* d = nullptr;
+    RT_HIP(c, hipMalloc(&d, 16));
+    RT_HIP(c, hipMemsetAsync(d, 0, 16, c->stream));
+    k_spatial_bytes<<<launch_grid(c), BLOCK, 0, c->stream>>>(make_params(c, frame, pass), c->d_g1, c->d_rec[c->res_map[in]], d);
+    RT_HIP(c, hipGetLastError());
+    unsigned long long h[2] = {0, 0};
+    RT_HIP(c, hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    hipFree(d);
+    if (bytes) *bytes = h[0];
+    if (accepted) *accepted = h[1];
     return RT_OK;
 }
 

@@ -152,6 +152,11 @@ int rt_ray_count(rt_ctx* ctx, uint64_t* rays, uint64_t* shaded_pixels);
 int rt_timing_enable(rt_ctx* ctx, int on);
 int rt_timing(rt_ctx* ctx, float ms[9]);
 
+/* ALGORITHMIC bytes (reference record sizes) of the spatial_resampling launch
+ * (frame, pass) reading reservoir buffer `in`; `accepted` = neighbours that passed the
+ * on-screen / not-self tests. Replays the RNG; independent of reservoir contents. */
+int rt_spatial_bytes(rt_ctx* ctx, int frame, int pass, int in, uint64_t* bytes, uint64_t* accepted);
+
 /* ---- BVH utilities (parity tests: LBVH == brute force) ----
  * rays: n x {ox,oy,oz, dx,dy,dz, tmin,tmax}; hits: n x {t,u,v, bits(index)}; host pointers. */
 int rt_trace_closest(rt_ctx* ctx, const float* rays, uint32_t n, float* hits);
