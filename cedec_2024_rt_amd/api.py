@@ -24,7 +24,7 @@ EXPORTS = [
     "rt_raycast", "rt_generate_candidate", "rt_temporal_resampling", "rt_save_temporal_reservoir",
     "rt_spatial_resampling", "rt_resolve", "rt_tone_mapping", "rt_frame", "rt_local_rows", "rt_download",
     "rt_upload", "rt_halo_bytes", "rt_halo_pack", "rt_halo_unpack", "rt_ray_count", "rt_timing_enable",
-    "rt_timing", "rt_spatial_bytes", "rt_trace_closest", "rt_math_eval",
+    "rt_timing", "rt_spatial_bytes", "rt_trace_closest", "rt_trace_stats", "rt_bvh_config", "rt_bvh_info", "rt_math_eval",
 ]
 
 
@@ -88,6 +88,9 @@ def load_library():
     L.rt_spatial_bytes.argtypes = [vp, ci, ci, ci, vp, vp]
     L.rt_trace_closest.argtypes = [vp, vp, C.c_uint32, vp]
     L.rt_math_eval.argtypes = [vp, ci, vp, C.c_uint32, vp]
+    L.rt_trace_stats.argtypes = [vp, vp, C.c_uint32, vp]
+    L.rt_bvh_config.argtypes = [vp, cf]
+    L.rt_bvh_info.argtypes = [vp, vp, vp]
     _lib = L
     return L
 
@@ -273,6 +276,20 @@ class Renderer:
         hits = np.zeros((len(r), 4), dtype=np.float32)
         self._ck(self.L.rt_trace_closest(self.h, _p(r), len(r), _p(hits)))
         return hits
+
+    def trace_stats(self, rays):
+        r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        st = np.zeros((len(r), 2), dtype=np.uint32)
+        self._ck(self.L.rt_trace_stats(self.h, _p(r), len(r), _p(st)))
+        return st
+
+    def bvh_config(self, split_factor):
+        self._ck(self.L.rt_bvh_config(self.h, C.c_float(split_factor)))
+
+    def bvh_info(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        self._ck(self.L.rt_bvh_info(self.h, C.byref(a), C.byref(b)))
+        return dict(references=a.value, nodes=b.value)
 
     def math_eval(self, fn, x):
         x = np.ascontiguousarray(x, dtype=np.float32)

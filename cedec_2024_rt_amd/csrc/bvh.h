@@ -3,9 +3,12 @@
  * reference's HIPRT geometry: build common/loader.hpp:68-112, traversal
  * common/raytrace.hpp:18-52).
  *
- * Build (device): 63-bit Morton codes of triangle centroids -> radix sort (rocPRIM) ->
- * Karras 2012 hierarchy (one thread per internal node) -> bottom-up AABB refit with
- * arrival counters -> 64-byte "pair" nodes holding BOTH children's boxes.
+ * Build: large triangles are first cut into box fragments ("references", host, early split
+ * clipping) because a Morton-order hierarchy over mixed-size triangles overlaps badly; then on
+ * the device: 63-bit Morton codes of the reference centres -> radix sort (rocPRIM) -> Karras
+ * 2012 hierarchy (one thread per internal node) -> bottom-up AABB refit (one launch per tree
+ * level) -> 64-byte "pair" nodes holding BOTH children's boxes. Leaves name the ORIGINAL
+ * triangle, so a triangle may be reached through several leaves (harmless: same t, tie rule).
  *
  * Traversal (device, per lane): stackless. A 64-bit trail word records, per level, whether
  * the sibling subtree is still pending; backtracking follows parent/sibling links stored in
@@ -63,8 +66,11 @@ RT_DEV bool slab(f3 lo, f3 hi, f3 ro, f3 inv, float t0, float t1, float& tnear)
     const float az = (lo.z - ro.z) * inv.z, bz = (hi.z - ro.z) * inv.z;
     float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
     float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-    tn = tn - fabsf(tn) * 4e-7f;
-    tf = tf + fabsf(tf) * 4e-7f;
+    /* relative slack as a product: +-inf (ray parallel to a slab) must stay inf, `x - |x|*eps`
+     * would turn it into NaN and a NaN bound accepts the box. Negative values end up on the
+     * non-conservative side by eps, but tmin >= 0 makes them irrelevant. */
+    tn = tn * (1.0f - 4e-7f);
+    tf = tf * (1.0f + 4e-7f);
     tn = fmaxf(tn, t0);
     tf = fminf(tf, t1);
     tnear = tn;
@@ -73,8 +79,8 @@ RT_DEV bool slab(f3 lo, f3 hi, f3 ro, f3 inv, float t0, float t1, float& tnear)
 
 /* ANY = true: stop at the first accepted hit (shadow rays: only the boolean is consumed,
  * common/raytrace.hpp:45-52). */
-template <bool ANY>
-RT_DEV bool trace(const BvhView& bvh, f3 ro, f3 rd, float tmin, float tmax, Hit& hit)
+template <bool ANY, bool STATS = false>
+RT_DEV bool trace(const BvhView& bvh, f3 ro, f3 rd, float tmin, float tmax, Hit& hit, uint32_t* stats = nullptr)
 {
     if (bvh.n_tris <= 0) return false;
     const f3 inv = F3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
@@ -87,6 +93,7 @@ RT_DEV bool trace(const BvhView& bvh, f3 ro, f3 rd, float tmin, float tmax, Hit&
     for (;;)
     {
         const BvhNode* nd = bvh.nodes + node;
+        if (STATS) stats[0]++;
         const float4 a = nd->a, b = nd->b, c = nd->c;
         const int4 d = nd->d;
         float t0, t1;
@@ -101,6 +108,7 @@ RT_DEV bool trace(const BvhView& bvh, f3 ro, f3 rd, float tmin, float tmax, Hit&
             if (h && ch < 0)
             {
                 const int pi = ~ch;
+                if (STATS) stats[1]++;
                 f3 v0, v1, v2;
                 load_tri(bvh.tv, pi, v0, v1, v2);
                 float t, u, v;
@@ -180,26 +188,28 @@ RT_DEV uint64_t expand21(uint32_t v)
     return x;
 }
 
-/* per triangle: traversal vertex records, padded AABB, Morton key */
-__global__ void k_bvh_prims(const float* __restrict__ tris /* 15 floats each */, int n, float3 slo, float3 sext,
-                            float pad, float4* __restrict__ tv, float* __restrict__ boxes /* 6 per prim */,
-                            uint64_t* __restrict__ keys, uint32_t* __restrict__ ids)
+/* per triangle: traversal vertex records */
+__global__ void k_bvh_tv(const float* __restrict__ tris /* 15 floats each */, int n, float4* __restrict__ tv)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* t = tris + 15 * (size_t)i;
-    const f3 v0 = F3(t[0], t[1], t[2]), v1 = F3(t[3], t[4], t[5]), v2 = F3(t[6], t[7], t[8]);
-    tv[3 * (size_t)i + 0] = make_float4(v0.x, v0.y, v0.z, v1.x);
-    tv[3 * (size_t)i + 1] = make_float4(v1.y, v1.z, v2.x, v2.y);
-    tv[3 * (size_t)i + 2] = make_float4(v2.z, 0.0f, 0.0f, 0.0f);
-    const f3 lo = F3(fminf(v0.x, fminf(v1.x, v2.x)), fminf(v0.y, fminf(v1.y, v2.y)), fminf(v0.z, fminf(v1.z, v2.z)));
-    const f3 hi = F3(fmaxf(v0.x, fmaxf(v1.x, v2.x)), fmaxf(v0.y, fmaxf(v1.y, v2.y)), fmaxf(v0.z, fmaxf(v1.z, v2.z)));
-    float* bx = boxes + 6 * (size_t)i;
-    bx[0] = lo.x - pad; bx[1] = lo.y - pad; bx[2] = lo.z - pad;
-    bx[3] = hi.x + pad; bx[4] = hi.y + pad; bx[5] = hi.z + pad;
-    const float cx = ((lo.x + hi.x) * 0.5f - slo.x) / sext.x;
-    const float cy = ((lo.y + hi.y) * 0.5f - slo.y) / sext.y;
-    const float cz = ((lo.z + hi.z) * 0.5f - slo.z) / sext.z;
+    tv[3 * (size_t)i + 0] = make_float4(t[0], t[1], t[2], t[3]);
+    tv[3 * (size_t)i + 1] = make_float4(t[4], t[5], t[6], t[7]);
+    tv[3 * (size_t)i + 2] = make_float4(t[8], 0.0f, 0.0f, 0.0f);
+}
+
+/* per reference (a triangle or a fragment of a pre-split triangle, see build_bvh): Morton key of
+ * the centre of its (already padded) box */
+__global__ void k_bvh_keys(const float* __restrict__ boxes /* 6 per ref */, int n, float3 slo, float3 sext,
+                           uint64_t* __restrict__ keys, uint32_t* __restrict__ ids)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* bx = boxes + 6 * (size_t)i;
+    const float cx = ((bx[0] + bx[3]) * 0.5f - slo.x) / sext.x;
+    const float cy = ((bx[1] + bx[4]) * 0.5f - slo.y) / sext.y;
+    const float cz = ((bx[2] + bx[5]) * 0.5f - slo.z) / sext.z;
     const uint32_t qx = (uint32_t)fminf(fmaxf(cx * 2097152.0f, 0.0f), 2097151.0f);
     const uint32_t qy = (uint32_t)fminf(fmaxf(cy * 2097152.0f, 0.0f), 2097151.0f);
     const uint32_t qz = (uint32_t)fminf(fmaxf(cz * 2097152.0f, 0.0f), 2097151.0f);
@@ -283,9 +293,10 @@ __global__ void k_bvh_refit_pass(int n, int pass, const uint32_t* __restrict__ i
 }
 
 /* emit traversal nodes */
-__global__ void k_bvh_emit(int n, const uint32_t* __restrict__ ids, const float* __restrict__ prim_boxes,
-                           const int2* __restrict__ children, const int* __restrict__ parent_inner,
-                           const float* __restrict__ node_boxes, BvhNode* __restrict__ nodes)
+__global__ void k_bvh_emit(int n, const uint32_t* __restrict__ ids, const int* __restrict__ ref_tri,
+                           const float* __restrict__ prim_boxes, const int2* __restrict__ children,
+                           const int* __restrict__ parent_inner, const float* __restrict__ node_boxes,
+                           BvhNode* __restrict__ nodes)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
@@ -296,8 +307,8 @@ __global__ void k_bvh_emit(int n, const uint32_t* __restrict__ ids, const float*
     nd.a = make_float4(b0[0], b0[1], b0[2], b1[0]);
     nd.b = make_float4(b0[3], b0[4], b0[5], b1[1]);
     nd.c = make_float4(b1[3], b1[4], b1[5], b1[2]);
-    const int c0 = ch.x < 0 ? ~(int)ids[~ch.x] : ch.x;
-    const int c1 = ch.y < 0 ? ~(int)ids[~ch.y] : ch.y;
+    const int c0 = ch.x < 0 ? ~ref_tri[ids[~ch.x]] : ch.x;
+    const int c1 = ch.y < 0 ? ~ref_tri[ids[~ch.y]] : ch.y;
     const int parent = parent_inner[i];
     int sibling = -1;
     if (parent >= 0)

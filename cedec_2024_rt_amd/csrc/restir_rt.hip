@@ -17,6 +17,7 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -583,6 +584,17 @@ __global__ void k_trace_closest(BvhView bvh, const float* __restrict__ rays, int
     float* o = hits + 4 * (size_t)i;
     o[0] = h.t; o[1] = h.u; o[2] = h.v; o[3] = as_float(h.prim);
 }
+__global__ void k_trace_stats(BvhView bvh, const float* __restrict__ rays, int n, uint32_t* __restrict__ stats)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rays + 8 * (size_t)i;
+    Hit h;
+    uint32_t st[2] = {0u, 0u};
+    trace<false, true>(bvh, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7], h, st);
+    stats[2 * (size_t)i] = st[0];
+    stats[2 * (size_t)i + 1] = st[1];
+}
 __global__ void k_math_eval(int fn, const float* __restrict__ in, int n, float* __restrict__ out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -612,7 +624,8 @@ struct rt_ctx
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::string err;
 
-    int n_tris = 0, n_lights = 0, bvh_height = 0;
+    int n_tris = 0, n_lights = 0, bvh_height = 0, n_refs = 0;
+    float bvh_split_factor = 8.0f; /* fragment length in median triangle extents; 0 = no pre-split */
     float* d_tris = nullptr;
     float4* d_tv = nullptr;
     BvhNode* d_nodes = nullptr;
@@ -786,37 +799,163 @@ static int ensure_stage(rt_ctx* c, size_t bytes)
     return RT_OK;
 }
 
+/* ---- early split clipping (host): cut triangles whose box is longer than L into fragments ---- */
+struct BvhRef
+{
+    float lo[3], hi[3];
+    int tri;
+};
+struct ClipPoly
+{
+    int n;
+    float v[12][3];
+};
+static void poly_bounds(const ClipPoly& p, float* lo, float* hi)
+{
+    for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+    for (int i = 0; i < p.n; ++i)
+        for (int a = 0; a < 3; ++a)
+        {
+            lo[a] = fminf(lo[a], p.v[i][a]);
+            hi[a] = fmaxf(hi[a], p.v[i][a]);
+        }
+}
+/* keep the part of p with (sign > 0 ? x_a >= s : x_a <= s) */
+static ClipPoly poly_clip(const ClipPoly& p, int a, float s, int sign)
+{
+    ClipPoly o;
+    o.n = 0;
+    for (int i = 0; i < p.n; ++i)
+    {
+        const float* c = p.v[i];
+        const float* d = p.v[(i + 1) % p.n];
+        const bool cin = sign > 0 ? c[a] >= s : c[a] <= s;
+        const bool din = sign > 0 ? d[a] >= s : d[a] <= s;
+        if (cin && o.n < 12) { memcpy(o.v[o.n++], c, 12); }
+        if (cin != din && o.n < 12)
+        {
+            const float t = (s - c[a]) / (d[a] - c[a]);
+            for (int k = 0; k < 3; ++k) o.v[o.n][k] = c[k] + (d[k] - c[k]) * t;
+            o.v[o.n][a] = s;
+            o.n++;
+        }
+    }
+    return o;
+}
+static void split_refs(const rt_triangle* tris, int n, float L, float pad, std::vector<BvhRef>& out)
+{
+    out.clear();
+    std::vector<ClipPoly> stack;
+    for (int i = 0; i < n; ++i)
+    {
+        ClipPoly p;
+        p.n = 3;
+        for (int k = 0; k < 3; ++k) memcpy(p.v[k], tris[i].v[k], 12);
+        stack.clear();
+        stack.push_back(p);
+        int emitted = 0;
+        while (!stack.empty())
+        {
+            ClipPoly q = stack.back();
+            stack.pop_back();
+            float lo[3], hi[3];
+            poly_bounds(q, lo, hi);
+            int a = 0;
+            for (int k = 1; k < 3; ++k)
+                if (hi[k] - lo[k] > hi[a] - lo[a]) a = k;
+            const float ext = hi[a] - lo[a];
+            bool split = L > 0.0f && ext > L && emitted + (int)stack.size() < 4096 && q.n >= 3;
+            float s = 0.0f;
+            if (split)
+            {
+                /* split plane on the global L-grid so that fragments of neighbours line up */
+                const float mid = 0.5f * (lo[a] + hi[a]);
+                s = L * floorf(mid / L + 0.5f);
+                if (!(s > lo[a] + 0.01f * ext && s < hi[a] - 0.01f * ext)) s = mid;
+                if (!(s > lo[a] && s < hi[a])) split = false;
+            }
+            if (split)
+            {
+                ClipPoly l = poly_clip(q, a, s, -1), r = poly_clip(q, a, s, +1);
+                if (l.n >= 3 && r.n >= 3)
+                {
+                    stack.push_back(l);
+                    stack.push_back(r);
+                    continue;
+                }
+            }
+            BvhRef ref;
+            for (int k = 0; k < 3; ++k) { ref.lo[k] = lo[k] - pad; ref.hi[k] = hi[k] + pad; }
+            ref.tri = i;
+            out.push_back(ref);
+            ++emitted;
+        }
+    }
+}
+
 /* LBVH build, see bvh.h */
-static int build_bvh(rt_ctx* c, const rt_triangle* tris, int n)
+static int build_bvh(rt_ctx* c, const rt_triangle* tris, int n_tris)
 {
     hipStream_t st = c->stream;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = 0; i < n; ++i)
+    std::vector<float> extents((size_t)n_tris);
+    for (int i = 0; i < n_tris; ++i)
+    {
+        float tl[3] = {INFINITY, INFINITY, INFINITY}, th[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (int k = 0; k < 3; ++k)
             for (int a = 0; a < 3; ++a)
             {
                 const float v = tris[i].v[k][a];
-                if (v < lo[a]) lo[a] = v;
-                if (v > hi[a]) hi[a] = v;
+                tl[a] = fminf(tl[a], v);
+                th[a] = fmaxf(th[a], v);
             }
+        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], tl[a]); hi[a] = fmaxf(hi[a], th[a]); }
+        extents[i] = fmaxf(th[0] - tl[0], fmaxf(th[1] - tl[1], th[2] - tl[2]));
+    }
     float ext = 0.0f;
     for (int a = 0; a < 3; ++a) ext = fmaxf(ext, fmaxf(fabsf(lo[a]), fabsf(hi[a])));
+    /* conservative padding: the accepted hit point of core.hpp:91-136 lies within rounding
+     * distance of the triangle, not exactly on it */
     const float pad = 4e-5f * (ext > 1.0f ? ext : 1.0f);
     float3 slo = make_float3(lo[0], lo[1], lo[2]);
     float3 sext = make_float3(fmaxf(hi[0] - lo[0], 1e-20f), fmaxf(hi[1] - lo[1], 1e-20f), fmaxf(hi[2] - lo[2], 1e-20f));
 
-    RT_HIP(c, hipMalloc(&c->d_tv, (size_t)n * 48));
+    /* fragment length: a few median triangle extents, relaxed until the reference count fits */
+    std::vector<BvhRef> refs;
+    {
+        std::vector<float> e2(extents);
+        std::nth_element(e2.begin(), e2.begin() + e2.size() / 2, e2.end());
+        float L = c->bvh_split_factor > 0.0f ? c->bvh_split_factor * e2[e2.size() / 2] : 0.0f;
+        const size_t budget = (size_t)n_tris * 4 + 1024;
+        for (int it = 0; it < 16; ++it)
+        {
+            split_refs(tris, n_tris, L, pad, refs);
+            if (refs.size() <= budget || L <= 0.0f) break;
+            L *= 1.5f;
+        }
+    }
+    const int n = (int)refs.size();
+    c->n_refs = n;
+    std::vector<float> h_boxes((size_t)n * 6);
+    std::vector<int> h_ref_tri((size_t)n);
+    for (int i = 0; i < n; ++i)
+    {
+        for (int k = 0; k < 3; ++k) { h_boxes[6 * (size_t)i + k] = refs[i].lo[k]; h_boxes[6 * (size_t)i + 3 + k] = refs[i].hi[k]; }
+        h_ref_tri[i] = refs[i].tri;
+    }
+
+    RT_HIP(c, hipMalloc(&c->d_tv, (size_t)n_tris * 48));
     RT_HIP(c, hipMalloc(&c->d_nodes, (size_t)(n > 1 ? n - 1 : 1) * sizeof(BvhNode)));
     float* d_boxes = nullptr; float* d_node_boxes = nullptr;
     uint64_t *d_keys = nullptr, *d_keys2 = nullptr;
     uint32_t *d_ids = nullptr, *d_ids2 = nullptr;
     int2* d_children = nullptr; int *d_parent_inner = nullptr, *d_parent_leaf = nullptr, *d_level = nullptr, *d_remaining = nullptr;
+    int* d_ref_tri = nullptr;
     void* d_temp = nullptr;
-    int rc = RT_OK;
     auto cleanup = [&]() {
         hipFree(d_boxes); hipFree(d_node_boxes); hipFree(d_keys); hipFree(d_keys2); hipFree(d_ids); hipFree(d_ids2);
         hipFree(d_children); hipFree(d_parent_inner); hipFree(d_parent_leaf); hipFree(d_level); hipFree(d_remaining);
-        hipFree(d_temp);
+        hipFree(d_temp); hipFree(d_ref_tri);
     };
 #define BV_HIP(call)                                                                               \
     do                                                                                             \
@@ -830,6 +969,7 @@ static int build_bvh(rt_ctx* c, const rt_triangle* tris, int n)
         }                                                                                          \
     } while (0)
     BV_HIP(hipMalloc(&d_boxes, (size_t)n * 24));
+    BV_HIP(hipMalloc(&d_ref_tri, (size_t)n * 4));
     BV_HIP(hipMalloc(&d_node_boxes, (size_t)n * 24));
     BV_HIP(hipMalloc(&d_keys, (size_t)n * 8));
     BV_HIP(hipMalloc(&d_keys2, (size_t)n * 8));
@@ -840,9 +980,13 @@ static int build_bvh(rt_ctx* c, const rt_triangle* tris, int n)
     BV_HIP(hipMalloc(&d_parent_leaf, (size_t)n * 4));
     BV_HIP(hipMalloc(&d_level, (size_t)n * 4));
     BV_HIP(hipMalloc(&d_remaining, 4));
+    BV_HIP(hipMemcpyAsync(d_boxes, h_boxes.data(), (size_t)n * 24, hipMemcpyHostToDevice, st));
+    BV_HIP(hipMemcpyAsync(d_ref_tri, h_ref_tri.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
 
     const int grid = (n + 255) / 256;
-    k_bvh_prims<<<grid, 256, 0, st>>>(c->d_tris, n, slo, sext, pad, c->d_tv, d_boxes, d_keys, d_ids);
+    k_bvh_tv<<<(n_tris + 255) / 256, 256, 0, st>>>(c->d_tris, n_tris, c->d_tv);
+    BV_HIP(hipGetLastError());
+    k_bvh_keys<<<grid, 256, 0, st>>>(d_boxes, n, slo, sext, d_keys, d_ids);
     BV_HIP(hipGetLastError());
     size_t temp_bytes = 0;
     BV_HIP(rocprim::radix_sort_pairs(nullptr, temp_bytes, d_keys, d_keys2, d_ids, d_ids2, (size_t)n, 0, 64, st));
@@ -851,15 +995,13 @@ static int build_bvh(rt_ctx* c, const rt_triangle* tris, int n)
 
     if (n == 1)
     {
-        /* one triangle: both children are the same leaf (the second test is rejected by the tie rule) */
+        /* one reference: both children are the same leaf (the second test is rejected by the tie rule) */
         BvhNode nd;
-        float hb[6];
-        BV_HIP(hipMemcpyAsync(hb, d_boxes, 24, hipMemcpyDeviceToHost, st));
-        BV_HIP(hipStreamSynchronize(st));
+        const float* hb = h_boxes.data();
         nd.a = make_float4(hb[0], hb[1], hb[2], hb[0]);
         nd.b = make_float4(hb[3], hb[4], hb[5], hb[1]);
         nd.c = make_float4(hb[3], hb[4], hb[5], hb[2]);
-        nd.d = make_int4(~0, ~0, -1, -1);
+        nd.d = make_int4(~h_ref_tri[0], ~h_ref_tri[0], -1, -1);
         BV_HIP(hipMemcpyAsync(c->d_nodes, &nd, sizeof(nd), hipMemcpyHostToDevice, st));
         BV_HIP(hipStreamSynchronize(st));
         c->bvh_height = 1;
@@ -890,12 +1032,12 @@ static int build_bvh(rt_ctx* c, const rt_triangle* tris, int n)
         c->err = b; cleanup();
         return RT_ERR_BVH_DEPTH;
     }
-    k_bvh_emit<<<grid, 256, 0, st>>>(n, d_ids2, d_boxes, d_children, d_parent_inner, d_node_boxes, c->d_nodes);
+    k_bvh_emit<<<grid, 256, 0, st>>>(n, d_ids2, d_ref_tri, d_boxes, d_children, d_parent_inner, d_node_boxes, c->d_nodes);
     BV_HIP(hipGetLastError());
     BV_HIP(hipStreamSynchronize(st));
     cleanup();
 #undef BV_HIP
-    return rc;
+    return RT_OK;
 }
 
 int rt_scene_set(rt_ctx* c, const rt_triangle* triangles, uint32_t count)
@@ -943,6 +1085,13 @@ int rt_scene_info(rt_ctx* c, uint32_t* n_triangles, uint32_t* n_lights, uint32_t
     if (n_triangles) *n_triangles = (uint32_t)c->n_tris;
     if (n_lights) *n_lights = (uint32_t)c->n_lights;
     if (bvh_height) *bvh_height = (uint32_t)c->bvh_height;
+    return RT_OK;
+}
+int rt_bvh_info(rt_ctx* c, uint32_t* n_refs, uint32_t* n_nodes)
+{
+    RT_CHECK_CTX(c);
+    if (n_refs) *n_refs = (uint32_t)c->n_refs;
+    if (n_nodes) *n_nodes = (uint32_t)(c->n_refs > 1 ? c->n_refs - 1 : 1);
     return RT_OK;
 }
 
@@ -1383,6 +1532,34 @@ int rt_trace_closest(rt_ctx* c, const float* rays, uint32_t n, float* hits)
     RT_HIP(c, hipMemcpyAsync(hits, d_h, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     hipFree(d_r); hipFree(d_h);
+    return RT_OK;
+}
+
+/* per ray: {BVH nodes visited, triangle tests} of the closest-hit traversal */
+int rt_trace_stats(rt_ctx* c, const float* rays, uint32_t n, uint32_t* stats)
+{
+    RT_CHECK_CTX(c);
+    if (!c->has_scene) RT_FAIL(c, RT_ERR_STATE, "no scene");
+    if (n == 0) return RT_OK;
+    float* d_r = nullptr;
+    uint32_t* d_s = nullptr;
+    RT_HIP(c, hipMalloc(&d_r, (size_t)n * 32));
+    RT_HIP(c, hipMalloc(&d_s, (size_t)n * 8));
+    RT_HIP(c, hipMemcpyAsync(d_r, rays, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
+    k_trace_stats<<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c).bvh, d_r, (int)n, d_s);
+    RT_HIP(c, hipGetLastError());
+    RT_HIP(c, hipMemcpyAsync(stats, d_s, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    hipFree(d_r); hipFree(d_s);
+    return RT_OK;
+}
+/* BVH build knob (before rt_scene_set): fragment length of the triangle pre-split in median
+ * triangle extents; 0 disables splitting. */
+int rt_bvh_config(rt_ctx* c, float split_factor)
+{
+    RT_CHECK_CTX(c);
+    if (!(split_factor >= 0.0f)) RT_FAIL(c, RT_ERR_ARG, "split_factor must be >= 0");
+    c->bvh_split_factor = split_factor;
     return RT_OK;
 }
 

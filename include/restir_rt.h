@@ -160,6 +160,12 @@ int rt_spatial_bytes(rt_ctx* ctx, int frame, int pass, int in, uint64_t* bytes, 
 /* ---- BVH utilities (parity tests: LBVH == brute force) ----
  * rays: n x {ox,oy,oz, dx,dy,dz, tmin,tmax}; hits: n x {t,u,v, bits(index)}; host pointers. */
 int rt_trace_closest(rt_ctx* ctx, const float* rays, uint32_t n, float* hits);
+/* per ray {nodes visited, triangle tests} of the same traversal (BVH quality diagnostics) */
+int rt_trace_stats(rt_ctx* ctx, const float* rays, uint32_t n, uint32_t* stats);
+/* BVH build knob, call before rt_scene_set: large triangles are pre-split into fragments no
+ * longer than split_factor x (median triangle extent); 0 = no pre-split. Default 8. */
+int rt_bvh_config(rt_ctx* ctx, float split_factor);
+int rt_bvh_info(rt_ctx* ctx, uint32_t* n_references, uint32_t* n_nodes);
 /* elementwise device evaluation of the portable math / IEEE div & sqrt (parity tests);
  * fn ids as in tests/test_portable_math.py */
 int rt_math_eval(rt_ctx* ctx, int fn, const float* in, uint32_t n, float* out);

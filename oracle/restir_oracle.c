@@ -548,8 +548,9 @@ static inline int slab(const ONode* nd, v3 ro, const float* inv, float t0, float
         float tb = (nd->hi[a] - o[a]) * inv[a];
         if (ta > tb) { const float tmp = ta; ta = tb; tb = tmp; }
         /* NaN (0*inf) compares false => the bound is left unchanged (conservative) */
-        ta = ta - fabsf(ta) * 4e-7f;
-        tb = tb + fabsf(tb) * 4e-7f;
+        /* relative slack as a product so that +-inf (ray parallel to the slab) stays inf */
+        ta = ta * (1.0f - 4e-7f);
+        tb = tb * (1.0f + 4e-7f);
         if (ta > tn) tn = ta;
         if (tb < tf) tf = tb;
     }
