@@ -1,0 +1,60 @@
+"""The C-ABI library loads and exports every symbol include/restir_rt.h declares (no compute
+calls: this runs without a GPU), PODs have the reference's sizes, and the product has no CPU
+fallback."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "restir_rt.h")).read()
+    return sorted(set(re.findall(r"\b(rt_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from cedec_2024_rt_amd import api
+
+    lib = api.load_library()
+    names = _declared()
+    assert len(names) >= 30
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert sorted(api.EXPORTS) == names
+
+
+def test_pod_sizes_match_reference():
+    from cedec_2024_rt_amd import types
+
+    assert types.TRIANGLE.itemsize == 60 and types.VISIBILITY.itemsize == 16 and types.RESERVOIR.itemsize == 76
+    assert types.OPTIONS.itemsize == 48 and types.RAYGEN.itemsize == 36
+    assert types.RESERVOIR.fields["w_sum"][1] == 64 and types.RESERVOIR.fields["M"][1] == 72
+    assert types.OPTIONS.fields["use_shadowed_target_function"][1] == 44
+    d = types.default_options()
+    assert d["ris_sample_count"][0] == 32 and d["use_temporal_resampling"][0] == 0 and d["use_visibility_reuse"][0] == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+
+    from cedec_2024_rt_amd import api
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(api.RtError):
+        api.Renderer(16, 16)
+
+
+def test_product_never_touches_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use oracle/."""
+    pkg = os.path.join(ROOT, "cedec_2024_rt_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                assert "restir_oracle" not in txt and "liboracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+    for f in ("include/restir_rt.h",):
+        assert "oracle" not in open(os.path.join(ROOT, f)).read().lower().replace("design.md \"oracle\"", "")
