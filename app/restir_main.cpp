@@ -1,0 +1,220 @@
+/*
+ * restir_main.cpp — headless C++ host of the hot path: the frame loop of the reference's
+ * examples/10_restir_di/10_restir_di.cpp:23-416 without GLFW/OpenGL/Orochi/HIPRT, written
+ * against the C-ABI (include/restir_rt.h) only.
+ *
+ *   restir_app [--obj scene.obj | --tris scene.tris] [--size W H] [--frames N]
+ *              [--eye x y z] [--lookat x y z] [--temporal 0|1] [--spatial 0|1]
+ *              [--shadowed 0|1] [--visreuse 0|1] [--accumulate 0|1] [--by-kernel]
+ *              [--ppm out.ppm] [--pfm out.pfm]
+ *
+ * Keys 1,2,3,4,A of the example (10_restir_di.cpp:143-174) are the --temporal/--spatial/
+ * --shadowed/--visreuse/--accumulate flags; key S (screenshot) is --ppm. `--tris` reads a raw
+ * array of 60-byte Triangle records (cedec_2024_rt_amd.scenes can write one); `--obj` uses the
+ * OBJ/MTL subset the reference's loader consumes (common/loader.hpp:11-66: positions, faces as
+ * triangle fans, per-face usemtl -> Kd/Ke).
+ */
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../include/restir_rt.h"
+
+static void die(rt_ctx* c, const char* what, int rc)
+{
+    fprintf(stderr, "%s failed (%d): %s\n", what, rc, c ? rt_last_error(c) : "");
+    exit(1);
+}
+#define CK(call)                                  \
+    do                                            \
+    {                                             \
+        int _rc = (call);                         \
+        if (_rc != RT_OK) die(ctx, #call, _rc);   \
+    } while (0)
+
+struct Mtl { float kd[3] = {0, 0, 0}, ke[3] = {0, 0, 0}; };
+
+static std::map<std::string, Mtl> load_mtl(const std::string& path)
+{
+    std::map<std::string, Mtl> m;
+    std::ifstream f(path);
+    std::string line, cur;
+    while (std::getline(f, line))
+    {
+        std::istringstream ss(line);
+        std::string k;
+        ss >> k;
+        if (k == "newmtl") { ss >> cur; m[cur] = Mtl(); }
+        else if (k == "Kd" && !cur.empty()) ss >> m[cur].kd[0] >> m[cur].kd[1] >> m[cur].kd[2];
+        else if (k == "Ke" && !cur.empty()) ss >> m[cur].ke[0] >> m[cur].ke[1] >> m[cur].ke[2];
+    }
+    return m;
+}
+
+static std::vector<rt_triangle> load_obj(const std::string& path)
+{
+    std::vector<rt_triangle> out;
+    std::ifstream f(path);
+    if (!f) { fprintf(stderr, "cannot open %s\n", path.c_str()); exit(1); }
+    const std::string dir = path.find('/') == std::string::npos ? "." : path.substr(0, path.rfind('/'));
+    std::vector<float> v;
+    std::map<std::string, Mtl> mats;
+    Mtl cur;
+    std::string line;
+    while (std::getline(f, line))
+    {
+        std::istringstream ss(line);
+        std::string k;
+        ss >> k;
+        if (k == "v") { float x, y, z; ss >> x >> y >> z; v.push_back(x); v.push_back(y); v.push_back(z); }
+        else if (k == "mtllib") { std::string n; ss >> n; auto m = load_mtl(dir + "/" + n); mats.insert(m.begin(), m.end()); }
+        else if (k == "usemtl") { std::string n; ss >> n; cur = mats.count(n) ? mats[n] : Mtl(); }
+        else if (k == "f")
+        {
+            std::vector<int> idx;
+            std::string w;
+            while (ss >> w)
+            {
+                const int i = atoi(w.substr(0, w.find('/')).c_str());
+                idx.push_back(i > 0 ? i - 1 : (int)(v.size() / 3) + i);
+            }
+            for (size_t t = 2; t < idx.size(); ++t) /* triangle fan, tiny_obj_loader.h:908-931 */
+            {
+                rt_triangle tri;
+                const int id[3] = {idx[0], idx[t - 1], idx[t]};
+                for (int a = 0; a < 3; ++a)
+                    for (int c = 0; c < 3; ++c) tri.v[a][c] = v[3 * (size_t)id[a] + c];
+                memcpy(tri.color, cur.kd, 12);
+                memcpy(tri.emissive, cur.ke, 12);
+                out.push_back(tri);
+            }
+        }
+    }
+    return out;
+}
+
+static std::vector<rt_triangle> load_tris(const std::string& path)
+{
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) { fprintf(stderr, "cannot open %s\n", path.c_str()); exit(1); }
+    const size_t bytes = (size_t)f.tellg();
+    std::vector<rt_triangle> t(bytes / sizeof(rt_triangle));
+    f.seekg(0);
+    f.read((char*)t.data(), (std::streamsize)(t.size() * sizeof(rt_triangle)));
+    return t;
+}
+
+int main(int argc, char** argv)
+{
+    int W = 1920, H = 1080, frames = 8; /* 10_restir_di.cpp:26-27 */
+    /* camera "blocks_restir.obj 1", 10_restir_di.cpp:188-189 */
+    float eye[3] = {-0.579885f, 22.194597f, -6.567105f}, lookat[3] = {5.224952f, 20.847435f, 1.431192f};
+    const float up[3] = {0, 1, 0};
+    std::string obj, tris_path, ppm, pfm;
+    bool by_kernel = false;
+    rt_options opt;
+    memset(&opt, 0, sizeof(opt));
+    opt.max_depth = 6; opt.ris_sample_count = 32; opt.rejection_heuristics_threshold = 0.2f;
+    opt.spatial_resampling_sample_count = 5; opt.spatial_resampling_radius = 30.0f;
+    opt.spatial_resampling_passes = 3; opt.use_visibility_reuse = 1; /* common/options.hpp:6-22 */
+    opt.use_temporal_resampling = 1; opt.use_spatial_resampling = 1;  /* keys 1, 2 */
+    for (int i = 1; i < argc; ++i)
+    {
+        const std::string a = argv[i];
+        auto f = [&](int k) { return (float)atof(argv[i + k]); };
+        if (a == "--obj") obj = argv[++i];
+        else if (a == "--tris") tris_path = argv[++i];
+        else if (a == "--size") { W = atoi(argv[i + 1]); H = atoi(argv[i + 2]); i += 2; }
+        else if (a == "--frames") frames = atoi(argv[++i]);
+        else if (a == "--eye") { eye[0] = f(1); eye[1] = f(2); eye[2] = f(3); i += 3; }
+        else if (a == "--lookat") { lookat[0] = f(1); lookat[1] = f(2); lookat[2] = f(3); i += 3; }
+        else if (a == "--temporal") opt.use_temporal_resampling = (uint8_t)atoi(argv[++i]);
+        else if (a == "--spatial") opt.use_spatial_resampling = (uint8_t)atoi(argv[++i]);
+        else if (a == "--shadowed") opt.use_shadowed_target_function = (uint8_t)atoi(argv[++i]);
+        else if (a == "--visreuse") opt.use_visibility_reuse = (uint8_t)atoi(argv[++i]);
+        else if (a == "--accumulate") opt.accumulate = (uint8_t)atoi(argv[++i]);
+        else if (a == "--by-kernel") by_kernel = true;
+        else if (a == "--ppm") ppm = argv[++i];
+        else if (a == "--pfm") pfm = argv[++i];
+        else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
+    }
+    std::vector<rt_triangle> triangles = !obj.empty() ? load_obj(obj) : load_tris(tris_path);
+    if (triangles.empty()) { fprintf(stderr, "no triangles (use --obj or --tris)\n"); return 2; }
+
+    rt_ctx* ctx = nullptr;
+    int rc = rt_create(0, W, H, 0, H, 0, &ctx);
+    if (rc != RT_OK) die(ctx, "rt_create", rc);
+    CK(rt_scene_set(ctx, triangles.data(), (uint32_t)triangles.size()));
+    uint32_t nt, nl, bh;
+    CK(rt_scene_info(ctx, &nt, &nl, &bh));
+    printf("triangles: %u\nlights: %u\nbvh height: %u\n", nt, nl, bh); /* cf. 10_restir_di.cpp:206 */
+    CK(rt_camera_lookat(ctx, eye, lookat, up, 3.14159265358979323846f / 4.0f)); /* :242-251 */
+    CK(rt_options_set(ctx, &opt));
+    CK(rt_timing_enable(ctx, 1));
+    CK(rt_clear(ctx)); /* :222-226 */
+
+    for (int frame = 1; frame <= frames; ++frame) /* frame++ before the first launch, :233-234 */
+    {
+        if (!by_kernel) { CK(rt_frame(ctx, frame, 0, nullptr)); }
+        else
+        {
+            /* the launch sequence of 10_restir_di.cpp:270-379, one C-ABI call per kernel */
+            CK(rt_raycast(ctx));
+            CK(rt_generate_candidate(ctx, frame, RT_RES_0));
+            CK(rt_temporal_resampling(ctx, frame, RT_RES_TEMPORAL, RT_RES_0));
+            CK(rt_save_temporal_reservoir(ctx, RT_RES_0, RT_RES_TEMPORAL));
+            int in = RT_RES_0, out = RT_RES_1;
+            for (int k = 0; k < opt.spatial_resampling_passes; ++k)
+            {
+                if (k != 0) { const int t = in; in = out; out = t; }
+                CK(rt_spatial_resampling(ctx, frame, k, in, out));
+            }
+            CK(rt_resolve(ctx, out));
+            CK(rt_tone_mapping(ctx));
+        }
+        CK(rt_sync(ctx));
+        if (!by_kernel)
+        {
+            float ms[9];
+            CK(rt_timing(ctx, ms));
+            printf("frame %d kernel: %.3f ms (raycast %.3f, candidates %.3f, spatial %.3f+%.3f+%.3f, resolve %.3f)\n", frame,
+                   ms[8], ms[1], ms[2], ms[3], ms[4], ms[5], ms[6]); /* cf. the overlay of :410 */
+        }
+    }
+    uint64_t rays = 0, shaded = 0;
+    CK(rt_ray_count(ctx, &rays, &shaded));
+    printf("rays/frame: %llu (shaded pixels %llu)\n", (unsigned long long)rays, (unsigned long long)shaded);
+
+    if (!ppm.empty())
+    {
+        std::vector<uint8_t> px((size_t)W * H * 4);
+        CK(rt_download(ctx, RT_BUF_PIXELS, px.data(), px.size()));
+        FILE* f = fopen(ppm.c_str(), "wb");
+        fprintf(f, "P6\n%d %d\n255\n", W, H);
+        for (int y = H - 1; y >= 0; --y) /* storage is bottom-up (pixel_idx = x + (H-yi-1)*W) */
+            for (int x = 0; x < W; ++x) fwrite(&px[4 * ((size_t)y * W + x)], 1, 3, f);
+        fclose(f);
+    }
+    if (!pfm.empty())
+    {
+        std::vector<float> acc((size_t)W * H * 4);
+        CK(rt_download(ctx, RT_BUF_ACCUMULATION, acc.data(), acc.size() * 4));
+        FILE* f = fopen(pfm.c_str(), "wb");
+        fprintf(f, "PF\n%d %d\n-1.0\n", W, H);
+        for (size_t i = 0; i < (size_t)W * H; ++i)
+        {
+            const float w = acc[4 * i + 3];
+            const float rgb[3] = {acc[4 * i] / w, acc[4 * i + 1] / w, acc[4 * i + 2] / w};
+            fwrite(rgb, 4, 3, f);
+        }
+        fclose(f);
+    }
+    CK(rt_destroy(ctx));
+    return 0;
+}
