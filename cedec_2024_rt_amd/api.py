@@ -24,7 +24,7 @@ EXPORTS = [
     "rt_raycast", "rt_generate_candidate", "rt_temporal_resampling", "rt_save_temporal_reservoir",
     "rt_spatial_resampling", "rt_resolve", "rt_tone_mapping", "rt_frame", "rt_local_rows", "rt_download",
     "rt_upload", "rt_halo_bytes", "rt_halo_pack", "rt_halo_unpack", "rt_ray_count", "rt_timing_enable",
-    "rt_timing", "rt_spatial_bytes", "rt_trace_closest", "rt_trace_stats", "rt_bvh_config", "rt_bvh_info", "rt_math_eval",
+    "rt_timing", "rt_spatial_bytes", "rt_trace_closest", "rt_trace_stats", "rt_bvh_config", "rt_bvh_info", "rt_trace_mode", "rt_math_eval",
 ]
 
 
@@ -91,6 +91,7 @@ def load_library():
     L.rt_trace_stats.argtypes = [vp, vp, C.c_uint32, vp]
     L.rt_bvh_config.argtypes = [vp, cf]
     L.rt_bvh_info.argtypes = [vp, vp, vp]
+    L.rt_trace_mode.argtypes = [vp, ci]
     _lib = L
     return L
 
@@ -286,10 +287,13 @@ class Renderer:
     def bvh_config(self, split_factor):
         self._ck(self.L.rt_bvh_config(self.h, C.c_float(split_factor)))
 
+    def trace_mode(self, mode):
+        self._ck(self.L.rt_trace_mode(self.h, int(mode)))
+
     def bvh_info(self):
         a, b = C.c_uint32(), C.c_uint32()
         self._ck(self.L.rt_bvh_info(self.h, C.byref(a), C.byref(b)))
-        return dict(references=a.value, nodes=b.value)
+        return dict(references=a.value, wide_records=b.value)
 
     def math_eval(self, fn, x):
         x = np.ascontiguousarray(x, dtype=np.float32)

@@ -56,7 +56,8 @@ struct FrameParams
 
 struct SceneView
 {
-    BvhView bvh;
+    BvhView bvh;   /* binary LBVH, stackless trail traversal (kept for A/B measurements) */
+    WideView wide; /* production traversal structure */
     const float4* __restrict__ trimat; /* 2 per triangle: {Kd.xyz, bits(emissive?)}, {Ke.xyz, 0} */
     const float4* __restrict__ lights; /* 5 per light, see k_light_table */
 };
@@ -117,6 +118,7 @@ RT_DEV void gbuffer_write(const SceneView& S, const FrameParams& P, float4* __re
 __global__ __launch_bounds__(BLOCK) void k_raycast(SceneView S, FrameParams P, float4* __restrict__ vis,
                                                     float4* __restrict__ g0, float4* __restrict__ g1)
 {
+    __shared__ uint32_t s_stack[WIDE_LDS_STACK * BLOCK];
     int x, row;
     if (!tile_pixel(P, x, row)) return;
     const int yi = P.H - 1 - row;
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(BLOCK) void k_raycast(SceneView S, FrameParams P, f
 
     Hit h;
     h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.prim = -1;
-    trace<false>(S.bvh, P.rg_origin, rd, 0.0f, kFltMax, h);
+    trace_wide<false>(S.wide, s_stack, P.rg_origin, rd, 0.0f, kFltMax, h);
     vis[li] = make_float4(h.u, h.v, as_float(h.prim), as_float(0));
     gbuffer_write(S, P, g0, g1, li, h.u, h.v, h.prim);
 }
@@ -149,13 +151,13 @@ __global__ __launch_bounds__(BLOCK) void k_gbuffer_from_vis(SceneView S, FramePa
 /* ------------------------------------------------------- target function helper */
 /* common/reservoir.hpp:42-59 */
 template <bool SHADOWED>
-RT_DEV float target_function(const SceneView& S, f3 op, f3 on, f3 hp, f3 hn, float lum)
+RT_DEV float target_function(const SceneView& S, uint32_t* s_stack, f3 op, f3 on, f3 hp, f3 hn, float lum)
 {
     if (SHADOWED)
     {
         const float brdf = 1.0f / kPI;
         const float G = geometry_term(op, on, hp, hn);
-        const float V = check_visibility(S.bvh, op, on, hp) ? 1.0f : 0.0f;
+        const float V = check_visibility_wide(S.wide, s_stack, op, on, hp) ? 1.0f : 0.0f;
         return brdf * G * V * lum;
     }
     return target_unshadowed(op, on, hp, hn, lum);
@@ -169,12 +171,13 @@ RT_DEV void res_take_sample(Res& r, const Res& o)
 
 /* temporal merge of 10_restir_di.cu:177-233; r = current, pr = previous frame, same pixel */
 template <bool SHADOWED>
-RT_DEV void temporal_merge(const SceneView& S, const FrameParams& P, int x, int yi, f3 sp, f3 sn, Res& r, Res pr)
+RT_DEV void temporal_merge(const SceneView& S, uint32_t* s_stack, const FrameParams& P, int x, int yi, f3 sp, f3 sn, Res& r,
+                           Res pr)
 {
     PCG rng = pcg_init(hashPCG4((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame, 1u), 0);
     const int cap = 20 * P.ris_sample_count;
     pr.M = pr.M < cap ? pr.M : cap;
-    float p_hat_y = target_function<SHADOWED>(S, sp, sn, pr.hit_p, pr.hit_n, pr.lum);
+    float p_hat_y = target_function<SHADOWED>(S, s_stack, sp, sn, pr.hit_p, pr.hit_n, pr.lum);
     if (P.vis_reuse) p_hat_y *= pr.vis ? 1.0f : 0.0f;
     pr.M = scale_M(pr.M, rejection_heuristics(r.org_p, r.org_n, pr.org_p, pr.org_n, P.eye));
     const float weight = p_hat_y * pr.ucw * (float)pr.M;
@@ -182,7 +185,7 @@ RT_DEV void temporal_merge(const SceneView& S, const FrameParams& P, int x, int 
     r.w_sum += weight;
     r.M += pr.M;
     if (u < weight / r.w_sum) res_take_sample(r, pr);
-    const float p_hat = target_function<SHADOWED>(S, sp, sn, r.hit_p, r.hit_n, r.lum);
+    const float p_hat = target_function<SHADOWED>(S, s_stack, sp, sn, r.hit_p, r.hit_n, r.lum);
     r.ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
 }
 
@@ -195,6 +198,7 @@ __global__ __launch_bounds__(BLOCK) void k_generate_candidate(
     const float4* __restrict__ prev_rec, const float4* __restrict__ prev_rad, float4* __restrict__ out_rec,
     float4* __restrict__ out_rad)
 {
+    __shared__ uint32_t s_stack[WIDE_LDS_STACK * BLOCK];
     int x, row;
     if (!tile_pixel(P, x, row)) return;
     const int yi = P.H - 1 - row;
@@ -242,10 +246,10 @@ __global__ __launch_bounds__(BLOCK) void k_generate_candidate(
         }
     }
     {
-        const float p_hat = target_function<SHADOWED>(S, sp, sn, r.hit_p, r.hit_n, r.lum);
+        const float p_hat = target_function<SHADOWED>(S, s_stack, sp, sn, r.hit_p, r.hit_n, r.lum);
         r.ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
     }
-    if (P.vis_reuse) r.vis = check_visibility(S.bvh, sp, sn, r.hit_p);
+    if (P.vis_reuse) r.vis = check_visibility_wide(S.wide, s_stack, sp, sn, r.hit_p);
 
     if (FUSE_TEMPORAL)
     {
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(BLOCK) void k_generate_candidate(
         Res pr = res_load(prev_rec, li, dummy);
         const float4 pq = prev_rad[li];
         pr.rad = F3(pq.x, pq.y, pq.z);
-        temporal_merge<SHADOWED>(S, P, x, yi, sp, sn, r, pr);
+        temporal_merge<SHADOWED>(S, s_stack, P, x, yi, sp, sn, r, pr);
     }
     res_store(out_rec, out_rad, li, r, true);
 }
@@ -267,6 +271,7 @@ __global__ __launch_bounds__(BLOCK) void k_temporal(SceneView S, FrameParams P, 
                                                      const float4* __restrict__ prev_rad,
                                                      float4* __restrict__ rec, float4* __restrict__ radb)
 {
+    __shared__ uint32_t s_stack[WIDE_LDS_STACK * BLOCK];
     int x, row;
     if (!tile_pixel(P, x, row)) return;
     const int yi = P.H - 1 - row;
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(BLOCK) void k_temporal(SceneView S, FrameParams P, 
     Res pr = res_load(prev_rec, li, dummy);
     const float4 pq = prev_rad[li];
     pr.rad = F3(pq.x, pq.y, pq.z);
-    temporal_merge<SHADOWED>(S, P, x, yi, sp, sn, r, pr);
+    temporal_merge<SHADOWED>(S, s_stack, P, x, yi, sp, sn, r, pr);
     res_store(rec, radb, li, r, true);
 }
 
@@ -299,6 +304,7 @@ __global__ __launch_bounds__(BLOCK) void k_spatial(SceneView S, FrameParams P, c
                                                     const float4* __restrict__ in_rad,
                                                     float4* __restrict__ out_rec, float4* __restrict__ out_rad)
 {
+    __shared__ uint32_t s_stack[WIDE_LDS_STACK * BLOCK];
     int x, row;
     if (!tile_pixel(P, x, row)) return;
     const int yi = P.H - 1 - row;
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(BLOCK) void k_spatial(SceneView S, FrameParams P, c
             Res nr = res_load(in_rec, pid, n_shaded);
             if (!n_shaded) continue; /* sky or emissive neighbour (:326-338) */
 
-            float p_hat_y = target_function<SHADOWED>(S, sp, sn, nr.hit_p, nr.hit_n, nr.lum);
+            float p_hat_y = target_function<SHADOWED>(S, s_stack, sp, sn, nr.hit_p, nr.hit_n, nr.lum);
             if (P.vis_reuse) p_hat_y *= nr.vis ? 1.0f : 0.0f;
             nr.M = scale_M(nr.M, rejection_heuristics(r.org_p, r.org_n, nr.org_p, nr.org_n, P.eye));
             const float weight = p_hat_y * nr.ucw * (float)nr.M;
@@ -353,7 +359,7 @@ __global__ __launch_bounds__(BLOCK) void k_spatial(SceneView S, FrameParams P, c
                 rad_from = pid;
             }
         }
-        const float p_hat = target_function<SHADOWED>(S, sp, sn, r.hit_p, r.hit_n, r.lum);
+        const float p_hat = target_function<SHADOWED>(S, s_stack, sp, sn, r.hit_p, r.hit_n, r.lum);
         r.ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
     }
     const float4 rq = in_rad[rad_from];
@@ -427,6 +433,7 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(SceneView S, FrameParams P, c
                                                     const float4* __restrict__ rec,
                                                     const float4* __restrict__ radb, float4* __restrict__ accum)
 {
+    __shared__ uint32_t s_stack[WIDE_LDS_STACK * BLOCK];
     int x, row;
     if (!tile_pixel(P, x, row)) return;
     const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
@@ -447,7 +454,7 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(SceneView S, FrameParams P, c
     const f3 hp = F3(q0.x, q0.y, q0.z), hn = F3(q1.x, q1.y, q1.z);
     const f3 brdf = (1.0f / kPI) * F3(kd.x, kd.y, kd.z);
     const float G = geometry_term(sp, sn, hp, hn);
-    const float V = check_visibility(S.bvh, sp, sn, hp) ? 1.0f : 0.0f;
+    const float V = check_visibility_wide(S.wide, s_stack, sp, sn, hp) ? 1.0f : 0.0f;
     const f3 radiance = brdf * G * V * F3(rq.x, rq.y, rq.z) * q0.w;
     if (P.accumulate)
     {
@@ -573,25 +580,31 @@ __global__ void k_count_shaded(FrameParams P, const float4* __restrict__ g1, uns
     const unsigned long long m = __ballot(shaded);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
 }
-__global__ void k_trace_closest(BvhView bvh, const float* __restrict__ rays, int n, float* __restrict__ hits)
+template <int MODE> /* 0 = wide (production), 1 = binary stackless */
+__global__ __launch_bounds__(BLOCK) void k_trace_closest(SceneView S, const float* __restrict__ rays, int n, float* __restrict__ hits)
 {
+    __shared__ uint32_t s_stack[MODE == 0 ? WIDE_LDS_STACK * BLOCK : 1];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* r = rays + 8 * (size_t)i;
     Hit h;
     h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.prim = -1;
-    trace<false>(bvh, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7], h);
+    if (MODE == 0) trace_wide<false>(S.wide, s_stack, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7], h);
+    else trace<false>(S.bvh, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7], h);
     float* o = hits + 4 * (size_t)i;
     o[0] = h.t; o[1] = h.u; o[2] = h.v; o[3] = as_float(h.prim);
 }
-__global__ void k_trace_stats(BvhView bvh, const float* __restrict__ rays, int n, uint32_t* __restrict__ stats)
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_trace_stats(SceneView S, const float* __restrict__ rays, int n, uint32_t* __restrict__ stats)
 {
+    __shared__ uint32_t s_stack[MODE == 0 ? WIDE_LDS_STACK * BLOCK : 1];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* r = rays + 8 * (size_t)i;
     Hit h;
     uint32_t st[2] = {0u, 0u};
-    trace<false, true>(bvh, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7], h, st);
+    if (MODE == 0) trace_wide<false, true>(S.wide, s_stack, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7], h, st);
+    else trace<false, true>(S.bvh, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7], h, st);
     stats[2 * (size_t)i] = st[0];
     stats[2 * (size_t)i + 1] = st[1];
 }
@@ -625,10 +638,13 @@ struct rt_ctx
     std::string err;
 
     int n_tris = 0, n_lights = 0, bvh_height = 0, n_refs = 0;
+    int trace_mode = 0; /* rt_trace_closest / rt_trace_stats: 0 = wide (what the frame kernels use), 1 = binary stackless */
     float bvh_split_factor = 8.0f; /* fragment length in median triangle extents; 0 = no pre-split */
     float* d_tris = nullptr;
     float4* d_tv = nullptr;
     BvhNode* d_nodes = nullptr;
+    float4* d_wide = nullptr;
+    int n_wide = 0, wide_height = 0;
     float4* d_trimat = nullptr;
     float4* d_lights = nullptr;
 
@@ -704,6 +720,7 @@ static SceneView make_scene(const rt_ctx* c)
 {
     SceneView S;
     S.bvh.nodes = c->d_nodes; S.bvh.tv = c->d_tv; S.bvh.n_tris = c->n_tris;
+    S.wide.rec = c->d_wide; S.wide.n_tris = c->n_tris;
     S.trimat = c->d_trimat; S.lights = c->d_lights;
     return S;
 }
@@ -755,7 +772,8 @@ int rt_create(int device, int width, int height, int row_begin, int row_end, int
 
 static void free_scene(rt_ctx* c)
 {
-    hipFree(c->d_tris); hipFree(c->d_tv); hipFree(c->d_nodes); hipFree(c->d_trimat); hipFree(c->d_lights);
+    hipFree(c->d_tris); hipFree(c->d_tv); hipFree(c->d_nodes); hipFree(c->d_trimat); hipFree(c->d_lights); hipFree(c->d_wide);
+    c->d_wide = nullptr;
     c->d_tris = nullptr; c->d_tv = nullptr; c->d_nodes = nullptr; c->d_trimat = nullptr; c->d_lights = nullptr;
     c->has_scene = false;
 }
@@ -893,6 +911,145 @@ static void split_refs(const rt_triangle* tris, int n, float L, float pad, std::
     }
 }
 
+/* ---- collapse the binary LBVH into the 4-wide quantised structure of bvh.h (host) ---- */
+struct WideRec
+{
+    uint32_t w[12];
+}; /* 48 B */
+static_assert(sizeof(WideRec) == 48, "wide record");
+
+static inline float box_area6(const float* lo, const float* hi)
+{
+    const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+struct WideChild
+{
+    int bin; /* >= 0 binary inner node, < 0: ~triangle */
+    float lo[3], hi[3];
+};
+static void bin_children(const BvhNode& n, WideChild out[2])
+{
+    out[0].bin = n.d.x; out[1].bin = n.d.y;
+    out[0].lo[0] = n.a.x; out[0].lo[1] = n.a.y; out[0].lo[2] = n.a.z;
+    out[0].hi[0] = n.b.x; out[0].hi[1] = n.b.y; out[0].hi[2] = n.b.z;
+    out[1].lo[0] = n.a.w; out[1].lo[1] = n.b.w; out[1].lo[2] = n.c.w;
+    out[1].hi[0] = n.c.x; out[1].hi[1] = n.c.y; out[1].hi[2] = n.c.z;
+}
+/* returns the wide height, fills recs */
+static int collapse_wide(const std::vector<BvhNode>& bin, const rt_triangle* tris, std::vector<WideRec>& recs)
+{
+    struct Work { int bin; uint32_t out; int depth; };
+    recs.clear();
+    recs.reserve(bin.size() * 2 + 8);
+    recs.push_back(WideRec());
+    std::vector<Work> stack;
+    stack.push_back({0, 0u, 1});
+    int height = 1;
+    while (!stack.empty())
+    {
+        const Work wk = stack.back();
+        stack.pop_back();
+        height = std::max(height, wk.depth);
+        WideChild ch[4];
+        int n = 2;
+        bin_children(bin[(size_t)wk.bin], ch);
+        while (n < 4)
+        {
+            int pick = -1;
+            float best = -1.0f;
+            for (int k = 0; k < n; ++k)
+                if (ch[k].bin >= 0)
+                {
+                    const float a = box_area6(ch[k].lo, ch[k].hi);
+                    if (a > best) { best = a; pick = k; }
+                }
+            if (pick < 0) break;
+            WideChild two[2];
+            bin_children(bin[(size_t)ch[pick].bin], two);
+            ch[pick] = two[0];
+            ch[n++] = two[1];
+        }
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int k = 0; k < n; ++k)
+            for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], ch[k].lo[a]); hi[a] = fmaxf(hi[a], ch[k].hi[a]); }
+        const uint32_t base = (uint32_t)recs.size();
+        recs.resize(recs.size() + (size_t)n);
+        /* per-axis power-of-two scale with 255 steps covering the node box */
+        uint32_t ebits[3];
+        float scale[3];
+        for (int a = 0; a < 3; ++a)
+        {
+            const float ext = fmaxf(hi[a] - lo[a], 1e-30f);
+            int e;
+            frexpf(ext / 255.0f, &e); /* ext/255 = m * 2^e, m in [0.5,1) => 2^e >= ext/255 */
+            int biased = e + 127;
+            if (biased < 1) biased = 1;
+            if (biased > 254) biased = 254;
+            ebits[a] = (uint32_t)biased;
+            scale[a] = ldexpf(1.0f, biased - 127);
+        }
+        uint32_t q[6] = {0, 0, 0, 0, 0, 0}, meta = 0;
+        for (int k = 0; k < n; ++k)
+        {
+            for (int a = 0; a < 3; ++a)
+            {
+                int ql = (int)floorf((ch[k].lo[a] - lo[a]) / scale[a]);
+                int qh = (int)ceilf((ch[k].hi[a] - lo[a]) / scale[a]);
+                /* the device decodes lo + q*scale in binary32: make sure the decoded box contains the child box */
+                while (ql > 0 && lo[a] + (float)ql * scale[a] > ch[k].lo[a]) --ql;
+                while (qh < 255 && lo[a] + (float)qh * scale[a] < ch[k].hi[a]) ++qh;
+                ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql);
+                qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
+                q[a] |= (uint32_t)ql << (8 * k);
+                q[3 + a] |= (uint32_t)qh << (8 * k);
+            }
+            if (ch[k].bin >= 0)
+            {
+                meta |= 1u << (8 * k);
+                stack.push_back({ch[k].bin, base + (uint32_t)k, wk.depth + 1});
+            }
+            else
+            {
+                meta |= 2u << (8 * k);
+                const int ti = ~ch[k].bin;
+                const rt_triangle& t = tris[ti];
+                WideRec& L = recs[base + (size_t)k];
+                const float f[9] = {t.v[0][0], t.v[0][1], t.v[0][2], t.v[1][0], t.v[1][1], t.v[1][2], t.v[2][0], t.v[2][1], t.v[2][2]};
+                for (int i = 0; i < 9; ++i) L.w[i] = f2u(f[i]);
+                L.w[9] = (uint32_t)ti;
+                L.w[10] = L.w[11] = 0u;
+            }
+        }
+        WideRec& R = recs[wk.out];
+        R.w[0] = f2u(lo[0]); R.w[1] = f2u(lo[1]); R.w[2] = f2u(lo[2]);
+        R.w[3] = ebits[0] | (ebits[1] << 8) | (ebits[2] << 16);
+        R.w[4] = base; R.w[5] = meta; R.w[6] = q[0]; R.w[7] = q[1];
+        R.w[8] = q[2]; R.w[9] = q[3]; R.w[10] = q[4]; R.w[11] = q[5];
+    }
+    return height;
+}
+
+static int build_wide(rt_ctx* c, const rt_triangle* tris, int n_refs)
+{
+    const size_t n_bin = (size_t)(n_refs > 1 ? n_refs - 1 : 1);
+    std::vector<BvhNode> bin(n_bin);
+    RT_HIP(c, hipMemcpyAsync(bin.data(), c->d_nodes, n_bin * sizeof(BvhNode), hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    std::vector<WideRec> recs;
+    c->wide_height = collapse_wide(bin, tris, recs);
+    if (3 * c->wide_height + 1 > WIDE_LDS_STACK + WIDE_OVF_STACK)
+        RT_FAIL(c, RT_ERR_BVH_DEPTH, "wide BVH height %d exceeds the traversal stack (%d entries)", c->wide_height,
+                WIDE_LDS_STACK + WIDE_OVF_STACK);
+    c->n_wide = (int)recs.size();
+    RT_HIP(c, hipMalloc(&c->d_wide, recs.size() * sizeof(WideRec)));
+    RT_HIP(c, hipMemcpyAsync(c->d_wide, recs.data(), recs.size() * sizeof(WideRec), hipMemcpyHostToDevice, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
 /* LBVH build, see bvh.h */
 static int build_bvh(rt_ctx* c, const rt_triangle* tris, int n_tris)
 {
@@ -1006,7 +1163,7 @@ static int build_bvh(rt_ctx* c, const rt_triangle* tris, int n_tris)
         BV_HIP(hipStreamSynchronize(st));
         c->bvh_height = 1;
         cleanup();
-        return RT_OK;
+        return build_wide(c, tris, n);
     }
 
     k_bvh_hierarchy<<<grid, 256, 0, st>>>(d_keys2, n, d_children, d_parent_inner, d_parent_leaf);
@@ -1037,7 +1194,7 @@ static int build_bvh(rt_ctx* c, const rt_triangle* tris, int n_tris)
     BV_HIP(hipStreamSynchronize(st));
     cleanup();
 #undef BV_HIP
-    return RT_OK;
+    return build_wide(c, tris, n);
 }
 
 int rt_scene_set(rt_ctx* c, const rt_triangle* triangles, uint32_t count)
@@ -1091,7 +1248,7 @@ int rt_bvh_info(rt_ctx* c, uint32_t* n_refs, uint32_t* n_nodes)
 {
     RT_CHECK_CTX(c);
     if (n_refs) *n_refs = (uint32_t)c->n_refs;
-    if (n_nodes) *n_nodes = (uint32_t)(c->n_refs > 1 ? c->n_refs - 1 : 1);
+    if (n_nodes) *n_nodes = (uint32_t)c->n_wide;
     return RT_OK;
 }
 
@@ -1526,8 +1683,8 @@ int rt_trace_closest(rt_ctx* c, const float* rays, uint32_t n, float* hits)
     RT_HIP(c, hipMalloc(&d_r, (size_t)n * 32));
     RT_HIP(c, hipMalloc(&d_h, (size_t)n * 16));
     RT_HIP(c, hipMemcpyAsync(d_r, rays, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
-    BvhView b = make_scene(c).bvh;
-    k_trace_closest<<<(n + 255) / 256, 256, 0, c->stream>>>(b, d_r, (int)n, d_h);
+    if (c->trace_mode == 0) k_trace_closest<0><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_h);
+    else k_trace_closest<1><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_h);
     RT_HIP(c, hipGetLastError());
     RT_HIP(c, hipMemcpyAsync(hits, d_h, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
@@ -1546,7 +1703,8 @@ int rt_trace_stats(rt_ctx* c, const float* rays, uint32_t n, uint32_t* stats)
     RT_HIP(c, hipMalloc(&d_r, (size_t)n * 32));
     RT_HIP(c, hipMalloc(&d_s, (size_t)n * 8));
     RT_HIP(c, hipMemcpyAsync(d_r, rays, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
-    k_trace_stats<<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c).bvh, d_r, (int)n, d_s);
+    if (c->trace_mode == 0) k_trace_stats<0><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_s);
+    else k_trace_stats<1><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_s);
     RT_HIP(c, hipGetLastError());
     RT_HIP(c, hipMemcpyAsync(stats, d_s, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
@@ -1560,6 +1718,15 @@ int rt_bvh_config(rt_ctx* c, float split_factor)
     RT_CHECK_CTX(c);
     if (!(split_factor >= 0.0f)) RT_FAIL(c, RT_ERR_ARG, "split_factor must be >= 0");
     c->bvh_split_factor = split_factor;
+    return RT_OK;
+}
+/* which traversal rt_trace_closest / rt_trace_stats exercise: 0 = 4-wide quantised BVH with the
+ * LDS stack (the one every frame kernel uses), 1 = binary LBVH with the stackless trail. */
+int rt_trace_mode(rt_ctx* c, int mode)
+{
+    RT_CHECK_CTX(c);
+    if (mode != 0 && mode != 1) RT_FAIL(c, RT_ERR_ARG, "mode must be 0 or 1");
+    c->trace_mode = mode;
     return RT_OK;
 }
 

@@ -165,7 +165,10 @@ int rt_trace_stats(rt_ctx* ctx, const float* rays, uint32_t n, uint32_t* stats);
 /* BVH build knob, call before rt_scene_set: large triangles are pre-split into fragments no
  * longer than split_factor x (median triangle extent); 0 = no pre-split. Default 8. */
 int rt_bvh_config(rt_ctx* ctx, float split_factor);
-int rt_bvh_info(rt_ctx* ctx, uint32_t* n_references, uint32_t* n_nodes);
+int rt_bvh_info(rt_ctx* ctx, uint32_t* n_references, uint32_t* n_wide_records);
+/* which traversal rt_trace_closest / rt_trace_stats exercise: 0 = 4-wide quantised BVH + LDS stack
+ * (what every frame kernel uses, default), 1 = binary LBVH + stackless trail (A/B measurements). */
+int rt_trace_mode(rt_ctx* ctx, int mode);
 /* elementwise device evaluation of the portable math / IEEE div & sqrt (parity tests);
  * fn ids as in tests/test_portable_math.py */
 int rt_math_eval(rt_ctx* ctx, int fn, const float* in, uint32_t n, float* out);

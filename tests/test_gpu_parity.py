@@ -118,10 +118,12 @@ def test_lbvh_equals_brute_force(api, oracle, scenes, golden_scenes):
         v = tris["v"].reshape(-1, 3)
         lo, hi = v.min(0), v.max(0)
         rays = _random_rays(rng, 60000 if len(tris) < 1000 else 20000, lo - 0.5, hi + 0.5)
-        dev = r.trace_closest(rays)
         sc = oracle.Scene(tris, use_bvh=False)
         ref = sc.trace_closest(rays, force_brute=True)
-        assert _eq_bits(dev, ref), f"{name}: {(dev.view(np.uint32) != ref.view(np.uint32)).any(axis=1).sum()} rays differ"
+        for mode in (0, 1):  # 0: 4-wide quantised BVH + LDS stack (production), 1: binary LBVH + stackless trail
+            r.trace_mode(mode)
+            dev = r.trace_closest(rays)
+            assert _eq_bits(dev, ref), f"{name} mode {mode}: {(dev.view(np.uint32) != ref.view(np.uint32)).any(axis=1).sum()} rays differ"
         assert (ref[:, 3].view(np.int32) >= 0).mean() > 0.2
         r.close()
 
@@ -137,10 +139,13 @@ def test_lbvh_blocks_scene_vs_oracle_bvh(api, oracle, scenes):
     rng = np.random.default_rng(3)
     v = tris["v"].reshape(-1, 3)
     rays = _random_rays(rng, 200000, np.float32([-20, 0, -10]), np.float32([40, 40, 60]))
-    dev = r.trace_closest(rays)
     sc = oracle.Scene(tris, use_bvh=True)
     ref = sc.trace_closest(rays)
-    assert _eq_bits(dev, ref), f"{(dev.view(np.uint32) != ref.view(np.uint32)).any(axis=1).sum()} rays differ"
+    for mode in (0, 1):
+        r.trace_mode(mode)
+        dev = r.trace_closest(rays)
+        assert _eq_bits(dev, ref), f"mode {mode}: {(dev.view(np.uint32) != ref.view(np.uint32)).any(axis=1).sum()} rays differ"
+    r.trace_mode(0)
     # a 2000-ray subset against true brute force
     sub = rays[:2000]
     assert _eq_bits(r.trace_closest(sub), sc.trace_closest(sub, force_brute=True))

@@ -11,6 +11,7 @@ r = api.Renderer(W, H)
 r.bvh_config(float(sys.argv[1]) if len(sys.argv) > 1 else 0.0)
 r.set_scene(tris)
 r.lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)
+r.trace_mode(int(os.environ.get("TRACE_MODE", "0")))
 rg = r.raygen()[0]
 o = rg["origin"]; right = rg["right"]; up = rg["up"]
 fw = np.cross(up, right); fw /= np.linalg.norm(fw)
