@@ -59,7 +59,8 @@ struct SceneView
     BvhView bvh;   /* binary LBVH, stackless trail traversal (kept for A/B measurements) */
     WideView wide; /* production traversal structure */
     const float4* __restrict__ trimat; /* 2 per triangle: {Kd.xyz, bits(emissive?)}, {Ke.xyz, 0} */
-    const float4* __restrict__ lights; /* 5 per light, see k_light_table */
+    const float4* __restrict__ lights;   /* 3 per light, see k_light_table */
+    const float4* __restrict__ light_ke; /* 1 per light: {Ke.xyz, 0} */
 };
 
 constexpr int TILE_W = 32, TILE_H = 8, BLOCK = 256;
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(BLOCK) void k_generate_candidate(
 
     PCG rng = pcg_init(hashPCG4((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame, 0u), 0);
     const float fL = (float)(size_t)P.n_lights;
+    int sel = -1;
     for (int i = 0; i < P.ris_sample_count; ++i)
     {
         /* draw order rv0, rv1, rv2, u: left-to-right argument evaluation (hipcc) */
@@ -225,14 +227,17 @@ __global__ __launch_bounds__(BLOCK) void k_generate_candidate(
         /* common/core.hpp:261-285 */
         uint32_t nth = (uint32_t)(rv0 * fL);
         if (nth == (uint32_t)P.n_lights) nth = (uint32_t)P.n_lights - 1u;
-        const float4* L = S.lights + 5 * (size_t)nth;
-        const float4 L0 = L[0], L1 = L[1], L2 = L[2], L3 = L[3], L4 = L[4];
+        /* 48-B light record = 3 lane-loads (the loop is bound by the number of divergent per-lane
+         * loads, not by ALU): vertices + luminance(Ke) + pdf; the normal is recomputed with the
+         * reference's exact expression (common/core.hpp:50-55), Ke is fetched once at the end. */
+        const float4* L = S.lights + 3 * (size_t)nth;
+        const float4 L0 = L[0], L1 = L[1], L2 = L[2];
         const f3 v0 = F3(L0.x, L0.y, L0.z), v1 = F3(L0.w, L1.x, L1.y), v2 = F3(L1.z, L1.w, L2.x);
         warp_unit_triangle(bx, by);
         const f3 lp = (1.0f - bx - by) * v0 + bx * v1 + by * v2;
-        const f3 ln = F3(L2.y, L2.z, L2.w);
-        const float lum = L3.w;
-        const float light_pdf = L4.x; /* 1/L * 1/area (:98-99) */
+        const f3 ln = tri_normal(v0, v1, v2);
+        const float lum = L2.y;
+        const float light_pdf = L2.z; /* 1/L * 1/area (:98-99) */
         const float p_hat = target_unshadowed(sp, sn, lp, ln, lum); /* unshadowed always (:104) */
         const float weight = p_hat / light_pdf;
         const float u = rng.uniformf();
@@ -241,9 +246,15 @@ __global__ __launch_bounds__(BLOCK) void k_generate_candidate(
         r.M += 1;
         if (u < weight / r.w_sum)
         {
-            r.hit_p = lp; r.hit_n = ln; r.rad = F3(L3.x, L3.y, L3.z); r.lum = lum;
+            r.hit_p = lp; r.hit_n = ln; r.lum = lum;
             r.org_p = sp; r.org_n = sn; r.vis = false;
+            sel = (int)nth;
         }
+    }
+    if (sel >= 0)
+    {
+        const float4 ke = S.light_ke[sel];
+        r.rad = F3(ke.x, ke.y, ke.z);
     }
     {
         const float p_hat = target_function<SHADOWED>(S, s_stack, sp, sn, r.hit_p, r.hit_n, r.lum);
@@ -537,12 +548,12 @@ __global__ void k_res_from_ref(int n, const uint32_t* __restrict__ in, const flo
 }
 
 /* ------------------------------------------------------------- scene tables */
-/* per emissive triangle (index order, 10_restir_di.cpp:196-205), 5 x float4:
- *   {v0.xyz, v1.x} {v1.yz, v2.xy} {v2.z, n.xyz} {Ke.xyz, luminance(Ke)} {pdf, bits(tri), 0, 0}
- * n = normal_of, pdf = 1/L * 1/area_of — the exact expressions of common/core.hpp:45-62 and
+/* per emissive triangle (index order, 10_restir_di.cpp:196-205), 3 x float4:
+ *   {v0.xyz, v1.x} {v1.yz, v2.xy} {v2.z, luminance(Ke), pdf, bits(tri)}   + a side table {Ke.xyz, 0}
+ * pdf = 1/L * 1/area_of — the exact expression of common/core.hpp:57-62 and
  * 10_restir_di.cu:98-99, evaluated once instead of once per candidate. */
 __global__ void k_light_table(int n_lights, const uint32_t* __restrict__ light_ids, const float* __restrict__ tris,
-                              float4* __restrict__ lights)
+                              float4* __restrict__ lights, float4* __restrict__ light_ke)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_lights) return;
@@ -550,14 +561,12 @@ __global__ void k_light_table(int n_lights, const uint32_t* __restrict__ light_i
     const float* t = tris + 15 * (size_t)ti;
     const f3 v0 = F3(t[0], t[1], t[2]), v1 = F3(t[3], t[4], t[5]), v2 = F3(t[6], t[7], t[8]);
     const f3 ke = F3(t[12], t[13], t[14]);
-    const f3 n = tri_normal(v0, v1, v2);
     const float pdf = 1.0f / (float)(size_t)n_lights * 1.0f / tri_area(v0, v1, v2);
-    float4* L = lights + 5 * (size_t)i;
+    float4* L = lights + 3 * (size_t)i;
     L[0] = make_float4(v0.x, v0.y, v0.z, v1.x);
     L[1] = make_float4(v1.y, v1.z, v2.x, v2.y);
-    L[2] = make_float4(v2.z, n.x, n.y, n.z);
-    L[3] = make_float4(ke.x, ke.y, ke.z, luminance(ke));
-    L[4] = make_float4(pdf, as_float(ti), 0.0f, 0.0f);
+    L[2] = make_float4(v2.z, luminance(ke), pdf, as_float(ti));
+    light_ke[i] = make_float4(ke.x, ke.y, ke.z, 0.0f);
 }
 __global__ void k_trimat(int n, const float* __restrict__ tris, float4* __restrict__ trimat)
 {
@@ -647,6 +656,7 @@ struct rt_ctx
     int n_wide = 0, wide_height = 0;
     float4* d_trimat = nullptr;
     float4* d_lights = nullptr;
+    float4* d_light_ke = nullptr;
 
     float4 *d_vis = nullptr, *d_g0 = nullptr, *d_g1 = nullptr, *d_accum = nullptr;
     uint32_t* d_pixels = nullptr;
@@ -721,7 +731,7 @@ static SceneView make_scene(const rt_ctx* c)
     SceneView S;
     S.bvh.nodes = c->d_nodes; S.bvh.tv = c->d_tv; S.bvh.n_tris = c->n_tris;
     S.wide.rec = c->d_wide; S.wide.n_tris = c->n_tris;
-    S.trimat = c->d_trimat; S.lights = c->d_lights;
+    S.trimat = c->d_trimat; S.lights = c->d_lights; S.light_ke = c->d_light_ke;
     return S;
 }
 static size_t local_pixels(const rt_ctx* c) { return (size_t)c->W * (size_t)c->lrows; }
@@ -772,7 +782,8 @@ int rt_create(int device, int width, int height, int row_begin, int row_end, int
 
 static void free_scene(rt_ctx* c)
 {
-    hipFree(c->d_tris); hipFree(c->d_tv); hipFree(c->d_nodes); hipFree(c->d_trimat); hipFree(c->d_lights); hipFree(c->d_wide);
+    hipFree(c->d_tris); hipFree(c->d_tv); hipFree(c->d_nodes); hipFree(c->d_trimat); hipFree(c->d_lights); hipFree(c->d_light_ke); hipFree(c->d_wide);
+    c->d_light_ke = nullptr;
     c->d_wide = nullptr;
     c->d_tris = nullptr; c->d_tv = nullptr; c->d_nodes = nullptr; c->d_trimat = nullptr; c->d_lights = nullptr;
     c->has_scene = false;
@@ -1224,8 +1235,9 @@ int rt_scene_set(rt_ctx* c, const rt_triangle* triangles, uint32_t count)
         uint32_t* d_ids = nullptr;
         RT_HIP(c, hipMalloc(&d_ids, lights.size() * 4));
         RT_HIP(c, hipMemcpyAsync(d_ids, lights.data(), lights.size() * 4, hipMemcpyHostToDevice, c->stream));
-        RT_HIP(c, hipMalloc(&c->d_lights, lights.size() * 80));
-        k_light_table<<<(c->n_lights + 255) / 256, 256, 0, c->stream>>>(c->n_lights, d_ids, c->d_tris, c->d_lights);
+        RT_HIP(c, hipMalloc(&c->d_lights, lights.size() * 48));
+        RT_HIP(c, hipMalloc(&c->d_light_ke, lights.size() * 16));
+        k_light_table<<<(c->n_lights + 255) / 256, 256, 0, c->stream>>>(c->n_lights, d_ids, c->d_tris, c->d_lights, c->d_light_ke);
         RT_HIP(c, hipGetLastError());
         RT_HIP(c, hipStreamSynchronize(c->stream));
         hipFree(d_ids);
