@@ -24,7 +24,7 @@ EXPORTS = [
     "rt_raycast", "rt_generate_candidate", "rt_temporal_resampling", "rt_save_temporal_reservoir",
     "rt_spatial_resampling", "rt_resolve", "rt_tone_mapping", "rt_frame", "rt_local_rows", "rt_download",
     "rt_upload", "rt_halo_bytes", "rt_halo_pack", "rt_halo_unpack", "rt_ray_count", "rt_timing_enable",
-    "rt_timing", "rt_spatial_bytes", "rt_trace_closest", "rt_trace_stats", "rt_bvh_config", "rt_bvh_info", "rt_trace_mode", "rt_math_eval",
+    "rt_timing", "rt_spatial_bytes", "rt_trace_closest", "rt_trace_stats", "rt_bvh_config", "rt_bvh_info", "rt_trace_mode", "rt_tuning", "rt_math_eval",
 ]
 
 
@@ -92,6 +92,7 @@ def load_library():
     L.rt_bvh_config.argtypes = [vp, cf]
     L.rt_bvh_info.argtypes = [vp, vp, vp]
     L.rt_trace_mode.argtypes = [vp, ci]
+    L.rt_tuning.argtypes = [vp, ci, ci]
     _lib = L
     return L
 
@@ -289,6 +290,9 @@ class Renderer:
 
     def trace_mode(self, mode):
         self._ck(self.L.rt_trace_mode(self.h, int(mode)))
+
+    def tuning(self, key, value):
+        self._ck(self.L.rt_tuning(self.h, int(key), int(value)))
 
     def bvh_info(self):
         a, b = C.c_uint32(), C.c_uint32()

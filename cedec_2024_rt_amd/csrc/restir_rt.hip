@@ -52,6 +52,7 @@ struct FrameParams
     /* options (common/options.hpp) */
     int accumulate, ris_sample_count, use_temporal, use_spatial, spatial_count, vis_reuse;
     float spatial_radius;
+    int tile_mode; /* workgroup -> tile order inside an XCD's band: 0 row-major, 1 column-major */
 };
 
 struct SceneView
@@ -65,25 +66,46 @@ struct SceneView
 
 constexpr int TILE_W = 32, TILE_H = 8, BLOCK = 256;
 
-/* XCD-aware workgroup -> tile -> pixel. Returns false for threads outside the row range. */
+/* XCD-aware workgroup -> tile -> pixel. Returns false for threads outside the row range.
+ * Workgroup b runs on XCD b % 8 (round-robin dispatch); slot b / 8 walks that XCD's band of
+ * tile rows either row by row (mode 0) or column by column (mode 1: the set of tiles in flight
+ * on an XCD is then ~13 tiles wide x the band height instead of full-width x 4 rows, which is
+ * what keeps the spatial pass's neighbour window inside the 4 MiB L2). */
 RT_DEV bool tile_pixel(const FrameParams& P, int& x, int& row)
 {
     const int tiles_x = (P.W + TILE_W - 1) / TILE_W;
     const int tiles_y = (P.row1 - P.row0 + TILE_H - 1) / TILE_H;
-    const int n_tiles = tiles_x * tiles_y;
-    const int per_xcd = (n_tiles + 7) / 8;
     const int b = blockIdx.x;
-    const int tile = (b & 7) * per_xcd + (b >> 3);
-    if (tile >= n_tiles) return false;
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    int tx, ty;
+    if (P.tile_mode == 1)
+    {
+        const int band_rows = (tiles_y + 7) / 8;
+        const int slot = b >> 3;
+        tx = slot / band_rows;
+        ty = (b & 7) * band_rows + (slot - tx * band_rows);
+        if (tx >= tiles_x || ty >= tiles_y) return false;
+    }
+    else
+    {
+        const int n_tiles = tiles_x * tiles_y;
+        const int per_xcd = (n_tiles + 7) / 8;
+        const int slot = b >> 3;
+        if (slot >= per_xcd) return false; /* the grid is sized for either order */
+        const int tile = (b & 7) * per_xcd + slot;
+        if (tile >= n_tiles) return false;
+        ty = tile / tiles_x;
+        tx = tile - ty * tiles_x;
+    }
     x = tx * TILE_W + (threadIdx.x & (TILE_W - 1));
     row = P.row0 + ty * TILE_H + (threadIdx.x >> 5);
     return x < P.W && row < P.row1;
 }
 static inline int tile_grid(int W, int rows)
 {
-    const int tiles = ((W + TILE_W - 1) / TILE_W) * ((rows + TILE_H - 1) / TILE_H);
-    return ((tiles + 7) / 8) * 8;
+    /* covers both orders: mode 1 needs 8 * ceil(tiles_y/8) * tiles_x workgroups */
+    const int tx = (W + TILE_W - 1) / TILE_W, ty = (rows + TILE_H - 1) / TILE_H;
+    const int a = ((tx * ty + 7) / 8) * 8, b = 8 * ((ty + 7) / 8) * tx;
+    return a > b ? a : b;
 }
 
 /* common/core.hpp:189-207: surface point + normal flipped toward the eye [parity] */
@@ -647,6 +669,10 @@ struct rt_ctx
     std::string err;
 
     int n_tris = 0, n_lights = 0, bvh_height = 0, n_refs = 0;
+    /* rt_tuning: tile order per kernel {raycast, generate, spatial, resolve, other} and the spatial
+     * pass's occupancy limiter (extra dynamic LDS). Defaults from the sweep in DESIGN.md §5. */
+    int tune_tile_mode[5] = {1, 0, 1, 0, 0};
+    int tune_spatial_lds = 32768;
     int trace_mode = 0; /* rt_trace_closest / rt_trace_stats: 0 = wide (what the frame kernels use), 1 = binary stackless */
     float bvh_split_factor = 8.0f; /* fragment length in median triangle extents; 0 = no pre-split */
     float* d_tris = nullptr;
@@ -708,7 +734,8 @@ static rt_options default_options()
     return o;
 }
 
-static FrameParams make_params(const rt_ctx* c, int frame, int pass)
+enum { K_RAYCAST = 0, K_GENERATE = 1, K_SPATIAL = 2, K_RESOLVE = 3, K_OTHER = 4 };
+static FrameParams make_params(const rt_ctx* c, int frame, int pass, int kernel = K_OTHER)
 {
     FrameParams P;
     P.W = c->W; P.H = c->H;
@@ -724,6 +751,7 @@ static FrameParams make_params(const rt_ctx* c, int frame, int pass)
     P.use_temporal = c->opt.use_temporal_resampling; P.use_spatial = c->opt.use_spatial_resampling;
     P.spatial_count = c->opt.spatial_resampling_sample_count; P.vis_reuse = c->opt.use_visibility_reuse;
     P.spatial_radius = c->opt.spatial_resampling_radius;
+    P.tile_mode = c->tune_tile_mode[kernel];
     return P;
 }
 static SceneView make_scene(const rt_ctx* c)
@@ -1335,7 +1363,7 @@ int rt_raycast(rt_ctx* c)
 {
     RT_CHECK_CTX(c);
     NEED_SCENE(c);
-    k_raycast<<<launch_grid(c), BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0), c->d_vis, c->d_g0, c->d_g1);
+    k_raycast<<<launch_grid(c), BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_vis, c->d_g0, c->d_g1);
     RT_HIP(c, hipGetLastError());
     c->has_gbuffer = true;
     return RT_OK;
@@ -1346,7 +1374,7 @@ static int launch_generate(rt_ctx* c, int frame, int dst_phys, int prev_phys, bo
     if (c->n_lights == 0 && c->opt.ris_sample_count > 0)
         RT_FAIL(c, RT_ERR_STATE, "scene has no emissive triangle (the reference divides by zero here)");
     const SceneView S = make_scene(c);
-    const FrameParams P = make_params(c, frame, 0);
+    const FrameParams P = make_params(c, frame, 0, K_GENERATE);
     const bool sh = c->opt.use_shadowed_target_function;
     float4 *orec = c->d_rec[dst_phys], *orad = c->d_rad[dst_phys];
     const float4 *prec = fuse ? c->d_rec[prev_phys] : nullptr, *prad = fuse ? c->d_rad[prev_phys] : nullptr;
@@ -1404,11 +1432,11 @@ int rt_save_temporal_reservoir(rt_ctx* c, int src, int dst)
 static int launch_spatial(rt_ctx* c, int frame, int pass, int in_phys, int out_phys)
 {
     const SceneView S = make_scene(c);
-    const FrameParams P = make_params(c, frame, pass);
+    const FrameParams P = make_params(c, frame, pass, K_SPATIAL);
     if (c->opt.use_shadowed_target_function)
-        k_spatial<true><<<launch_grid(c), BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys]);
+        k_spatial<true><<<launch_grid(c), BLOCK, (size_t)c->tune_spatial_lds, c->stream>>>(S, P, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys]);
     else
-        k_spatial<false><<<launch_grid(c), BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys]);
+        k_spatial<false><<<launch_grid(c), BLOCK, (size_t)c->tune_spatial_lds, c->stream>>>(S, P, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys]);
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }
@@ -1425,7 +1453,7 @@ int rt_spatial_resampling(rt_ctx* c, int frame, int pass, int in, int out)
 
 static int launch_resolve(rt_ctx* c, int phys)
 {
-    k_resolve<<<launch_grid(c), BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0), c->d_g0, c->d_g1,
+    k_resolve<<<launch_grid(c), BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RESOLVE), c->d_g0, c->d_g1,
                                                         c->d_rec[phys], c->d_rad[phys], c->d_accum);
     RT_HIP(c, hipGetLastError());
     return RT_OK;
@@ -1730,6 +1758,17 @@ int rt_bvh_config(rt_ctx* c, float split_factor)
     RT_CHECK_CTX(c);
     if (!(split_factor >= 0.0f)) RT_FAIL(c, RT_ERR_ARG, "split_factor must be >= 0");
     c->bvh_split_factor = split_factor;
+    return RT_OK;
+}
+/* performance knobs (results never depend on them): keys 0..3 = tile order of raycast /
+ * generate_candidate(+temporal) / spatial_resampling / resolve (0 row-major, 1 column-major inside
+ * each XCD band); key 4 = extra LDS bytes per spatial workgroup (limits resident workgroups per CU). */
+int rt_tuning(rt_ctx* c, int key, int value)
+{
+    RT_CHECK_CTX(c);
+    if (key >= 0 && key <= 3 && (value == 0 || value == 1)) c->tune_tile_mode[key] = value;
+    else if (key == 4 && value >= 0 && value <= 160 * 1024) c->tune_spatial_lds = value;
+    else RT_FAIL(c, RT_ERR_ARG, "bad tuning key/value %d/%d", key, value);
     return RT_OK;
 }
 /* which traversal rt_trace_closest / rt_trace_stats exercise: 0 = 4-wide quantised BVH with the

@@ -169,6 +169,11 @@ int rt_bvh_info(rt_ctx* ctx, uint32_t* n_references, uint32_t* n_wide_records);
 /* which traversal rt_trace_closest / rt_trace_stats exercise: 0 = 4-wide quantised BVH + LDS stack
  * (what every frame kernel uses, default), 1 = binary LBVH + stackless trail (A/B measurements). */
 int rt_trace_mode(rt_ctx* ctx, int mode);
+/* performance knobs; results never depend on them. keys 0..3: workgroup->tile order inside an XCD
+ * band for raycast / generate_candidate / spatial_resampling / resolve (0 row-major, 1 column-major);
+ * key 4: extra LDS bytes per spatial_resampling workgroup (limits the workgroups resident per CU,
+ * i.e. the neighbour window that must stay in L2). Defaults: {1,0,1,0}, 32768. */
+int rt_tuning(rt_ctx* ctx, int key, int value);
 /* elementwise device evaluation of the portable math / IEEE div & sqrt (parity tests);
  * fn ids as in tests/test_portable_math.py */
 int rt_math_eval(rt_ctx* ctx, int fn, const float* in, uint32_t n, float* out);
