@@ -84,13 +84,21 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if os.environ.get("BENCH_SHARE_GPU0"):  # test aid: several ranks on one GPU (1-GPU dev box)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=dev)
+        # RCCL over xGMI; BENCH_BACKEND=gloo (host-staged halos) only exists to exercise the N>1
+        # path on a single-GPU development box, where RCCL rejects two ranks on one device
+        backend = os.environ.get("BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     width, height = args.width, args.height
     tris = scenes.make_blocks_restir()
@@ -165,10 +173,11 @@ def main():
             sf.frame(frame)
         barrier()
         dt = time.perf_counter() - t0
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        rr = torch.tensor([my_rays], dtype=torch.int64, device=dev)
+        rr = torch.tensor([my_rays], dtype=torch.int64, device=cdev)
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
         total_rays = int(rr.item())
         info = r.scene_info()

@@ -16,13 +16,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "librestir_rt.so")
 
 RT_RES_0, RT_RES_1, RT_RES_TEMPORAL = 0, 1, 2
+RT_RES_PHYS = 16
 RT_BUF_VISIBILITY, RT_BUF_RES_0, RT_BUF_RES_1, RT_BUF_RES_TEMPORAL, RT_BUF_ACCUMULATION, RT_BUF_PIXELS = range(6)
 
 EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_sync", "rt_scene_set", "rt_scene_info",
     "rt_camera_lookat", "rt_camera_set", "rt_camera_get", "rt_options_set", "rt_options_get", "rt_clear",
     "rt_raycast", "rt_generate_candidate", "rt_temporal_resampling", "rt_save_temporal_reservoir",
-    "rt_spatial_resampling", "rt_resolve", "rt_tone_mapping", "rt_frame", "rt_local_rows", "rt_download",
+    "rt_spatial_resampling", "rt_resolve", "rt_tone_mapping", "rt_frame", "rt_frame_stage", "rt_frame_stage_input", "rt_local_rows", "rt_download",
     "rt_upload", "rt_halo_bytes", "rt_halo_pack", "rt_halo_unpack", "rt_ray_count", "rt_timing_enable",
     "rt_timing", "rt_spatial_bytes", "rt_trace_closest", "rt_trace_stats", "rt_bvh_config", "rt_bvh_info", "rt_trace_mode", "rt_tuning", "rt_math_eval",
 ]
@@ -75,6 +76,8 @@ def load_library():
     L.rt_resolve.argtypes = [vp, ci]
     L.rt_tone_mapping.argtypes = [vp]
     L.rt_frame.argtypes = [vp, ci, ci, vp]
+    L.rt_frame_stage.argtypes = [vp, ci, ci, ci]
+    L.rt_frame_stage_input.argtypes = [vp, ci, vp]
     L.rt_local_rows.argtypes = [vp, vp, vp]
     L.rt_download.argtypes = [vp, ci, vp, C.c_size_t]
     L.rt_upload.argtypes = [vp, ci, vp, C.c_size_t]
@@ -227,6 +230,14 @@ class Renderer:
         out = C.c_int(-1)
         self._ck(self.L.rt_frame(self.h, int(frame), int(bool(clear_first)), C.byref(out)))
         return out.value
+
+    def frame_stage(self, frame, stage, clear_first=False):
+        self._ck(self.L.rt_frame_stage(self.h, int(frame), int(stage), int(bool(clear_first))))
+
+    def frame_stage_input(self, stage):
+        p = C.c_int(-1)
+        self._ck(self.L.rt_frame_stage_input(self.h, int(stage), C.byref(p)))
+        return RT_RES_PHYS + p.value
 
     def sync(self):
         self._ck(self.L.rt_sync(self.h))

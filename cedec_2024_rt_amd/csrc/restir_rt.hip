@@ -689,6 +689,7 @@ struct rt_ctx
     float4* d_rec[3] = {nullptr, nullptr, nullptr};
     float4* d_rad[3] = {nullptr, nullptr, nullptr};
     int res_map[3] = {0, 1, 2};
+    int fX = 0, fY = 1, fZ = 2, f_in = 0, f_out = 1, f_stage = 0, f_final = RT_RES_1; /* rt_frame_stage state */
     unsigned long long* d_counter = nullptr;
     void* d_stage = nullptr;
     size_t stage_bytes = 0;
@@ -1487,53 +1488,96 @@ int rt_timing_enable(rt_ctx* c, int on)
     return RT_OK;
 }
 
+/* The frame as a sequence of stages, so that a strip context can exchange halos in between:
+ *   stage 0            [clear] raycast, generate_candidate(+temporal) into the rotating buffers
+ *   stage 1..passes    spatial pass stage-1      (its input buffer must have valid halos)
+ *   stage passes+1     resolve, tone_mapping, buffer renaming
+ * rt_frame runs them back to back. */
+int rt_frame_stage(rt_ctx* c, int frame, int stage, int clear_first)
+{
+    RT_CHECK_CTX(c);
+    NEED_SCENE(c);
+    const int passes = c->opt.spatial_resampling_passes;
+    const bool T = c->timing;
+    auto mark = [&](int i) { if (T && i <= 8) hipEventRecord(c->ev[i], c->stream); };
+    int rc;
+    if (stage == 0)
+    {
+        mark(0);
+        if (clear_first) { if ((rc = rt_clear(c)) != RT_OK) return rc; }
+        mark(1);
+        if ((rc = rt_raycast(c)) != RT_OK) return rc;
+        mark(2);
+        /* X = history, Y = candidates(+temporal) -> next history, Z = spatial ping-pong partner */
+        c->fX = c->res_map[RT_RES_TEMPORAL]; c->fY = c->res_map[RT_RES_0]; c->fZ = c->res_map[RT_RES_1];
+        if ((rc = launch_generate(c, frame, c->fY, c->fX, c->opt.use_temporal_resampling != 0)) != RT_OK) return rc;
+        mark(3);
+        c->f_in = c->fY; c->f_out = c->fZ;
+        c->f_stage = 1;
+        return RT_OK;
+    }
+    if (stage != c->f_stage) RT_FAIL(c, RT_ERR_STATE, "rt_frame_stage: expected stage %d, got %d", c->f_stage, stage);
+    if (stage <= passes)
+    {
+        const int k = stage - 1;
+        if (k != 0) { c->f_in = c->f_out; c->f_out = (c->f_in == c->fZ) ? c->fX : c->fZ; }
+        if ((rc = launch_spatial(c, frame, k, c->f_in, c->f_out)) != RT_OK) return rc;
+        if (k < 3) mark(4 + k);
+        c->f_stage = stage + 1;
+        return RT_OK;
+    }
+    if (stage == passes + 1)
+    {
+        for (int k = passes; k < 3; ++k) mark(4 + k);
+        const int X = c->fX, Y = c->fY, Z = c->fZ;
+        if (passes < 2)
+        {
+            /* logical RT_RES_0 still equals the post-temporal reservoirs: materialise the copy the
+             * reference's save_temporal_reservoir makes (10_restir_di.cpp:314-321) */
+            const size_t n = local_pixels(c);
+            RT_HIP(c, hipMemcpyAsync(c->d_rec[X], c->d_rec[Y], n * 64, hipMemcpyDeviceToDevice, c->stream));
+            RT_HIP(c, hipMemcpyAsync(c->d_rad[X], c->d_rad[Y], n * 16, hipMemcpyDeviceToDevice, c->stream));
+        }
+        const int final_phys = passes > 0 ? c->f_out : Z;
+        if ((rc = launch_resolve(c, final_phys)) != RT_OK) return rc;
+        mark(7);
+        if ((rc = rt_tone_mapping(c)) != RT_OK) return rc;
+        mark(8);
+        /* new logical names: TEMPORAL = Y; RES_1 = Z; RES_0 = X (pass-1 output / copy) */
+        c->res_map[RT_RES_TEMPORAL] = Y;
+        c->res_map[RT_RES_0] = X;
+        c->res_map[RT_RES_1] = Z;
+        c->f_final = (final_phys == Z) ? RT_RES_1 : RT_RES_0;
+        c->f_stage = 0;
+        c->last_valid = T;
+        return RT_OK;
+    }
+    RT_FAIL(c, RT_ERR_ARG, "bad stage %d", stage);
+}
+
+/* physical buffer that spatial pass `stage-1` of the running frame will read (for rt_halo_*_phys) */
+int rt_frame_stage_input(rt_ctx* c, int stage, int* phys)
+{
+    RT_CHECK_CTX(c);
+    if (!phys || stage < 1 || stage != c->f_stage) RT_FAIL(c, RT_ERR_STATE, "no such pending stage %d", stage);
+    const int k = stage - 1;
+    *phys = (k == 0) ? c->f_in : c->f_out;
+    return RT_OK;
+}
+
 int rt_frame(rt_ctx* c, int frame, int clear_first, int* final_res)
 {
     RT_CHECK_CTX(c);
     NEED_SCENE(c);
     if (c->row_begin != 0 || c->row_end != c->H)
-        RT_FAIL(c, RT_ERR_STATE, "rt_frame is for single-strip contexts; strips run the passes and exchange halos");
-    const bool T = c->timing;
-    int ei = 0;
-    auto mark = [&]() { if (T) hipEventRecord(c->ev[ei], c->stream); ++ei; };
-    int rc;
-    mark(); /* 0 */
-    if (clear_first) { if ((rc = rt_clear(c)) != RT_OK) return rc; }
-    mark(); /* 1 */
-    if ((rc = rt_raycast(c)) != RT_OK) return rc;
-    mark(); /* 2 */
-    /* X = history, Y = candidates(+temporal) -> next history, Z = spatial ping-pong partner */
-    const int X = c->res_map[RT_RES_TEMPORAL], Y = c->res_map[RT_RES_0], Z = c->res_map[RT_RES_1];
-    if ((rc = launch_generate(c, frame, Y, X, c->opt.use_temporal_resampling != 0)) != RT_OK) return rc;
-    mark(); /* 3 */
+        RT_FAIL(c, RT_ERR_STATE, "rt_frame is for single-strip contexts; strips run rt_frame_stage and exchange halos");
     const int passes = c->opt.spatial_resampling_passes;
-    int in = Y, out = Z;
-    for (int k = 0; k < passes; ++k)
+    for (int st = 0; st <= passes + 1; ++st)
     {
-        if (k != 0) { in = out; out = (in == Z) ? X : Z; }
-        if ((rc = launch_spatial(c, frame, k, in, out)) != RT_OK) return rc;
-        if (k < 3) mark(); /* 4,5,6 */
+        const int rc = rt_frame_stage(c, frame, st, clear_first);
+        if (rc != RT_OK) return rc;
     }
-    for (int k = passes; k < 3; ++k) mark();
-    if (passes < 2)
-    {
-        /* logical RT_RES_0 still equals the post-temporal reservoirs: materialise the copy the
-         * reference's save_temporal_reservoir makes (10_restir_di.cpp:314-321) */
-        const size_t n = local_pixels(c);
-        RT_HIP(c, hipMemcpyAsync(c->d_rec[X], c->d_rec[Y], n * 64, hipMemcpyDeviceToDevice, c->stream));
-        RT_HIP(c, hipMemcpyAsync(c->d_rad[X], c->d_rad[Y], n * 16, hipMemcpyDeviceToDevice, c->stream));
-    }
-    const int final_phys = passes > 0 ? out : Z;
-    if ((rc = launch_resolve(c, final_phys)) != RT_OK) return rc;
-    mark(); /* 7 */
-    if ((rc = rt_tone_mapping(c)) != RT_OK) return rc;
-    mark(); /* 8 */
-    /* new logical names: TEMPORAL = Y; RES_1 = Z; RES_0 = X (pass-1 output / copy) */
-    c->res_map[RT_RES_TEMPORAL] = Y;
-    c->res_map[RT_RES_0] = X;
-    c->res_map[RT_RES_1] = Z;
-    if (final_res) *final_res = (final_phys == Z) ? RT_RES_1 : RT_RES_0;
-    c->last_valid = T;
+    if (final_res) *final_res = c->f_final;
     return RT_OK;
 }
 
@@ -1645,13 +1689,21 @@ static int halo_range(rt_ctx* c, int row0, int n_rows)
         RT_FAIL(c, RT_ERR_ARG, "rows [%d,%d) outside the rows held [%d,%d)", row0, row0 + n_rows, c->lrow0, c->lrow0 + c->lrows);
     return RT_OK;
 }
+/* res: RT_RES_* (logical) or RT_RES_PHYS + p for the physical buffer p that
+ * rt_frame_stage_input reported */
+static int halo_phys(rt_ctx* c, int res)
+{
+    if (res >= RT_RES_PHYS && res < RT_RES_PHYS + 3) return res - RT_RES_PHYS;
+    if (res >= 0 && res <= 2) return c->res_map[res];
+    return -1;
+}
 int rt_halo_pack(rt_ctx* c, int res, int row0, int n_rows, void* device_dst)
 {
     RT_CHECK_CTX(c);
-    NEED_RES(c, res);
+    const int phys = halo_phys(c, res);
+    if (phys < 0) RT_FAIL(c, RT_ERR_ARG, "bad reservoir buffer id %d", res);
     int rc = halo_range(c, row0, n_rows);
     if (rc != RT_OK) return rc;
-    const int phys = c->res_map[res];
     const size_t off = (size_t)(row0 - c->lrow0) * c->W, n = (size_t)n_rows * c->W;
     RT_HIP(c, hipMemcpyAsync(device_dst, c->d_rec[phys] + 4 * off, n * 64, hipMemcpyDeviceToDevice, c->stream));
     RT_HIP(c, hipMemcpyAsync((char*)device_dst + n * 64, c->d_rad[phys] + off, n * 16, hipMemcpyDeviceToDevice, c->stream));
@@ -1660,10 +1712,10 @@ int rt_halo_pack(rt_ctx* c, int res, int row0, int n_rows, void* device_dst)
 int rt_halo_unpack(rt_ctx* c, int res, int row0, int n_rows, const void* device_src)
 {
     RT_CHECK_CTX(c);
-    NEED_RES(c, res);
+    const int phys = halo_phys(c, res);
+    if (phys < 0) RT_FAIL(c, RT_ERR_ARG, "bad reservoir buffer id %d", res);
     int rc = halo_range(c, row0, n_rows);
     if (rc != RT_OK) return rc;
-    const int phys = c->res_map[res];
     const size_t off = (size_t)(row0 - c->lrow0) * c->W, n = (size_t)n_rows * c->W;
     RT_HIP(c, hipMemcpyAsync(c->d_rec[phys] + 4 * off, device_src, n * 64, hipMemcpyDeviceToDevice, c->stream));
     RT_HIP(c, hipMemcpyAsync(c->d_rad[phys] + off, (const char*)device_src + n * 64, n * 16, hipMemcpyDeviceToDevice, c->stream));

@@ -87,6 +87,14 @@ class StripFrame:
 
     def frame(self, frame, clear_first=False):
         b = self.b
+        if getattr(b, "staged", False):
+            # fused stages of the C-ABI (generate+temporal in one kernel, rotating buffers)
+            b.frame_stage(frame, 0, clear_first)
+            for k in range(b.passes):
+                self.exchange(b.frame_stage_input(k + 1))
+                b.frame_stage(frame, k + 1)
+            b.frame_stage(frame, b.passes + 1)
+            return None
         if clear_first:
             b.clear()
         b.raycast()
@@ -108,25 +116,38 @@ class HipStripBackend:
     """Product backend: one C-ABI context on this rank's GPU, work enqueued on torch's current
     stream so that RCCL's stream dependencies order packs, sends, receives and unpacks."""
 
-    def __init__(self, renderer, device):
+    def __init__(self, renderer, device, host_staging=False):
         import torch
 
         self.r, self.torch, self.device = renderer, torch, device
         self.passes = int(renderer.options()["spatial_resampling_passes"][0])
+        # host_staging: the transport cannot move device memory (gloo; used to exercise this path
+        # with several ranks on ONE GPU, where RCCL refuses duplicate devices)
+        self.host_staging = host_staging
+        self.staged = True  # use rt_frame_stage
 
     def __getattr__(self, name):  # kernel entry points pass straight through
         return getattr(self.r, name)
 
-    def halo_empty(self, n_rows):
+    def _dev_empty(self, n_rows):
         return self.torch.empty(self.r.halo_bytes(n_rows), dtype=self.torch.uint8, device=self.device)
 
+    def halo_empty(self, n_rows):
+        if self.host_staging:
+            return self.torch.empty(self.r.halo_bytes(n_rows), dtype=self.torch.uint8)
+        return self._dev_empty(n_rows)
+
     def halo_export(self, res, row0, n_rows):
-        t = self.halo_empty(n_rows)
+        t = self._dev_empty(n_rows)
         self.r.halo_pack(res, row0, n_rows, t.data_ptr())
-        return t
+        return t.cpu() if self.host_staging else t
 
     def halo_import(self, res, row0, n_rows, t):
+        if self.host_staging:
+            t = t.to(self.device)
         self.r.halo_unpack(res, row0, n_rows, t.data_ptr())
+        if self.host_staging:
+            self.torch.cuda.current_stream().synchronize()  # t is freed on return
 
 
 def make_hip_strip(width, height, rank, world, triangles, eye, center, options, device_index=None):
@@ -144,16 +165,34 @@ def make_hip_strip(width, height, rank, world, triangles, eye, center, options, 
     r.set_scene(triangles)
     r.lookat(eye, center)
     r.set_options(options)
-    be = HipStripBackend(r, torch.device("cuda", dev))
+    host_staging = world > 1 and dist.get_backend() == "gloo"
+    be = HipStripBackend(r, torch.device("cuda", dev), host_staging=host_staging)
     return r, StripFrame(be, bounds, rank, dist if world > 1 else None)
 
 
-def run_frame_local(renderers, bounds, frame, device, halo=HALO_ROWS):
+def run_frame_local(renderers, bounds, frame, device, halo=HALO_ROWS, staged=False):
     """Single-process variant for tests: several strip contexts on ONE GPU, halos moved through a
     device staging tensor with explicit stream syncs (no torch.distributed)."""
     import torch
 
     passes = int(renderers[0].options()["spatial_resampling_passes"][0])
+    if staged:
+        for r in renderers:
+            r.frame_stage(frame, 0)
+        for k in range(passes):
+            for rank, r in enumerate(renderers):
+                for peer, s0, sn, r0, rn in exchange_plan(bounds, rank, halo):
+                    t = torch.empty(renderers[peer].halo_bytes(rn), dtype=torch.uint8, device=device)
+                    renderers[peer].halo_pack(renderers[peer].frame_stage_input(k + 1), r0, rn, t.data_ptr())
+                    renderers[peer].sync()
+                    r.halo_unpack(r.frame_stage_input(k + 1), r0, rn, t.data_ptr())
+                    r.sync()
+            for r in renderers:
+                r.frame_stage(frame, k + 1)
+        for r in renderers:
+            r.frame_stage(frame, passes + 1)
+            r.sync()
+        return None
     for r in renderers:
         r.raycast()
         r.generate_candidate(frame, RT_RES_0)

@@ -71,7 +71,7 @@ enum
 };
 
 /* reservoir buffers of 10_restir_di.cpp:113-122 */
-enum { RT_RES_0 = 0, RT_RES_1 = 1, RT_RES_TEMPORAL = 2 };
+enum { RT_RES_0 = 0, RT_RES_1 = 1, RT_RES_TEMPORAL = 2, RT_RES_PHYS = 16 /* + physical index, see rt_frame_stage_input */ };
 /* rt_download / rt_upload targets (reference layouts) */
 enum
 {
@@ -126,6 +126,12 @@ int rt_tone_mapping(rt_ctx* ctx);                            /* tone_mapping    
  * resolve read. Single-strip contexts only; strips drive the passes themselves and exchange
  * halos between spatial passes (rt_halo_*). */
 int rt_frame(rt_ctx* ctx, int frame, int clear_first, int* final_res);
+/* The same frame cut into stages for strip contexts (multi-GPU): stage 0 = [clear,] raycast,
+ * generate_candidate(+temporal); stage k in 1..passes = spatial pass k-1; stage passes+1 = resolve,
+ * tone_mapping, buffer renaming. Before stage k in 1..passes the caller must fill the halo rows of
+ * the buffer rt_frame_stage_input(ctx, k, &p) names (use RT_RES_PHYS + p with rt_halo_pack/unpack). */
+int rt_frame_stage(rt_ctx* ctx, int frame, int stage, int clear_first);
+int rt_frame_stage_input(rt_ctx* ctx, int stage, int* physical_buffer);
 
 /* ---- host <-> device in the reference's layouts (fixture injection, result read-back) ----
  * Element counts are W * (rows held) where rows held = owned rows + halos clipped to the

@@ -282,7 +282,8 @@ def test_frame_parity_blocks_restir_quarter_res(api, oracle, scenes):
     r.close()
 
 
-def test_strip_contexts_match_full_frame(api, oracle, scenes):
+@pytest.mark.parametrize("staged", [False, True])
+def test_strip_contexts_match_full_frame(api, oracle, scenes, staged):
     """Two row-strip contexts on one GPU with an 87-row halo exchanged through the C-ABI halo
     calls reproduce the single-context frame bit for bit."""
     import ctypes as C
@@ -310,7 +311,7 @@ def test_strip_contexts_match_full_frame(api, oracle, scenes):
     for frame in (1, 2):
         full.frame(frame)
         ref = full.download(api.RT_BUF_ACCUMULATION).reshape(H, W, 4)
-        strips.run_frame_local(ctxs, bounds, frame, torch.device("cuda:0"))
+        strips.run_frame_local(ctxs, bounds, frame, torch.device("cuda:0"), staged=staged)
         for c, (a, b) in zip(ctxs, bounds):
             acc = c.download(api.RT_BUF_ACCUMULATION).reshape(c.local_rows, W, 4)
             mine = acc[a - c.local_row0: b - c.local_row0]
