@@ -23,7 +23,7 @@ EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_sync", "rt_scene_set", "rt_scene_info",
     "rt_camera_lookat", "rt_camera_set", "rt_camera_get", "rt_options_set", "rt_options_get", "rt_clear",
     "rt_raycast", "rt_generate_candidate", "rt_temporal_resampling", "rt_save_temporal_reservoir",
-    "rt_spatial_resampling", "rt_resolve", "rt_tone_mapping", "rt_frame", "rt_frame_stage", "rt_frame_stage_input", "rt_local_rows", "rt_download",
+    "rt_spatial_resampling", "rt_resolve", "rt_tone_mapping", "rt_frame", "rt_frame_stage", "rt_frame_stage_input", "rt_path_trace", "rt_path_trace_rays", "rt_local_rows", "rt_download",
     "rt_upload", "rt_halo_bytes", "rt_halo_pack", "rt_halo_unpack", "rt_ray_count", "rt_timing_enable",
     "rt_timing", "rt_spatial_bytes", "rt_trace_closest", "rt_trace_stats", "rt_bvh_config", "rt_bvh_info", "rt_trace_mode", "rt_tuning", "rt_math_eval",
 ]
@@ -76,6 +76,8 @@ def load_library():
     L.rt_resolve.argtypes = [vp, ci]
     L.rt_tone_mapping.argtypes = [vp]
     L.rt_frame.argtypes = [vp, ci, ci, vp]
+    L.rt_path_trace.argtypes = [vp, ci, ci]
+    L.rt_path_trace_rays.argtypes = [vp, vp]
     L.rt_frame_stage.argtypes = [vp, ci, ci, ci]
     L.rt_frame_stage_input.argtypes = [vp, ci, vp]
     L.rt_local_rows.argtypes = [vp, vp, vp]
@@ -230,6 +232,15 @@ class Renderer:
         out = C.c_int(-1)
         self._ck(self.L.rt_frame(self.h, int(frame), int(bool(clear_first)), C.byref(out)))
         return out.value
+
+    def path_trace(self, example, frame):
+        """`path_trace` of examples/07_pt (example=7) or examples/09_ris (example=9)."""
+        self._ck(self.L.rt_path_trace(self.h, int(example), int(frame)))
+
+    def path_trace_rays(self):
+        a = C.c_uint64()
+        self._ck(self.L.rt_path_trace_rays(self.h, C.byref(a)))
+        return a.value
 
     def frame_stage(self, frame, stage, clear_first=False):
         self._ck(self.L.rt_frame_stage(self.h, int(frame), int(stage), int(bool(clear_first))))

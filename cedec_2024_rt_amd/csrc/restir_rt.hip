@@ -497,6 +497,136 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(SceneView S, FrameParams P, c
     else { accum[li] = make_float4(radiance.x, radiance.y, radiance.z, 1.0f); }
 }
 
+
+/* ------------------------------------------------------- configs #2 / #3: path tracers */
+/* common/core.hpp:76-89 with portable cos/sin [parity] */
+RT_DEV f3 sample_hemisphere(float r0, float r1, float r2)
+{
+    const float theta = r0 * 2.0f * kPI;
+    float radius = r1 + r2;
+    if (1.0f < radius) radius = 2.0f - radius;
+    const float x = pm_cosf(theta) * radius;
+    const float z = pm_sinf(theta) * radius;
+    const float a = 1.0f - radius * radius;
+    const float y = sqrtf((a < 0.0f) ? 0.0f : a);
+    return F3(x, y, z);
+}
+
+/* examples/07_pt/07_pt.cu:11-90 (EXAMPLE 7) and examples/09_ris/09_ris.cu:11-166 (EXAMPLE 9): the
+ * `path_trace` kernels, one thread per pixel, whole path in one launch. rays[0] accumulates the
+ * number of raytrace() calls (one atomic per wave). */
+template <int EXAMPLE, bool SHADOWED>
+__global__ __launch_bounds__(BLOCK) void k_path_trace(SceneView S, FrameParams P, int max_depth, f3 sky,
+                                                       float4* __restrict__ accum,
+                                                       unsigned long long* __restrict__ rays)
+{
+    __shared__ uint32_t s_stack[WIDE_LDS_STACK * BLOCK];
+    int x, row;
+    const bool ok = tile_pixel(P, x, row);
+    unsigned long long nrays = 0;
+    if (ok)
+    {
+        const int yi = P.H - 1 - row;
+        const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
+        PCG rng = pcg_init(hashPCG3((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame), 0);
+        const float u = (float)x / (float)P.W, v = (float)yi / (float)P.H;
+        const f3 forward = normalize(cross(P.rg_up, P.rg_right));
+        const f3 to = P.rg_origin + forward + mix(-P.rg_right, P.rg_right, u) + mix(P.rg_up, -P.rg_up, v);
+        f3 ro = P.rg_origin;
+        f3 rd = normalize(to - P.rg_origin);
+        f3 radiance = F3(0.0f, 0.0f, 0.0f), throughput = F3(1.0f, 1.0f, 1.0f);
+        const float fL = (float)(size_t)P.n_lights;
+        for (int depth = 0; depth < max_depth; ++depth)
+        {
+            Hit h;
+            ++nrays;
+            if (!trace_wide<false>(S.wide, s_stack, ro, rd, 0.0f, kFltMax, h))
+            {
+                if (EXAMPLE == 7) radiance = radiance + throughput * sky;
+                break;
+            }
+            const float4 kd4 = S.trimat[2 * (size_t)h.prim];
+            if (as_uint(kd4.w) != 0u)
+            {
+                const float4 ke4 = S.trimat[2 * (size_t)h.prim + 1];
+                if (EXAMPLE == 7 || depth == 0) radiance = radiance + throughput * F3(ke4.x, ke4.y, ke4.z);
+                break;
+            }
+            /* common/core.hpp:152-165 */
+            f3 v0, v1, v2;
+            load_tri(S.bvh.tv, h.prim, v0, v1, v2);
+            const f3 sp = ro + h.t * rd;
+            f3 sn = tri_normal(v0, v1, v2);
+            if (dot(-rd, sn) < 0.0f) sn = -sn;
+            const f3 kd = F3(kd4.x, kd4.y, kd4.z);
+
+            if (EXAMPLE == 9)
+            {
+                /* RIS over the lights (09_ris.cu:61-99), then the shaded contribution (:101-126) */
+                Res r = res_zero();
+                for (int i = 0; i < P.ris_sample_count; ++i)
+                {
+                    const float rv0 = rng.uniformf();
+                    float bx = rng.uniformf();
+                    float by = rng.uniformf();
+                    uint32_t nth = (uint32_t)(rv0 * fL);
+                    if (nth == (uint32_t)P.n_lights) nth = (uint32_t)P.n_lights - 1u;
+                    const float4* L = S.lights + 3 * (size_t)nth;
+                    const float4 L0 = L[0], L1 = L[1], L2 = L[2];
+                    const f3 a0 = F3(L0.x, L0.y, L0.z), a1 = F3(L0.w, L1.x, L1.y), a2 = F3(L1.z, L1.w, L2.x);
+                    warp_unit_triangle(bx, by);
+                    const f3 lp = (1.0f - bx - by) * a0 + bx * a1 + by * a2;
+                    const f3 ln = tri_normal(a0, a1, a2);
+                    float p_hat;
+                    if (SHADOWED)
+                    {
+                        p_hat = target_function<true>(S, s_stack, sp, sn, lp, ln, L2.y);
+                        ++nrays;
+                    }
+                    else { p_hat = target_unshadowed(sp, sn, lp, ln, L2.y); }
+                    const float weight = p_hat / L2.z;
+                    const float uu = rng.uniformf();
+                    r.w_sum += weight;
+                    r.M += 1;
+                    if (uu < weight / r.w_sum)
+                    {
+                        r.hit_p = lp; r.hit_n = ln; r.lum = L2.y;
+                        const float4 ke = S.light_ke[nth];
+                        r.rad = F3(ke.x, ke.y, ke.z);
+                    }
+                }
+                const f3 brdf = (1.0f / kPI) * kd;
+                const float G = geometry_term(sp, sn, r.hit_p, r.hit_n);
+                const float V = check_visibility_wide(S.wide, s_stack, sp, sn, r.hit_p) ? 1.0f : 0.0f;
+                ++nrays;
+                const float p_hat = target_function<SHADOWED>(S, s_stack, sp, sn, r.hit_p, r.hit_n, r.lum);
+                if (SHADOWED) ++nrays;
+                const float ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
+                radiance = radiance + throughput * brdf * G * V * r.rad * ucw;
+            }
+            /* next direction (07_pt.cu:61-70 / 09_ris.cu:128-137): common/core.hpp:216-235 */
+            const float r0 = rng.uniformf();
+            const float r1 = rng.uniformf();
+            const float r2 = rng.uniformf();
+            const f3 wl = sample_hemisphere(r0, r1, r2);
+            const f3 tg = normalize(v1 - v0);
+            const f3 bt = normalize(cross(tg, sn));
+            const f3 wo = wl.x * tg + wl.y * sn + wl.z * bt;
+            throughput = throughput * kd;
+            ro = sp + 0.001f * sn;
+            rd = wo;
+        }
+        if (P.accumulate)
+        {
+            const float4 a = accum[li];
+            accum[li] = make_float4(a.x + radiance.x, a.y + radiance.y, a.z + radiance.z, a.w + 1.0f);
+        }
+        else { accum[li] = make_float4(radiance.x, radiance.y, radiance.z, 1.0f); }
+    }
+    for (int off = 32; off > 0; off >>= 1) nrays += __shfl_down(nrays, off);
+    if ((threadIdx.x & 63) == 0 && nrays) atomicAdd(rays, nrays);
+}
+
 /* --------------------------------------------------------- clear / tone_mapping */
 /* common/kernels/common.cu:4-17 */
 __global__ __launch_bounds__(BLOCK) void k_clear(FrameParams P, float4* __restrict__ accum)
@@ -1472,6 +1602,37 @@ int rt_tone_mapping(rt_ctx* c)
     RT_CHECK_CTX(c);
     k_tone_mapping<<<launch_grid(c), BLOCK, 0, c->stream>>>(make_params(c, 0, 0), c->d_accum, c->d_pixels);
     RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+
+/* examples/07_pt/07_pt.cu (example 7) or examples/09_ris/09_ris.cu (example 9) `path_trace` */
+int rt_path_trace(rt_ctx* c, int example, int frame)
+{
+    RT_CHECK_CTX(c);
+    NEED_SCENE(c);
+    if (example != 7 && example != 9) RT_FAIL(c, RT_ERR_ARG, "example must be 7 (07_pt) or 9 (09_ris)");
+    if (example == 9 && c->n_lights == 0) RT_FAIL(c, RT_ERR_STATE, "09_ris needs at least one emissive triangle");
+    const SceneView S = make_scene(c);
+    const FrameParams P = make_params(c, frame, 0, K_RAYCAST);
+    const f3 sky = F3(c->opt.sky_color[0], c->opt.sky_color[1], c->opt.sky_color[2]);
+    const int g = launch_grid(c);
+    const int md = c->opt.max_depth;
+    RT_HIP(c, hipMemsetAsync(c->d_counter, 0, 8, c->stream));
+    if (example == 7) k_path_trace<7, false><<<g, BLOCK, 0, c->stream>>>(S, P, md, sky, c->d_accum, c->d_counter);
+    else if (c->opt.use_shadowed_target_function) k_path_trace<9, true><<<g, BLOCK, 0, c->stream>>>(S, P, md, sky, c->d_accum, c->d_counter);
+    else k_path_trace<9, false><<<g, BLOCK, 0, c->stream>>>(S, P, md, sky, c->d_accum, c->d_counter);
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+/* raytrace() calls made by the last rt_path_trace (synchronises the stream) */
+int rt_path_trace_rays(rt_ctx* c, uint64_t* rays)
+{
+    RT_CHECK_CTX(c);
+    if (!rays) return RT_ERR_ARG;
+    unsigned long long h = 0;
+    RT_HIP(c, hipMemcpyAsync(&h, c->d_counter, 8, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    *rays = h;
     return RT_OK;
 }
 

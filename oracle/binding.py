@@ -121,6 +121,8 @@ def lib():
         L.o_tone_mapping.argtypes = [vp, vp, ci, ci, ci, ci]
         L.o_frame.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.o_ao_04.argtypes = [vp, vp, vp, ci, ci]
+        L.o_path_trace_07.argtypes = [vp, ci, ci, ci, vp, vp, vp, ci, ci, vp]
+        L.o_path_trace_09.argtypes = [vp, ci, ci, ci, vp, vp, vp, ci, ci, vp]
         _lib = L
     return _lib
 
@@ -144,6 +146,7 @@ def max_threads():
 FN = dict(warp_unit_triangle=(0, 2, 2), sample_hemisphere=(1, 3, 3), sample_2d_gaussian=(2, 2, 2),
           geometry_term=(3, 12, 1), intersect_ray_triangle=(4, 17, 4), luminance=(5, 3, 1),
           normal_rejection=(6, 6, 1), depth_rejection=(7, 9, 1), triangle_props=(8, 9, 7), aces=(9, 1, 1),
+          surface_ray=(10, 16, 6), tangent_world=(11, 15, 3),
           logf=(20, 1, 1), cosf=(21, 1, 1), sinf=(22, 1, 1), expf=(23, 1, 1), pow8=(24, 1, 1),
           pow_gamma=(25, 1, 1), div=(26, 2, 1), sqrt=(27, 1, 1))
 
@@ -237,6 +240,13 @@ class Scene:
                       _p(state["r1"]), _p(state["temporal"]), _p(state["accum"]),
                       _p(state["pixels"]) if tone_map else None, _p(cnt))
         return state
+
+    def path_trace(self, example, W, H, frame, raygen, opt, accum, rows=None, cnt=None):
+        """examples/07_pt (example=7) or examples/09_ris (example=9) `path_trace` kernel."""
+        r0, r1 = rows or (0, H)
+        fn = lib().o_path_trace_07 if example == 7 else lib().o_path_trace_09
+        fn(self.h, W, H, frame, _p(raygen), _p(opt), _p(accum), r0, r1, _p(cnt))
+        return accum
 
     def ao_04(self, W, H, raygen):
         px = np.zeros((H, W, 4), dtype=np.uint8)

@@ -210,6 +210,23 @@ static void cmd_fn(Blobs& b, FILE* out)
                 o.push_back(nn.x); o.push_back(nn.y); o.push_back(nn.z); o.push_back(ref::area_of(t));
                 o.push_back(tg.x); o.push_back(tg.y); o.push_back(tg.z); break; }
             case 9: { o.push_back(ref::aces_tone_mapping(in[i])); break; }
+            case 10: { /* make_surface_info(ray, isect, triangles), common/core.hpp:152-165 */
+                const float* a = in + 16 * i;
+                ref::Triangle t; t.vertices[0] = f3(a); t.vertices[1] = f3(a + 3); t.vertices[2] = f3(a + 6);
+                TBTri tb; view(tb, &t, 1);
+                ref::Ray ray = ref::make_ray(f3(a + 9), f3(a + 12));
+                ref::Intersection is; is.t = a[15]; is.index = 0;
+                ref::SurfaceInfo sf = ref::make_surface_info(ray, is, tb);
+                o.push_back(sf.p.x); o.push_back(sf.p.y); o.push_back(sf.p.z); o.push_back(sf.n.x); o.push_back(sf.n.y); o.push_back(sf.n.z);
+                break; }
+            case 11: { /* make_tangent_basis + local_to_world, common/core.hpp:216-235 */
+                const float* a = in + 15 * i;
+                ref::Triangle t; t.vertices[0] = f3(a); t.vertices[1] = f3(a + 3); t.vertices[2] = f3(a + 6);
+                TBTri tb; view(tb, &t, 1);
+                ref::TangentBasis b = ref::make_tangent_basis(f3(a + 9), 0, tb);
+                float3 w = ref::local_to_world(f3(a + 12), b);
+                o.push_back(w.x); o.push_back(w.y); o.push_back(w.z);
+                break; }
             default: o.push_back(0.0f);
         }
     }

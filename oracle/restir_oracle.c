@@ -695,6 +695,23 @@ static inline Surf make_surface_info_eye(const OVisibility* vis, const OTriangle
     return r;
 }
 
+/* common/core.hpp:152-165: surface info from a ray hit (07_pt / 08_nee / 09_ris) */
+static inline Surf make_surface_info_ray(const OTriangle* tri, v3 ro, v3 rd, float t)
+{
+    Surf r;
+    r.p = add(ro, muls(rd, t));
+    r.n = normal_of(tri);
+    if (dot(neg(rd), r.n) < 0.0f) { r.n = neg(r.n); }
+    return r;
+}
+/* common/core.hpp:216-235: make_tangent_basis(n, index, triangles) then local_to_world(v, basis) */
+static inline v3 tangent_to_world(const OTriangle* tri, v3 n, v3 v)
+{
+    const v3 t = a_tangent_of(tri);
+    const v3 b = normalize(cross(t, n));
+    return add(add(muls(t, v.x), muls(n, v.y)), muls(b, v.z));
+}
+
 typedef struct { v3 p, n; int index; } LightSample;
 /* common/core.hpp:261-285 */
 static inline LightSample sample_light(const OScene* s, float rv0, float rv1, float rv2)
@@ -829,6 +846,20 @@ ORACLE_API void o_fn_bulk(int fn, const float* in, float* out, int n)
                 const float x = in[i];
                 const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
                 out[i] = (x * (a * x + b)) / (x * (c * x + d) + e); break; }
+            case 10: { /* make_surface_info(ray, isect, triangles) core.hpp:152-165: in 16 (tri9, ro3, rd3, t) -> out 6 */
+                OTriangle t; const float* a = in + 16 * i;
+                t.v[0] = V3(a[0], a[1], a[2]); t.v[1] = V3(a[3], a[4], a[5]); t.v[2] = V3(a[6], a[7], a[8]);
+                const Surf sf = make_surface_info_ray(&t, V3(a[9], a[10], a[11]), V3(a[12], a[13], a[14]), a[15]);
+                float* o = out + 6 * i;
+                o[0] = sf.p.x; o[1] = sf.p.y; o[2] = sf.p.z; o[3] = sf.n.x; o[4] = sf.n.y; o[5] = sf.n.z;
+                break; }
+            case 11: { /* make_tangent_basis + local_to_world core.hpp:216-235: in 15 (tri9, n3, v3) -> out 3 */
+                OTriangle t; const float* a = in + 15 * i;
+                t.v[0] = V3(a[0], a[1], a[2]); t.v[1] = V3(a[3], a[4], a[5]); t.v[2] = V3(a[6], a[7], a[8]);
+                const v3 w = tangent_to_world(&t, V3(a[9], a[10], a[11]), V3(a[12], a[13], a[14]));
+                float* o = out + 3 * i;
+                o[0] = w.x; o[1] = w.y; o[2] = w.z;
+                break; }
             /* raw math functions in the current mode: in 1 -> out 1 */
             case 20: out[i] = m_log(in[i]); break;
             case 21: out[i] = m_cos(in[i]); break;
@@ -1241,4 +1272,144 @@ ORACLE_API void o_ao_04(const OScene* s, uint8_t* pixels, const ORayGen* rg, int
                 pixels[pixelIdx * 4 + 2] = 32; pixels[pixelIdx * 4 + 3] = 255;
             }
         }
+}
+
+/* ------------------------------------- configs #2 / #3: 07_pt and 09_ris path tracers */
+/* examples/07_pt/07_pt.cu:11-90 */
+ORACLE_API void o_path_trace_07(const OScene* s, int W, int H, int frame, const ORayGen* rg,
+                                const OOptions* opt, v4* accum, int row0, int row1, OCounters* cnt)
+{
+    long rays = 0;
+#pragma omp parallel for schedule(dynamic, 2) reduction(+ : rays)
+    for (int row = row0; row < row1; ++row)
+    {
+        const int yi = H - 1 - row;
+        for (int xi = 0; xi < W; ++xi)
+        {
+            const int pixel_idx = xi + row * W;
+            PCG rng = pcg_init(hashPCG3((uint32_t)xi, (uint32_t)yi, (uint32_t)frame), 0);
+            v3 ro, rd;
+            raygen_shoot(rg, &ro, &rd, (float)xi / (float)W, (float)yi / (float)H);
+            v3 radiance = V3(0.0f, 0.0f, 0.0f), throughput = V3(1.0f, 1.0f, 1.0f);
+            for (int depth = 0; depth < opt->max_depth; ++depth)
+            {
+                OHit h;
+                ++rays;
+                if (!raytrace(s, ro, rd, 0.0f, O_FLT_MAX, &h))
+                {
+                    radiance = add(radiance, mulv(throughput, opt->sky_color));
+                    break;
+                }
+                const OTriangle* tri = &s->tris[h.index];
+                if (has_emission(tri))
+                {
+                    radiance = add(radiance, mulv(throughput, tri->emissive));
+                    break;
+                }
+                const Surf surf = make_surface_info_ray(tri, ro, rd, h.t);
+                const float r0 = pcg_uniformf(&rng);
+                const float r1 = pcg_uniformf(&rng);
+                const float r2 = pcg_uniformf(&rng);
+                const v3 wo = tangent_to_world(tri, surf.n, sample_hemisphere(r0, r1, r2));
+                throughput = mulv(throughput, tri->color);
+                ro = add(surf.p, muls(surf.n, 0.001f));
+                rd = wo;
+            }
+            if (opt->accumulate)
+            {
+                accum[pixel_idx].x += radiance.x; accum[pixel_idx].y += radiance.y;
+                accum[pixel_idx].z += radiance.z; accum[pixel_idx].w += 1.0f;
+            }
+            else
+            {
+                const v4 o = {radiance.x, radiance.y, radiance.z, 1.0f};
+                accum[pixel_idx] = o;
+            }
+        }
+    }
+    if (cnt) cnt->rays += rays;
+}
+
+/* examples/09_ris/09_ris.cu:11-166 */
+ORACLE_API void o_path_trace_09(const OScene* s, int W, int H, int frame, const ORayGen* rg,
+                                const OOptions* opt, v4* accum, int row0, int row1, OCounters* cnt)
+{
+    long rays = 0;
+#pragma omp parallel for schedule(dynamic, 2) reduction(+ : rays)
+    for (int row = row0; row < row1; ++row)
+    {
+        const int yi = H - 1 - row;
+        for (int xi = 0; xi < W; ++xi)
+        {
+            const int pixel_idx = xi + row * W;
+            PCG rng = pcg_init(hashPCG3((uint32_t)xi, (uint32_t)yi, (uint32_t)frame), 0);
+            v3 ro, rd;
+            raygen_shoot(rg, &ro, &rd, (float)xi / (float)W, (float)yi / (float)H);
+            v3 radiance = V3(0.0f, 0.0f, 0.0f), throughput = V3(1.0f, 1.0f, 1.0f);
+            for (int depth = 0; depth < opt->max_depth; ++depth)
+            {
+                OHit h;
+                ++rays;
+                if (!raytrace(s, ro, rd, 0.0f, O_FLT_MAX, &h)) break;
+                const OTriangle* tri = &s->tris[h.index];
+                if (has_emission(tri))
+                {
+                    if (depth == 0) radiance = add(radiance, mulv(throughput, tri->emissive));
+                    break;
+                }
+                const Surf surf = make_surface_info_ray(tri, ro, rd, h.t);
+                OReservoir r = reservoir_zero();
+                for (int i = 0; i < opt->ris_sample_count; ++i)
+                {
+                    OSample smp;
+                    memset(&smp, 0, sizeof(smp));
+                    smp.origin_position = surf.p;
+                    smp.origin_normal = surf.n;
+                    const float rv0 = pcg_uniformf(&rng);
+                    const float rv1 = pcg_uniformf(&rng);
+                    const float rv2 = pcg_uniformf(&rng);
+                    const LightSample ls = sample_light(s, rv0, rv1, rv2);
+                    smp.hit_position = ls.p;
+                    smp.hit_normal = ls.n;
+                    const OTriangle* lt = &s->tris[ls.index];
+                    smp.radiance = lt->emissive;
+                    const float light_pdf = 1.0f / (float)(size_t)s->n_lights * 1.0f / area_of(lt);
+                    const float p_hat = evaluate_target_function(s, surf.p, surf.n, smp.hit_position, smp.hit_normal,
+                                                                 smp.radiance, opt->use_shadowed_target_function, &rays);
+                    const float weight = p_hat / light_pdf;
+                    reservoir_update(&r, &smp, weight, pcg_uniformf(&rng));
+                }
+                {
+                    const v3 brdf = muls(tri->color, 1.0f / O_PI);
+                    const float G = geometry_term(surf.p, surf.n, r.sample.hit_position, r.sample.hit_normal);
+                    const float V = check_visibility(s, surf.p, surf.n, r.sample.hit_position);
+                    ++rays;
+                    const float p_hat = evaluate_target_function(s, surf.p, surf.n, r.sample.hit_position,
+                                                                 r.sample.hit_normal, r.sample.radiance,
+                                                                 opt->use_shadowed_target_function, &rays);
+                    const float ucw = ucw_of(&r, p_hat);
+                    const v3 c = muls(mulv(muls(muls(mulv(throughput, brdf), G), V), r.sample.radiance), ucw);
+                    radiance = add(radiance, c);
+                }
+                const float r0 = pcg_uniformf(&rng);
+                const float r1 = pcg_uniformf(&rng);
+                const float r2 = pcg_uniformf(&rng);
+                const v3 wo = tangent_to_world(tri, surf.n, sample_hemisphere(r0, r1, r2));
+                throughput = mulv(throughput, tri->color);
+                ro = add(surf.p, muls(surf.n, 0.001f));
+                rd = wo;
+            }
+            if (opt->accumulate)
+            {
+                accum[pixel_idx].x += radiance.x; accum[pixel_idx].y += radiance.y;
+                accum[pixel_idx].z += radiance.z; accum[pixel_idx].w += 1.0f;
+            }
+            else
+            {
+                const v4 o = {radiance.x, radiance.y, radiance.z, 1.0f};
+                accum[pixel_idx] = o;
+            }
+        }
+    }
+    if (cnt) cnt->rays += rays;
 }

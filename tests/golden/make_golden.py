@@ -49,7 +49,7 @@ def main():
             x = (x * 2 - 1).astype(np.float32)
             x[:, 6] = 0.0
             x[:, 7] = 1e30
-        elif name in ("geometry_term", "normal_rejection", "depth_rejection", "triangle_props"):
+        elif name in ("geometry_term", "normal_rejection", "depth_rejection", "triangle_props", "surface_ray", "tangent_world"):
             x = (x * 4 - 2).astype(np.float32)
         elif name == "aces":
             x = (x * 8).astype(np.float32)

@@ -319,3 +319,45 @@ def test_strip_contexts_match_full_frame(api, oracle, scenes, staged):
     for c in ctxs:
         c.close()
     full.close()
+
+
+@pytest.mark.parametrize("example,scene_name,W,H,frames,optkw", [
+    (7, "cornellbox2", 512, 512, 4, dict(accumulate=1)),                       # BASELINE config #2
+    (7, "quad_room", 96, 54, 2, dict(accumulate=1, sky_color=(0.3, 0.4, 0.5))),
+    (9, "quad_room", 96, 54, 2, dict(accumulate=1)),
+    (9, "quad_room", 64, 36, 1, dict(use_shadowed_target_function=1, ris_sample_count=8)),
+    (9, "blocks", 320, 180, 1, dict()),                                        # config #3 at quarter res
+])
+def test_path_tracers_07_and_09(api, oracle, scenes, golden_scenes, example, scene_name, W, H, frames, optkw):
+    """Configs #2/#3: the `path_trace` kernels of 07_pt and 09_ris, bit-identical radiance and the
+    same number of raytrace() calls as the oracle."""
+    from cedec_2024_rt_amd.types import default_options
+
+    if scene_name == "cornellbox2":
+        tris, eye, center = golden_scenes["cornellbox2"], scenes.CORNELLBOX_EYE, scenes.CORNELLBOX_LOOKAT
+    elif scene_name == "blocks":
+        tris, eye, center = scenes.make_blocks_restir(), scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT
+    else:
+        tris, eye, center = scenes.make_quad_room(), (0.5, 2.5, 6.0), (0.0, 1.5, -1.0)
+    oracle.set_math_mode(oracle.MATH_PORTABLE)
+    r = api.Renderer(W, H)
+    r.set_scene(tris)
+    r.lookat(eye, center)
+    r.set_options(default_options(**optkw))
+    sc = oracle.Scene(tris, use_bvh=True)
+    rg = oracle.raygen_lookat(eye, center, (0, 1, 0), FOVY, W, H)
+    opt = oracle.default_options(**optkw)
+    acc = np.zeros((W * H, 4), np.float32)
+    r.clear()
+    for frame in range(1, frames + 1):
+        cnt = oracle.new_counters()
+        r.path_trace(example, frame)
+        sc.path_trace(example, W, H, frame, rg, opt, acc, cnt=cnt)
+        got = r.download(api.RT_BUF_ACCUMULATION)
+        nbad = int((got.view(np.uint32) != acc.view(np.uint32)).any(axis=1).sum())
+        assert nbad == 0, f"frame {frame}: {nbad} pixels differ, rel-L2 {_rel_l2(got[:, :3], acc[:, :3])}"
+        assert r.path_trace_rays() == int(cnt["rays"][0])
+    assert acc[:, :3].max() > 0
+    r.tone_mapping()
+    assert np.array_equal(r.download(api.RT_BUF_PIXELS).reshape(H, W, 4), oracle.tone_mapping(acc, W, H))
+    r.close()

@@ -30,7 +30,7 @@ def _libm(oracle):
 
 
 FNS = ["warp_unit_triangle", "sample_hemisphere", "sample_2d_gaussian", "geometry_term", "intersect_ray_triangle",
-       "luminance", "normal_rejection", "depth_rejection", "triangle_props", "aces"]
+       "luminance", "normal_rejection", "depth_rejection", "triangle_props", "aces", "surface_ray", "tangent_world"]
 
 
 @pytest.mark.parametrize("name", FNS)
