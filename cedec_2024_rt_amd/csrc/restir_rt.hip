@@ -769,6 +769,153 @@ __global__ __launch_bounds__(BLOCK) void k_trace_stats(SceneView S, const float*
     stats[2 * (size_t)i] = st[0];
     stats[2 * (size_t)i + 1] = st[1];
 }
+
+/* Persistent wavefront tracing over a ray queue with LANE refill: a lane whose ray is finished
+ * pulls the next ray index while the other lanes keep traversing (ballot of idle lanes -> one
+ * aggregated atomic -> prefix popcount), instead of idling until the slowest lane of its wave is
+ * done. Refill is attempted when at least REFILL_MIN lanes are idle. ANY = shadow rays
+ * (hits[i].x = 1 if occluded). Same traversal steps / results as trace_wide. */
+template <bool ANY>
+__global__ __launch_bounds__(BLOCK) void k_trace_queue(WideView wide, const float* __restrict__ rays, int n,
+                                                        float* __restrict__ hits, unsigned int* __restrict__ head)
+{
+    __shared__ uint32_t s_stack[WIDE_LDS_STACK * BLOCK];
+    constexpr int REFILL_MIN = 20;
+    constexpr uint32_t IDLE = 0x7ffffffeu;
+    const int lane = threadIdx.x & 63;
+    const int slot = threadIdx.x;
+    uint32_t ovf[WIDE_OVF_STACK];
+    /* per-lane ray state */
+    uint32_t cur = IDLE;
+    int sp = 0, prim = -1, ray_id = -1;
+    f3 ro = F3(0, 0, 0), rd = F3(0, 0, 1), inv = F3(0, 0, 1);
+    float tmin = 0.0f, tmax = 0.0f, best = 0.0f, bu = 0.0f, bv = 0.0f;
+    bool exhausted = false;
+    for (;;)
+    {
+        const unsigned long long idle = __ballot(cur == IDLE);
+        if (idle)
+        {
+            const int n_idle = __popcll(idle);
+            if (!exhausted && (n_idle >= REFILL_MIN || n_idle == 64 || true))
+            {
+                if (n_idle >= REFILL_MIN || n_idle == 64)
+                {
+                    const int leader = __ffsll((long long)idle) - 1;
+                    unsigned int base = 0;
+                    if (lane == leader) base = atomicAdd(head, (unsigned)n_idle);
+                    base = __shfl(base, leader);
+                    if (cur == IDLE)
+                    {
+                        const unsigned my = base + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
+                        if (my < (unsigned)n)
+                        {
+                            const float* r = rays + 8 * (size_t)my;
+                            ray_id = (int)my;
+                            ro = F3(r[0], r[1], r[2]); rd = F3(r[3], r[4], r[5]);
+                            tmin = r[6]; tmax = r[7];
+                            inv = F3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                            inv.x = fminf(fmaxf(inv.x, -1e30f), 1e30f);
+                            inv.y = fminf(fmaxf(inv.y, -1e30f), 1e30f);
+                            inv.z = fminf(fmaxf(inv.z, -1e30f), 1e30f);
+                            best = tmax; prim = -1; bu = 0.0f; bv = 0.0f; sp = 0;
+                            cur = 0u;
+                        }
+                    }
+                    if (base + (unsigned)n_idle >= (unsigned)n) exhausted = true;
+                }
+            }
+            if (exhausted && __ballot(cur != IDLE) == 0ull) return;
+        }
+        /* no `continue` for idle lanes: they must fall through to the loop header together with
+         * the working lanes (a spinning divergent path would starve the others) */
+        bool done = false;
+        const float4* r = wide.rec + 3 * (size_t)(cur & ~WIDE_LEAF_BIT);
+        if (cur == IDLE) {}
+        else if (cur & WIDE_LEAF_BIT)
+        {
+            const float4 t0 = r[0], t1 = r[1], t2 = r[2];
+            const f3 v0 = F3(t0.x, t0.y, t0.z), v1 = F3(t0.w, t1.x, t1.y), v2 = F3(t1.z, t1.w, t2.x);
+            const int pi = as_int(t2.y);
+            float t, u, v;
+            if (intersect_ray_triangle(t, u, v, ro, rd, tmin, tmax, v0, v1, v2))
+            {
+                if (prim < 0 || t < best || (t == best && pi > prim))
+                {
+                    best = t; bu = u; bv = v; prim = pi;
+                    if (ANY) done = true;
+                }
+            }
+            if (!done)
+            {
+                if (sp == 0) done = true;
+                else { --sp; cur = sp < WIDE_LDS_STACK ? s_stack[sp * BLOCK + slot] : ovf[sp - WIDE_LDS_STACK]; }
+            }
+        }
+        else
+        {
+            const float4 q0 = r[0], q1f = r[1], q2f = r[2];
+            const uint32_t e = as_uint(q0.w);
+            const uint32_t base = as_uint(q1f.x), meta = as_uint(q1f.y);
+            const uint32_t lx = as_uint(q1f.z), ly = as_uint(q1f.w), lz = as_uint(q2f.x);
+            const uint32_t hx = as_uint(q2f.y), hy = as_uint(q2f.z), hz = as_uint(q2f.w);
+            const float sx = as_float((e & 0xffu) << 23), sy = as_float(((e >> 8) & 0xffu) << 23),
+                        sz = as_float(((e >> 16) & 0xffu) << 23);
+            const float Ax = (q0.x - ro.x) * inv.x, Ay = (q0.y - ro.y) * inv.y, Az = (q0.z - ro.z) * inv.z;
+            const float Bx = sx * inv.x, By = sy * inv.y, Bz = sz * inv.z;
+            float td[4];
+            uint32_t ce[4];
+            int nhit = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+            {
+                const uint32_t m = (meta >> (8 * k)) & 0xffu;
+                const float x0 = __builtin_fmaf(wide_byte(lx, k), Bx, Ax), x1 = __builtin_fmaf(wide_byte(hx, k), Bx, Ax);
+                const float y0 = __builtin_fmaf(wide_byte(ly, k), By, Ay), y1 = __builtin_fmaf(wide_byte(hy, k), By, Ay);
+                const float z0 = __builtin_fmaf(wide_byte(lz, k), Bz, Az), z1 = __builtin_fmaf(wide_byte(hz, k), Bz, Az);
+                float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+                float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+                tn = fmaxf(tn * (1.0f - 4e-7f), tmin);
+                tf = fminf(tf * (1.0f + 4e-7f), best);
+                const bool h = (m != 0u) && (tn <= tf);
+                td[k] = h ? tn : 3.0e38f;
+                ce[k] = (base + (uint32_t)k) | (m == 2u ? WIDE_LEAF_BIT : 0u);
+                nhit += h ? 1 : 0;
+            }
+            if (nhit > 0)
+            {
+#define RT_CSWAP(i, j)                                                     \
+    if (td[j] < td[i])                                                     \
+    {                                                                      \
+        const float _t = td[i]; td[i] = td[j]; td[j] = _t;                 \
+        const uint32_t _e = ce[i]; ce[i] = ce[j]; ce[j] = _e;             \
+    }
+                RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
+#undef RT_CSWAP
+                for (int k = nhit - 1; k >= 1; --k)
+                {
+                    if (sp < WIDE_LDS_STACK) s_stack[sp * BLOCK + slot] = ce[k];
+                    else ovf[sp - WIDE_LDS_STACK] = ce[k];
+                    ++sp;
+                }
+                cur = ce[0];
+            }
+            else
+            {
+                if (sp == 0) done = true;
+                else { --sp; cur = sp < WIDE_LDS_STACK ? s_stack[sp * BLOCK + slot] : ovf[sp - WIDE_LDS_STACK]; }
+            }
+        }
+        if (done)
+        {
+            float* o = hits + 4 * (size_t)ray_id;
+            if (ANY) { o[0] = prim >= 0 ? 1.0f : 0.0f; o[1] = 0.0f; o[2] = 0.0f; o[3] = as_float(prim); }
+            else { o[0] = prim >= 0 ? best : 0.0f; o[1] = bu; o[2] = bv; o[3] = as_float(prim); }
+            cur = IDLE;
+        }
+    }
+}
+
 __global__ void k_math_eval(int fn, const float* __restrict__ in, int n, float* __restrict__ out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -804,7 +951,8 @@ struct rt_ctx
     int tune_tile_mode[5] = {1, 0, 1, 0, 0};
     int tune_spatial_lds = 32768;
     int trace_mode = 0; /* rt_trace_closest / rt_trace_stats: 0 = wide (what the frame kernels use), 1 = binary stackless */
-    float bvh_split_factor = 8.0f; /* fragment length in median triangle extents; 0 = no pre-split */
+    float bvh_split_factor = 8.0f;
+    int bvh_builder = 1; /* 0 = device LBVH (Morton/Karras), 1 = host binned SAH (high quality) */ /* fragment length in median triangle extents; 0 = no pre-split */
     float* d_tris = nullptr;
     float4* d_tv = nullptr;
     BvhNode* d_nodes = nullptr;
@@ -1202,6 +1350,129 @@ static int collapse_wide(const std::vector<BvhNode>& bin, const rt_triangle* tri
     return height;
 }
 
+/* ---- high-quality build (the reference asks HIPRT for hiprtBuildFlagBitPreferHighQualityBuild,
+ * common/loader.hpp:98-99): top-down binned-SAH binary tree over the references on the host, in
+ * the same BvhNode format the device LBVH emits (so both traversals and the wide collapse work
+ * on either). One reference per leaf. ---- */
+struct SahBuilder
+{
+    const std::vector<BvhRef>& refs;
+    std::vector<int> order;
+    std::vector<float> cent; /* 3 per ref */
+    std::vector<BvhNode> nodes;
+    int height = 0;
+    explicit SahBuilder(const std::vector<BvhRef>& r) : refs(r)
+    {
+        order.resize(r.size());
+        cent.resize(r.size() * 3);
+        for (size_t i = 0; i < r.size(); ++i)
+        {
+            order[i] = (int)i;
+            for (int a = 0; a < 3; ++a) cent[3 * i + a] = 0.5f * (r[i].lo[a] + r[i].hi[a]);
+        }
+        nodes.reserve(r.size());
+    }
+    void bounds(int first, int count, float* lo, float* hi, float* clo, float* chi) const
+    {
+        for (int a = 0; a < 3; ++a) { lo[a] = clo[a] = INFINITY; hi[a] = chi[a] = -INFINITY; }
+        for (int i = first; i < first + count; ++i)
+        {
+            const BvhRef& r = refs[(size_t)order[i]];
+            for (int a = 0; a < 3; ++a)
+            {
+                lo[a] = fminf(lo[a], r.lo[a]); hi[a] = fmaxf(hi[a], r.hi[a]);
+                const float c = cent[3 * (size_t)order[i] + a];
+                clo[a] = fminf(clo[a], c); chi[a] = fmaxf(chi[a], c);
+            }
+        }
+    }
+    /* returns child code: >= 0 node index, < 0 ~triangle; box of the subtree in lo/hi */
+    int build(int first, int count, int parent, int depth, float* lo, float* hi)
+    {
+        float clo[3], chi[3];
+        bounds(first, count, lo, hi, clo, chi);
+        if (depth > height) height = depth;
+        if (count == 1) return ~refs[(size_t)order[first]].tri;
+        constexpr int NB = 16;
+        int best_axis = -1, best_split = -1;
+        float best_cost = INFINITY;
+        for (int a = 0; a < 3; ++a)
+        {
+            const float ext = chi[a] - clo[a];
+            if (!(ext > 0.0f)) continue;
+            float blo[NB][3], bhi[NB][3];
+            int bc[NB];
+            for (int b = 0; b < NB; ++b) { bc[b] = 0; for (int k = 0; k < 3; ++k) { blo[b][k] = INFINITY; bhi[b][k] = -INFINITY; } }
+            const float sc = (float)NB / ext;
+            for (int i = first; i < first + count; ++i)
+            {
+                const int id = order[i];
+                int b = (int)((cent[3 * (size_t)id + a] - clo[a]) * sc);
+                b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+                bc[b]++;
+                for (int k = 0; k < 3; ++k) { blo[b][k] = fminf(blo[b][k], refs[(size_t)id].lo[k]); bhi[b][k] = fmaxf(bhi[b][k], refs[(size_t)id].hi[k]); }
+            }
+            float ra[NB]; int rc[NB];
+            float l3[3] = {INFINITY, INFINITY, INFINITY}, h3[3] = {-INFINITY, -INFINITY, -INFINITY};
+            int cnt = 0;
+            for (int b = NB - 1; b > 0; --b)
+            {
+                for (int k = 0; k < 3; ++k) { l3[k] = fminf(l3[k], blo[b][k]); h3[k] = fmaxf(h3[k], bhi[b][k]); }
+                cnt += bc[b];
+                ra[b] = cnt ? box_area6(l3, h3) : 0.0f;
+                rc[b] = cnt;
+            }
+            for (int k = 0; k < 3; ++k) { l3[k] = INFINITY; h3[k] = -INFINITY; }
+            cnt = 0;
+            for (int b = 0; b < NB - 1; ++b)
+            {
+                for (int k = 0; k < 3; ++k) { l3[k] = fminf(l3[k], blo[b][k]); h3[k] = fmaxf(h3[k], bhi[b][k]); }
+                cnt += bc[b];
+                if (cnt == 0 || rc[b + 1] == 0) continue;
+                const float cost = box_area6(l3, h3) * (float)cnt + ra[b + 1] * (float)rc[b + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = b; }
+            }
+        }
+        int mid;
+        if (best_axis < 0) mid = first + count / 2;
+        else
+        {
+            const float ext = chi[best_axis] - clo[best_axis];
+            const float sc = (float)NB / ext;
+            int i = first, j = first + count - 1;
+            while (i <= j)
+            {
+                int b = (int)((cent[3 * (size_t)order[i] + best_axis] - clo[best_axis]) * sc);
+                b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+                if (b <= best_split) ++i;
+                else { std::swap(order[i], order[j]); --j; }
+            }
+            mid = i;
+            if (mid == first || mid == first + count) mid = first + count / 2;
+        }
+        const int me = (int)nodes.size();
+        nodes.push_back(BvhNode());
+        float l0[3], h0[3], l1[3], h1[3];
+        const int c0 = build(first, mid - first, me, depth + 1, l0, h0);
+        const int c1 = build(mid, first + count - mid, me, depth + 1, l1, h1);
+        BvhNode& n = nodes[(size_t)me];
+        n.a = make_float4(l0[0], l0[1], l0[2], l1[0]);
+        n.b = make_float4(h0[0], h0[1], h0[2], l1[1]);
+        n.c = make_float4(h1[0], h1[1], h1[2], l1[2]);
+        n.d = make_int4(c0, c1, parent, -1);
+        return me;
+    }
+    void link_siblings()
+    {
+        for (size_t i = 0; i < nodes.size(); ++i)
+        {
+            const int c0 = nodes[i].d.x, c1 = nodes[i].d.y;
+            if (c0 >= 0) nodes[(size_t)c0].d.w = c1;
+            if (c1 >= 0) nodes[(size_t)c1].d.w = c0;
+        }
+    }
+};
+
 static int build_wide(rt_ctx* c, const rt_triangle* tris, int n_refs)
 {
     const size_t n_bin = (size_t)(n_refs > 1 ? n_refs - 1 : 1);
@@ -1263,6 +1534,22 @@ static int build_bvh(rt_ctx* c, const rt_triangle* tris, int n_tris)
     }
     const int n = (int)refs.size();
     c->n_refs = n;
+    if (c->bvh_builder == 1 && n >= 2)
+    {
+        SahBuilder sb(refs);
+        float rl[3], rh[3];
+        sb.build(0, n, -1, 1, rl, rh);
+        sb.link_siblings();
+        c->bvh_height = sb.height;
+        if (sb.height > 62) RT_FAIL(c, RT_ERR_BVH_DEPTH, "SAH tree height %d exceeds the 63-level trail word", sb.height);
+        RT_HIP(c, hipMalloc(&c->d_tv, (size_t)n_tris * 48));
+        k_bvh_tv<<<(n_tris + 255) / 256, 256, 0, st>>>(c->d_tris, n_tris, c->d_tv);
+        RT_HIP(c, hipGetLastError());
+        RT_HIP(c, hipMalloc(&c->d_nodes, sb.nodes.size() * sizeof(BvhNode)));
+        RT_HIP(c, hipMemcpyAsync(c->d_nodes, sb.nodes.data(), sb.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice, st));
+        RT_HIP(c, hipStreamSynchronize(st));
+        return build_wide(c, tris, n);
+    }
     std::vector<float> h_boxes((size_t)n * 6);
     std::vector<int> h_ref_tri((size_t)n);
     for (int i = 0; i < n; ++i)
@@ -1936,7 +2223,15 @@ int rt_trace_closest(rt_ctx* c, const float* rays, uint32_t n, float* hits)
     RT_HIP(c, hipMalloc(&d_r, (size_t)n * 32));
     RT_HIP(c, hipMalloc(&d_h, (size_t)n * 16));
     RT_HIP(c, hipMemcpyAsync(d_r, rays, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
-    if (c->trace_mode == 0) k_trace_closest<0><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_h);
+    if (c->trace_mode == 2 || c->trace_mode == 3)
+    {
+        unsigned int* d_head = (unsigned int*)c->d_counter;
+        RT_HIP(c, hipMemsetAsync(d_head, 0, 8, c->stream));
+        const int grid = 256 * 6; /* persistent: 6 workgroups per CU (24 KB LDS each) */
+        if (c->trace_mode == 2) k_trace_queue<false><<<grid, BLOCK, 0, c->stream>>>(make_scene(c).wide, d_r, (int)n, d_h, d_head);
+        else k_trace_queue<true><<<grid, BLOCK, 0, c->stream>>>(make_scene(c).wide, d_r, (int)n, d_h, d_head);
+    }
+    else if (c->trace_mode == 0) k_trace_closest<0><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_h);
     else k_trace_closest<1><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_h);
     RT_HIP(c, hipGetLastError());
     RT_HIP(c, hipMemcpyAsync(hits, d_h, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
@@ -1981,6 +2276,7 @@ int rt_tuning(rt_ctx* c, int key, int value)
     RT_CHECK_CTX(c);
     if (key >= 0 && key <= 3 && (value == 0 || value == 1)) c->tune_tile_mode[key] = value;
     else if (key == 4 && value >= 0 && value <= 160 * 1024) c->tune_spatial_lds = value;
+    else if (key == 5 && (value == 0 || value == 1)) c->bvh_builder = value; /* before rt_scene_set */
     else RT_FAIL(c, RT_ERR_ARG, "bad tuning key/value %d/%d", key, value);
     return RT_OK;
 }
@@ -1989,7 +2285,7 @@ int rt_tuning(rt_ctx* c, int key, int value)
 int rt_trace_mode(rt_ctx* c, int mode)
 {
     RT_CHECK_CTX(c);
-    if (mode != 0 && mode != 1) RT_FAIL(c, RT_ERR_ARG, "mode must be 0 or 1");
+    if (mode < 0 || mode > 3) RT_FAIL(c, RT_ERR_ARG, "mode must be 0..3");
     c->trace_mode = mode;
     return RT_OK;
 }

@@ -185,7 +185,10 @@ int rt_trace_mode(rt_ctx* ctx, int mode);
 /* performance knobs; results never depend on them. keys 0..3: workgroup->tile order inside an XCD
  * band for raycast / generate_candidate / spatial_resampling / resolve (0 row-major, 1 column-major);
  * key 4: extra LDS bytes per spatial_resampling workgroup (limits the workgroups resident per CU,
- * i.e. the neighbour window that must stay in L2). Defaults: {1,0,1,0}, 32768. */
+ * i.e. the neighbour window that must stay in L2). Defaults: {1,0,1,0}, 32768.
+ * key 5 (before rt_scene_set): binary-tree builder, 0 = device LBVH (Morton codes + Karras, fast),
+ * 1 = host binned SAH (default; the reference requests HIPRT's high-quality build,
+ * common/loader.hpp:98-99). Both feed the same wide-BVH collapse and both traversals. */
 int rt_tuning(rt_ctx* ctx, int key, int value);
 /* elementwise device evaluation of the portable math / IEEE div & sqrt (parity tests);
  * fn ids as in tests/test_portable_math.py */

@@ -113,43 +113,48 @@ def test_lbvh_equals_brute_force(api, oracle, scenes, golden_scenes):
     rng = np.random.default_rng(11)
     for name, tris in (("cornellbox1", golden_scenes["cornellbox1"]), ("cornellbox2", golden_scenes["cornellbox2"]),
                        ("quad_room", scenes.make_quad_room())):
-        r = api.Renderer(8, 8)
-        r.set_scene(tris)
         v = tris["v"].reshape(-1, 3)
         lo, hi = v.min(0), v.max(0)
         rays = _random_rays(rng, 60000 if len(tris) < 1000 else 20000, lo - 0.5, hi + 0.5)
         sc = oracle.Scene(tris, use_bvh=False)
         ref = sc.trace_closest(rays, force_brute=True)
-        for mode in (0, 1):  # 0: 4-wide quantised BVH + LDS stack (production), 1: binary LBVH + stackless trail
-            r.trace_mode(mode)
-            dev = r.trace_closest(rays)
-            assert _eq_bits(dev, ref), f"{name} mode {mode}: {(dev.view(np.uint32) != ref.view(np.uint32)).any(axis=1).sum()} rays differ"
+        for builder in (0, 1):  # 0: device LBVH (Morton + Karras), 1: host binned SAH
+            r = api.Renderer(8, 8)
+            r.tuning(5, builder)
+            r.set_scene(tris)
+            # 0: 4-wide quantised BVH + LDS stack (production), 1: binary tree + stackless trail,
+            # 2: persistent ray queue with lane refill (closest hit)
+            for mode in (0, 1, 2):
+                r.trace_mode(mode)
+                dev = r.trace_closest(rays)
+                assert _eq_bits(dev, ref), f"{name} builder {builder} mode {mode}: {(dev.view(np.uint32) != ref.view(np.uint32)).any(axis=1).sum()} rays differ"
+            r.close()
         assert (ref[:, 3].view(np.int32) >= 0).mean() > 0.2
-        r.close()
 
 
 def test_lbvh_blocks_scene_vs_oracle_bvh(api, oracle, scenes):
     """On the benchmark stand-in (212k triangles) the oracle's own BVH (itself == brute force on
     the small scenes, tests/test_oracle_bvh.py) and the device LBVH agree on 200k rays."""
     tris = scenes.make_blocks_restir()
-    r = api.Renderer(8, 8)
-    r.set_scene(tris)
-    info = r.scene_info()
-    assert info["triangles"] == len(tris) and info["lights"] == len(scenes.light_indices(tris))
     rng = np.random.default_rng(3)
-    v = tris["v"].reshape(-1, 3)
     rays = _random_rays(rng, 200000, np.float32([-20, 0, -10]), np.float32([40, 40, 60]))
     sc = oracle.Scene(tris, use_bvh=True)
     ref = sc.trace_closest(rays)
-    for mode in (0, 1):
-        r.trace_mode(mode)
-        dev = r.trace_closest(rays)
-        assert _eq_bits(dev, ref), f"mode {mode}: {(dev.view(np.uint32) != ref.view(np.uint32)).any(axis=1).sum()} rays differ"
-    r.trace_mode(0)
-    # a 2000-ray subset against true brute force
-    sub = rays[:2000]
-    assert _eq_bits(r.trace_closest(sub), sc.trace_closest(sub, force_brute=True))
-    r.close()
+    for builder in (0, 1):
+        r = api.Renderer(8, 8)
+        r.tuning(5, builder)
+        r.set_scene(tris)
+        info = r.scene_info()
+        assert info["triangles"] == len(tris) and info["lights"] == len(scenes.light_indices(tris))
+        for mode in (0, 1, 2):
+            r.trace_mode(mode)
+            dev = r.trace_closest(rays)
+            assert _eq_bits(dev, ref), f"builder {builder} mode {mode}: {(dev.view(np.uint32) != ref.view(np.uint32)).any(axis=1).sum()} rays differ"
+        r.trace_mode(0)
+        # a 2000-ray subset against true brute force
+        sub = rays[:2000]
+        assert _eq_bits(r.trace_closest(sub), sc.trace_closest(sub, force_brute=True))
+        r.close()
 
 
 def _setup(api, oracle, tris, W, H, eye, center, **optkw):
