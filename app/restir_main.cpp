@@ -6,7 +6,7 @@
  *   restir_app [--obj scene.obj | --tris scene.tris] [--size W H] [--frames N]
  *              [--eye x y z] [--lookat x y z] [--temporal 0|1] [--spatial 0|1]
  *              [--shadowed 0|1] [--visreuse 0|1] [--accumulate 0|1] [--by-kernel]
- *              [--ppm out.ppm] [--pfm out.pfm]
+ *              [--ppm out.ppm] [--pfm out.pfm] [--dump-tris out.tris]
  *
  * Keys 1,2,3,4,A of the example (10_restir_di.cpp:143-174) are the --temporal/--spatial/
  * --shadowed/--visreuse/--accumulate flags; key S (screenshot) is --ppm. `--tris` reads a raw
@@ -116,7 +116,7 @@ int main(int argc, char** argv)
     /* camera "blocks_restir.obj 1", 10_restir_di.cpp:188-189 */
     float eye[3] = {-0.579885f, 22.194597f, -6.567105f}, lookat[3] = {5.224952f, 20.847435f, 1.431192f};
     const float up[3] = {0, 1, 0};
-    std::string obj, tris_path, ppm, pfm;
+    std::string obj, tris_path, ppm, pfm, dump;
     bool by_kernel = false;
     rt_options opt;
     memset(&opt, 0, sizeof(opt));
@@ -140,12 +140,21 @@ int main(int argc, char** argv)
         else if (a == "--visreuse") opt.use_visibility_reuse = (uint8_t)atoi(argv[++i]);
         else if (a == "--accumulate") opt.accumulate = (uint8_t)atoi(argv[++i]);
         else if (a == "--by-kernel") by_kernel = true;
+        else if (a == "--dump-tris") dump = argv[++i]; /* write the loaded triangle array and exit (no GPU needed) */
         else if (a == "--ppm") ppm = argv[++i];
         else if (a == "--pfm") pfm = argv[++i];
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     std::vector<rt_triangle> triangles = !obj.empty() ? load_obj(obj) : load_tris(tris_path);
     if (triangles.empty()) { fprintf(stderr, "no triangles (use --obj or --tris)\n"); return 2; }
+    if (!dump.empty())
+    {
+        FILE* f = fopen(dump.c_str(), "wb");
+        fwrite(triangles.data(), sizeof(rt_triangle), triangles.size(), f);
+        fclose(f);
+        printf("triangles: %zu\n", triangles.size());
+        return 0;
+    }
 
     rt_ctx* ctx = nullptr;
     int rc = rt_create(0, W, H, 0, H, 0, &ctx);

@@ -113,6 +113,7 @@ def main():
         torch.cuda.synchronize()
 
     spatial_ms = None
+    pcie_ms = None
     per_kernel = None
     algo_bytes = None
     if world == 1:
@@ -154,6 +155,17 @@ def main():
         per_kernel = dict(zip(("clear", "raycast", "generate_candidate", "spatial0", "spatial1", "spatial2",
                                "resolve", "tone_mapping", "frame"), (round(float(x), 4) for x in acc_ms)))
         spatial_ms = float(acc_ms[3:6].mean())
+        # PCIe-inclusive variant (never `value`): the reference copies the RGBA8 image to the host and
+        # synchronises every frame (10_restir_di.cpp:386-389)
+        r.timing_enable(False)
+        n_pcie = max(5, K // 2)
+        barrier()
+        tp = time.perf_counter()
+        for _ in range(n_pcie):
+            frame += 1
+            r.frame(frame)
+            r.download(api.RT_BUF_PIXELS)
+        pcie_ms = (time.perf_counter() - tp) / n_pcie * 1e3
         total_rays = rays_per_frame
         info = r.scene_info()
         elapsed = dt
@@ -210,6 +222,8 @@ def main():
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                                "algorithmic_bytes_per_launch": algo_bytes, "ms_per_launch": spatial_ms}
             out["kernel_ms"] = per_kernel
+            out["pcie_inclusive"] = {"ms_per_frame": pcie_ms, "value": total_rays / pcie_ms / 1e3, "unit": "Mray/s",
+                                     "note": "frame + RGBA8 read-back to pageable host memory + sync, as the reference's loop does"}
             if not args.no_cpu_baseline and (width, height) == (W, H):
                 cb, _ = cpu_baseline(tris, eye, center)
                 out["cpu_baseline"] = cb
