@@ -366,3 +366,67 @@ def test_path_tracers_07_and_09(api, oracle, scenes, golden_scenes, example, sce
     r.tone_mapping()
     assert np.array_equal(r.download(api.RT_BUF_PIXELS).reshape(H, W, 4), oracle.tone_mapping(acc, W, H))
     r.close()
+
+
+def test_edge_cases_and_error_codes(api, oracle, scenes):
+    """Odd image sizes (not multiples of the 32x8 tile), all-sky frames, scenes without lights,
+    a single triangle, zero spatial passes, and the error behaviour of the C-ABI (codes, no aborts)."""
+    from cedec_2024_rt_amd.types import bench_options, default_options
+
+    oracle.set_math_mode(oracle.MATH_PORTABLE)
+    tris = scenes.make_quad_room()
+    eye, center = (0.5, 2.5, 6.0), (0.0, 1.5, -1.0)
+    # 1. odd sizes, 1 and 0 spatial passes
+    for (W, H, kw) in ((37, 23, dict()), (33, 9, dict(spatial_resampling_passes=1)), (65, 17, dict(spatial_resampling_passes=0))):
+        r, sc, rg, opt, eyev = _setup(api, oracle, tris, W, H, eye, center, **kw)
+        st = oracle.new_state(W, H)
+        for frame in (1, 2):
+            r.frame(frame)
+            sc.frame(W, H, frame, rg, eyev, opt, st)
+            acc = r.download(api.RT_BUF_ACCUMULATION)
+            if kw.get("spatial_resampling_passes", 3) > 0:  # with 0 passes the reference resolves a stale buffer
+                assert _eq_bits(acc, st["accum"].reshape(acc.shape)), (W, H, kw, frame)
+        r.close()
+    # 2. camera looking away: every pixel is sky
+    r, sc, rg, opt, eyev = _setup(api, oracle, tris, 40, 24, (0.0, 50.0, 0.0), (0.0, 100.0, 0.0))
+    r.frame(1)
+    acc = r.download(api.RT_BUF_ACCUMULATION)
+    assert np.all(acc[:, :3] == 0) and np.all(acc[:, 3] == 1)
+    assert r.ray_count() == (40 * 24, 0)
+    r.close()
+    # 3. a scene without emissive triangles: raycast works, generate_candidate reports an error code
+    dark = tris.copy()
+    dark["emissive"] = 0
+    r = api.Renderer(32, 16)
+    r.set_scene(dark)
+    r.lookat(eye, center)
+    r.set_options(bench_options())
+    r.raycast()
+    assert (r.download(api.RT_BUF_VISIBILITY)["index"] >= 0).any()
+    with pytest.raises(api.RtError, match="no emissive"):
+        r.generate_candidate(1)
+    with pytest.raises(api.RtError):
+        r.frame(1)
+    # 4. single triangle / empty scene
+    one = tris[:1].copy()
+    r.set_scene(one)
+    h = r.trace_closest(np.float32([[-3.0, 5.0, -3.0, 0, -1, 0, 0, 1e30], [50, 5, 50, 0, -1, 0, 0, 1e30]]))
+    ref = oracle.Scene(one, use_bvh=False).trace_closest(np.float32([[-3.0, 5.0, -3.0, 0, -1, 0, 0, 1e30], [50, 5, 50, 0, -1, 0, 0, 1e30]]), force_brute=True)
+    assert _eq_bits(h, ref)
+    r.set_scene(tris[:0])
+    r.raycast()
+    assert (r.download(api.RT_BUF_VISIBILITY)["index"] == -1).all()
+    # 5. argument / state errors come back as codes with a message
+    with pytest.raises(api.RtError):
+        r.spatial_resampling(1, 0, api.RT_RES_0, api.RT_RES_0)  # in == out
+    with pytest.raises(api.RtError):
+        r.upload(api.RT_BUF_RES_0, np.zeros(3, dtype=np.uint8))  # size mismatch
+    with pytest.raises(api.RtError):
+        r.halo_pack(api.RT_RES_0, 0, 10_000, 0)  # rows outside the context
+    r.close()
+    with pytest.raises(api.RtError):
+        api.Renderer(0, 10)
+    r2 = api.Renderer(16, 16)
+    with pytest.raises(api.RtError, match="scene and camera"):
+        r2.raycast()
+    r2.close()
