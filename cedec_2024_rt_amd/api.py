@@ -23,7 +23,7 @@ EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_sync", "rt_scene_set", "rt_scene_info",
     "rt_camera_lookat", "rt_camera_set", "rt_camera_get", "rt_options_set", "rt_options_get", "rt_clear",
     "rt_raycast", "rt_generate_candidate", "rt_temporal_resampling", "rt_save_temporal_reservoir",
-    "rt_spatial_resampling", "rt_resolve", "rt_tone_mapping", "rt_frame", "rt_frame_stage", "rt_frame_stage_input", "rt_path_trace", "rt_path_trace_rays", "rt_local_rows", "rt_download",
+    "rt_spatial_resampling", "rt_resolve", "rt_tone_mapping", "rt_frame", "rt_frame_stage", "rt_frame_stage_input", "rt_frame_stage_begin", "rt_frame_stage_run", "rt_frame_stage_end", "rt_frame_stage_output", "rt_path_trace", "rt_path_trace_rays", "rt_local_rows", "rt_download",
     "rt_upload", "rt_halo_bytes", "rt_halo_pack", "rt_halo_unpack", "rt_ray_count", "rt_timing_enable",
     "rt_timing", "rt_spatial_bytes", "rt_trace_closest", "rt_trace_stats", "rt_bvh_config", "rt_bvh_info", "rt_trace_mode", "rt_tuning", "rt_math_eval",
 ]
@@ -80,6 +80,10 @@ def load_library():
     L.rt_path_trace_rays.argtypes = [vp, vp]
     L.rt_frame_stage.argtypes = [vp, ci, ci, ci]
     L.rt_frame_stage_input.argtypes = [vp, ci, vp]
+    L.rt_frame_stage_begin.argtypes = [vp, ci, ci, ci]
+    L.rt_frame_stage_run.argtypes = [vp, ci, ci, ci, ci]
+    L.rt_frame_stage_end.argtypes = [vp, ci]
+    L.rt_frame_stage_output.argtypes = [vp, ci, vp]
     L.rt_local_rows.argtypes = [vp, vp, vp]
     L.rt_download.argtypes = [vp, ci, vp, C.c_size_t]
     L.rt_upload.argtypes = [vp, ci, vp, C.c_size_t]
@@ -244,6 +248,20 @@ class Renderer:
 
     def frame_stage(self, frame, stage, clear_first=False):
         self._ck(self.L.rt_frame_stage(self.h, int(frame), int(stage), int(bool(clear_first))))
+
+    def frame_stage_begin(self, frame, stage, clear_first=False):
+        self._ck(self.L.rt_frame_stage_begin(self.h, int(frame), int(stage), int(bool(clear_first))))
+
+    def frame_stage_run(self, frame, stage, row0, row1):
+        self._ck(self.L.rt_frame_stage_run(self.h, int(frame), int(stage), int(row0), int(row1)))
+
+    def frame_stage_end(self, stage):
+        self._ck(self.L.rt_frame_stage_end(self.h, int(stage)))
+
+    def frame_stage_output(self, stage):
+        p = C.c_int(-1)
+        self._ck(self.L.rt_frame_stage_output(self.h, int(stage), C.byref(p)))
+        return RT_RES_PHYS + p.value
 
     def frame_stage_input(self, stage):
         p = C.c_int(-1)

@@ -967,7 +967,9 @@ struct rt_ctx
     float4* d_rec[3] = {nullptr, nullptr, nullptr};
     float4* d_rad[3] = {nullptr, nullptr, nullptr};
     int res_map[3] = {0, 1, 2};
-    int fX = 0, fY = 1, fZ = 2, f_in = 0, f_out = 1, f_stage = 0, f_final = RT_RES_1; /* rt_frame_stage state */
+    int sub0 = -1, sub1 = -1; /* row sub-range of the running rt_frame_stage_run (-1: all owned rows) */
+    int fX = 0, fY = 1, fZ = 2, f_in = 0, f_out = 1, f_stage = 0, f_final = RT_RES_1;
+    bool f_clear = false; /* rt_frame_stage state */
     unsigned long long* d_counter = nullptr;
     void* d_stage = nullptr;
     size_t stage_bytes = 0;
@@ -1018,7 +1020,8 @@ static FrameParams make_params(const rt_ctx* c, int frame, int pass, int kernel 
 {
     FrameParams P;
     P.W = c->W; P.H = c->H;
-    P.row0 = c->row_begin; P.row1 = c->row_end;
+    P.row0 = c->sub0 >= 0 ? c->sub0 : c->row_begin;
+    P.row1 = c->sub0 >= 0 ? c->sub1 : c->row_end;
     P.lrow0 = c->lrow0; P.lrows = c->lrows;
     P.frame = frame; P.pass = pass;
     P.eye = F3(c->eye[0], c->eye[1], c->eye[2]);
@@ -1767,7 +1770,10 @@ int rt_options_get(rt_ctx* c, rt_options* o)
 #define NEED_RES(c, id) \
     if ((id) < 0 || (id) > 2) RT_FAIL(c, RT_ERR_ARG, "bad reservoir buffer id %d", (id));
 
-static int launch_grid(const rt_ctx* c) { return tile_grid(c->W, c->row_end - c->row_begin); }
+static int launch_grid(const rt_ctx* c)
+{
+    return c->sub0 >= 0 ? tile_grid(c->W, c->sub1 - c->sub0) : tile_grid(c->W, c->row_end - c->row_begin);
+}
 
 int rt_clear(rt_ctx* c)
 {
@@ -1941,66 +1947,111 @@ int rt_timing_enable(rt_ctx* c, int on)
  *   stage 1..passes    spatial pass stage-1      (its input buffer must have valid halos)
  *   stage passes+1     resolve, tone_mapping, buffer renaming
  * rt_frame runs them back to back. */
-int rt_frame_stage(rt_ctx* c, int frame, int stage, int clear_first)
+/* begin: buffer roles of the stage; run: its kernels over storage rows [row0,row1) of the owned
+ * rows (several runs per stage allowed: boundary rows first, interior later, so that halos can
+ * travel while the interior is computed); end: advance. */
+int rt_frame_stage_begin(rt_ctx* c, int frame, int stage, int clear_first)
 {
     RT_CHECK_CTX(c);
     NEED_SCENE(c);
+    (void)frame;
     const int passes = c->opt.spatial_resampling_passes;
-    const bool T = c->timing;
-    auto mark = [&](int i) { if (T && i <= 8) hipEventRecord(c->ev[i], c->stream); };
-    int rc;
     if (stage == 0)
     {
-        mark(0);
-        if (clear_first) { if ((rc = rt_clear(c)) != RT_OK) return rc; }
-        mark(1);
-        if ((rc = rt_raycast(c)) != RT_OK) return rc;
-        mark(2);
         /* X = history, Y = candidates(+temporal) -> next history, Z = spatial ping-pong partner */
         c->fX = c->res_map[RT_RES_TEMPORAL]; c->fY = c->res_map[RT_RES_0]; c->fZ = c->res_map[RT_RES_1];
-        if ((rc = launch_generate(c, frame, c->fY, c->fX, c->opt.use_temporal_resampling != 0)) != RT_OK) return rc;
-        mark(3);
         c->f_in = c->fY; c->f_out = c->fZ;
-        c->f_stage = 1;
+        c->f_clear = clear_first != 0;
+        c->f_stage = 0;
         return RT_OK;
     }
     if (stage != c->f_stage) RT_FAIL(c, RT_ERR_STATE, "rt_frame_stage: expected stage %d, got %d", c->f_stage, stage);
-    if (stage <= passes)
+    if (stage >= 2 && stage <= passes) { c->f_in = c->f_out; c->f_out = (c->f_in == c->fZ) ? c->fX : c->fZ; }
+    if (stage > passes + 1) RT_FAIL(c, RT_ERR_ARG, "bad stage %d", stage);
+    return RT_OK;
+}
+
+int rt_frame_stage_run(rt_ctx* c, int frame, int stage, int row0, int row1)
+{
+    RT_CHECK_CTX(c);
+    NEED_SCENE(c);
+    if (stage != c->f_stage) RT_FAIL(c, RT_ERR_STATE, "rt_frame_stage_run: expected stage %d, got %d", c->f_stage, stage);
+    if (row0 < c->row_begin) row0 = c->row_begin;
+    if (row1 > c->row_end) row1 = c->row_end;
+    if (row0 >= row1) return RT_OK;
+    const int passes = c->opt.spatial_resampling_passes;
+    const bool whole = row0 == c->row_begin && row1 == c->row_end;
+    const bool T = c->timing && whole;
+    auto mark = [&](int i) { if (T && i <= 8) hipEventRecord(c->ev[i], c->stream); };
+    c->sub0 = row0; c->sub1 = row1;
+    int rc = RT_OK;
+    if (stage == 0)
+    {
+        mark(0);
+        if (c->f_clear) rc = rt_clear(c);
+        mark(1);
+        if (rc == RT_OK) rc = rt_raycast(c);
+        mark(2);
+        if (rc == RT_OK) rc = launch_generate(c, frame, c->fY, c->fX, c->opt.use_temporal_resampling != 0);
+        mark(3);
+    }
+    else if (stage <= passes)
     {
         const int k = stage - 1;
-        if (k != 0) { c->f_in = c->f_out; c->f_out = (c->f_in == c->fZ) ? c->fX : c->fZ; }
-        if ((rc = launch_spatial(c, frame, k, c->f_in, c->f_out)) != RT_OK) return rc;
+        rc = launch_spatial(c, frame, k, c->f_in, c->f_out);
         if (k < 3) mark(4 + k);
-        c->f_stage = stage + 1;
-        return RT_OK;
     }
-    if (stage == passes + 1)
+    else
     {
         for (int k = passes; k < 3; ++k) mark(4 + k);
-        const int X = c->fX, Y = c->fY, Z = c->fZ;
-        if (passes < 2)
-        {
-            /* logical RT_RES_0 still equals the post-temporal reservoirs: materialise the copy the
-             * reference's save_temporal_reservoir makes (10_restir_di.cpp:314-321) */
-            const size_t n = local_pixels(c);
-            RT_HIP(c, hipMemcpyAsync(c->d_rec[X], c->d_rec[Y], n * 64, hipMemcpyDeviceToDevice, c->stream));
-            RT_HIP(c, hipMemcpyAsync(c->d_rad[X], c->d_rad[Y], n * 16, hipMemcpyDeviceToDevice, c->stream));
-        }
-        const int final_phys = passes > 0 ? c->f_out : Z;
-        if ((rc = launch_resolve(c, final_phys)) != RT_OK) return rc;
+        const int final_phys = passes > 0 ? c->f_out : c->fZ;
+        rc = launch_resolve(c, final_phys);
         mark(7);
-        if ((rc = rt_tone_mapping(c)) != RT_OK) return rc;
+        if (rc == RT_OK) rc = rt_tone_mapping(c);
         mark(8);
-        /* new logical names: TEMPORAL = Y; RES_1 = Z; RES_0 = X (pass-1 output / copy) */
-        c->res_map[RT_RES_TEMPORAL] = Y;
-        c->res_map[RT_RES_0] = X;
-        c->res_map[RT_RES_1] = Z;
-        c->f_final = (final_phys == Z) ? RT_RES_1 : RT_RES_0;
-        c->f_stage = 0;
-        c->last_valid = T;
-        return RT_OK;
     }
-    RT_FAIL(c, RT_ERR_ARG, "bad stage %d", stage);
+    c->sub0 = c->sub1 = -1;
+    return rc;
+}
+
+int rt_frame_stage_end(rt_ctx* c, int stage)
+{
+    RT_CHECK_CTX(c);
+    if (stage != c->f_stage) RT_FAIL(c, RT_ERR_STATE, "rt_frame_stage_end: expected stage %d, got %d", c->f_stage, stage);
+    const int passes = c->opt.spatial_resampling_passes;
+    if (stage <= passes) { c->f_stage = stage + 1; return RT_OK; }
+    const int X = c->fX, Y = c->fY, Z = c->fZ;
+    if (passes < 2)
+    {
+        /* logical RT_RES_0 still equals the post-temporal reservoirs: materialise the copy the
+         * reference's save_temporal_reservoir makes (10_restir_di.cpp:314-321) */
+        const size_t n = local_pixels(c);
+        RT_HIP(c, hipMemcpyAsync(c->d_rec[X], c->d_rec[Y], n * 64, hipMemcpyDeviceToDevice, c->stream));
+        RT_HIP(c, hipMemcpyAsync(c->d_rad[X], c->d_rad[Y], n * 16, hipMemcpyDeviceToDevice, c->stream));
+    }
+    const int final_phys = passes > 0 ? c->f_out : Z;
+    /* new logical names: TEMPORAL = Y; RES_1 = Z; RES_0 = X (pass-1 output / copy) */
+    c->res_map[RT_RES_TEMPORAL] = Y;
+    c->res_map[RT_RES_0] = X;
+    c->res_map[RT_RES_1] = Z;
+    c->f_final = (final_phys == Z) ? RT_RES_1 : RT_RES_0;
+    c->f_stage = 0;
+    c->last_valid = c->timing;
+    return RT_OK;
+}
+
+/* The frame as a sequence of stages, so that a strip context can exchange halos in between:
+ *   stage 0            [clear] raycast, generate_candidate(+temporal) into the rotating buffers
+ *   stage 1..passes    spatial pass stage-1      (its input buffer must have valid halos)
+ *   stage passes+1     resolve, tone_mapping, buffer renaming
+ * rt_frame runs them back to back. */
+int rt_frame_stage(rt_ctx* c, int frame, int stage, int clear_first)
+{
+    RT_CHECK_CTX(c);
+    int rc = rt_frame_stage_begin(c, frame, stage, clear_first);
+    if (rc == RT_OK) rc = rt_frame_stage_run(c, frame, stage, c->row_begin, c->row_end);
+    if (rc == RT_OK) rc = rt_frame_stage_end(c, stage);
+    return rc;
 }
 
 /* physical buffer that spatial pass `stage-1` of the running frame will read (for rt_halo_*_phys) */
@@ -2010,6 +2061,15 @@ int rt_frame_stage_input(rt_ctx* c, int stage, int* phys)
     if (!phys || stage < 1 || stage != c->f_stage) RT_FAIL(c, RT_ERR_STATE, "no such pending stage %d", stage);
     const int k = stage - 1;
     *phys = (k == 0) ? c->f_in : c->f_out;
+    return RT_OK;
+}
+/* physical buffer the CURRENT stage (after its _begin) writes: stage 0 -> the candidates(+temporal)
+ * buffer, spatial stage -> its output; this is what the next spatial pass will gather from */
+int rt_frame_stage_output(rt_ctx* c, int stage, int* phys)
+{
+    RT_CHECK_CTX(c);
+    if (!phys || stage != c->f_stage) RT_FAIL(c, RT_ERR_STATE, "stage %d is not running", stage);
+    *phys = (stage == 0) ? c->fY : c->f_out;
     return RT_OK;
 }
 

@@ -55,61 +55,133 @@ def exchange_plan(bounds, rank, halo=HALO_ROWS):
     return plan
 
 
-class StripFrame:
-    """One rank's frame loop: examples/10_restir_di/10_restir_di.cpp:257-379 on its strip, with a
-    halo exchange in front of every spatial pass.
+def row_bands(bounds, rank, halo=HALO_ROWS):
+    """(boundary, interior): owned row ranges whose results a neighbour needs (computed and sent
+    first) and the rest (computed while the halos travel)."""
+    a, b = bounds[rank]
+    cuts = []
+    if rank > 0:
+        cuts.append((a, min(a + halo, b)))
+    if rank + 1 < len(bounds):
+        cuts.append((max(b - halo, a), b))
+    if not cuts:
+        return [], [(a, b)]
+    cuts.sort()
+    boundary = [cuts[0]]
+    for r0, r1 in cuts[1:]:
+        if r0 <= boundary[-1][1]:
+            boundary[-1] = (boundary[-1][0], max(boundary[-1][1], r1))
+        else:
+            boundary.append((r0, r1))
+    interior, cur = [], a
+    for r0, r1 in boundary:
+        if cur < r0:
+            interior.append((cur, r0))
+        cur = r1
+    if cur < b:
+        interior.append((cur, b))
+    return boundary, interior
 
-    backend needs: raycast(), generate_candidate(frame, dst), temporal_resampling(frame, prev, inout),
-    save_temporal_reservoir(src, dst), spatial_resampling(frame, k, src, dst), resolve(res),
-    tone_mapping(), clear(), passes (int), halo_export(res, row0, n) -> tensor,
-    halo_import(res, row0, n, tensor), halo_empty(n) -> tensor.
+
+class DistTransport:
+    """torch.distributed point-to-point (RCCL with backend "nccl", gloo in the CPU tests)."""
+
+    def __init__(self, dist):
+        self.d = dist
+
+    def post(self, rank, items):
+        """items: [(peer, send_tensor, recv_tensor)] -> handle"""
+        d = self.d
+        ops = []
+        for peer, ts, tr in items:
+            ops.append(d.P2POp(d.isend, ts, peer))
+            ops.append(d.P2POp(d.irecv, tr, peer))
+        return d.batch_isend_irecv(ops) if ops else []
+
+    def finish(self, rank, handle, items):
+        for w in handle:
+            w.wait()
+
+
+class LocalTransport:
+    """In-process mailbox for several strip contexts driven in lock-step (tests on one GPU)."""
+
+    def __init__(self):
+        self.box = {}
+        self.sent = {}
+
+    def post(self, rank, items):
+        # messages of successive stages between the same pair are told apart by a sequence number
+        seqs = []
+        for peer, ts, tr in items:
+            n = self.sent.get((rank, peer), 0)
+            self.sent[(rank, peer)] = n + 1
+            self.box[(rank, peer, n)] = ts
+            seqs.append(n)
+        return seqs
+
+    def finish(self, rank, handle, items):
+        for (peer, ts, tr), n in zip(items, handle):
+            tr.copy_(self.box.pop((peer, rank, n)))
+
+
+class StripFrame:
+    """One rank's frame loop: examples/10_restir_di/10_restir_di.cpp:257-379 on its strip.
+
+    Stage 0 = [clear,] raycast, generate_candidate, temporal_resampling; stage k = spatial pass k-1;
+    stage passes+1 = resolve + tone_mapping. Each producing stage computes the boundary rows first,
+    posts the halo exchange of what it just wrote, then computes the interior rows while the halos
+    travel; the next stage waits for them. Backend protocol: passes, stage_begin(frame, s, clear),
+    stage_run(frame, s, r0, r1), stage_end(frame, s), stage_output(s) -> buffer handle,
+    halo_export(buf, row0, n) -> tensor, halo_import(buf, row0, n, tensor), halo_empty(n) -> tensor.
     """
 
-    def __init__(self, backend, bounds, rank, dist=None, halo=HALO_ROWS):
-        self.b, self.bounds, self.rank, self.dist, self.halo = backend, bounds, rank, dist, halo
-        self.plan = exchange_plan(bounds, rank, halo)
+    def __init__(self, backend, bounds, rank, transport=None, halo=HALO_ROWS):
+        self.b, self.bounds, self.rank, self.t, self.halo = backend, bounds, rank, transport, halo
+        self.plan = exchange_plan(bounds, rank, halo) if transport is not None else []
+        self.boundary, self.interior = row_bands(bounds, rank, halo) if self.plan else ([], [bounds[rank]])
 
-    def exchange(self, res):
-        if not self.plan:
-            return
-        d = self.dist
-        ops, recvs = [], []
+    def _post(self, buf):
+        items, recvs = [], []
         for peer, s0, sn, r0, rn in self.plan:
-            t_send = self.b.halo_export(res, s0, sn)
-            t_recv = self.b.halo_empty(rn)
-            ops.append(d.P2POp(d.isend, t_send, peer))
-            ops.append(d.P2POp(d.irecv, t_recv, peer))
-            recvs.append((r0, rn, t_recv))
-        for w in d.batch_isend_irecv(ops):
-            w.wait()
-        for r0, rn, t in recvs:
-            self.b.halo_import(res, r0, rn, t)
+            ts = self.b.halo_export(buf, s0, sn)
+            tr = self.b.halo_empty(rn)
+            items.append((peer, ts, tr))
+            recvs.append((r0, rn, tr))
+        return (self.t.post(self.rank, items), items, recvs, buf)
+
+    def _finish(self, pending):
+        handle, items, recvs, buf = pending
+        self.t.finish(self.rank, handle, items)
+        for r0, rn, tr in recvs:
+            self.b.halo_import(buf, r0, rn, tr)
+
+    def frame_gen(self, frame, clear_first=False):
+        """Generator: yields after every posted exchange (lets a single-process driver interleave
+        several ranks); `frame` just exhausts it."""
+        b, P = self.b, self.b.passes
+        pending = None
+        for s in range(0, P + 1):
+            if pending is not None:
+                self._finish(pending)
+                pending = None
+            b.stage_begin(frame, s, clear_first if s == 0 else False)
+            for r0, r1 in self.boundary:
+                b.stage_run(frame, s, r0, r1)
+            if s < P and self.plan:
+                pending = self._post(b.stage_output(s))
+                yield s
+            for r0, r1 in self.interior:
+                b.stage_run(frame, s, r0, r1)
+            b.stage_end(frame, s)
+        a, e = self.bounds[self.rank]
+        b.stage_begin(frame, P + 1, False)
+        b.stage_run(frame, P + 1, a, e)
+        b.stage_end(frame, P + 1)
 
     def frame(self, frame, clear_first=False):
-        b = self.b
-        if getattr(b, "staged", False):
-            # fused stages of the C-ABI (generate+temporal in one kernel, rotating buffers)
-            b.frame_stage(frame, 0, clear_first)
-            for k in range(b.passes):
-                self.exchange(b.frame_stage_input(k + 1))
-                b.frame_stage(frame, k + 1)
-            b.frame_stage(frame, b.passes + 1)
-            return None
-        if clear_first:
-            b.clear()
-        b.raycast()
-        b.generate_candidate(frame, RT_RES_0)
-        b.temporal_resampling(frame, RT_RES_TEMPORAL, RT_RES_0)
-        b.save_temporal_reservoir(RT_RES_0, RT_RES_TEMPORAL)
-        src, dst = RT_RES_0, RT_RES_1
-        for k in range(b.passes):
-            if k != 0:
-                src, dst = dst, src
-            self.exchange(src)
-            b.spatial_resampling(frame, k, src, dst)
-        b.resolve(dst)
-        b.tone_mapping()
-        return dst
+        for _ in self.frame_gen(frame, clear_first):
+            pass
 
 
 class HipStripBackend:
@@ -124,10 +196,18 @@ class HipStripBackend:
         # host_staging: the transport cannot move device memory (gloo; used to exercise this path
         # with several ranks on ONE GPU, where RCCL refuses duplicate devices)
         self.host_staging = host_staging
-        self.staged = True  # use rt_frame_stage
 
-    def __getattr__(self, name):  # kernel entry points pass straight through
-        return getattr(self.r, name)
+    def stage_begin(self, frame, s, clear_first=False):
+        self.r.frame_stage_begin(frame, s, clear_first)
+
+    def stage_run(self, frame, s, r0, r1):
+        self.r.frame_stage_run(frame, s, r0, r1)
+
+    def stage_end(self, frame, s):
+        self.r.frame_stage_end(s)
+
+    def stage_output(self, s):
+        return self.r.frame_stage_output(s)
 
     def _dev_empty(self, n_rows):
         return self.torch.empty(self.r.halo_bytes(n_rows), dtype=self.torch.uint8, device=self.device)
@@ -167,53 +247,34 @@ def make_hip_strip(width, height, rank, world, triangles, eye, center, options, 
     r.set_options(options)
     host_staging = world > 1 and dist.get_backend() == "gloo"
     be = HipStripBackend(r, torch.device("cuda", dev), host_staging=host_staging)
-    return r, StripFrame(be, bounds, rank, dist if world > 1 else None)
+    return r, StripFrame(be, bounds, rank, DistTransport(dist) if world > 1 else None)
 
 
-def run_frame_local(renderers, bounds, frame, device, halo=HALO_ROWS, staged=False):
-    """Single-process variant for tests: several strip contexts on ONE GPU, halos moved through a
-    device staging tensor with explicit stream syncs (no torch.distributed)."""
+def run_frame_local(renderers, bounds, frame, device, halo=HALO_ROWS):
+    """Single-process variant for tests: several strip contexts on ONE GPU driven in lock-step
+    through the same StripFrame logic, halos moved through an in-process mailbox."""
     import torch
 
-    passes = int(renderers[0].options()["spatial_resampling_passes"][0])
-    if staged:
-        for r in renderers:
-            r.frame_stage(frame, 0)
-        for k in range(passes):
-            for rank, r in enumerate(renderers):
-                for peer, s0, sn, r0, rn in exchange_plan(bounds, rank, halo):
-                    t = torch.empty(renderers[peer].halo_bytes(rn), dtype=torch.uint8, device=device)
-                    renderers[peer].halo_pack(renderers[peer].frame_stage_input(k + 1), r0, rn, t.data_ptr())
-                    renderers[peer].sync()
-                    r.halo_unpack(r.frame_stage_input(k + 1), r0, rn, t.data_ptr())
-                    r.sync()
-            for r in renderers:
-                r.frame_stage(frame, k + 1)
-        for r in renderers:
-            r.frame_stage(frame, passes + 1)
-            r.sync()
-        return None
+    class _Sync(HipStripBackend):
+        # contexts have their own streams here: make every hand-off visible before the peer reads it
+        def halo_export(self, res, row0, n_rows):
+            t = super().halo_export(res, row0, n_rows)
+            self.r.sync()
+            return t
+
+        def halo_import(self, res, row0, n_rows, t):
+            super().halo_import(res, row0, n_rows, t)
+            self.r.sync()
+
+    tr = LocalTransport()
+    frames = [StripFrame(_Sync(r, device), bounds, k, tr, halo) for k, r in enumerate(renderers)]
+    gens = [f.frame_gen(frame) for f in frames]
+    live = list(range(len(gens)))
+    while live:
+        for k in list(live):
+            try:
+                next(gens[k])
+            except StopIteration:
+                live.remove(k)
     for r in renderers:
-        r.raycast()
-        r.generate_candidate(frame, RT_RES_0)
-        r.temporal_resampling(frame, RT_RES_TEMPORAL, RT_RES_0)
-        r.save_temporal_reservoir(RT_RES_0, RT_RES_TEMPORAL)
-    src, dst = RT_RES_0, RT_RES_1
-    for k in range(passes):
-        if k != 0:
-            src, dst = dst, src
-        for rank, r in enumerate(renderers):
-            for peer, s0, sn, r0, rn in exchange_plan(bounds, rank, halo):
-                # what `rank` receives is what `peer` owns: rows [r0, r0+rn)
-                t = torch.empty(renderers[peer].halo_bytes(rn), dtype=torch.uint8, device=device)
-                renderers[peer].halo_pack(src, r0, rn, t.data_ptr())
-                renderers[peer].sync()
-                r.halo_unpack(src, r0, rn, t.data_ptr())
-                r.sync()
-        for r in renderers:
-            r.spatial_resampling(frame, k, src, dst)
-    for r in renderers:
-        r.resolve(dst)
-        r.tone_mapping()
         r.sync()
-    return dst

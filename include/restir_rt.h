@@ -139,6 +139,13 @@ int rt_frame(rt_ctx* ctx, int frame, int clear_first, int* final_res);
  * the buffer rt_frame_stage_input(ctx, k, &p) names (use RT_RES_PHYS + p with rt_halo_pack/unpack). */
 int rt_frame_stage(rt_ctx* ctx, int frame, int stage, int clear_first);
 int rt_frame_stage_input(rt_ctx* ctx, int stage, int* physical_buffer);
+/* Finer control for overlapping halo traffic with compute: rt_frame_stage == _begin, one _run over
+ * all owned rows, _end. A caller may instead _run the boundary rows first, start sending them
+ * (rt_frame_stage_output names the buffer being written), _run the interior rows, then _end. */
+int rt_frame_stage_begin(rt_ctx* ctx, int frame, int stage, int clear_first);
+int rt_frame_stage_run(rt_ctx* ctx, int frame, int stage, int row0, int row1);
+int rt_frame_stage_end(rt_ctx* ctx, int stage);
+int rt_frame_stage_output(rt_ctx* ctx, int stage, int* physical_buffer);
 
 /* ---- host <-> device in the reference's layouts (fixture injection, result read-back) ----
  * Element counts are W * (rows held) where rows held = owned rows + halos clipped to the

@@ -287,14 +287,14 @@ def test_frame_parity_blocks_restir_quarter_res(api, oracle, scenes):
     r.close()
 
 
-@pytest.mark.parametrize("staged", [False, True])
-def test_strip_contexts_match_full_frame(api, oracle, scenes, staged):
+@pytest.mark.parametrize("n_strips,H", [(2, 240), (3, 300)])
+def test_strip_contexts_match_full_frame(api, oracle, scenes, n_strips, H):
     """Two row-strip contexts on one GPU with an 87-row halo exchanged through the C-ABI halo
     calls reproduce the single-context frame bit for bit."""
     import ctypes as C
 
     tris = scenes.make_quad_room()
-    W, H = 64, 240
+    W = 64
     from cedec_2024_rt_amd.types import bench_options
     from cedec_2024_rt_amd import strips
 
@@ -303,7 +303,7 @@ def test_strip_contexts_match_full_frame(api, oracle, scenes, staged):
     full.lookat((0.5, 2.5, 6.0), (0.0, 1.5, -1.0))
     full.set_options(bench_options())
     ctxs = []
-    bounds = strips.partition_rows(H, 2)
+    bounds = strips.partition_rows(H, n_strips)
     for (a, b) in bounds:
         c = api.Renderer(W, H, rows=(a, b), halo=strips.HALO_ROWS)
         c.set_scene(tris)
@@ -316,7 +316,7 @@ def test_strip_contexts_match_full_frame(api, oracle, scenes, staged):
     for frame in (1, 2):
         full.frame(frame)
         ref = full.download(api.RT_BUF_ACCUMULATION).reshape(H, W, 4)
-        strips.run_frame_local(ctxs, bounds, frame, torch.device("cuda:0"), staged=staged)
+        strips.run_frame_local(ctxs, bounds, frame, torch.device("cuda:0"))
         for c, (a, b) in zip(ctxs, bounds):
             acc = c.download(api.RT_BUF_ACCUMULATION).reshape(c.local_rows, W, 4)
             mine = acc[a - c.local_row0: b - c.local_row0]

@@ -22,6 +22,11 @@ def test_halo_bound_and_partition():
     plan = strips.exchange_plan(b, 3)
     assert plan == [(2, 810, 87, 723, 87), (4, 993, 87, 1080, 87)]
     assert strips.exchange_plan(b, 0) == [(1, 183, 87, 270, 87)]
+    # boundary rows (needed by a neighbour) are computed first, the interior while halos travel
+    assert strips.row_bands(b, 3) == ([(810, 897), (993, 1080)], [(897, 993)])
+    assert strips.row_bands(b, 0) == ([(183, 270)], [(0, 183)])
+    assert strips.row_bands(strips.partition_rows(1080, 8), 3) == ([(405, 540)], [])  # 135-row strips: all boundary
+    assert strips.row_bands([(0, 100)], 0) == ([], [(0, 100)])
 
 
 class OracleBackend:
@@ -41,6 +46,8 @@ class OracleBackend:
         st = ob.new_state(W, H)
         self.vis, self.accum, self.pixels = st["vis"], st["accum"], st["pixels"]
         self.res = [st["r0"], st["r1"], st["temporal"]]
+        self.staged_temporal = []
+        self.src, self.dst = 0, 1
         # poison everything this rank must never read: rows outside [l0, l1)
         for r in self.res:
             v = r.view(np.uint8).reshape(H, -1)
@@ -49,32 +56,39 @@ class OracleBackend:
         self.vis["index"][: self.l0 * W] = -12345
         self.vis["index"][self.l1 * W:] = -12345
 
-    def clear(self):
-        self.ob.clear(self.accum, self.W, self.H)
+    # ---- StripFrame backend protocol (stages of the frame, restricted to row ranges)
+    def stage_begin(self, frame, s, clear_first=False):
+        if s == 0:
+            if clear_first:
+                self.ob.clear(self.accum, self.W, self.H)
+            # visibility of the halo rows is recomputed locally (the oracle's spatial pass reads the
+            # neighbour's Visibility; the HIP path keeps that bit inside the exchanged record)
+            self.sc.raycast(self.W, self.H, self.rg, self.vis, rows=(self.l0, self.l1))
+            self.src, self.dst = 0, 1
+        elif 2 <= s <= self.passes:
+            self.src, self.dst = self.dst, self.src
 
-    def raycast(self):
-        # visibility of the halo rows is recomputed locally (the oracle's spatial pass reads the
-        # neighbour's Visibility; the HIP path keeps that bit inside the exchanged record)
-        self.sc.raycast(self.W, self.H, self.rg, self.vis, rows=(self.l0, self.l1))
+    def stage_run(self, frame, s, r0, r1):
+        assert self.a <= r0 < r1 <= self.b
+        W, H, rows = self.W, self.H, (r0, r1)
+        if s == 0:
+            self.sc.generate_candidate(W, H, frame, self.vis, self.eye, self.opt, self.res[0], rows=rows)
+            self.sc.temporal_resampling(W, H, frame, self.vis, self.eye, self.opt, self.res[2], self.res[0], rows=rows)
+            sl = slice(r0 * W, r1 * W)
+            self.staged_temporal.append(sl)  # save_temporal_reservoir after ALL rows merged with the old history
+        elif s <= self.passes:
+            self.sc.spatial_resampling(W, H, frame, s - 1, self.vis, self.eye, self.opt, self.res[self.src], self.res[self.dst], rows=rows)
+        else:
+            self.sc.resolve(self.accum, W, H, self.vis, self.eye, self.opt, self.res[self.dst], rows=rows)
 
-    def generate_candidate(self, frame, dst):
-        self.sc.generate_candidate(self.W, self.H, frame, self.vis, self.eye, self.opt, self.res[dst], rows=(self.a, self.b))
+    def stage_end(self, frame, s):
+        if s == 0:
+            for sl in self.staged_temporal:
+                self.res[2][sl] = self.res[0][sl]
+            self.staged_temporal = []
 
-    def temporal_resampling(self, frame, prev, inout):
-        self.sc.temporal_resampling(self.W, self.H, frame, self.vis, self.eye, self.opt, self.res[prev], self.res[inout], rows=(self.a, self.b))
-
-    def save_temporal_reservoir(self, src, dst):
-        s = slice(self.a * self.W, self.b * self.W)
-        self.res[dst][s] = self.res[src][s]
-
-    def spatial_resampling(self, frame, k, src, dst):
-        self.sc.spatial_resampling(self.W, self.H, frame, k, self.vis, self.eye, self.opt, self.res[src], self.res[dst], rows=(self.a, self.b))
-
-    def resolve(self, res):
-        self.sc.resolve(self.accum, self.W, self.H, self.vis, self.eye, self.opt, self.res[res], rows=(self.a, self.b))
-
-    def tone_mapping(self):
-        pass
+    def stage_output(self, s):
+        return 0 if s == 0 else self.dst
 
     def halo_empty(self, n):
         return self.torch.empty(n * self.W * 76, dtype=self.torch.uint8)
@@ -110,7 +124,7 @@ def _worker(rank, world, port, W, H, frames, q):
         opt = ob.bench_options()
         bounds = strips.partition_rows(H, world)
         be = OracleBackend(ob, tris, W, H, bounds[rank], strips.HALO_ROWS, eye, center, opt)
-        sf = strips.StripFrame(be, bounds, rank, dist)
+        sf = strips.StripFrame(be, bounds, rank, strips.DistTransport(dist))
         # single-rank truth
         sc = ob.Scene(tris, use_bvh=True)
         rg = ob.raygen_lookat(eye, center, (0, 1, 0), np.float32(np.pi) / np.float32(4), W, H)
