@@ -194,6 +194,9 @@ struct WideView
 constexpr int WIDE_LDS_STACK = 24;
 constexpr int WIDE_OVF_STACK = 40; /* total 64 >= 3 * wide height + 1 (checked at build) */
 constexpr uint32_t WIDE_LEAF_BIT = 0x80000000u;
+#ifndef WIDE_ANY_SORTED
+#define WIDE_ANY_SORTED 0 /* any-hit rays: visit children nearest-first (1) or in slot order (0) */
+#endif
 
 RT_DEV float wide_byte(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }
 
@@ -279,7 +282,7 @@ RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3
             }
             if (nhit > 0)
             {
-                if (!ANY)
+                if (!ANY || WIDE_ANY_SORTED)
                 {
                     /* sort ascending by entry distance (5 compare-exchanges) */
 #define RT_CSWAP(i, j)                                                     \

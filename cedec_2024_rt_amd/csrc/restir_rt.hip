@@ -65,6 +65,9 @@ struct SceneView
 };
 
 constexpr int TILE_W = 32, TILE_H = 8, BLOCK = 256;
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES 1 /* min waves per SIMD requested for the tracing kernels (register budget) */
+#endif
 
 /* XCD-aware workgroup -> tile -> pixel. Returns false for threads outside the row range.
  * Workgroup b runs on XCD b % 8 (round-robin dispatch); slot b / 8 walks that XCD's band of
@@ -138,7 +141,7 @@ RT_DEV void gbuffer_write(const SceneView& S, const FrameParams& P, float4* __re
 
 /* -------------------------------------------------------------------- raycast */
 /* examples/10_restir_di/10_restir_di.cu:9-34 (+ common/camera.hpp:27-35) */
-__global__ __launch_bounds__(BLOCK) void k_raycast(SceneView S, FrameParams P, float4* __restrict__ vis,
+__global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_raycast(SceneView S, FrameParams P, float4* __restrict__ vis,
                                                     float4* __restrict__ g0, float4* __restrict__ g1)
 {
     __shared__ uint32_t s_stack[WIDE_LDS_STACK * BLOCK];
@@ -216,7 +219,7 @@ RT_DEV void temporal_merge(const SceneView& S, uint32_t* s_stack, const FramePar
 /* examples/10_restir_di/10_restir_di.cu:36-135; with FUSE_TEMPORAL also :137-237 on the
  * value still in registers (the reference round-trips it through reservoir_buffer0). */
 template <bool FUSE_TEMPORAL, bool SHADOWED>
-__global__ __launch_bounds__(BLOCK) void k_generate_candidate(
+__global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_generate_candidate(
     SceneView S, FrameParams P, const float4* __restrict__ g0, const float4* __restrict__ g1,
     const float4* __restrict__ prev_rec, const float4* __restrict__ prev_rad, float4* __restrict__ out_rec,
     float4* __restrict__ out_rad)
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(BLOCK) void k_spatial_bytes(FrameParams P, const fl
 
 /* -------------------------------------------------------------------- resolve */
 /* examples/10_restir_di/10_restir_di.cu:390-459 */
-__global__ __launch_bounds__(BLOCK) void k_resolve(SceneView S, FrameParams P, const float4* __restrict__ g0,
+__global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_resolve(SceneView S, FrameParams P, const float4* __restrict__ g0,
                                                     const float4* __restrict__ g1,
                                                     const float4* __restrict__ rec,
                                                     const float4* __restrict__ radb, float4* __restrict__ accum)
