@@ -21,7 +21,8 @@ RT_BUF_VISIBILITY, RT_BUF_RES_0, RT_BUF_RES_1, RT_BUF_RES_TEMPORAL, RT_BUF_ACCUM
 
 EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_sync", "rt_scene_set", "rt_scene_info",
-    "rt_camera_lookat", "rt_camera_set", "rt_camera_get", "rt_options_set", "rt_options_get", "rt_clear",
+    "rt_camera_lookat", "rt_camera_set", "rt_camera_get", "rt_camera_orbit", "rt_camera_zoom", "rt_camera_pan",
+    "rt_camera_updated", "rt_camera_pose", "rt_options_set", "rt_options_get", "rt_clear",
     "rt_raycast", "rt_generate_candidate", "rt_temporal_resampling", "rt_save_temporal_reservoir",
     "rt_spatial_resampling", "rt_resolve", "rt_tone_mapping", "rt_frame", "rt_frame_stage", "rt_frame_stage_input", "rt_frame_stage_begin", "rt_frame_stage_run", "rt_frame_stage_end", "rt_frame_stage_output", "rt_path_trace", "rt_path_trace_rays", "rt_local_rows", "rt_download",
     "rt_upload", "rt_halo_bytes", "rt_halo_pack", "rt_halo_unpack", "rt_ray_count", "rt_timing_enable",
@@ -65,6 +66,11 @@ def load_library():
     L.rt_camera_lookat.argtypes = [vp, vp, vp, vp, cf]
     L.rt_camera_set.argtypes = [vp, vp, vp]
     L.rt_camera_get.argtypes = [vp, vp]
+    L.rt_camera_orbit.argtypes = [vp, cf, cf]
+    L.rt_camera_zoom.argtypes = [vp, cf]
+    L.rt_camera_pan.argtypes = [vp, cf, cf]
+    L.rt_camera_updated.argtypes = [vp, vp]
+    L.rt_camera_pose.argtypes = [vp, vp, vp]
     L.rt_options_set.argtypes = [vp, vp]
     L.rt_options_get.argtypes = [vp, vp]
     L.rt_clear.argtypes = [vp]
@@ -166,6 +172,26 @@ class Renderer:
         fovy = np.float32(np.pi) / np.float32(4.0) if fovy is None else np.float32(fovy)  # 10_restir_di.cpp:242
         e, c, u = (np.asarray(v, dtype=np.float32) for v in (eye, center, up))
         self._ck(self.L.rt_camera_lookat(self.h, _p(e), _p(c), _p(u), C.c_float(fovy)))
+
+    # CameraControl of common/misc.hpp:108-224 (mouse drags as calls)
+    def orbit(self, dx, dy):
+        self._ck(self.L.rt_camera_orbit(self.h, C.c_float(dx), C.c_float(dy)))
+
+    def zoom(self, dy):
+        self._ck(self.L.rt_camera_zoom(self.h, C.c_float(dy)))
+
+    def pan(self, dx, dy):
+        self._ck(self.L.rt_camera_pan(self.h, C.c_float(dx), C.c_float(dy)))
+
+    def camera_updated(self):
+        f = C.c_int(0)
+        self._ck(self.L.rt_camera_updated(self.h, C.byref(f)))
+        return bool(f.value)
+
+    def camera_pose(self):
+        e, a = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        self._ck(self.L.rt_camera_pose(self.h, _p(e), _p(a)))
+        return e, a
 
     def set_raygen(self, raygen, eye):
         rg = np.ascontiguousarray(raygen, dtype=RAYGEN)

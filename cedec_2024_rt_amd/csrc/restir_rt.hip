@@ -981,6 +981,8 @@ struct rt_ctx
     rt_raygen rg;
     float eye[3] = {0, 0, 0};
     bool has_camera = false, has_scene = false, has_gbuffer = false;
+    float cam_eye[3] = {8.0f, 8.0f, 8.0f}, cam_at[3] = {0.0f, 0.0f, 0.0f}, cam_fovy = 0.78539816339f; /* misc.hpp:217-218 */
+    bool cam_updated = false;
 
     bool timing = false;
     hipEvent_t ev[10] = {};
@@ -1732,9 +1734,98 @@ int rt_camera_lookat(rt_ctx* c, const float eye[3], const float center[3], const
     c->rg.right[0] = r.x; c->rg.right[1] = r.y; c->rg.right[2] = r.z;
     c->rg.up[0] = uu.x; c->rg.up[1] = uu.y; c->rg.up[2] = uu.z;
     c->eye[0] = e.x; c->eye[1] = e.y; c->eye[2] = e.z;
+    memcpy(c->cam_eye, eye, 12);
+    memcpy(c->cam_at, center, 12);
+    c->cam_fovy = fovy;
     c->has_camera = true;
     return RT_OK;
 }
+/* ---- interactive camera of the examples (common/misc.hpp:108-224 CameraControl): the mouse
+ * callbacks restated as explicit calls; the window system stays out of scope. Each call updates
+ * eye / look-at, re-derives the RayGenerator (fovy and up as last set) and raises the `updated`
+ * flag that the frame loop turns into a `clear` (10_restir_di.cpp:257-267). ---- */
+static void camera_refresh(rt_ctx* c)
+{
+    const float up[3] = {0.0f, 1.0f, 0.0f};
+    rt_camera_lookat(c, c->cam_eye, c->cam_at, up, c->cam_fovy);
+    c->cam_updated = true;
+}
+/* left-button drag by (dx, dy) pixels: orbit around the look-at point (misc.hpp:147-181) */
+int rt_camera_orbit(rt_ctx* c, float dx, float dy)
+{
+    RT_CHECK_CTX(c);
+    if (!c->has_camera) RT_FAIL(c, RT_ERR_STATE, "set the camera first");
+    float lx = c->cam_eye[0] - c->cam_at[0], ly = c->cam_eye[1] - c->cam_at[1], lz = c->cam_eye[2] - c->cam_at[2];
+    const float r = sqrtf(lx * lx + ly * ly + lz * lz);
+    const float sensitivity = 0.004f;
+    {
+        const float st = sinf(dx * sensitivity), ct = cosf(dx * sensitivity);
+        const float nx = ct * lx - st * lz, nz = st * lx + ct * lz;
+        lx = nx; lz = nz;
+    }
+    {
+        const float xz = sqrtf(lx * lx + lz * lz);
+        const float st = sinf(dy * sensitivity), ct = cosf(dy * sensitivity);
+        const float new_xz = ct * xz - st * ly, new_y = st * xz + ct * ly;
+        if (-r + r * 0.01f < new_y && new_y < r - r * 0.01f)
+        {
+            lx = lx * (new_xz / xz); lz = lz * (new_xz / xz); ly = new_y;
+        }
+    }
+    c->cam_eye[0] = c->cam_at[0] + lx; c->cam_eye[1] = c->cam_at[1] + ly; c->cam_eye[2] = c->cam_at[2] + lz;
+    camera_refresh(c);
+    return RT_OK;
+}
+/* right-button drag: dolly towards / away from the look-at point (misc.hpp:183-190) */
+int rt_camera_zoom(rt_ctx* c, float dy)
+{
+    RT_CHECK_CTX(c);
+    if (!c->has_camera) RT_FAIL(c, RT_ERR_STATE, "set the camera first");
+    const float lx = c->cam_eye[0] - c->cam_at[0], ly = c->cam_eye[1] - c->cam_at[1], lz = c->cam_eye[2] - c->cam_at[2];
+    const float r = sqrtf(lx * lx + ly * ly + lz * lz);
+    const float sensitivity = 0.002f;
+    const float new_r = fmaxf(r - r * sensitivity * dy, 0.01f);
+    const float s = new_r / r;
+    c->cam_eye[0] = c->cam_at[0] + lx * s; c->cam_eye[1] = c->cam_at[1] + ly * s; c->cam_eye[2] = c->cam_at[2] + lz * s;
+    camera_refresh(c);
+    return RT_OK;
+}
+/* middle-button drag: pan eye and look-at in the view plane (misc.hpp:192-205) */
+int rt_camera_pan(rt_ctx* c, float dx, float dy)
+{
+    RT_CHECK_CTX(c);
+    if (!c->has_camera) RT_FAIL(c, RT_ERR_STATE, "set the camera first");
+    const f3 eye = F3(c->cam_eye[0], c->cam_eye[1], c->cam_eye[2]), at = F3(c->cam_at[0], c->cam_at[1], c->cam_at[2]);
+    const float r = length(eye - at);
+    const float sensitivity = 0.001f;
+    const f3 forward = normalize(at - eye);
+    const f3 right = normalize(cross(forward, F3(0.0f, 1.0f, 0.0f)));
+    const f3 up = cross(right, forward);
+    const float amount = fmaxf(r * sensitivity, 0.01f);
+    const f3 delta = (-right) * dx * amount + up * dy * amount;
+    const f3 e2 = eye + delta, a2 = at + delta;
+    c->cam_eye[0] = e2.x; c->cam_eye[1] = e2.y; c->cam_eye[2] = e2.z;
+    c->cam_at[0] = a2.x; c->cam_at[1] = a2.y; c->cam_at[2] = a2.z;
+    camera_refresh(c);
+    return RT_OK;
+}
+/* CameraControl::is_updated(): returns the flag and clears it */
+int rt_camera_updated(rt_ctx* c, int* updated)
+{
+    RT_CHECK_CTX(c);
+    if (!updated) return RT_ERR_ARG;
+    *updated = c->cam_updated ? 1 : 0;
+    c->cam_updated = false;
+    return RT_OK;
+}
+int rt_camera_pose(rt_ctx* c, float eye[3], float lookat[3])
+{
+    RT_CHECK_CTX(c);
+    if (eye) memcpy(eye, c->cam_eye, 12);
+    if (lookat) memcpy(lookat, c->cam_at, 12);
+    return RT_OK;
+}
+
 int rt_camera_set(rt_ctx* c, const rt_raygen* rg, const float eye[3])
 {
     RT_CHECK_CTX(c);

@@ -106,6 +106,15 @@ int rt_scene_info(rt_ctx* ctx, uint32_t* n_triangles, uint32_t* n_lights, uint32
 int rt_camera_lookat(rt_ctx* ctx, const float eye[3], const float center[3], const float up[3], float fovy);
 int rt_camera_set(rt_ctx* ctx, const rt_raygen* raygen, const float eye[3]);
 int rt_camera_get(rt_ctx* ctx, rt_raygen* raygen);
+/* the examples' interactive camera (common/misc.hpp:108-224 CameraControl), mouse drags as calls:
+ * orbit = left button (dx, dy in pixels), zoom = right button, pan = middle button. They update the
+ * pose set by rt_camera_lookat, re-derive the RayGenerator and raise the flag rt_camera_updated
+ * returns-and-clears (CameraControl::is_updated -> `clear`, 10_restir_di.cpp:257-267). */
+int rt_camera_orbit(rt_ctx* ctx, float dx, float dy);
+int rt_camera_zoom(rt_ctx* ctx, float dy);
+int rt_camera_pan(rt_ctx* ctx, float dx, float dy);
+int rt_camera_updated(rt_ctx* ctx, int* updated);
+int rt_camera_pose(rt_ctx* ctx, float eye[3], float lookat[3]);
 int rt_options_set(rt_ctx* ctx, const rt_options* options);
 int rt_options_get(rt_ctx* ctx, rt_options* options);
 

@@ -430,3 +430,61 @@ def test_edge_cases_and_error_codes(api, oracle, scenes):
     with pytest.raises(api.RtError, match="scene and camera"):
         r2.raycast()
     r2.close()
+
+
+def test_interactive_camera_and_accumulation_reset(api, oracle, scenes):
+    """CameraControl (common/misc.hpp:108-224) as C-ABI calls: orbit keeps the distance, zoom scales it,
+    pan moves eye and look-at together; a moved camera raises `updated`, which the frame loop turns into
+    a clear of the accumulation buffer (10_restir_di.cpp:257-267)."""
+    from cedec_2024_rt_amd.types import bench_options
+
+    tris = scenes.make_quad_room()
+    W, H = 64, 36
+    r = api.Renderer(W, H)
+    r.set_scene(tris)
+    eye0, at0 = np.float32([0.5, 2.5, 6.0]), np.float32([0.0, 1.5, -1.0])
+    r.lookat(eye0, at0)
+    r.set_options(bench_options(accumulate=1))
+    assert not r.camera_updated()
+    r.clear()
+    for f in (1, 2, 3):
+        r.frame(f, clear_first=r.camera_updated())
+    vis = r.download(api.RT_BUF_VISIBILITY)
+    shaded = (vis["index"] >= 0) & ~np.isin(vis["index"], scenes.light_indices(tris))
+    w = r.download(api.RT_BUF_ACCUMULATION)[:, 3]
+    # shaded pixels accumulate; sky / emissive pixels are assigned {.., 1} every frame (10_restir_di.cu:408-425)
+    assert shaded.any() and np.all(w[shaded] == 3.0) and np.all(w[~shaded] == 1.0)
+    # orbit: distance to the look-at point is preserved, look-at unchanged
+    r.orbit(40.0, -25.0)
+    e, a = r.camera_pose()
+    assert np.allclose(a, at0) and abs(np.linalg.norm(e - a) - np.linalg.norm(eye0 - at0)) < 1e-4 and not np.allclose(e, eye0)
+    # expected pose by an independent float32 restatement of misc.hpp:147-181
+    l = (eye0 - at0).astype(np.float32)
+    rr = np.float32(np.sqrt(np.float32(l @ l)))
+    s, c = np.float32(np.sin(np.float32(40.0 * 0.004))), np.float32(np.cos(np.float32(40.0 * 0.004)))
+    l = np.float32([c * l[0] - s * l[2], l[1], s * l[0] + c * l[2]])
+    xz = np.float32(np.sqrt(l[0] * l[0] + l[2] * l[2]))
+    s, c = np.float32(np.sin(np.float32(-25.0 * 0.004))), np.float32(np.cos(np.float32(-25.0 * 0.004)))
+    nxz, ny = c * xz - s * l[1], s * xz + c * l[1]
+    l = np.float32([l[0] * (nxz / xz), ny, l[2] * (nxz / xz)])
+    assert np.allclose(e, at0 + l, atol=2e-6)
+    assert r.camera_updated() and not r.camera_updated()
+    # the frame after a camera move starts a new accumulation
+    r.frame(4, clear_first=True)
+    assert np.all(r.download(api.RT_BUF_ACCUMULATION)[:, 3] == 1.0)
+    # and equals a fresh renderer's first accumulated frame at that pose (same frame index)
+    r2 = api.Renderer(W, H)
+    r2.set_scene(tris)
+    r2.lookat(e, a)
+    r2.set_options(bench_options(accumulate=1))
+    assert r2.raygen().tobytes() == r.raygen().tobytes()
+    # zoom / pan
+    d0 = np.linalg.norm(e - a)
+    r.zoom(100.0)
+    e2, a2 = r.camera_pose()
+    assert abs(np.linalg.norm(e2 - a2) - d0 * (1 - 0.002 * 100.0)) < 1e-4 and np.allclose(a2, a)
+    r.pan(10.0, 5.0)
+    e3, a3 = r.camera_pose()
+    assert np.allclose(e3 - e2, a3 - a2, atol=1e-6) and np.linalg.norm(e3 - e2) > 0
+    r.close()
+    r2.close()
