@@ -123,6 +123,11 @@ class LocalTransport:
     def finish(self, rank, handle, items):
         for (peer, ts, tr), n in zip(items, handle):
             tr.copy_(self.box.pop((peer, rank, n)))
+        if items and items[0][2].is_cuda:
+            # the copies ran on torch's stream, the contexts unpack on their own streams
+            import torch
+
+            torch.cuda.synchronize()
 
 
 class StripFrame:

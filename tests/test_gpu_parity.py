@@ -488,3 +488,51 @@ def test_interactive_camera_and_accumulation_reset(api, oracle, scenes):
     assert np.allclose(e3 - e2, a3 - a2, atol=1e-6) and np.linalg.norm(e3 - e2) > 0
     r.close()
     r2.close()
+
+
+def test_full_size_properties_1080p(api, scenes):
+    """At BASELINE.json's full size (blocks_restir stand-in, 1920x1080, bench options) the oracle is too
+    slow for a per-pixel check in a test, so size-independent properties are asserted instead:
+    (1) the fused rt_frame == the reference's kernel-by-kernel launch sequence, bit for bit;
+    (2) 8 row strips (135 rows, 87-row halos, the 8-GPU partition) == the single-context frame;
+    (3) ray count = pixels + 2 x shaded pixels; the spatial pass's algorithmic bytes are bounded by
+        16 + 152 + 5 x 92 per pixel and are the same for every pass input that shares the G-buffer."""
+    import torch
+
+    from cedec_2024_rt_amd import strips
+    from cedec_2024_rt_amd.types import bench_options
+
+    W, H = 1920, 1080
+    tris = scenes.make_blocks_restir()
+    eye, at = scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT
+
+    def make(rows=None, halo=0):
+        r = api.Renderer(W, H, rows=rows, halo=halo)
+        r.set_scene(tris)
+        r.lookat(eye, at)
+        r.set_options(bench_options())
+        return r
+
+    fused, bykernel = make(), make()
+    bounds = strips.partition_rows(H, 8)
+    ctxs = [make(rows=b, halo=strips.HALO_ROWS) for b in bounds]
+    for frame in (1, 2):
+        fused.frame(frame)
+        bykernel.frame_by_kernels(frame)
+        a = fused.download(api.RT_BUF_ACCUMULATION)
+        b = bykernel.download(api.RT_BUF_ACCUMULATION)
+        assert _eq_bits(a, b), f"fused vs kernel-by-kernel, frame {frame}: {(a != b).any(axis=1).sum()} pixels"
+        assert np.array_equal(fused.download(api.RT_BUF_PIXELS), bykernel.download(api.RT_BUF_PIXELS))
+        strips.run_frame_local(ctxs, bounds, frame, torch.device("cuda:0"))
+        full = a.reshape(H, W, 4)
+        for c, (r0, r1) in zip(ctxs, bounds):
+            mine = c.download(api.RT_BUF_ACCUMULATION).reshape(c.local_rows, W, 4)[r0 - c.local_row0: r1 - c.local_row0]
+            assert _eq_bits(mine, full[r0:r1]), f"strip rows {r0}:{r1}, frame {frame}"
+    rays, shaded = fused.ray_count()
+    assert rays == W * H + 2 * shaded and 0.5 < shaded / (W * H) <= 1.0
+    assert sum(c.ray_count()[0] for c in ctxs) == rays
+    nbytes = [fused.spatial_bytes(3, k, api.RT_RES_0)[0] for k in range(3)]
+    assert all(16 * W * H + 152 * shaded < n <= 16 * W * H + (152 + 5 * 92) * shaded for n in nbytes)
+    assert fused.spatial_bytes(3, 0, api.RT_RES_0) == fused.spatial_bytes(3, 0, api.RT_RES_1)
+    for c in ctxs + [fused, bykernel]:
+        c.close()
