@@ -4,7 +4,7 @@
  * Kernels restate, per pixel, examples/10_restir_di/10_restir_di.cu and
  * common/kernels/common.cu of the reference (file:line cited at each kernel) over the
  * MI355X-native data layout of rt_device.h (32-B G-buffer, 64-B aligned reservoir records)
- * and the software LBVH of bvh.h. Compile with -ffp-contract=off (parity, rt_device.h).
+ * and the software BVH of bvh.h. Compile with -ffp-contract=off (parity, rt_device.h).
  *
  * Launch shape: one thread per pixel, 256-thread workgroups covering 32 x 8 pixel tiles
  * (a wave = two 32-pixel row segments => own-pixel record traffic is 2-KiB contiguous runs).
@@ -954,8 +954,8 @@ struct rt_ctx
     int tune_tile_mode[5] = {1, 0, 1, 0, 0};
     int tune_spatial_lds = 32768;
     int trace_mode = 0; /* rt_trace_closest / rt_trace_stats: 0 = wide (what the frame kernels use), 1 = binary stackless */
-    float bvh_split_factor = 8.0f;
-    int bvh_builder = 1; /* 0 = device LBVH (Morton/Karras), 1 = host binned SAH (high quality) */ /* fragment length in median triangle extents; 0 = no pre-split */
+    float bvh_split_factor = 8.0f; /* fragment length in median triangle extents; 0 = no pre-split */
+    int bvh_builder = 1; /* 0 = device LBVH (Morton/Karras), 1 = host binned SAH (high quality) */
     float* d_tris = nullptr;
     float4* d_tv = nullptr;
     BvhNode* d_nodes = nullptr;
@@ -1237,7 +1237,7 @@ static void split_refs(const rt_triangle* tris, int n, float L, float pad, std::
     }
 }
 
-/* ---- collapse the binary LBVH into the 4-wide quantised structure of bvh.h (host) ---- */
+/* ---- collapse the binary tree (LBVH or SAH) into the 4-wide quantised structure of bvh.h (host) ---- */
 struct WideRec
 {
     uint32_t w[12];

@@ -65,7 +65,7 @@ enum
     RT_ERR_ARG = 1,         /* bad argument / size mismatch */
     RT_ERR_HIP = 2,         /* a HIP call failed */
     RT_ERR_STATE = 3,       /* call order (e.g. no scene) */
-    RT_ERR_BVH_DEPTH = 4,   /* LBVH deeper than the 63-level trail word */
+    RT_ERR_BVH_DEPTH = 4,   /* BVH deeper than the traversal stack / trail word can follow */
     RT_ERR_UNSUPPORTED = 5, /* option combination not built yet */
     RT_ERR_NO_DEVICE = 6
 };
@@ -96,7 +96,8 @@ int rt_sync(rt_ctx* ctx);
 
 /* ---- scene (replaces loadTrianglesFromObj + light list + buildHiprtGeometry, :184-220) ---- */
 /* Uploads the triangles, extracts the emissive-triangle list in index order (:196-205) and
- * builds the LBVH on the device. */
+ * builds the BVH (pre-split of large triangles, binary tree by the host SAH builder or the device
+ * LBVH kernels, collapse to the 4-wide quantised structure the kernels traverse; rt_tuning key 5). */
 int rt_scene_set(rt_ctx* ctx, const rt_triangle* triangles, uint32_t count);
 int rt_scene_info(rt_ctx* ctx, uint32_t* n_triangles, uint32_t* n_lights, uint32_t* bvh_height);
 
@@ -186,7 +187,7 @@ int rt_timing(rt_ctx* ctx, float ms[9]);
  * on-screen / not-self tests. Replays the RNG; independent of reservoir contents. */
 int rt_spatial_bytes(rt_ctx* ctx, int frame, int pass, int in, uint64_t* bytes, uint64_t* accepted);
 
-/* ---- BVH utilities (parity tests: LBVH == brute force) ----
+/* ---- BVH utilities (parity tests: BVH traversal == brute force) ----
  * rays: n x {ox,oy,oz, dx,dy,dz, tmin,tmax}; hits: n x {t,u,v, bits(index)}; host pointers. */
 int rt_trace_closest(rt_ctx* ctx, const float* rays, uint32_t n, float* hits);
 /* per ray {nodes visited, triangle tests} of the same traversal (BVH quality diagnostics) */
