@@ -113,6 +113,7 @@ def main():
         torch.cuda.synchronize()
 
     spatial_ms = None
+    verified = None
     pcie_ms = None
     per_kernel = None
     algo_bytes = None
@@ -193,6 +194,24 @@ def main():
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
         total_rays = int(rr.item())
         info = r.scene_info()
+        verified = None
+        if os.environ.get("BENCH_VERIFY"):
+            # development aid: the assembled N-rank image of the last frame must equal, bit for bit,
+            # what a single full-frame context renders for the same frame sequence
+            a, b = strips.partition_rows(height, world)[rank]
+            mine = r.download(api.RT_BUF_ACCUMULATION).reshape(r.local_rows, width, 4)[a - r.local_row0: b - r.local_row0].copy()
+            parts = [None] * world
+            dist.gather_object(mine, parts if rank == 0 else None, dst=0)
+            if rank == 0:
+                full = api.Renderer(width, height, device=local_rank)
+                full.set_scene(tris)
+                full.lookat(eye, center)
+                full.set_options(opt)
+                for f in range(1, frame + 1):
+                    full.frame(f)
+                ref = full.download(api.RT_BUF_ACCUMULATION).reshape(height, width, 4)
+                verified = bool(np.array_equal(np.concatenate(parts, axis=0).view(np.uint32), ref.view(np.uint32)))
+                full.close()
 
     if rank == 0:
         ms = elapsed / K * 1e3
@@ -208,6 +227,8 @@ def main():
                 "rays_per_frame": total_rays, "parallelism": f"row-strips x{world}" if world > 1 else "single GPU",
             },
         }
+        if world > 1 and verified is not None:
+            out["verified_vs_single_context"] = verified
         if world == 1:
             ach = algo_bytes / (spatial_ms * 1e-3) / 1e9
             traffic = None

@@ -20,11 +20,12 @@ RT_RES_PHYS = 16
 RT_BUF_VISIBILITY, RT_BUF_RES_0, RT_BUF_RES_1, RT_BUF_RES_TEMPORAL, RT_BUF_ACCUMULATION, RT_BUF_PIXELS = range(6)
 
 EXPORTS = [
-    "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_sync", "rt_scene_set", "rt_scene_info",
+    "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_set_stream_own", "rt_sync", "rt_scene_set", "rt_scene_info",
     "rt_camera_lookat", "rt_camera_set", "rt_camera_get", "rt_camera_orbit", "rt_camera_zoom", "rt_camera_pan",
     "rt_camera_updated", "rt_camera_pose", "rt_options_set", "rt_options_get", "rt_clear",
     "rt_raycast", "rt_generate_candidate", "rt_temporal_resampling", "rt_save_temporal_reservoir",
-    "rt_spatial_resampling", "rt_resolve", "rt_tone_mapping", "rt_frame", "rt_frame_stage", "rt_frame_stage_input", "rt_frame_stage_begin", "rt_frame_stage_run", "rt_frame_stage_end", "rt_frame_stage_output", "rt_path_trace", "rt_path_trace_rays", "rt_local_rows", "rt_download",
+    "rt_spatial_resampling", "rt_resolve", "rt_tone_mapping", "rt_frame", "rt_frame_stage", "rt_frame_stage_input", "rt_frame_stage_begin", "rt_frame_stage_run", "rt_frame_stage_end", "rt_frame_stage_output", "rt_frame_stage_run_part", "rt_halo_bitmap_words", "rt_halo_flags_bytes",
+    "rt_halo_flags_pack", "rt_halo_flags_unpack", "rt_halo_mark", "rt_halo_scan", "rt_halo_pack_sparse", "rt_halo_unpack_sparse", "rt_path_trace", "rt_path_trace_rays", "rt_local_rows", "rt_download",
     "rt_upload", "rt_halo_bytes", "rt_halo_pack", "rt_halo_unpack", "rt_ray_count", "rt_timing_enable",
     "rt_timing", "rt_spatial_bytes", "rt_trace_closest", "rt_trace_stats", "rt_bvh_config", "rt_bvh_info", "rt_trace_mode", "rt_tuning", "rt_math_eval",
 ]
@@ -60,6 +61,7 @@ def load_library():
     L.rt_last_error.argtypes = [vp]
     L.rt_last_error.restype = C.c_char_p
     L.rt_set_stream.argtypes = [vp, vp]
+    L.rt_set_stream_own.argtypes = [vp]
     L.rt_sync.argtypes = [vp]
     L.rt_scene_set.argtypes = [vp, vp, C.c_uint32]
     L.rt_scene_info.argtypes = [vp, vp, vp, vp]
@@ -89,6 +91,17 @@ def load_library():
     L.rt_frame_stage_begin.argtypes = [vp, ci, ci, ci]
     L.rt_frame_stage_run.argtypes = [vp, ci, ci, ci, ci]
     L.rt_frame_stage_end.argtypes = [vp, ci]
+    L.rt_frame_stage_run_part.argtypes = [vp, ci, ci, ci, ci, ci]
+    L.rt_halo_bitmap_words.argtypes = [vp, ci]
+    L.rt_halo_bitmap_words.restype = C.c_size_t
+    L.rt_halo_flags_bytes.argtypes = [vp, ci]
+    L.rt_halo_flags_bytes.restype = C.c_size_t
+    L.rt_halo_flags_pack.argtypes = [vp, ci, ci, vp]
+    L.rt_halo_flags_unpack.argtypes = [vp, ci, ci, vp]
+    L.rt_halo_mark.argtypes = [vp, ci, ci, ci, vp]
+    L.rt_halo_scan.argtypes = [vp, ci, vp]
+    L.rt_halo_pack_sparse.argtypes = [vp, ci, ci, ci, vp, vp]
+    L.rt_halo_unpack_sparse.argtypes = [vp, ci, ci, ci, vp, vp]
     L.rt_frame_stage_output.argtypes = [vp, ci, vp]
     L.rt_local_rows.argtypes = [vp, vp, vp]
     L.rt_download.argtypes = [vp, ci, vp, C.c_size_t]
@@ -280,6 +293,33 @@ class Renderer:
 
     def frame_stage_run(self, frame, stage, row0, row1):
         self._ck(self.L.rt_frame_stage_run(self.h, int(frame), int(stage), int(row0), int(row1)))
+
+    def frame_stage_run_part(self, frame, stage, part, row0, row1):
+        self._ck(self.L.rt_frame_stage_run_part(self.h, int(frame), int(stage), int(part), int(row0), int(row1)))
+
+    def halo_bitmap_words(self, n_rows):
+        return int(self.L.rt_halo_bitmap_words(self.h, int(n_rows)))
+
+    def halo_flags_bytes(self, n_rows):
+        return int(self.L.rt_halo_flags_bytes(self.h, int(n_rows)))
+
+    def halo_flags_pack(self, row0, n_rows, ptr):
+        self._ck(self.L.rt_halo_flags_pack(self.h, int(row0), int(n_rows), C.c_void_p(int(ptr))))
+
+    def halo_flags_unpack(self, row0, n_rows, ptr):
+        self._ck(self.L.rt_halo_flags_unpack(self.h, int(row0), int(n_rows), C.c_void_p(int(ptr))))
+
+    def halo_mark(self, frame, pas, side, ptr):
+        self._ck(self.L.rt_halo_mark(self.h, int(frame), int(pas), int(side), C.c_void_p(int(ptr))))
+
+    def halo_scan(self, n_rows, ptr):
+        self._ck(self.L.rt_halo_scan(self.h, int(n_rows), C.c_void_p(int(ptr))))
+
+    def halo_pack_sparse(self, res, row0, n_rows, bitmap_ptr, dst_ptr):
+        self._ck(self.L.rt_halo_pack_sparse(self.h, int(res), int(row0), int(n_rows), C.c_void_p(int(bitmap_ptr)), C.c_void_p(int(dst_ptr))))
+
+    def halo_unpack_sparse(self, res, row0, n_rows, bitmap_ptr, src_ptr):
+        self._ck(self.L.rt_halo_unpack_sparse(self.h, int(res), int(row0), int(n_rows), C.c_void_p(int(bitmap_ptr)), C.c_void_p(int(src_ptr))))
 
     def frame_stage_end(self, stage):
         self._ck(self.L.rt_frame_stage_end(self.h, int(stage)))

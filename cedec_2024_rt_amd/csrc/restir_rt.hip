@@ -462,6 +462,107 @@ __global__ __launch_bounds__(BLOCK) void k_spatial_bytes(FrameParams P, const fl
     }
 }
 
+/* ------------------------------------------------------- sparse reservoir halos (multi-GPU)
+ * A strip only needs those neighbour-strip records its own pixels will actually gather. Which
+ * ones is a pure function of the RNG and the shaded bits (exactly the replay of
+ * k_spatial_bytes), so the RECEIVER marks them in a bitmap over the neighbour's boundary rows
+ * (k_halo_mark), ships the bitmap once per frame, and the owner answers every pass with the
+ * marked records only, in bitmap order (k_halo_sparse). Bitmap buffer (uint32 words):
+ *   [0] = number of marked records, [1 .. nw] = bits (bit i of word w = pixel 32*w + i of the
+ *   region, row-major from region row 0), [1+nw .. 1+2nw) = exclusive prefix counts per word. */
+__global__ __launch_bounds__(BLOCK) void k_halo_mark(FrameParams P, const float4* __restrict__ g1, int reg_row0,
+                                                      int reg_rows, uint32_t* __restrict__ bitmap)
+{
+    int x, row;
+    if (!tile_pixel(P, x, row)) return;
+    const int yi = P.H - 1 - row;
+    const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
+    if (!(as_uint(g1[li].w) & GB_SHADED) || !P.use_spatial) return;
+    PCG rng = pcg_init(hashPCG4((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame, (uint32_t)(2 + P.pass)), 0);
+    const float scale = P.spatial_radius / 1.96f;
+    for (int k = 0; k < P.spatial_count; ++k)
+    {
+        const float rv0 = rng.uniformf();
+        const float rv1 = rng.uniformf();
+        const float radius = sqrtf(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
+        const float phi = 2.0f * kPI * rv1;
+        const int nx = f2i_sat((float)x + scale * (radius * pm_cosf(phi)));
+        const int ny = f2i_sat((float)yi + scale * (radius * pm_sinf(phi)));
+        if (nx < 0 || nx >= P.W || ny < 0 || ny >= P.H) continue;
+        if (nx == x && ny == yi) continue;
+        const int nrow = P.H - 1 - ny;
+        const int lr = nrow - P.lrow0;
+        if (lr < 0 || lr >= P.lrows) continue;
+        if (nrow >= reg_row0 && nrow < reg_row0 + reg_rows)
+        {
+            const uint32_t bit = (uint32_t)(nrow - reg_row0) * (uint32_t)P.W + (uint32_t)nx;
+            atomicOr(&bitmap[1 + (bit >> 5)], 1u << (bit & 31u));
+        }
+        if (!(as_uint(g1[(size_t)nx + (size_t)lr * P.W].w) & GB_SHADED)) continue;
+        rng.uniformf();
+    }
+}
+/* one workgroup: exclusive prefix of the per-word popcounts, total into word 0 */
+__global__ void k_halo_scan(uint32_t* __restrict__ bitmap, int nw)
+{
+    __shared__ uint32_t s_sum[1024];
+    const int t = threadIdx.x, T = blockDim.x;
+    const int per = (nw + T - 1) / T;
+    const int w0 = t * per, w1 = min(nw, w0 + per);
+    uint32_t local = 0;
+    for (int w = w0; w < w1; ++w) local += (uint32_t)__popc(bitmap[1 + w]);
+    s_sum[t] = local;
+    __syncthreads();
+    for (int off = 1; off < T; off <<= 1)
+    {
+        const uint32_t v = t >= off ? s_sum[t - off] : 0u;
+        __syncthreads();
+        s_sum[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_sum[t] - local;
+    for (int w = w0; w < w1; ++w)
+    {
+        bitmap[1 + nw + w] = run;
+        run += (uint32_t)__popc(bitmap[1 + w]);
+    }
+    if (t == T - 1) bitmap[0] = s_sum[t];
+}
+/* PACK: marked records of rows [row0, row0+rows) -> dense list (64 B record + 16 B radiance each);
+ * UNPACK: the reverse. */
+template <bool PACK>
+__global__ void k_halo_sparse(const uint32_t* __restrict__ bitmap, int nw, int W, size_t region_off, int n_pix,
+                              float4* __restrict__ rec, float4* __restrict__ radb, float4* __restrict__ list)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pix) return;
+    const uint32_t word = bitmap[1 + (i >> 5)];
+    if (!(word & (1u << (i & 31)))) return;
+    const uint32_t idx = bitmap[1 + nw + (i >> 5)] + (uint32_t)__popc(word & ((1u << (i & 31)) - 1u));
+    float4* L = list + 5 * (size_t)idx;
+    const size_t p = region_off + (size_t)i;
+    if (PACK)
+    {
+        L[0] = rec[4 * p + 0]; L[1] = rec[4 * p + 1]; L[2] = rec[4 * p + 2]; L[3] = rec[4 * p + 3];
+        L[4] = radb[p];
+    }
+    else
+    {
+        rec[4 * p + 0] = L[0]; rec[4 * p + 1] = L[1]; rec[4 * p + 2] = L[2]; rec[4 * p + 3] = L[3];
+        radb[p] = L[4];
+    }
+    (void)W;
+}
+/* shaded flags of rows as bytes (halo rows of the G-buffer only ever hold these flags) */
+template <bool PACK>
+__global__ void k_halo_flags(float4* __restrict__ g1, size_t off, int n_pix, uint8_t* __restrict__ bytes)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pix) return;
+    if (PACK) bytes[i] = (uint8_t)(as_uint(g1[off + i].w) & 0xffu);
+    else g1[off + i] = make_float4(0.0f, 0.0f, 0.0f, as_float((uint32_t)bytes[i]));
+}
+
 /* -------------------------------------------------------------------- resolve */
 /* examples/10_restir_di/10_restir_di.cu:390-459 */
 __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_resolve(SceneView S, FrameParams P, const float4* __restrict__ g0,
@@ -1124,7 +1225,15 @@ const char* rt_last_error(rt_ctx* c) { return c ? c->err.c_str() : "null context
 int rt_set_stream(rt_ctx* c, void* s)
 {
     RT_CHECK_CTX(c);
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    /* exactly the caller's stream; NULL is HIP's null (default) stream, which is what
+     * torch.cuda.current_stream() is unless the caller entered a stream context */
+    c->stream = (hipStream_t)s;
+    return RT_OK;
+}
+int rt_set_stream_own(rt_ctx* c)
+{
+    RT_CHECK_CTX(c);
+    c->stream = c->own_stream;
     return RT_OK;
 }
 int rt_sync(rt_ctx* c)
@@ -2065,7 +2174,7 @@ int rt_frame_stage_begin(rt_ctx* c, int frame, int stage, int clear_first)
     return RT_OK;
 }
 
-int rt_frame_stage_run(rt_ctx* c, int frame, int stage, int row0, int row1)
+int rt_frame_stage_run_part(rt_ctx* c, int frame, int stage, int part, int row0, int row1)
 {
     RT_CHECK_CTX(c);
     NEED_SCENE(c);
@@ -2082,11 +2191,11 @@ int rt_frame_stage_run(rt_ctx* c, int frame, int stage, int row0, int row1)
     if (stage == 0)
     {
         mark(0);
-        if (c->f_clear) rc = rt_clear(c);
+        if (part != 2 && c->f_clear) rc = rt_clear(c);
         mark(1);
-        if (rc == RT_OK) rc = rt_raycast(c);
+        if (part != 2 && rc == RT_OK) rc = rt_raycast(c);
         mark(2);
-        if (rc == RT_OK) rc = launch_generate(c, frame, c->fY, c->fX, c->opt.use_temporal_resampling != 0);
+        if (part != 1 && rc == RT_OK) rc = launch_generate(c, frame, c->fY, c->fX, c->opt.use_temporal_resampling != 0);
         mark(3);
     }
     else if (stage <= passes)
@@ -2106,6 +2215,12 @@ int rt_frame_stage_run(rt_ctx* c, int frame, int stage, int row0, int row1)
     }
     c->sub0 = c->sub1 = -1;
     return rc;
+}
+
+/* all parts of the stage (part 0); stage 0 can be split: part 1 = [clear,] raycast, part 2 = generate */
+int rt_frame_stage_run(rt_ctx* c, int frame, int stage, int row0, int row1)
+{
+    return rt_frame_stage_run_part(c, frame, stage, 0, row0, row1);
 }
 
 int rt_frame_stage_end(rt_ctx* c, int stage)
@@ -2322,6 +2437,101 @@ int rt_halo_unpack(rt_ctx* c, int res, int row0, int n_rows, const void* device_
     RT_HIP(c, hipMemcpyAsync(c->d_rec[phys] + 4 * off, device_src, n * 64, hipMemcpyDeviceToDevice, c->stream));
     RT_HIP(c, hipMemcpyAsync(c->d_rad[phys] + off, (const char*)device_src + n * 64, n * 16, hipMemcpyDeviceToDevice, c->stream));
     return RT_OK;
+}
+
+/* ---- sparse halos: see k_halo_mark. side 0 = the strip below (rows [row_begin-halo, row_begin)),
+ * side 1 = the strip above (rows [row_end, row_end+halo)). ---- */
+static int halo_side_region(rt_ctx* c, int side, int* r0, int* n)
+{
+    if (side == 0) { *r0 = c->lrow0; *n = c->row_begin - c->lrow0; }
+    else if (side == 1) { *r0 = c->row_end; *n = c->lrow0 + c->lrows - c->row_end; }
+    else RT_FAIL(c, RT_ERR_ARG, "side must be 0 or 1");
+    if (*n <= 0) RT_FAIL(c, RT_ERR_STATE, "no halo rows on side %d", side);
+    return RT_OK;
+}
+size_t rt_halo_bitmap_words(rt_ctx* c, int n_rows)
+{
+    if (!c) return 0;
+    const size_t nw = ((size_t)n_rows * c->W + 31) / 32;
+    return 1 + 2 * nw; /* count, bits, prefix; only the first 1 + nw words travel */
+}
+size_t rt_halo_flags_bytes(rt_ctx* c, int n_rows) { return c ? (size_t)n_rows * c->W : 0; }
+int rt_halo_flags_pack(rt_ctx* c, int row0, int n_rows, void* device_dst)
+{
+    RT_CHECK_CTX(c);
+    int rc = halo_range(c, row0, n_rows);
+    if (rc != RT_OK) return rc;
+    const int n = n_rows * c->W;
+    k_halo_flags<true><<<(n + 255) / 256, 256, 0, c->stream>>>(c->d_g1, (size_t)(row0 - c->lrow0) * c->W, n, (uint8_t*)device_dst);
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+int rt_halo_flags_unpack(rt_ctx* c, int row0, int n_rows, const void* device_src)
+{
+    RT_CHECK_CTX(c);
+    int rc = halo_range(c, row0, n_rows);
+    if (rc != RT_OK) return rc;
+    if (row0 < c->row_end && row0 + n_rows > c->row_begin) RT_FAIL(c, RT_ERR_ARG, "flags may only be unpacked into halo rows");
+    const int n = n_rows * c->W;
+    k_halo_flags<false><<<(n + 255) / 256, 256, 0, c->stream>>>(c->d_g1, (size_t)(row0 - c->lrow0) * c->W, n, (uint8_t*)const_cast<void*>(device_src));
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+/* records of the neighbour on `side` that spatial pass `pass` of `frame` will gather */
+int rt_halo_mark(rt_ctx* c, int frame, int pass, int side, void* device_bitmap)
+{
+    RT_CHECK_CTX(c);
+    if (!c->has_gbuffer) RT_FAIL(c, RT_ERR_STATE, "no G-buffer yet");
+    int r0, n;
+    int rc = halo_side_region(c, side, &r0, &n);
+    if (rc != RT_OK) return rc;
+    const size_t words = rt_halo_bitmap_words(c, n);
+    const int nw = (int)((words - 1) / 2);
+    RT_HIP(c, hipMemsetAsync(device_bitmap, 0, words * 4, c->stream));
+    /* only own rows within `halo` rows of that side can reach across */
+    c->sub0 = side == 0 ? c->row_begin : (c->row_end - c->halo > c->row_begin ? c->row_end - c->halo : c->row_begin);
+    c->sub1 = side == 0 ? (c->row_begin + c->halo < c->row_end ? c->row_begin + c->halo : c->row_end) : c->row_end;
+    const FrameParams P = make_params(c, frame, pass, K_OTHER);
+    const int grid = launch_grid(c);
+    c->sub0 = c->sub1 = -1;
+    k_halo_mark<<<grid, BLOCK, 0, c->stream>>>(P, c->d_g1, r0, n, (uint32_t*)device_bitmap);
+    RT_HIP(c, hipGetLastError());
+    k_halo_scan<<<1, 1024, 0, c->stream>>>((uint32_t*)device_bitmap, nw);
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+/* rebuild the prefix part of a bitmap received from a neighbour (rows [row0,row0+n_rows)) */
+int rt_halo_scan(rt_ctx* c, int n_rows, void* device_bitmap)
+{
+    RT_CHECK_CTX(c);
+    const int nw = (int)((rt_halo_bitmap_words(c, n_rows) - 1) / 2);
+    k_halo_scan<<<1, 1024, 0, c->stream>>>((uint32_t*)device_bitmap, nw);
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+static int halo_sparse(rt_ctx* c, bool pack, int res, int row0, int n_rows, const void* device_bitmap, void* device_list)
+{
+    const int phys = halo_phys(c, res);
+    if (phys < 0) RT_FAIL(c, RT_ERR_ARG, "bad reservoir buffer id %d", res);
+    int rc = halo_range(c, row0, n_rows);
+    if (rc != RT_OK) return rc;
+    const int n = n_rows * c->W;
+    const int nw = (int)((rt_halo_bitmap_words(c, n_rows) - 1) / 2);
+    const size_t off = (size_t)(row0 - c->lrow0) * c->W;
+    if (pack) k_halo_sparse<true><<<(n + 255) / 256, 256, 0, c->stream>>>((const uint32_t*)device_bitmap, nw, c->W, off, n, c->d_rec[phys], c->d_rad[phys], (float4*)device_list);
+    else k_halo_sparse<false><<<(n + 255) / 256, 256, 0, c->stream>>>((const uint32_t*)device_bitmap, nw, c->W, off, n, c->d_rec[phys], c->d_rad[phys], (float4*)device_list);
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+int rt_halo_pack_sparse(rt_ctx* c, int res, int row0, int n_rows, const void* device_bitmap, void* device_dst)
+{
+    RT_CHECK_CTX(c);
+    return halo_sparse(c, true, res, row0, n_rows, device_bitmap, device_dst);
+}
+int rt_halo_unpack_sparse(rt_ctx* c, int res, int row0, int n_rows, const void* device_bitmap, const void* device_src)
+{
+    RT_CHECK_CTX(c);
+    return halo_sparse(c, false, res, row0, n_rows, device_bitmap, const_cast<void*>(device_src));
 }
 
 int rt_ray_count(rt_ctx* c, uint64_t* rays, uint64_t* shaded_pixels)

@@ -141,43 +141,94 @@ class StripFrame:
     halo_export(buf, row0, n) -> tensor, halo_import(buf, row0, n, tensor), halo_empty(n) -> tensor.
     """
 
-    def __init__(self, backend, bounds, rank, transport=None, halo=HALO_ROWS):
+    def __init__(self, backend, bounds, rank, transport=None, halo=HALO_ROWS, sparse=None):
         self.b, self.bounds, self.rank, self.t, self.halo = backend, bounds, rank, transport, halo
         self.plan = exchange_plan(bounds, rank, halo) if transport is not None else []
         self.boundary, self.interior = row_bands(bounds, rank, halo) if self.plan else ([], [bounds[rank]])
+        # sparse halos: only the records the neighbour's RNG will gather travel (needs backend support)
+        self.sparse = bool(getattr(backend, "sparse_supported", False)) if sparse is None else bool(sparse)
+        self.need, self.give, self.need_cnt, self.give_cnt = {}, {}, {}, {}
 
-    def _post(self, buf):
+    def _post(self, buf, k=0):
         items, recvs = [], []
         for peer, s0, sn, r0, rn in self.plan:
-            ts = self.b.halo_export(buf, s0, sn)
-            tr = self.b.halo_empty(rn)
+            if self.sparse:
+                ts = self.b.pack_sparse(buf, s0, sn, self.give[peer][k], self.give_cnt[peer][k])
+                tr = self.b.list_empty(self.need_cnt[peer][k])
+            else:
+                ts = self.b.halo_export(buf, s0, sn)
+                tr = self.b.halo_empty(rn)
             items.append((peer, ts, tr))
-            recvs.append((r0, rn, tr))
-        return (self.t.post(self.rank, items), items, recvs, buf)
+            recvs.append((peer, r0, rn, tr))
+        return (self.t.post(self.rank, items), items, recvs, buf, k)
 
     def _finish(self, pending):
-        handle, items, recvs, buf = pending
+        handle, items, recvs, buf, k = pending
         self.t.finish(self.rank, handle, items)
-        for r0, rn, tr in recvs:
-            self.b.halo_import(buf, r0, rn, tr)
+        for peer, r0, rn, tr in recvs:
+            if self.sparse:
+                self.b.unpack_sparse(buf, r0, rn, self.need[peer][k], tr)
+            else:
+                self.b.halo_import(buf, r0, rn, tr)
+
+    # ---- sparse halo set-up of one frame (generator: yields once, after posting the bitmaps)
+    def _sparse_setup_gen(self, frame):
+        b, P = self.b, self.b.passes
+        # 1. shaded flags of the neighbours' boundary rows (static for the frame)
+        items = [(peer, b.flags_export(s0, sn), b.flags_empty(rn)) for peer, s0, sn, r0, rn in self.plan]
+        h = self.t.post(self.rank, items)
+        yield "flags"
+        self.t.finish(self.rank, h, items)
+        for (peer, s0, sn, r0, rn), (_, _, tr) in zip(self.plan, items):
+            b.flags_import(r0, rn, tr)
+        # 2. what I will gather from each neighbour, per pass (RNG replay on the device)
+        items = []
+        for peer, s0, sn, r0, rn in self.plan:
+            side = 0 if peer < self.rank else 1
+            self.need[peer] = [b.mark(frame, k, side) for k in range(P)]
+            ts = b.bitmap_message(self.need[peer], rn)
+            tr = b.bitmap_message_empty(P, sn)
+            items.append((peer, ts, tr))
+        self.need_cnt = {peer: b.bitmap_counts(self.need[peer]) for peer in self.need}  # host sync
+        h = self.t.post(self.rank, items)
+        yield "bitmaps"
+        self._bitmap_pending = (h, items)
+
+    def _sparse_setup_finish(self):
+        b, P = self.b, self.b.passes
+        h, items = self._bitmap_pending
+        self.t.finish(self.rank, h, items)
+        for (peer, s0, sn, r0, rn), (_, _, tr) in zip(self.plan, items):
+            self.give[peer] = b.bitmap_split(tr, P, sn)  # scanned on the device
+            self.give_cnt[peer] = b.bitmap_counts(self.give[peer])  # host sync
 
     def frame_gen(self, frame, clear_first=False):
         """Generator: yields after every posted exchange (lets a single-process driver interleave
         several ranks); `frame` just exhausts it."""
         b, P = self.b, self.b.passes
         pending = None
+        sparse = self.sparse and self.plan and P > 0
         for s in range(0, P + 1):
             if pending is not None:
                 self._finish(pending)
                 pending = None
             b.stage_begin(frame, s, clear_first if s == 0 else False)
+            part = 0
+            if s == 0 and sparse:
+                a0, e0 = self.bounds[self.rank]
+                b.stage_run_part(frame, 0, 1, a0, e0)  # [clear,] raycast of all owned rows
+                for tag in self._sparse_setup_gen(frame):
+                    yield tag
+                part = 2  # only generate_candidate(+temporal) is left
             for r0, r1 in self.boundary:
-                b.stage_run(frame, s, r0, r1)
+                b.stage_run_part(frame, s, part, r0, r1) if part else b.stage_run(frame, s, r0, r1)
             if s < P and self.plan:
-                pending = self._post(b.stage_output(s))
+                if s == 0 and sparse:
+                    self._sparse_setup_finish()
+                pending = self._post(b.stage_output(s), s)
                 yield s
             for r0, r1 in self.interior:
-                b.stage_run(frame, s, r0, r1)
+                b.stage_run_part(frame, s, part, r0, r1) if part else b.stage_run(frame, s, r0, r1)
             b.stage_end(frame, s)
         a, e = self.bounds[self.rank]
         b.stage_begin(frame, P + 1, False)
@@ -213,6 +264,84 @@ class HipStripBackend:
 
     def stage_output(self, s):
         return self.r.frame_stage_output(s)
+
+    def stage_run_part(self, frame, s, part, r0, r1):
+        self.r.frame_stage_run_part(frame, s, part, r0, r1)
+
+    # ---- sparse halos (receiver-marked bitmaps, see include/restir_rt.h)
+    sparse_supported = True
+
+    def _to_wire(self, t):
+        return t.cpu() if self.host_staging else t
+
+    def _from_wire(self, t):
+        return t.to(self.device) if self.host_staging else t
+
+    def _wire_empty(self, n, dtype):
+        return self.torch.empty(n, dtype=dtype, device=None if self.host_staging else self.device)
+
+    def flags_empty(self, n_rows):
+        return self._wire_empty(self.r.halo_flags_bytes(n_rows), self.torch.uint8)
+
+    def flags_export(self, row0, n_rows):
+        t = self.torch.empty(self.r.halo_flags_bytes(n_rows), dtype=self.torch.uint8, device=self.device)
+        self.r.halo_flags_pack(row0, n_rows, t.data_ptr())
+        return self._to_wire(t)
+
+    def flags_import(self, row0, n_rows, t):
+        t = self._from_wire(t)
+        self.r.halo_flags_unpack(row0, n_rows, t.data_ptr())
+        self._keep = t
+
+    def mark(self, frame, k, side):
+        n_rows = self.r.halo if True else 0
+        r0, n = self._side_region(side)
+        t = self.torch.empty(self.r.halo_bitmap_words(n), dtype=self.torch.int32, device=self.device)
+        self.r.halo_mark(frame, k, side, t.data_ptr())
+        return t
+
+    def _side_region(self, side):
+        a, b = self.r.rows
+        l0, l1 = self.r.local_row0, self.r.local_row0 + self.r.local_rows
+        return (l0, a - l0) if side == 0 else (b, l1 - b)
+
+    def bitmap_counts(self, bitmaps):
+        return [int(x) for x in self.torch.stack([bm[0] for bm in bitmaps]).cpu().tolist()]
+
+    def bitmap_message(self, bitmaps, n_rows):
+        nw = (self.r.halo_bitmap_words(n_rows) - 1) // 2
+        return self._to_wire(self.torch.cat([bm[: 1 + nw] for bm in bitmaps]))
+
+    def bitmap_message_empty(self, passes, n_rows):
+        nw = (self.r.halo_bitmap_words(n_rows) - 1) // 2
+        return self._wire_empty(passes * (1 + nw), self.torch.int32)
+
+    def bitmap_split(self, msg, passes, n_rows):
+        msg = self._from_wire(msg)
+        words = self.r.halo_bitmap_words(n_rows)
+        nw = (words - 1) // 2
+        out = []
+        for k in range(passes):
+            t = self.torch.zeros(words, dtype=self.torch.int32, device=self.device)
+            t[: 1 + nw] = msg[k * (1 + nw): (k + 1) * (1 + nw)]
+            self.r.halo_scan(n_rows, t.data_ptr())
+            out.append(t)
+        return out
+
+    def list_empty(self, count):
+        return self._wire_empty(max(count, 1) * 80, self.torch.uint8)
+
+    def pack_sparse(self, res, row0, n_rows, bitmap, count):
+        t = self.torch.empty(max(count, 1) * 80, dtype=self.torch.uint8, device=self.device)
+        self.r.halo_pack_sparse(res, row0, n_rows, bitmap.data_ptr(), t.data_ptr())
+        return self._to_wire(t)
+
+    def unpack_sparse(self, res, row0, n_rows, bitmap, t):
+        t = self._from_wire(t)
+        self.r.halo_unpack_sparse(res, row0, n_rows, bitmap.data_ptr(), t.data_ptr())
+        self._keep2 = t
+        if self.host_staging:
+            self.torch.cuda.current_stream().synchronize()
 
     def _dev_empty(self, n_rows):
         return self.torch.empty(self.r.halo_bytes(n_rows), dtype=self.torch.uint8, device=self.device)
@@ -255,7 +384,7 @@ def make_hip_strip(width, height, rank, world, triangles, eye, center, options, 
     return r, StripFrame(be, bounds, rank, DistTransport(dist) if world > 1 else None)
 
 
-def run_frame_local(renderers, bounds, frame, device, halo=HALO_ROWS):
+def run_frame_local(renderers, bounds, frame, device, halo=HALO_ROWS, sparse=False, stats=None):
     """Single-process variant for tests: several strip contexts on ONE GPU driven in lock-step
     through the same StripFrame logic, halos moved through an in-process mailbox."""
     import torch
@@ -271,8 +400,38 @@ def run_frame_local(renderers, bounds, frame, device, halo=HALO_ROWS):
             super().halo_import(res, row0, n_rows, t)
             self.r.sync()
 
+        def flags_export(self, row0, n_rows):
+            t = super().flags_export(row0, n_rows)
+            self.r.sync()
+            return t
+
+        def flags_import(self, row0, n_rows, t):
+            super().flags_import(row0, n_rows, t)
+            self.r.sync()
+
+        def mark(self, frame, k, side):
+            t = super().mark(frame, k, side)
+            self.r.sync()
+            return t
+
+        def bitmap_split(self, msg, passes, n_rows):
+            out = super().bitmap_split(msg, passes, n_rows)
+            self.r.sync()
+            return out
+
+        def pack_sparse(self, res, row0, n_rows, bitmap, count):
+            t = super().pack_sparse(res, row0, n_rows, bitmap, count)
+            self.r.sync()
+            if stats is not None:
+                stats.append((count, n_rows * self.r.W))
+            return t
+
+        def unpack_sparse(self, res, row0, n_rows, bitmap, t):
+            super().unpack_sparse(res, row0, n_rows, bitmap, t)
+            self.r.sync()
+
     tr = LocalTransport()
-    frames = [StripFrame(_Sync(r, device), bounds, k, tr, halo) for k, r in enumerate(renderers)]
+    frames = [StripFrame(_Sync(r, device), bounds, k, tr, halo, sparse=sparse) for k, r in enumerate(renderers)]
     gens = [f.frame_gen(frame) for f in frames]
     live = list(range(len(gens)))
     while live:

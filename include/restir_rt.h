@@ -91,7 +91,8 @@ enum
 int rt_create(int device, int width, int height, int row_begin, int row_end, int halo, rt_ctx** out);
 int rt_destroy(rt_ctx* ctx);
 const char* rt_last_error(rt_ctx* ctx);
-int rt_set_stream(rt_ctx* ctx, void* hip_stream); /* NULL = context's own stream */
+int rt_set_stream(rt_ctx* ctx, void* hip_stream); /* enqueue on the caller's stream; NULL = HIP's null stream */
+int rt_set_stream_own(rt_ctx* ctx);                /* back to the context's own non-blocking stream (default) */
 int rt_sync(rt_ctx* ctx);
 
 /* ---- scene (replaces loadTrianglesFromObj + light list + buildHiprtGeometry, :184-220) ---- */
@@ -154,6 +155,7 @@ int rt_frame_stage_input(rt_ctx* ctx, int stage, int* physical_buffer);
  * (rt_frame_stage_output names the buffer being written), _run the interior rows, then _end. */
 int rt_frame_stage_begin(rt_ctx* ctx, int frame, int stage, int clear_first);
 int rt_frame_stage_run(rt_ctx* ctx, int frame, int stage, int row0, int row1);
+int rt_frame_stage_run_part(rt_ctx* ctx, int frame, int stage, int part, int row0, int row1); /* stage 0: part 1 = [clear,] raycast, 2 = generate, 0 = both */
 int rt_frame_stage_end(rt_ctx* ctx, int stage);
 int rt_frame_stage_output(rt_ctx* ctx, int stage, int* physical_buffer);
 
@@ -171,6 +173,22 @@ int rt_upload(rt_ctx* ctx, int buf, const void* src, size_t bytes);
 size_t rt_halo_bytes(rt_ctx* ctx, int n_rows);
 int rt_halo_pack(rt_ctx* ctx, int res, int row0, int n_rows, void* device_dst);
 int rt_halo_unpack(rt_ctx* ctx, int res, int row0, int n_rows, const void* device_src);
+
+/* Sparse halos: a strip only needs the neighbour records its own pixels will gather, which is a pure
+ * function of the RNG and the shaded bits. The RECEIVER marks them (rt_halo_mark: side 0 = strip
+ * below, 1 = strip above; needs the neighbour's shaded flags in its G-buffer halo rows, exchanged
+ * once per frame with rt_halo_flags_*), sends the bitmap (first 1 + (n_rows*W+31)/32 words; word 0 =
+ * record count) to the owner, and the owner answers each pass with the marked records only
+ * (rt_halo_pack_sparse after rt_halo_scan on the received bitmap; 80 bytes per record, bitmap order);
+ * rt_halo_unpack_sparse scatters them into the halo rows. Same results as the dense calls. */
+size_t rt_halo_bitmap_words(rt_ctx* ctx, int n_rows);
+size_t rt_halo_flags_bytes(rt_ctx* ctx, int n_rows);
+int rt_halo_flags_pack(rt_ctx* ctx, int row0, int n_rows, void* device_dst);
+int rt_halo_flags_unpack(rt_ctx* ctx, int row0, int n_rows, const void* device_src);
+int rt_halo_mark(rt_ctx* ctx, int frame, int pass, int side, void* device_bitmap);
+int rt_halo_scan(rt_ctx* ctx, int n_rows, void* device_bitmap);
+int rt_halo_pack_sparse(rt_ctx* ctx, int res, int row0, int n_rows, const void* device_bitmap, void* device_dst);
+int rt_halo_unpack_sparse(rt_ctx* ctx, int res, int row0, int n_rows, const void* device_bitmap, const void* device_src);
 
 /* ---- measurement ---- */
 /* rays per frame for the current G-buffer and options: N primary + per shaded pixel the

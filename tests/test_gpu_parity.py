@@ -287,8 +287,8 @@ def test_frame_parity_blocks_restir_quarter_res(api, oracle, scenes):
     r.close()
 
 
-@pytest.mark.parametrize("n_strips,H", [(2, 240), (3, 300)])
-def test_strip_contexts_match_full_frame(api, oracle, scenes, n_strips, H):
+@pytest.mark.parametrize("n_strips,H,sparse", [(2, 240, False), (3, 300, False), (2, 240, True), (3, 300, True)])
+def test_strip_contexts_match_full_frame(api, oracle, scenes, n_strips, H, sparse):
     """Two row-strip contexts on one GPU with an 87-row halo exchanged through the C-ABI halo
     calls reproduce the single-context frame bit for bit."""
     import ctypes as C
@@ -316,7 +316,7 @@ def test_strip_contexts_match_full_frame(api, oracle, scenes, n_strips, H):
     for frame in (1, 2):
         full.frame(frame)
         ref = full.download(api.RT_BUF_ACCUMULATION).reshape(H, W, 4)
-        strips.run_frame_local(ctxs, bounds, frame, torch.device("cuda:0"))
+        strips.run_frame_local(ctxs, bounds, frame, torch.device("cuda:0"), sparse=sparse)
         for c, (a, b) in zip(ctxs, bounds):
             acc = c.download(api.RT_BUF_ACCUMULATION).reshape(c.local_rows, W, 4)
             mine = acc[a - c.local_row0: b - c.local_row0]
@@ -523,7 +523,12 @@ def test_full_size_properties_1080p(api, scenes):
         b = bykernel.download(api.RT_BUF_ACCUMULATION)
         assert _eq_bits(a, b), f"fused vs kernel-by-kernel, frame {frame}: {(a != b).any(axis=1).sum()} pixels"
         assert np.array_equal(fused.download(api.RT_BUF_PIXELS), bykernel.download(api.RT_BUF_PIXELS))
-        strips.run_frame_local(ctxs, bounds, frame, torch.device("cuda:0"))
+        stats = []
+        strips.run_frame_local(ctxs, bounds, frame, torch.device("cuda:0"), sparse=(frame == 2), stats=stats)
+        if frame == 2:  # sparse halos: same image from a fraction of the records
+            sent, dense = sum(s[0] for s in stats), sum(s[1] for s in stats)
+            assert 0.05 < sent / dense < 0.5, (sent, dense)
+            print(f"sparse halos: {sent} of {dense} records = {sent / dense:.3f}")
         full = a.reshape(H, W, 4)
         for c, (r0, r1) in zip(ctxs, bounds):
             mine = c.download(api.RT_BUF_ACCUMULATION).reshape(c.local_rows, W, 4)[r0 - c.local_row0: r1 - c.local_row0]
