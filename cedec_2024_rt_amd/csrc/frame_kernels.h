@@ -1,0 +1,1016 @@
+/*
+ * frame_kernels.h — every gfx950 kernel of the hot path (included once, by restir_rt.hip).
+ *
+ * Per pixel restatements of examples/10_restir_di/10_restir_di.cu and common/kernels/common.cu
+ * (file:line cited at each kernel) over the layouts of rt_device.h, the path tracers of
+ * examples/07_pt and examples/09_ris, the layout converters behind rt_upload / rt_download,
+ * the sparse-halo kernels of the multi-GPU strips, and measurement / test utilities.
+ */
+#pragma once
+#include "bvh.h"
+#include "rt_device.h"
+
+using namespace rt;
+
+/* ------------------------------------------------------------------ params */
+
+struct FrameParams
+{
+    int W, H;           /* full image */
+    int row0, row1;     /* global storage rows processed by this launch */
+    int lrow0, lrows;   /* global row of local buffer row 0, local rows held */
+    int frame, pass;
+    f3 eye;
+    f3 rg_origin, rg_right, rg_up;
+    int n_lights;
+    /* options (common/options.hpp) */
+    int accumulate, ris_sample_count, use_temporal, use_spatial, spatial_count, vis_reuse;
+    float spatial_radius;
+    int tile_mode; /* workgroup -> tile order inside an XCD's band: 0 row-major, 1 column-major */
+};
+
+struct SceneView
+{
+    BvhView bvh;   /* binary LBVH, stackless trail traversal (kept for A/B measurements) */
+    WideView wide; /* production traversal structure */
+    const float4* __restrict__ trimat; /* 2 per triangle: {Kd.xyz, bits(emissive?)}, {Ke.xyz, 0} */
+    const float4* __restrict__ lights;   /* 3 per light, see k_light_table */
+    const float4* __restrict__ light_ke; /* 1 per light: {Ke.xyz, 0} */
+};
+
+constexpr int TILE_W = 32, TILE_H = 8, BLOCK = 256;
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES 1 /* min waves per SIMD requested for the tracing kernels (register budget) */
+#endif
+
+/* XCD-aware workgroup -> tile -> pixel. Returns false for threads outside the row range.
+ * Workgroup b runs on XCD b % 8 (round-robin dispatch); slot b / 8 walks that XCD's band of
+ * tile rows either row by row (mode 0) or column by column (mode 1: the set of tiles in flight
+ * on an XCD is then ~13 tiles wide x the band height instead of full-width x 4 rows, which is
+ * what keeps the spatial pass's neighbour window inside the 4 MiB L2). */
+RT_DEV bool tile_pixel(const FrameParams& P, int& x, int& row)
+{
+    const int tiles_x = (P.W + TILE_W - 1) / TILE_W;
+    const int tiles_y = (P.row1 - P.row0 + TILE_H - 1) / TILE_H;
+    const int b = blockIdx.x;
+    int tx, ty;
+    if (P.tile_mode == 1)
+    {
+        const int band_rows = (tiles_y + 7) / 8;
+        const int slot = b >> 3;
+        tx = slot / band_rows;
+        ty = (b & 7) * band_rows + (slot - tx * band_rows);
+        if (tx >= tiles_x || ty >= tiles_y) return false;
+    }
+    else
+    {
+        const int n_tiles = tiles_x * tiles_y;
+        const int per_xcd = (n_tiles + 7) / 8;
+        const int slot = b >> 3;
+        if (slot >= per_xcd) return false; /* the grid is sized for either order */
+        const int tile = (b & 7) * per_xcd + slot;
+        if (tile >= n_tiles) return false;
+        ty = tile / tiles_x;
+        tx = tile - ty * tiles_x;
+    }
+    x = tx * TILE_W + (threadIdx.x & (TILE_W - 1));
+    row = P.row0 + ty * TILE_H + (threadIdx.x >> 5);
+    return x < P.W && row < P.row1;
+}
+static inline int tile_grid(int W, int rows)
+{
+    /* covers both orders: mode 1 needs 8 * ceil(tiles_y/8) * tiles_x workgroups */
+    const int tx = (W + TILE_W - 1) / TILE_W, ty = (rows + TILE_H - 1) / TILE_H;
+    const int a = ((tx * ty + 7) / 8) * 8, b = 8 * ((ty + 7) / 8) * tx;
+    return a > b ? a : b;
+}
+
+/* common/core.hpp:189-207: surface point + normal flipped toward the eye [parity] */
+RT_DEV void surface_info(const BvhView& bvh, int tri, float u, float v, f3 eye, f3& p, f3& n)
+{
+    f3 v0, v1, v2;
+    load_tri(bvh.tv, tri, v0, v1, v2);
+    p = (1.0f - u - v) * v0 + u * v1 + v * v2;
+    n = tri_normal(v0, v1, v2);
+    const f3 view = normalize(eye - p);
+    if (dot(view, n) < 0.0f) n = -n;
+}
+
+/* G-buffer entry from a Visibility record */
+RT_DEV void gbuffer_write(const SceneView& S, const FrameParams& P, float4* __restrict__ g0,
+                          float4* __restrict__ g1, size_t li, float u, float v, int index)
+{
+    if (index < 0)
+    {
+        g0[li] = make_float4(0.0f, 0.0f, 0.0f, as_float(-1));
+        g1[li] = make_float4(0.0f, 0.0f, 0.0f, as_float(0u));
+        return;
+    }
+    const bool emissive = as_uint(S.trimat[2 * (size_t)index].w) != 0u;
+    f3 p, n;
+    surface_info(S.bvh, index, u, v, P.eye, p, n);
+    g0[li] = make_float4(p.x, p.y, p.z, as_float(index));
+    g1[li] = make_float4(n.x, n.y, n.z, as_float(emissive ? GB_EMISSIVE : GB_SHADED));
+}
+
+/* -------------------------------------------------------------------- raycast */
+/* examples/10_restir_di/10_restir_di.cu:9-34 (+ common/camera.hpp:27-35) */
+__global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_raycast(SceneView S, FrameParams P, float4* __restrict__ vis,
+                                                    float4* __restrict__ g0, float4* __restrict__ g1)
+{
+    __shared__ uint32_t s_stack[WIDE_LDS_STACK * BLOCK];
+    int x, row;
+    if (!tile_pixel(P, x, row)) return;
+    const int yi = P.H - 1 - row;
+    const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
+
+    const float u = (float)x / (float)P.W, v = (float)yi / (float)P.H;
+    const f3 forward = normalize(cross(P.rg_up, P.rg_right));
+    const f3 to = P.rg_origin + forward + mix(-P.rg_right, P.rg_right, u) + mix(P.rg_up, -P.rg_up, v);
+    const f3 rd = normalize(to - P.rg_origin);
+
+    Hit h;
+    h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.prim = -1;
+    trace_wide<false>(S.wide, s_stack, P.rg_origin, rd, 0.0f, kFltMax, h);
+    vis[li] = make_float4(h.u, h.v, as_float(h.prim), as_float(0));
+    gbuffer_write(S, P, g0, g1, li, h.u, h.v, h.prim);
+}
+
+/* rebuild the G-buffer from an uploaded Visibility buffer */
+__global__ __launch_bounds__(BLOCK) void k_gbuffer_from_vis(SceneView S, FrameParams P,
+                                                             const float4* __restrict__ vis,
+                                                             float4* __restrict__ g0, float4* __restrict__ g1)
+{
+    int x, row;
+    if (!tile_pixel(P, x, row)) return;
+    const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
+    const float4 vv = vis[li];
+    gbuffer_write(S, P, g0, g1, li, vv.x, vv.y, as_int(vv.z));
+}
+
+/* ------------------------------------------------------- target function helper */
+/* common/reservoir.hpp:42-59 */
+template <bool SHADOWED>
+RT_DEV float target_function(const SceneView& S, uint32_t* s_stack, f3 op, f3 on, f3 hp, f3 hn, float lum)
+{
+    if (SHADOWED)
+    {
+        const float brdf = 1.0f / kPI;
+        const float G = geometry_term(op, on, hp, hn);
+        const float V = check_visibility_wide(S.wide, s_stack, op, on, hp) ? 1.0f : 0.0f;
+        return brdf * G * V * lum;
+    }
+    return target_unshadowed(op, on, hp, hn, lum);
+}
+
+RT_DEV void res_take_sample(Res& r, const Res& o)
+{
+    r.hit_p = o.hit_p; r.hit_n = o.hit_n; r.org_p = o.org_p; r.org_n = o.org_n;
+    r.rad = o.rad; r.lum = o.lum; r.vis = o.vis;
+}
+
+/* temporal merge of 10_restir_di.cu:177-233; r = current, pr = previous frame, same pixel */
+template <bool SHADOWED>
+RT_DEV void temporal_merge(const SceneView& S, uint32_t* s_stack, const FrameParams& P, int x, int yi, f3 sp, f3 sn, Res& r,
+                           Res pr)
+{
+    PCG rng = pcg_init(hashPCG4((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame, 1u), 0);
+    const int cap = 20 * P.ris_sample_count;
+    pr.M = pr.M < cap ? pr.M : cap;
+    float p_hat_y = target_function<SHADOWED>(S, s_stack, sp, sn, pr.hit_p, pr.hit_n, pr.lum);
+    if (P.vis_reuse) p_hat_y *= pr.vis ? 1.0f : 0.0f;
+    pr.M = scale_M(pr.M, rejection_heuristics(r.org_p, r.org_n, pr.org_p, pr.org_n, P.eye));
+    const float weight = p_hat_y * pr.ucw * (float)pr.M;
+    const float u = rng.uniformf();
+    r.w_sum += weight;
+    r.M += pr.M;
+    if (u < weight / r.w_sum) res_take_sample(r, pr);
+    const float p_hat = target_function<SHADOWED>(S, s_stack, sp, sn, r.hit_p, r.hit_n, r.lum);
+    r.ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
+}
+
+/* --------------------------------------------------------- generate_candidate */
+/* examples/10_restir_di/10_restir_di.cu:36-135; with FUSE_TEMPORAL also :137-237 on the
+ * value still in registers (the reference round-trips it through reservoir_buffer0). */
+template <bool FUSE_TEMPORAL, bool SHADOWED>
+__global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_generate_candidate(
+    SceneView S, FrameParams P, const float4* __restrict__ g0, const float4* __restrict__ g1,
+    const float4* __restrict__ prev_rec, const float4* __restrict__ prev_rad, float4* __restrict__ out_rec,
+    float4* __restrict__ out_rad)
+{
+    __shared__ uint32_t s_stack[WIDE_LDS_STACK * BLOCK];
+    int x, row;
+    if (!tile_pixel(P, x, row)) return;
+    const int yi = P.H - 1 - row;
+    const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
+
+    const float4 G0 = g0[li], G1 = g1[li];
+    const uint32_t flags = as_uint(G1.w);
+    Res r = res_zero();
+    if (!(flags & GB_SHADED))
+    {
+        res_store(out_rec, out_rad, li, r, false); /* Reservoir{} (:56-70) */
+        return;
+    }
+    const f3 sp = F3(G0.x, G0.y, G0.z), sn = F3(G1.x, G1.y, G1.z);
+
+    PCG rng = pcg_init(hashPCG4((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame, 0u), 0);
+    const float fL = (float)(size_t)P.n_lights;
+    int sel = -1;
+    for (int i = 0; i < P.ris_sample_count; ++i)
+    {
+        /* draw order rv0, rv1, rv2, u: left-to-right argument evaluation (hipcc) */
+        const float rv0 = rng.uniformf();
+        float bx = rng.uniformf();
+        float by = rng.uniformf();
+        /* common/core.hpp:261-285 */
+        uint32_t nth = (uint32_t)(rv0 * fL);
+        if (nth == (uint32_t)P.n_lights) nth = (uint32_t)P.n_lights - 1u;
+        /* 48-B light record = 3 lane-loads (the loop is bound by the number of divergent per-lane
+         * loads, not by ALU): vertices + luminance(Ke) + pdf; the normal is recomputed with the
+         * reference's exact expression (common/core.hpp:50-55), Ke is fetched once at the end. */
+        const float4* L = S.lights + 3 * (size_t)nth;
+        const float4 L0 = L[0], L1 = L[1], L2 = L[2];
+        const f3 v0 = F3(L0.x, L0.y, L0.z), v1 = F3(L0.w, L1.x, L1.y), v2 = F3(L1.z, L1.w, L2.x);
+        warp_unit_triangle(bx, by);
+        const f3 lp = (1.0f - bx - by) * v0 + bx * v1 + by * v2;
+        const f3 ln = tri_normal(v0, v1, v2);
+        const float lum = L2.y;
+        const float light_pdf = L2.z; /* 1/L * 1/area (:98-99) */
+        const float p_hat = target_unshadowed(sp, sn, lp, ln, lum); /* unshadowed always (:104) */
+        const float weight = p_hat / light_pdf;
+        const float u = rng.uniformf();
+        /* common/reservoir.hpp:22-29 */
+        r.w_sum += weight;
+        r.M += 1;
+        if (u < weight / r.w_sum)
+        {
+            r.hit_p = lp; r.hit_n = ln; r.lum = lum;
+            r.org_p = sp; r.org_n = sn; r.vis = false;
+            sel = (int)nth;
+        }
+    }
+    if (sel >= 0)
+    {
+        const float4 ke = S.light_ke[sel];
+        r.rad = F3(ke.x, ke.y, ke.z);
+    }
+    {
+        const float p_hat = target_function<SHADOWED>(S, s_stack, sp, sn, r.hit_p, r.hit_n, r.lum);
+        r.ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
+    }
+    if (P.vis_reuse) r.vis = check_visibility_wide(S.wide, s_stack, sp, sn, r.hit_p);
+
+    if (FUSE_TEMPORAL)
+    {
+        bool dummy;
+        Res pr = res_load(prev_rec, li, dummy);
+        const float4 pq = prev_rad[li];
+        pr.rad = F3(pq.x, pq.y, pq.z);
+        temporal_merge<SHADOWED>(S, s_stack, P, x, yi, sp, sn, r, pr);
+    }
+    res_store(out_rec, out_rad, li, r, true);
+}
+
+/* -------------------------------------------------------- temporal_resampling */
+/* examples/10_restir_di/10_restir_di.cu:137-237 (stand-alone entry point) */
+template <bool SHADOWED>
+__global__ __launch_bounds__(BLOCK) void k_temporal(SceneView S, FrameParams P, const float4* __restrict__ g0,
+                                                     const float4* __restrict__ g1,
+                                                     const float4* __restrict__ prev_rec,
+                                                     const float4* __restrict__ prev_rad,
+                                                     float4* __restrict__ rec, float4* __restrict__ radb)
+{
+    __shared__ uint32_t s_stack[WIDE_LDS_STACK * BLOCK];
+    int x, row;
+    if (!tile_pixel(P, x, row)) return;
+    const int yi = P.H - 1 - row;
+    const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
+    const float4 G0 = g0[li], G1 = g1[li];
+    if (!(as_uint(G1.w) & GB_SHADED)) return;
+    if (!P.use_temporal) return;
+    const f3 sp = F3(G0.x, G0.y, G0.z), sn = F3(G1.x, G1.y, G1.z);
+    bool dummy;
+    Res r = res_load(rec, li, dummy);
+    const float4 rq = radb[li];
+    r.rad = F3(rq.x, rq.y, rq.z);
+    Res pr = res_load(prev_rec, li, dummy);
+    const float4 pq = prev_rad[li];
+    pr.rad = F3(pq.x, pq.y, pq.z);
+    temporal_merge<SHADOWED>(S, s_stack, P, x, yi, sp, sn, r, pr);
+    res_store(rec, radb, li, r, true);
+}
+
+/* --------------------------------------------------------- spatial_resampling */
+/* examples/10_restir_di/10_restir_di.cu:256-388 — the roofline kernel.
+ * Per neighbour ONE 64-B aligned record is gathered (the reference gathers a 16-B Visibility,
+ * a Triangle and a 76-B Reservoir); the "sky / emissive neighbour" test of :326-338 reads the
+ * shaded bit kept inside the record; radiance (side record) is fetched once, for the sample
+ * that survived. */
+template <bool SHADOWED>
+__global__ __launch_bounds__(BLOCK) void k_spatial(SceneView S, FrameParams P, const float4* __restrict__ g0,
+                                                    const float4* __restrict__ g1,
+                                                    const float4* __restrict__ in_rec,
+                                                    const float4* __restrict__ in_rad,
+                                                    float4* __restrict__ out_rec, float4* __restrict__ out_rad)
+{
+    __shared__ uint32_t s_stack[WIDE_LDS_STACK * BLOCK];
+    int x, row;
+    if (!tile_pixel(P, x, row)) return;
+    const int yi = P.H - 1 - row;
+    const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
+    const float4 G0 = g0[li], G1 = g1[li];
+    if (!(as_uint(G1.w) & GB_SHADED))
+    {
+        /* the reference stores nothing here (:275-287); we keep the shaded bit valid */
+        res_store(out_rec, out_rad, li, res_zero(), false);
+        return;
+    }
+    const f3 sp = F3(G0.x, G0.y, G0.z), sn = F3(G1.x, G1.y, G1.z);
+    PCG rng = pcg_init(hashPCG4((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame, (uint32_t)(2 + P.pass)), 0);
+
+    bool own_shaded;
+    Res r = res_load(in_rec, li, own_shaded);
+    size_t rad_from = li;
+
+    if (P.use_spatial)
+    {
+        const float scale = P.spatial_radius / 1.96f;
+        for (int k = 0; k < P.spatial_count; ++k)
+        {
+            const float rv0 = rng.uniformf();
+            const float rv1 = rng.uniformf();
+            /* common/reservoir.hpp:89-95 with portable log/cos/sin */
+            const float radius = sqrtf(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
+            const float phi = 2.0f * kPI * rv1;
+            const float gx = radius * pm_cosf(phi), gy = radius * pm_sinf(phi);
+            const int nx = f2i_sat((float)x + scale * gx);
+            const int ny = f2i_sat((float)yi + scale * gy);
+            if (nx < 0 || nx >= P.W || ny < 0 || ny >= P.H) continue;
+            if (nx == x && ny == yi) continue;
+            const int nrow = P.H - 1 - ny;
+            const int lr = nrow - P.lrow0;
+            if (lr < 0 || lr >= P.lrows) continue; /* only when halo < 87: outside the contract */
+            const size_t pid = (size_t)nx + (size_t)lr * P.W;
+            bool n_shaded;
+            Res nr = res_load(in_rec, pid, n_shaded);
+            if (!n_shaded) continue; /* sky or emissive neighbour (:326-338) */
+
+            float p_hat_y = target_function<SHADOWED>(S, s_stack, sp, sn, nr.hit_p, nr.hit_n, nr.lum);
+            if (P.vis_reuse) p_hat_y *= nr.vis ? 1.0f : 0.0f;
+            nr.M = scale_M(nr.M, rejection_heuristics(r.org_p, r.org_n, nr.org_p, nr.org_n, P.eye));
+            const float weight = p_hat_y * nr.ucw * (float)nr.M;
+            const float u = rng.uniformf();
+            r.w_sum += weight;
+            r.M += nr.M;
+            if (u < weight / r.w_sum)
+            {
+                res_take_sample(r, nr);
+                rad_from = pid;
+            }
+        }
+        const float p_hat = target_function<SHADOWED>(S, s_stack, sp, sn, r.hit_p, r.hit_n, r.lum);
+        r.ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
+    }
+    const float4 rq = in_rad[rad_from];
+    r.rad = F3(rq.x, rq.y, rq.z);
+    res_store(out_rec, out_rad, li, r, true);
+}
+
+
+/* SURVEY.md §8(d) ALGORITHMIC bytes of one spatial_resampling launch, counted with the
+ * reference's record sizes (Visibility 16 B, Reservoir 76 B): per pixel 16; per shaded pixel
+ * +76 in +76 out; per neighbour that passed the on-screen / not-self tests +16, and +76 more if
+ * it is shaded. Replays exactly the RNG draws of k_spatial (the accept decisions depend only on
+ * the RNG and the shaded bits, not on reservoir contents). Measurement aid, not on the hot path. */
+__global__ __launch_bounds__(BLOCK) void k_spatial_bytes(FrameParams P, const float4* __restrict__ g1,
+                                                          const float4* __restrict__ in_rec,
+                                                          unsigned long long* __restrict__ out)
+{
+    int x, row;
+    const bool ok = tile_pixel(P, x, row);
+    unsigned long long bytes = 0, accepted = 0;
+    if (ok)
+    {
+        const int yi = P.H - 1 - row;
+        const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
+        bytes = 16;
+        if (as_uint(g1[li].w) & GB_SHADED)
+        {
+            bytes += 152;
+            if (P.use_spatial)
+            {
+                PCG rng = pcg_init(hashPCG4((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame, (uint32_t)(2 + P.pass)), 0);
+                const float scale = P.spatial_radius / 1.96f;
+                for (int k = 0; k < P.spatial_count; ++k)
+                {
+                    const float rv0 = rng.uniformf();
+                    const float rv1 = rng.uniformf();
+                    const float radius = sqrtf(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
+                    const float phi = 2.0f * kPI * rv1;
+                    const int nx = f2i_sat((float)x + scale * (radius * pm_cosf(phi)));
+                    const int ny = f2i_sat((float)yi + scale * (radius * pm_sinf(phi)));
+                    if (nx < 0 || nx >= P.W || ny < 0 || ny >= P.H) continue;
+                    if (nx == x && ny == yi) continue;
+                    const int lr = P.H - 1 - ny - P.lrow0;
+                    if (lr < 0 || lr >= P.lrows) continue;
+                    bytes += 16;
+                    accepted += 1;
+                    const uint32_t mb = as_uint(in_rec[4 * ((size_t)nx + (size_t)lr * P.W) + 1].w);
+                    if (!(mb & RES_SHADED_BIT)) continue;
+                    bytes += 76;
+                    rng.uniformf();
+                }
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        bytes += __shfl_down(bytes, off);
+        accepted += __shfl_down(accepted, off);
+    }
+    if ((threadIdx.x & 63) == 0)
+    {
+        atomicAdd(&out[0], bytes);
+        atomicAdd(&out[1], accepted);
+    }
+}
+
+/* ------------------------------------------------------- sparse reservoir halos (multi-GPU)
+ * A strip only needs those neighbour-strip records its own pixels will actually gather. Which
+ * ones is a pure function of the RNG and the shaded bits (exactly the replay of
+ * k_spatial_bytes), so the RECEIVER marks them in a bitmap over the neighbour's boundary rows
+ * (k_halo_mark), ships the bitmap once per frame, and the owner answers every pass with the
+ * marked records only, in bitmap order (k_halo_sparse). Bitmap buffer (uint32 words):
+ *   [0] = number of marked records, [1 .. nw] = bits (bit i of word w = pixel 32*w + i of the
+ *   region, row-major from region row 0), [1+nw .. 1+2nw) = exclusive prefix counts per word. */
+__global__ __launch_bounds__(BLOCK) void k_halo_mark(FrameParams P, const float4* __restrict__ g1, int reg_row0,
+                                                      int reg_rows, uint32_t* __restrict__ bitmap)
+{
+    int x, row;
+    if (!tile_pixel(P, x, row)) return;
+    const int yi = P.H - 1 - row;
+    const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
+    if (!(as_uint(g1[li].w) & GB_SHADED) || !P.use_spatial) return;
+    PCG rng = pcg_init(hashPCG4((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame, (uint32_t)(2 + P.pass)), 0);
+    const float scale = P.spatial_radius / 1.96f;
+    for (int k = 0; k < P.spatial_count; ++k)
+    {
+        const float rv0 = rng.uniformf();
+        const float rv1 = rng.uniformf();
+        const float radius = sqrtf(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
+        const float phi = 2.0f * kPI * rv1;
+        const int nx = f2i_sat((float)x + scale * (radius * pm_cosf(phi)));
+        const int ny = f2i_sat((float)yi + scale * (radius * pm_sinf(phi)));
+        if (nx < 0 || nx >= P.W || ny < 0 || ny >= P.H) continue;
+        if (nx == x && ny == yi) continue;
+        const int nrow = P.H - 1 - ny;
+        const int lr = nrow - P.lrow0;
+        if (lr < 0 || lr >= P.lrows) continue;
+        if (nrow >= reg_row0 && nrow < reg_row0 + reg_rows)
+        {
+            const uint32_t bit = (uint32_t)(nrow - reg_row0) * (uint32_t)P.W + (uint32_t)nx;
+            atomicOr(&bitmap[1 + (bit >> 5)], 1u << (bit & 31u));
+        }
+        if (!(as_uint(g1[(size_t)nx + (size_t)lr * P.W].w) & GB_SHADED)) continue;
+        rng.uniformf();
+    }
+}
+/* one workgroup: exclusive prefix of the per-word popcounts, total into word 0 */
+__global__ void k_halo_scan(uint32_t* __restrict__ bitmap, int nw)
+{
+    __shared__ uint32_t s_sum[1024];
+    const int t = threadIdx.x, T = blockDim.x;
+    const int per = (nw + T - 1) / T;
+    const int w0 = t * per, w1 = min(nw, w0 + per);
+    uint32_t local = 0;
+    for (int w = w0; w < w1; ++w) local += (uint32_t)__popc(bitmap[1 + w]);
+    s_sum[t] = local;
+    __syncthreads();
+    for (int off = 1; off < T; off <<= 1)
+    {
+        const uint32_t v = t >= off ? s_sum[t - off] : 0u;
+        __syncthreads();
+        s_sum[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_sum[t] - local;
+    for (int w = w0; w < w1; ++w)
+    {
+        bitmap[1 + nw + w] = run;
+        run += (uint32_t)__popc(bitmap[1 + w]);
+    }
+    if (t == T - 1) bitmap[0] = s_sum[t];
+}
+/* PACK: marked records of rows [row0, row0+rows) -> dense list (64 B record + 16 B radiance each);
+ * UNPACK: the reverse. */
+template <bool PACK>
+__global__ void k_halo_sparse(const uint32_t* __restrict__ bitmap, int nw, int W, size_t region_off, int n_pix,
+                              float4* __restrict__ rec, float4* __restrict__ radb, float4* __restrict__ list)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pix) return;
+    const uint32_t word = bitmap[1 + (i >> 5)];
+    if (!(word & (1u << (i & 31)))) return;
+    const uint32_t idx = bitmap[1 + nw + (i >> 5)] + (uint32_t)__popc(word & ((1u << (i & 31)) - 1u));
+    float4* L = list + 5 * (size_t)idx;
+    const size_t p = region_off + (size_t)i;
+    if (PACK)
+    {
+        L[0] = rec[4 * p + 0]; L[1] = rec[4 * p + 1]; L[2] = rec[4 * p + 2]; L[3] = rec[4 * p + 3];
+        L[4] = radb[p];
+    }
+    else
+    {
+        rec[4 * p + 0] = L[0]; rec[4 * p + 1] = L[1]; rec[4 * p + 2] = L[2]; rec[4 * p + 3] = L[3];
+        radb[p] = L[4];
+    }
+    (void)W;
+}
+/* shaded flags of rows as bytes (halo rows of the G-buffer only ever hold these flags) */
+template <bool PACK>
+__global__ void k_halo_flags(float4* __restrict__ g1, size_t off, int n_pix, uint8_t* __restrict__ bytes)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pix) return;
+    if (PACK) bytes[i] = (uint8_t)(as_uint(g1[off + i].w) & 0xffu);
+    else g1[off + i] = make_float4(0.0f, 0.0f, 0.0f, as_float((uint32_t)bytes[i]));
+}
+
+/* -------------------------------------------------------------------- resolve */
+/* examples/10_restir_di/10_restir_di.cu:390-459 */
+__global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_resolve(SceneView S, FrameParams P, const float4* __restrict__ g0,
+                                                    const float4* __restrict__ g1,
+                                                    const float4* __restrict__ rec,
+                                                    const float4* __restrict__ radb, float4* __restrict__ accum)
+{
+    __shared__ uint32_t s_stack[WIDE_LDS_STACK * BLOCK];
+    int x, row;
+    if (!tile_pixel(P, x, row)) return;
+    const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
+    const float4 G0 = g0[li], G1 = g1[li];
+    const int tri = as_int(G0.w);
+    const uint32_t flags = as_uint(G1.w);
+    if (tri < 0) { accum[li] = make_float4(0.0f, 0.0f, 0.0f, 1.0f); return; }
+    if (flags & GB_EMISSIVE)
+    {
+        const float4 ke = S.trimat[2 * (size_t)tri + 1];
+        accum[li] = make_float4(ke.x, ke.y, ke.z, 1.0f);
+        return;
+    }
+    const f3 sp = F3(G0.x, G0.y, G0.z), sn = F3(G1.x, G1.y, G1.z);
+    const float4 q0 = rec[4 * li + 0], q1 = rec[4 * li + 1];
+    const float4 rq = radb[li];
+    const float4 kd = S.trimat[2 * (size_t)tri];
+    const f3 hp = F3(q0.x, q0.y, q0.z), hn = F3(q1.x, q1.y, q1.z);
+    const f3 brdf = (1.0f / kPI) * F3(kd.x, kd.y, kd.z);
+    const float G = geometry_term(sp, sn, hp, hn);
+    const float V = check_visibility_wide(S.wide, s_stack, sp, sn, hp) ? 1.0f : 0.0f;
+    const f3 radiance = brdf * G * V * F3(rq.x, rq.y, rq.z) * q0.w;
+    if (P.accumulate)
+    {
+        const float4 a = accum[li];
+        accum[li] = make_float4(a.x + radiance.x, a.y + radiance.y, a.z + radiance.z, a.w + 1.0f);
+    }
+    else { accum[li] = make_float4(radiance.x, radiance.y, radiance.z, 1.0f); }
+}
+
+
+/* ------------------------------------------------------- configs #2 / #3: path tracers */
+/* common/core.hpp:76-89 with portable cos/sin [parity] */
+RT_DEV f3 sample_hemisphere(float r0, float r1, float r2)
+{
+    const float theta = r0 * 2.0f * kPI;
+    float radius = r1 + r2;
+    if (1.0f < radius) radius = 2.0f - radius;
+    const float x = pm_cosf(theta) * radius;
+    const float z = pm_sinf(theta) * radius;
+    const float a = 1.0f - radius * radius;
+    const float y = sqrtf((a < 0.0f) ? 0.0f : a);
+    return F3(x, y, z);
+}
+
+/* examples/07_pt/07_pt.cu:11-90 (EXAMPLE 7) and examples/09_ris/09_ris.cu:11-166 (EXAMPLE 9): the
+ * `path_trace` kernels, one thread per pixel, whole path in one launch. rays[0] accumulates the
+ * number of raytrace() calls (one atomic per wave). */
+template <int EXAMPLE, bool SHADOWED>
+__global__ __launch_bounds__(BLOCK) void k_path_trace(SceneView S, FrameParams P, int max_depth, f3 sky,
+                                                       float4* __restrict__ accum,
+                                                       unsigned long long* __restrict__ rays)
+{
+    __shared__ uint32_t s_stack[WIDE_LDS_STACK * BLOCK];
+    int x, row;
+    const bool ok = tile_pixel(P, x, row);
+    unsigned long long nrays = 0;
+    if (ok)
+    {
+        const int yi = P.H - 1 - row;
+        const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
+        PCG rng = pcg_init(hashPCG3((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame), 0);
+        const float u = (float)x / (float)P.W, v = (float)yi / (float)P.H;
+        const f3 forward = normalize(cross(P.rg_up, P.rg_right));
+        const f3 to = P.rg_origin + forward + mix(-P.rg_right, P.rg_right, u) + mix(P.rg_up, -P.rg_up, v);
+        f3 ro = P.rg_origin;
+        f3 rd = normalize(to - P.rg_origin);
+        f3 radiance = F3(0.0f, 0.0f, 0.0f), throughput = F3(1.0f, 1.0f, 1.0f);
+        const float fL = (float)(size_t)P.n_lights;
+        for (int depth = 0; depth < max_depth; ++depth)
+        {
+            Hit h;
+            ++nrays;
+            if (!trace_wide<false>(S.wide, s_stack, ro, rd, 0.0f, kFltMax, h))
+            {
+                if (EXAMPLE == 7) radiance = radiance + throughput * sky;
+                break;
+            }
+            const float4 kd4 = S.trimat[2 * (size_t)h.prim];
+            if (as_uint(kd4.w) != 0u)
+            {
+                const float4 ke4 = S.trimat[2 * (size_t)h.prim + 1];
+                if (EXAMPLE == 7 || depth == 0) radiance = radiance + throughput * F3(ke4.x, ke4.y, ke4.z);
+                break;
+            }
+            /* common/core.hpp:152-165 */
+            f3 v0, v1, v2;
+            load_tri(S.bvh.tv, h.prim, v0, v1, v2);
+            const f3 sp = ro + h.t * rd;
+            f3 sn = tri_normal(v0, v1, v2);
+            if (dot(-rd, sn) < 0.0f) sn = -sn;
+            const f3 kd = F3(kd4.x, kd4.y, kd4.z);
+
+            if (EXAMPLE == 9)
+            {
+                /* RIS over the lights (09_ris.cu:61-99), then the shaded contribution (:101-126) */
+                Res r = res_zero();
+                for (int i = 0; i < P.ris_sample_count; ++i)
+                {
+                    const float rv0 = rng.uniformf();
+                    float bx = rng.uniformf();
+                    float by = rng.uniformf();
+                    uint32_t nth = (uint32_t)(rv0 * fL);
+                    if (nth == (uint32_t)P.n_lights) nth = (uint32_t)P.n_lights - 1u;
+                    const float4* L = S.lights + 3 * (size_t)nth;
+                    const float4 L0 = L[0], L1 = L[1], L2 = L[2];
+                    const f3 a0 = F3(L0.x, L0.y, L0.z), a1 = F3(L0.w, L1.x, L1.y), a2 = F3(L1.z, L1.w, L2.x);
+                    warp_unit_triangle(bx, by);
+                    const f3 lp = (1.0f - bx - by) * a0 + bx * a1 + by * a2;
+                    const f3 ln = tri_normal(a0, a1, a2);
+                    float p_hat;
+                    if (SHADOWED)
+                    {
+                        p_hat = target_function<true>(S, s_stack, sp, sn, lp, ln, L2.y);
+                        ++nrays;
+                    }
+                    else { p_hat = target_unshadowed(sp, sn, lp, ln, L2.y); }
+                    const float weight = p_hat / L2.z;
+                    const float uu = rng.uniformf();
+                    r.w_sum += weight;
+                    r.M += 1;
+                    if (uu < weight / r.w_sum)
+                    {
+                        r.hit_p = lp; r.hit_n = ln; r.lum = L2.y;
+                        const float4 ke = S.light_ke[nth];
+                        r.rad = F3(ke.x, ke.y, ke.z);
+                    }
+                }
+                const f3 brdf = (1.0f / kPI) * kd;
+                const float G = geometry_term(sp, sn, r.hit_p, r.hit_n);
+                const float V = check_visibility_wide(S.wide, s_stack, sp, sn, r.hit_p) ? 1.0f : 0.0f;
+                ++nrays;
+                const float p_hat = target_function<SHADOWED>(S, s_stack, sp, sn, r.hit_p, r.hit_n, r.lum);
+                if (SHADOWED) ++nrays;
+                const float ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
+                radiance = radiance + throughput * brdf * G * V * r.rad * ucw;
+            }
+            /* next direction (07_pt.cu:61-70 / 09_ris.cu:128-137): common/core.hpp:216-235 */
+            const float r0 = rng.uniformf();
+            const float r1 = rng.uniformf();
+            const float r2 = rng.uniformf();
+            const f3 wl = sample_hemisphere(r0, r1, r2);
+            const f3 tg = normalize(v1 - v0);
+            const f3 bt = normalize(cross(tg, sn));
+            const f3 wo = wl.x * tg + wl.y * sn + wl.z * bt;
+            throughput = throughput * kd;
+            ro = sp + 0.001f * sn;
+            rd = wo;
+        }
+        if (P.accumulate)
+        {
+            const float4 a = accum[li];
+            accum[li] = make_float4(a.x + radiance.x, a.y + radiance.y, a.z + radiance.z, a.w + 1.0f);
+        }
+        else { accum[li] = make_float4(radiance.x, radiance.y, radiance.z, 1.0f); }
+    }
+    for (int off = 32; off > 0; off >>= 1) nrays += __shfl_down(nrays, off);
+    if ((threadIdx.x & 63) == 0 && nrays) atomicAdd(rays, nrays);
+}
+
+/* --------------------------------------------------------- clear / tone_mapping */
+/* common/kernels/common.cu:4-17 */
+__global__ __launch_bounds__(BLOCK) void k_clear(FrameParams P, float4* __restrict__ accum)
+{
+    int x, row;
+    if (!tile_pixel(P, x, row)) return;
+    accum[(size_t)x + (size_t)(row - P.lrow0) * P.W] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+RT_DEV float aces(float x)
+{
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    return (x * (a * x + b)) / (x * (c * x + d) + e);
+}
+RT_DEV uint32_t to_u8(float v)
+{
+    const float c = fminf(fmax_dev(v, 0.0f), 255.0f);
+    return (uint32_t)(int)c;
+}
+/* common/kernels/common.cu:30-74 (display only; powf = portable exp(y*log(x))) */
+__global__ __launch_bounds__(BLOCK) void k_tone_mapping(FrameParams P, const float4* __restrict__ accum,
+                                                         uint32_t* __restrict__ pixels)
+{
+    int x, row;
+    if (!tile_pixel(P, x, row)) return;
+    const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
+    const float4 a = accum[li];
+    const float gamma = 1.0f / 2.2f;
+    const float r = pm_powf_pos(aces(a.x / a.w * 1.0f), gamma);
+    const float g = pm_powf_pos(aces(a.y / a.w * 1.0f), gamma);
+    const float b = pm_powf_pos(aces(a.z / a.w * 1.0f), gamma);
+    pixels[li] = to_u8(r * 255.0f) | (to_u8(g * 255.0f) << 8) | (to_u8(b * 255.0f) << 16) | 0xff000000u;
+}
+
+/* ------------------------------------------------ layout conversion (upload/download) */
+__global__ void k_res_to_ref(int n, const float4* __restrict__ rec, const float4* __restrict__ radb,
+                             uint32_t* __restrict__ out /* 19 words per pixel */)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool shaded;
+    Res r = res_load(rec, (size_t)i, shaded);
+    const float4 rq = radb[i];
+    uint32_t* o = out + 19 * (size_t)i;
+    const float f[15] = {r.org_p.x, r.org_p.y, r.org_p.z, r.org_n.x, r.org_n.y, r.org_n.z, r.hit_p.x, r.hit_p.y,
+                         r.hit_p.z, r.hit_n.x, r.hit_n.y, r.hit_n.z, rq.x, rq.y, rq.z};
+    for (int k = 0; k < 15; ++k) o[k] = as_uint(f[k]);
+    o[15] = r.vis ? 1u : 0u;
+    o[16] = as_uint(r.w_sum);
+    o[17] = as_uint(r.ucw);
+    o[18] = (uint32_t)r.M;
+}
+__global__ void k_res_from_ref(int n, const uint32_t* __restrict__ in, const float4* __restrict__ g1,
+                               float4* __restrict__ rec, float4* __restrict__ radb)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* s = in + 19 * (size_t)i;
+    Res r;
+    r.org_p = F3(as_float(s[0]), as_float(s[1]), as_float(s[2]));
+    r.org_n = F3(as_float(s[3]), as_float(s[4]), as_float(s[5]));
+    r.hit_p = F3(as_float(s[6]), as_float(s[7]), as_float(s[8]));
+    r.hit_n = F3(as_float(s[9]), as_float(s[10]), as_float(s[11]));
+    r.rad = F3(as_float(s[12]), as_float(s[13]), as_float(s[14]));
+    r.vis = (s[15] & 0xffu) != 0u;
+    r.w_sum = as_float(s[16]);
+    r.ucw = as_float(s[17]);
+    r.M = (int)s[18];
+    r.lum = luminance(r.rad);
+    const bool shaded = (as_uint(g1[i].w) & GB_SHADED) != 0u;
+    res_store(rec, radb, (size_t)i, r, shaded);
+}
+
+/* ------------------------------------------------------------- scene tables */
+/* per emissive triangle (index order, 10_restir_di.cpp:196-205), 3 x float4:
+ *   {v0.xyz, v1.x} {v1.yz, v2.xy} {v2.z, luminance(Ke), pdf, bits(tri)}   + a side table {Ke.xyz, 0}
+ * pdf = 1/L * 1/area_of — the exact expression of common/core.hpp:57-62 and
+ * 10_restir_di.cu:98-99, evaluated once instead of once per candidate. */
+__global__ void k_light_table(int n_lights, const uint32_t* __restrict__ light_ids, const float* __restrict__ tris,
+                              float4* __restrict__ lights, float4* __restrict__ light_ke)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_lights) return;
+    const int ti = (int)light_ids[i];
+    const float* t = tris + 15 * (size_t)ti;
+    const f3 v0 = F3(t[0], t[1], t[2]), v1 = F3(t[3], t[4], t[5]), v2 = F3(t[6], t[7], t[8]);
+    const f3 ke = F3(t[12], t[13], t[14]);
+    const float pdf = 1.0f / (float)(size_t)n_lights * 1.0f / tri_area(v0, v1, v2);
+    float4* L = lights + 3 * (size_t)i;
+    L[0] = make_float4(v0.x, v0.y, v0.z, v1.x);
+    L[1] = make_float4(v1.y, v1.z, v2.x, v2.y);
+    L[2] = make_float4(v2.z, luminance(ke), pdf, as_float(ti));
+    light_ke[i] = make_float4(ke.x, ke.y, ke.z, 0.0f);
+}
+__global__ void k_trimat(int n, const float* __restrict__ tris, float4* __restrict__ trimat)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* t = tris + 15 * (size_t)i;
+    /* has_emission, common/core.hpp:64-68 */
+    const bool e = t[12] > 0.0f || t[13] > 0.0f || t[14] > 0.0f;
+    trimat[2 * (size_t)i] = make_float4(t[9], t[10], t[11], as_float(e ? 1u : 0u));
+    trimat[2 * (size_t)i + 1] = make_float4(t[12], t[13], t[14], 0.0f);
+}
+
+/* ------------------------------------------------------------------ utilities */
+__global__ void k_count_shaded(FrameParams P, const float4* __restrict__ g1, unsigned long long* __restrict__ out)
+{
+    int x, row;
+    const bool ok = tile_pixel(P, x, row);
+    bool shaded = false;
+    if (ok) shaded = (as_uint(g1[(size_t)x + (size_t)(row - P.lrow0) * P.W].w) & GB_SHADED) != 0u;
+    const unsigned long long m = __ballot(shaded);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
+}
+template <int MODE> /* 0 = wide (production), 1 = binary stackless */
+__global__ __launch_bounds__(BLOCK) void k_trace_closest(SceneView S, const float* __restrict__ rays, int n, float* __restrict__ hits)
+{
+    __shared__ uint32_t s_stack[MODE == 0 ? WIDE_LDS_STACK * BLOCK : 1];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rays + 8 * (size_t)i;
+    Hit h;
+    h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.prim = -1;
+    if (MODE == 0) trace_wide<false>(S.wide, s_stack, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7], h);
+    else trace<false>(S.bvh, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7], h);
+    float* o = hits + 4 * (size_t)i;
+    o[0] = h.t; o[1] = h.u; o[2] = h.v; o[3] = as_float(h.prim);
+}
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_trace_stats(SceneView S, const float* __restrict__ rays, int n, uint32_t* __restrict__ stats)
+{
+    __shared__ uint32_t s_stack[MODE == 0 ? WIDE_LDS_STACK * BLOCK : 1];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rays + 8 * (size_t)i;
+    Hit h;
+    uint32_t st[2] = {0u, 0u};
+    if (MODE == 0) trace_wide<false, true>(S.wide, s_stack, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7], h, st);
+    else trace<false, true>(S.bvh, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7], h, st);
+    stats[2 * (size_t)i] = st[0];
+    stats[2 * (size_t)i + 1] = st[1];
+}
+
+/* Persistent wavefront tracing over a ray queue with LANE refill: a lane whose ray is finished
+ * pulls the next ray index while the other lanes keep traversing (ballot of idle lanes -> one
+ * aggregated atomic -> prefix popcount), instead of idling until the slowest lane of its wave is
+ * done. Refill is attempted when at least REFILL_MIN lanes are idle. ANY = shadow rays
+ * (hits[i].x = 1 if occluded). Same traversal steps / results as trace_wide. */
+template <bool ANY>
+__global__ __launch_bounds__(BLOCK) void k_trace_queue(WideView wide, const float* __restrict__ rays, int n,
+                                                        float* __restrict__ hits, unsigned int* __restrict__ head)
+{
+    __shared__ uint32_t s_stack[WIDE_LDS_STACK * BLOCK];
+    constexpr int REFILL_MIN = 20;
+    constexpr uint32_t IDLE = 0x7ffffffeu;
+    const int lane = threadIdx.x & 63;
+    const int slot = threadIdx.x;
+    uint32_t ovf[WIDE_OVF_STACK];
+    /* per-lane ray state */
+    uint32_t cur = IDLE;
+    int sp = 0, prim = -1, ray_id = -1;
+    f3 ro = F3(0, 0, 0), rd = F3(0, 0, 1), inv = F3(0, 0, 1);
+    float tmin = 0.0f, tmax = 0.0f, best = 0.0f, bu = 0.0f, bv = 0.0f;
+    bool exhausted = false;
+    for (;;)
+    {
+        const unsigned long long idle = __ballot(cur == IDLE);
+        if (idle)
+        {
+            const int n_idle = __popcll(idle);
+            if (!exhausted && (n_idle >= REFILL_MIN || n_idle == 64 || true))
+            {
+                if (n_idle >= REFILL_MIN || n_idle == 64)
+                {
+                    const int leader = __ffsll((long long)idle) - 1;
+                    unsigned int base = 0;
+                    if (lane == leader) base = atomicAdd(head, (unsigned)n_idle);
+                    base = __shfl(base, leader);
+                    if (cur == IDLE)
+                    {
+                        const unsigned my = base + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
+                        if (my < (unsigned)n)
+                        {
+                            const float* r = rays + 8 * (size_t)my;
+                            ray_id = (int)my;
+                            ro = F3(r[0], r[1], r[2]); rd = F3(r[3], r[4], r[5]);
+                            tmin = r[6]; tmax = r[7];
+                            inv = F3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                            inv.x = fminf(fmaxf(inv.x, -1e30f), 1e30f);
+                            inv.y = fminf(fmaxf(inv.y, -1e30f), 1e30f);
+                            inv.z = fminf(fmaxf(inv.z, -1e30f), 1e30f);
+                            best = tmax; prim = -1; bu = 0.0f; bv = 0.0f; sp = 0;
+                            cur = 0u;
+                        }
+                    }
+                    if (base + (unsigned)n_idle >= (unsigned)n) exhausted = true;
+                }
+            }
+            if (exhausted && __ballot(cur != IDLE) == 0ull) return;
+        }
+        /* no `continue` for idle lanes: they must fall through to the loop header together with
+         * the working lanes (a spinning divergent path would starve the others) */
+        bool done = false;
+        const float4* r = wide.rec + 3 * (size_t)(cur & ~WIDE_LEAF_BIT);
+        if (cur == IDLE) {}
+        else if (cur & WIDE_LEAF_BIT)
+        {
+            const float4 t0 = r[0], t1 = r[1], t2 = r[2];
+            const f3 v0 = F3(t0.x, t0.y, t0.z), v1 = F3(t0.w, t1.x, t1.y), v2 = F3(t1.z, t1.w, t2.x);
+            const int pi = as_int(t2.y);
+            float t, u, v;
+            if (intersect_ray_triangle(t, u, v, ro, rd, tmin, tmax, v0, v1, v2))
+            {
+                if (prim < 0 || t < best || (t == best && pi > prim))
+                {
+                    best = t; bu = u; bv = v; prim = pi;
+                    if (ANY) done = true;
+                }
+            }
+            if (!done)
+            {
+                if (sp == 0) done = true;
+                else { --sp; cur = sp < WIDE_LDS_STACK ? s_stack[sp * BLOCK + slot] : ovf[sp - WIDE_LDS_STACK]; }
+            }
+        }
+        else
+        {
+            const float4 q0 = r[0], q1f = r[1], q2f = r[2];
+            const uint32_t e = as_uint(q0.w);
+            const uint32_t base = as_uint(q1f.x), meta = as_uint(q1f.y);
+            const uint32_t lx = as_uint(q1f.z), ly = as_uint(q1f.w), lz = as_uint(q2f.x);
+            const uint32_t hx = as_uint(q2f.y), hy = as_uint(q2f.z), hz = as_uint(q2f.w);
+            const float sx = as_float((e & 0xffu) << 23), sy = as_float(((e >> 8) & 0xffu) << 23),
+                        sz = as_float(((e >> 16) & 0xffu) << 23);
+            const float Ax = (q0.x - ro.x) * inv.x, Ay = (q0.y - ro.y) * inv.y, Az = (q0.z - ro.z) * inv.z;
+            const float Bx = sx * inv.x, By = sy * inv.y, Bz = sz * inv.z;
+            float td[4];
+            uint32_t ce[4];
+            int nhit = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+            {
+                const uint32_t m = (meta >> (8 * k)) & 0xffu;
+                const float x0 = __builtin_fmaf(wide_byte(lx, k), Bx, Ax), x1 = __builtin_fmaf(wide_byte(hx, k), Bx, Ax);
+                const float y0 = __builtin_fmaf(wide_byte(ly, k), By, Ay), y1 = __builtin_fmaf(wide_byte(hy, k), By, Ay);
+                const float z0 = __builtin_fmaf(wide_byte(lz, k), Bz, Az), z1 = __builtin_fmaf(wide_byte(hz, k), Bz, Az);
+                float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+                float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+                tn = fmaxf(tn * (1.0f - 4e-7f), tmin);
+                tf = fminf(tf * (1.0f + 4e-7f), best);
+                const bool h = (m != 0u) && (tn <= tf);
+                td[k] = h ? tn : 3.0e38f;
+                ce[k] = (base + (uint32_t)k) | (m == 2u ? WIDE_LEAF_BIT : 0u);
+                nhit += h ? 1 : 0;
+            }
+            if (nhit > 0)
+            {
+#define RT_CSWAP(i, j)                                                     \
+    if (td[j] < td[i])                                                     \
+    {                                                                      \
+        const float _t = td[i]; td[i] = td[j]; td[j] = _t;                 \
+        const uint32_t _e = ce[i]; ce[i] = ce[j]; ce[j] = _e;             \
+    }
+                RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
+#undef RT_CSWAP
+                for (int k = nhit - 1; k >= 1; --k)
+                {
+                    if (sp < WIDE_LDS_STACK) s_stack[sp * BLOCK + slot] = ce[k];
+                    else ovf[sp - WIDE_LDS_STACK] = ce[k];
+                    ++sp;
+                }
+                cur = ce[0];
+            }
+            else
+            {
+                if (sp == 0) done = true;
+                else { --sp; cur = sp < WIDE_LDS_STACK ? s_stack[sp * BLOCK + slot] : ovf[sp - WIDE_LDS_STACK]; }
+            }
+        }
+        if (done)
+        {
+            float* o = hits + 4 * (size_t)ray_id;
+            if (ANY) { o[0] = prim >= 0 ? 1.0f : 0.0f; o[1] = 0.0f; o[2] = 0.0f; o[3] = as_float(prim); }
+            else { o[0] = prim >= 0 ? best : 0.0f; o[1] = bu; o[2] = bv; o[3] = as_float(prim); }
+            cur = IDLE;
+        }
+    }
+}
+
+__global__ void k_math_eval(int fn, const float* __restrict__ in, int n, float* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r = 0.0f;
+    switch (fn)
+    {
+        case 20: r = pm_logf(in[i]); break;
+        case 21: r = pm_cosf(in[i]); break;
+        case 22: r = pm_sinf(in[i]); break;
+        case 23: r = pm_expf(in[i]); break;
+        case 24: r = pm_pow8f(in[i]); break;
+        case 25: r = pm_powf_pos(in[i], 1.0f / 2.2f); break;
+        case 26: r = in[2 * (size_t)i] / in[2 * (size_t)i + 1]; break;
+        case 27: r = sqrtf(in[i]); break;
+        default: break;
+    }
+    out[i] = r;
+}
+
