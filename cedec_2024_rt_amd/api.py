@@ -346,7 +346,10 @@ class Renderer:
         return out
 
     def upload(self, buf, arr):
-        a = np.ascontiguousarray(arr, dtype=_BUF_DTYPE[buf])
+        if buf == RT_BUF_ACCUMULATION:
+            a = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1, 4)
+        else:
+            a = np.ascontiguousarray(arr, dtype=_BUF_DTYPE[buf])
         self._ck(self.L.rt_upload(self.h, buf, _p(a), a.nbytes))
 
     def halo_bytes(self, n_rows):

@@ -541,3 +541,40 @@ def test_full_size_properties_1080p(api, scenes):
     assert fused.spatial_bytes(3, 0, api.RT_RES_0) == fused.spatial_bytes(3, 0, api.RT_RES_1)
     for c in ctxs + [fused, bykernel]:
         c.close()
+
+
+def test_upload_download_round_trip_is_lossless(api, oracle, scenes):
+    """The internal 64-B record + 16-B radiance layout holds every field of the reference's 76-B
+    Reservoir: arbitrary reservoirs (random bits in the float fields, incl. NaN/inf/denormals,
+    0 <= M < 2^30) survive rt_upload -> rt_download unchanged; visibility / accumulation too."""
+    W, H = 40, 24
+    tris = scenes.make_quad_room()
+    r = api.Renderer(W, H)
+    r.set_scene(tris)
+    r.lookat((0.5, 2.5, 6.0), (0.0, 1.5, -1.0))
+    sc = oracle.Scene(tris, use_bvh=True)
+    rg = oracle.raygen_lookat((0.5, 2.5, 6.0), (0.0, 1.5, -1.0), (0, 1, 0), FOVY, W, H)
+    vis = sc.raycast(W, H, rg)
+    r.upload(api.RT_BUF_VISIBILITY, vis)
+    got = r.download(api.RT_BUF_VISIBILITY)
+    assert _eq_bits(got["uv"], vis["uv"]) and np.array_equal(got["index"], vis["index"])
+    # the G-buffer rebuilt from the uploaded visibility is the one raycast would have produced
+    r.generate_candidate(3, api.RT_RES_0)
+    want = sc.generate_candidate(W, H, 3, vis, np.float32([0.5, 2.5, 6.0]), oracle.default_options())
+    assert not _res_fields_equal(r.download(api.RT_BUF_RES_0), want)
+    rng = np.random.default_rng(8)
+    res = np.zeros(W * H, dtype=oracle.RESERVOIR)
+    for f in ("origin_position", "origin_normal", "hit_position", "hit_normal", "radiance"):
+        res[f] = rng.integers(0, 2 ** 32, size=(W * H, 3), dtype=np.uint64).astype(np.uint32).view(np.float32)
+    for f in ("w_sum", "ucw"):
+        res[f] = rng.integers(0, 2 ** 32, size=W * H, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    res["visibility"] = rng.integers(0, 2, size=W * H)
+    res["M"] = rng.integers(0, 2 ** 30, size=W * H)
+    for buf in (api.RT_BUF_RES_0, api.RT_BUF_RES_1, api.RT_BUF_RES_TEMPORAL):
+        r.upload(buf, res)
+        back = r.download(buf)
+        assert not _res_fields_equal(back, res), _res_fields_equal(back, res)
+    acc = rng.random((W * H, 4), dtype=np.float32)
+    r.upload(api.RT_BUF_ACCUMULATION, acc)
+    assert _eq_bits(r.download(api.RT_BUF_ACCUMULATION), acc)
+    r.close()
