@@ -98,8 +98,8 @@ def load_library():
     L.rt_halo_flags_bytes.restype = C.c_size_t
     L.rt_halo_flags_pack.argtypes = [vp, ci, ci, vp]
     L.rt_halo_flags_unpack.argtypes = [vp, ci, ci, vp]
-    L.rt_halo_mark.argtypes = [vp, ci, ci, ci, vp]
-    L.rt_halo_scan.argtypes = [vp, ci, vp]
+    L.rt_halo_mark.argtypes = [vp, ci, ci, ci, ci, vp]
+    L.rt_halo_scan.argtypes = [vp, ci, ci, vp]
     L.rt_halo_pack_sparse.argtypes = [vp, ci, ci, ci, vp, vp]
     L.rt_halo_unpack_sparse.argtypes = [vp, ci, ci, ci, vp, vp]
     L.rt_frame_stage_output.argtypes = [vp, ci, vp]
@@ -309,11 +309,11 @@ class Renderer:
     def halo_flags_unpack(self, row0, n_rows, ptr):
         self._ck(self.L.rt_halo_flags_unpack(self.h, int(row0), int(n_rows), C.c_void_p(int(ptr))))
 
-    def halo_mark(self, frame, pas, side, ptr):
-        self._ck(self.L.rt_halo_mark(self.h, int(frame), int(pas), int(side), C.c_void_p(int(ptr))))
+    def halo_mark(self, frame, first_pass, n_passes, side, ptr):
+        self._ck(self.L.rt_halo_mark(self.h, int(frame), int(first_pass), int(n_passes), int(side), C.c_void_p(int(ptr))))
 
-    def halo_scan(self, n_rows, ptr):
-        self._ck(self.L.rt_halo_scan(self.h, int(n_rows), C.c_void_p(int(ptr))))
+    def halo_scan(self, n_rows, n_bitmaps, ptr):
+        self._ck(self.L.rt_halo_scan(self.h, int(n_rows), int(n_bitmaps), C.c_void_p(int(ptr))))
 
     def halo_pack_sparse(self, res, row0, n_rows, bitmap_ptr, dst_ptr):
         self._ck(self.L.rt_halo_pack_sparse(self.h, int(res), int(row0), int(n_rows), C.c_void_p(int(bitmap_ptr)), C.c_void_p(int(dst_ptr))))

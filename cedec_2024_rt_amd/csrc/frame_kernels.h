@@ -445,41 +445,47 @@ __global__ __launch_bounds__(BLOCK) void k_spatial_bytes(FrameParams P, const fl
  *   [0] = number of marked records, [1 .. nw] = bits (bit i of word w = pixel 32*w + i of the
  *   region, row-major from region row 0), [1+nw .. 1+2nw) = exclusive prefix counts per word. */
 __global__ __launch_bounds__(BLOCK) void k_halo_mark(FrameParams P, const float4* __restrict__ g1, int reg_row0,
-                                                      int reg_rows, uint32_t* __restrict__ bitmap)
+                                                      int reg_rows, int pass0, int n_pass, size_t words_per_pass,
+                                                      uint32_t* __restrict__ bitmaps)
 {
     int x, row;
     if (!tile_pixel(P, x, row)) return;
     const int yi = P.H - 1 - row;
     const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
     if (!(as_uint(g1[li].w) & GB_SHADED) || !P.use_spatial) return;
-    PCG rng = pcg_init(hashPCG4((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame, (uint32_t)(2 + P.pass)), 0);
     const float scale = P.spatial_radius / 1.96f;
-    for (int k = 0; k < P.spatial_count; ++k)
+    for (int pi = 0; pi < n_pass; ++pi) /* one bitmap per spatial pass, same launch */
     {
-        const float rv0 = rng.uniformf();
-        const float rv1 = rng.uniformf();
-        const float radius = sqrtf(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
-        const float phi = 2.0f * kPI * rv1;
-        const int nx = f2i_sat((float)x + scale * (radius * pm_cosf(phi)));
-        const int ny = f2i_sat((float)yi + scale * (radius * pm_sinf(phi)));
-        if (nx < 0 || nx >= P.W || ny < 0 || ny >= P.H) continue;
-        if (nx == x && ny == yi) continue;
-        const int nrow = P.H - 1 - ny;
-        const int lr = nrow - P.lrow0;
-        if (lr < 0 || lr >= P.lrows) continue;
-        if (nrow >= reg_row0 && nrow < reg_row0 + reg_rows)
+        uint32_t* bitmap = bitmaps + (size_t)pi * words_per_pass;
+        PCG rng = pcg_init(hashPCG4((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame, (uint32_t)(2 + pass0 + pi)), 0);
+        for (int k = 0; k < P.spatial_count; ++k)
         {
-            const uint32_t bit = (uint32_t)(nrow - reg_row0) * (uint32_t)P.W + (uint32_t)nx;
-            atomicOr(&bitmap[1 + (bit >> 5)], 1u << (bit & 31u));
+            const float rv0 = rng.uniformf();
+            const float rv1 = rng.uniformf();
+            const float radius = sqrtf(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
+            const float phi = 2.0f * kPI * rv1;
+            const int nx = f2i_sat((float)x + scale * (radius * pm_cosf(phi)));
+            const int ny = f2i_sat((float)yi + scale * (radius * pm_sinf(phi)));
+            if (nx < 0 || nx >= P.W || ny < 0 || ny >= P.H) continue;
+            if (nx == x && ny == yi) continue;
+            const int nrow = P.H - 1 - ny;
+            const int lr = nrow - P.lrow0;
+            if (lr < 0 || lr >= P.lrows) continue;
+            if (nrow >= reg_row0 && nrow < reg_row0 + reg_rows)
+            {
+                const uint32_t bit = (uint32_t)(nrow - reg_row0) * (uint32_t)P.W + (uint32_t)nx;
+                atomicOr(&bitmap[1 + (bit >> 5)], 1u << (bit & 31u));
+            }
+            if (!(as_uint(g1[(size_t)nx + (size_t)lr * P.W].w) & GB_SHADED)) continue;
+            rng.uniformf();
         }
-        if (!(as_uint(g1[(size_t)nx + (size_t)lr * P.W].w) & GB_SHADED)) continue;
-        rng.uniformf();
     }
 }
-/* one workgroup: exclusive prefix of the per-word popcounts, total into word 0 */
-__global__ void k_halo_scan(uint32_t* __restrict__ bitmap, int nw)
+/* one workgroup per bitmap: exclusive prefix of the per-word popcounts, total into word 0 */
+__global__ void k_halo_scan(uint32_t* __restrict__ bitmaps, int nw, size_t words_per_bitmap)
 {
     __shared__ uint32_t s_sum[1024];
+    uint32_t* bitmap = bitmaps + (size_t)blockIdx.x * words_per_bitmap; /* one workgroup per bitmap */
     const int t = threadIdx.x, T = blockDim.x;
     const int per = (nw + T - 1) / T;
     const int w0 = t * per, w1 = min(nw, w0 + per);

@@ -1135,35 +1135,38 @@ int rt_halo_flags_unpack(rt_ctx* c, int row0, int n_rows, const void* device_src
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }
-/* records of the neighbour on `side` that spatial pass `pass` of `frame` will gather */
-int rt_halo_mark(rt_ctx* c, int frame, int pass, int side, void* device_bitmap)
+/* records of the neighbour on `side` that spatial passes [pass, pass + n_pass) of `frame` will
+ * gather: n_pass consecutive bitmaps of rt_halo_bitmap_words() words each, one launch */
+int rt_halo_mark(rt_ctx* c, int frame, int pass, int n_pass, int side, void* device_bitmaps)
 {
     RT_CHECK_CTX(c);
     if (!c->has_gbuffer) RT_FAIL(c, RT_ERR_STATE, "no G-buffer yet");
+    if (n_pass <= 0) return RT_OK;
     int r0, n;
     int rc = halo_side_region(c, side, &r0, &n);
     if (rc != RT_OK) return rc;
     const size_t words = rt_halo_bitmap_words(c, n);
     const int nw = (int)((words - 1) / 2);
-    RT_HIP(c, hipMemsetAsync(device_bitmap, 0, words * 4, c->stream));
+    RT_HIP(c, hipMemsetAsync(device_bitmaps, 0, words * 4 * (size_t)n_pass, c->stream));
     /* only own rows within `halo` rows of that side can reach across */
     c->sub0 = side == 0 ? c->row_begin : (c->row_end - c->halo > c->row_begin ? c->row_end - c->halo : c->row_begin);
     c->sub1 = side == 0 ? (c->row_begin + c->halo < c->row_end ? c->row_begin + c->halo : c->row_end) : c->row_end;
     const FrameParams P = make_params(c, frame, pass, K_OTHER);
     const int grid = launch_grid(c);
     c->sub0 = c->sub1 = -1;
-    k_halo_mark<<<grid, BLOCK, 0, c->stream>>>(P, c->d_g1, r0, n, (uint32_t*)device_bitmap);
+    k_halo_mark<<<grid, BLOCK, 0, c->stream>>>(P, c->d_g1, r0, n, pass, n_pass, words, (uint32_t*)device_bitmaps);
     RT_HIP(c, hipGetLastError());
-    k_halo_scan<<<1, 1024, 0, c->stream>>>((uint32_t*)device_bitmap, nw);
+    k_halo_scan<<<n_pass, 1024, 0, c->stream>>>((uint32_t*)device_bitmaps, nw, words);
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }
-/* rebuild the prefix part of a bitmap received from a neighbour (rows [row0,row0+n_rows)) */
-int rt_halo_scan(rt_ctx* c, int n_rows, void* device_bitmap)
+/* rebuild the prefix part of `count` consecutive bitmaps received from a neighbour */
+int rt_halo_scan(rt_ctx* c, int n_rows, int count, void* device_bitmaps)
 {
     RT_CHECK_CTX(c);
-    const int nw = (int)((rt_halo_bitmap_words(c, n_rows) - 1) / 2);
-    k_halo_scan<<<1, 1024, 0, c->stream>>>((uint32_t*)device_bitmap, nw);
+    if (count <= 0) return RT_OK;
+    const size_t words = rt_halo_bitmap_words(c, n_rows);
+    k_halo_scan<<<count, 1024, 0, c->stream>>>((uint32_t*)device_bitmaps, (int)((words - 1) / 2), words);
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }

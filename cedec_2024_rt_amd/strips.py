@@ -185,7 +185,7 @@ class StripFrame:
         items = []
         for peer, s0, sn, r0, rn in self.plan:
             side = 0 if peer < self.rank else 1
-            self.need[peer] = [b.mark(frame, k, side) for k in range(P)]
+            self.need[peer] = b.mark_all(frame, P, side)
             ts = b.bitmap_message(self.need[peer], rn)
             tr = b.bitmap_message_empty(P, sn)
             items.append((peer, ts, tr))
@@ -293,12 +293,13 @@ class HipStripBackend:
         self.r.halo_flags_unpack(row0, n_rows, t.data_ptr())
         self._keep = t
 
-    def mark(self, frame, k, side):
-        n_rows = self.r.halo if True else 0
+    def mark_all(self, frame, passes, side):
+        """need-bitmaps of all spatial passes of the frame for the neighbour on `side` (one launch)"""
         r0, n = self._side_region(side)
-        t = self.torch.empty(self.r.halo_bitmap_words(n), dtype=self.torch.int32, device=self.device)
-        self.r.halo_mark(frame, k, side, t.data_ptr())
-        return t
+        words = self.r.halo_bitmap_words(n)
+        t = self.torch.empty(passes * words, dtype=self.torch.int32, device=self.device)
+        self.r.halo_mark(frame, 0, passes, side, t.data_ptr())
+        return [t[k * words: (k + 1) * words] for k in range(passes)]
 
     def _side_region(self, side):
         a, b = self.r.rows
@@ -320,13 +321,10 @@ class HipStripBackend:
         msg = self._from_wire(msg)
         words = self.r.halo_bitmap_words(n_rows)
         nw = (words - 1) // 2
-        out = []
-        for k in range(passes):
-            t = self.torch.zeros(words, dtype=self.torch.int32, device=self.device)
-            t[: 1 + nw] = msg[k * (1 + nw): (k + 1) * (1 + nw)]
-            self.r.halo_scan(n_rows, t.data_ptr())
-            out.append(t)
-        return out
+        t = self.torch.zeros((passes, words), dtype=self.torch.int32, device=self.device)
+        t[:, : 1 + nw] = msg.view(passes, 1 + nw)
+        self.r.halo_scan(n_rows, passes, t.data_ptr())
+        return [t[k] for k in range(passes)]
 
     def list_empty(self, count):
         return self._wire_empty(max(count, 1) * 80, self.torch.uint8)
@@ -409,8 +407,8 @@ def run_frame_local(renderers, bounds, frame, device, halo=HALO_ROWS, sparse=Fal
             super().flags_import(row0, n_rows, t)
             self.r.sync()
 
-        def mark(self, frame, k, side):
-            t = super().mark(frame, k, side)
+        def mark_all(self, frame, passes, side):
+            t = super().mark_all(frame, passes, side)
             self.r.sync()
             return t
 

@@ -185,8 +185,8 @@ size_t rt_halo_bitmap_words(rt_ctx* ctx, int n_rows);
 size_t rt_halo_flags_bytes(rt_ctx* ctx, int n_rows);
 int rt_halo_flags_pack(rt_ctx* ctx, int row0, int n_rows, void* device_dst);
 int rt_halo_flags_unpack(rt_ctx* ctx, int row0, int n_rows, const void* device_src);
-int rt_halo_mark(rt_ctx* ctx, int frame, int pass, int side, void* device_bitmap);
-int rt_halo_scan(rt_ctx* ctx, int n_rows, void* device_bitmap);
+int rt_halo_mark(rt_ctx* ctx, int frame, int first_pass, int n_passes, int side, void* device_bitmaps); /* n_passes bitmaps, back to back */
+int rt_halo_scan(rt_ctx* ctx, int n_rows, int n_bitmaps, void* device_bitmaps);
 int rt_halo_pack_sparse(rt_ctx* ctx, int res, int row0, int n_rows, const void* device_bitmap, void* device_dst);
 int rt_halo_unpack_sparse(rt_ctx* ctx, int res, int row0, int n_rows, const void* device_bitmap, const void* device_src);
 
