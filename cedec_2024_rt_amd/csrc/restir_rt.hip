@@ -69,7 +69,8 @@ struct rt_ctx
     int res_map[3] = {0, 1, 2};
     int sub0 = -1, sub1 = -1; /* row sub-range of the running rt_frame_stage_run (-1: all owned rows) */
     int fX = 0, fY = 1, fZ = 2, f_in = 0, f_out = 1, f_stage = 0, f_final = RT_RES_1;
-    bool f_clear = false; /* rt_frame_stage state */
+    bool f_clear = false;
+    bool halo_flags_ok[2] = {false, false}; /* neighbour shaded flags unpacked since the last raycast */ /* rt_frame_stage state */
     unsigned long long* d_counter = nullptr;
     void* d_stage = nullptr;
     size_t stage_bytes = 0;
@@ -651,6 +652,7 @@ int rt_raycast(rt_ctx* c)
     k_raycast<<<launch_grid(c), BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_vis, c->d_g0, c->d_g1);
     RT_HIP(c, hipGetLastError());
     c->has_gbuffer = true;
+    c->halo_flags_ok[0] = c->halo_flags_ok[1] = false; /* the neighbours' G-buffers are new as well */
     return RT_OK;
 }
 
@@ -714,8 +716,20 @@ int rt_save_temporal_reservoir(rt_ctx* c, int src, int dst)
     return RT_OK;
 }
 
+/* rows a strip must hold beyond its own for spatial_resampling to be exact: the Gaussian offset is
+ * bounded by radius/1.96 * sqrt(2*23*ln 2) because rv0 >= 2^-23 when non-zero */
+static int halo_rows_needed(const rt_options& o)
+{
+    if (!o.use_spatial_resampling || o.spatial_resampling_sample_count <= 0) return 0;
+    return (int)ceilf(o.spatial_resampling_radius / 1.96f * 5.6471f);
+}
 static int launch_spatial(rt_ctx* c, int frame, int pass, int in_phys, int out_phys)
 {
+    const int need = halo_rows_needed(c->opt);
+    if ((c->row_begin > 0 && c->row_begin - c->lrow0 < (need < c->row_begin ? need : c->row_begin)) ||
+        (c->row_end < c->H && c->lrow0 + c->lrows - c->row_end < (need < c->H - c->row_end ? need : c->H - c->row_end)))
+        RT_FAIL(c, RT_ERR_STATE, "strip halo of %d rows is too small: spatial_resampling_radius %.1f needs %d", c->halo,
+                c->opt.spatial_resampling_radius, need);
     const SceneView S = make_scene(c);
     const FrameParams P = make_params(c, frame, pass, K_SPATIAL);
     if (c->opt.use_shadowed_target_function)
@@ -1133,6 +1147,8 @@ int rt_halo_flags_unpack(rt_ctx* c, int row0, int n_rows, const void* device_src
     const int n = n_rows * c->W;
     k_halo_flags<false><<<(n + 255) / 256, 256, 0, c->stream>>>(c->d_g1, (size_t)(row0 - c->lrow0) * c->W, n, (uint8_t*)const_cast<void*>(device_src));
     RT_HIP(c, hipGetLastError());
+    if (row0 == c->lrow0 && row0 + n_rows == c->row_begin) c->halo_flags_ok[0] = true;
+    if (row0 == c->row_end && row0 + n_rows == c->lrow0 + c->lrows) c->halo_flags_ok[1] = true;
     return RT_OK;
 }
 /* records of the neighbour on `side` that spatial passes [pass, pass + n_pass) of `frame` will
@@ -1145,6 +1161,9 @@ int rt_halo_mark(rt_ctx* c, int frame, int pass, int n_pass, int side, void* dev
     int r0, n;
     int rc = halo_side_region(c, side, &r0, &n);
     if (rc != RT_OK) return rc;
+    if (!c->halo_flags_ok[side])
+        RT_FAIL(c, RT_ERR_STATE, "rt_halo_mark: the neighbour's shaded flags (rt_halo_flags_unpack of all %d halo rows on side %d) "
+                                 "must be refreshed after every rt_raycast", n, side);
     const size_t words = rt_halo_bitmap_words(c, n);
     const int nw = (int)((words - 1) / 2);
     RT_HIP(c, hipMemsetAsync(device_bitmaps, 0, words * 4 * (size_t)n_pass, c->stream));

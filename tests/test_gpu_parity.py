@@ -430,6 +430,22 @@ def test_edge_cases_and_error_codes(api, oracle, scenes):
     with pytest.raises(api.RtError, match="scene and camera"):
         r2.raycast()
     r2.close()
+    # 6. a strip whose halo cannot cover the spatial radius is refused, not rendered wrongly
+    r3 = api.Renderer(32, 200, rows=(0, 100), halo=40)
+    r3.set_scene(tris)
+    r3.lookat(eye, center)
+    r3.set_options(bench_options())
+    r3.raycast()
+    r3.generate_candidate(1)
+    with pytest.raises(api.RtError, match="too small"):
+        r3.spatial_resampling(1, 0, api.RT_RES_0, api.RT_RES_1)
+    r3.set_options(bench_options(spatial_resampling_radius=10.0))  # 29 rows are enough now
+    r3.spatial_resampling(1, 0, api.RT_RES_0, api.RT_RES_1)
+    import torch
+    t = torch.empty(r3.halo_bitmap_words(40) * 4, dtype=torch.uint8, device="cuda")
+    with pytest.raises(api.RtError, match="shaded flags"):
+        r3.halo_mark(1, 0, 3, 1, t.data_ptr())  # neighbour flags not exchanged since the raycast
+    r3.close()
 
 
 def test_interactive_camera_and_accumulation_reset(api, oracle, scenes):
