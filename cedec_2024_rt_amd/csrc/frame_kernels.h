@@ -38,7 +38,11 @@ struct SceneView
     const float4* __restrict__ light_ke; /* 1 per light: {Ke.xyz, 0} */
 };
 
-constexpr int TILE_W = 32, TILE_H = 8, BLOCK = 256;
+#ifndef RT_TILE_W
+#define RT_TILE_W 32 /* pixels per tile row: 32x8, 16x16 or 8x32 tiles of 256 pixels */
+#endif
+constexpr int TILE_W = RT_TILE_W, TILE_H = 256 / RT_TILE_W, BLOCK = 256;
+constexpr int TILE_W_LOG2 = RT_TILE_W == 32 ? 5 : (RT_TILE_W == 16 ? 4 : 3);
 #ifndef RT_TRACE_WAVES
 #define RT_TRACE_WAVES 1 /* min waves per SIMD requested for the tracing kernels (register budget) */
 #endif
@@ -74,7 +78,7 @@ RT_DEV bool tile_pixel(const FrameParams& P, int& x, int& row)
         tx = tile - ty * tiles_x;
     }
     x = tx * TILE_W + (threadIdx.x & (TILE_W - 1));
-    row = P.row0 + ty * TILE_H + (threadIdx.x >> 5);
+    row = P.row0 + ty * TILE_H + (threadIdx.x >> TILE_W_LOG2);
     return x < P.W && row < P.row1;
 }
 static inline int tile_grid(int W, int rows)
@@ -596,8 +600,124 @@ RT_DEV f3 sample_hemisphere(float r0, float r1, float r2)
     return F3(x, y, z);
 }
 
-/* examples/07_pt/07_pt.cu:11-90 (EXAMPLE 7) and examples/09_ris/09_ris.cu:11-166 (EXAMPLE 9): the
- * `path_trace` kernels, one thread per pixel, whole path in one launch. rays[0] accumulates the
+/* One path of examples/07_pt/07_pt.cu:11-90 (EXAMPLE 7) / examples/09_ris/09_ris.cu:11-166 (EXAMPLE 9). */
+struct PathState
+{
+    f3 ro, rd, throughput, radiance;
+    PCG rng;
+};
+RT_DEV void path_begin(const FrameParams& P, int x, int yi, PathState& st)
+{
+    st.rng = pcg_init(hashPCG3((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame), 0);
+    const float u = (float)x / (float)P.W, v = (float)yi / (float)P.H;
+    const f3 forward = normalize(cross(P.rg_up, P.rg_right));
+    const f3 to = P.rg_origin + forward + mix(-P.rg_right, P.rg_right, u) + mix(P.rg_up, -P.rg_up, v);
+    st.ro = P.rg_origin;
+    st.rd = normalize(to - P.rg_origin);
+    st.radiance = F3(0.0f, 0.0f, 0.0f);
+    st.throughput = F3(1.0f, 1.0f, 1.0f);
+}
+/* one iteration of the depth loop (07_pt.cu:39-79 / 09_ris.cu:39-155); false = the path ended */
+template <int EXAMPLE, bool SHADOWED>
+RT_DEV bool path_bounce(const SceneView& S, uint32_t* s_stack, const FrameParams& P, int depth, f3 sky, PathState& st,
+                        unsigned long long& nrays)
+{
+    Hit h;
+    ++nrays;
+    if (!trace_wide<false>(S.wide, s_stack, st.ro, st.rd, 0.0f, kFltMax, h))
+    {
+        if (EXAMPLE == 7) st.radiance = st.radiance + st.throughput * sky;
+        return false;
+    }
+    const float4 kd4 = S.trimat[2 * (size_t)h.prim];
+    if (as_uint(kd4.w) != 0u)
+    {
+        const float4 ke4 = S.trimat[2 * (size_t)h.prim + 1];
+        if (EXAMPLE == 7 || depth == 0) st.radiance = st.radiance + st.throughput * F3(ke4.x, ke4.y, ke4.z);
+        return false;
+    }
+    /* common/core.hpp:152-165 */
+    f3 v0, v1, v2;
+    load_tri(S.bvh.tv, h.prim, v0, v1, v2);
+    const f3 sp = st.ro + h.t * st.rd;
+    f3 sn = tri_normal(v0, v1, v2);
+    if (dot(-st.rd, sn) < 0.0f) sn = -sn;
+    const f3 kd = F3(kd4.x, kd4.y, kd4.z);
+
+    if (EXAMPLE == 9)
+    {
+        /* RIS over the lights (09_ris.cu:61-99), then the shaded contribution (:101-126) */
+        const float fL = (float)(size_t)P.n_lights;
+        Res r = res_zero();
+        for (int i = 0; i < P.ris_sample_count; ++i)
+        {
+            const float rv0 = st.rng.uniformf();
+            float bx = st.rng.uniformf();
+            float by = st.rng.uniformf();
+            uint32_t nth = (uint32_t)(rv0 * fL);
+            if (nth == (uint32_t)P.n_lights) nth = (uint32_t)P.n_lights - 1u;
+            const float4* L = S.lights + 3 * (size_t)nth;
+            const float4 L0 = L[0], L1 = L[1], L2 = L[2];
+            const f3 a0 = F3(L0.x, L0.y, L0.z), a1 = F3(L0.w, L1.x, L1.y), a2 = F3(L1.z, L1.w, L2.x);
+            warp_unit_triangle(bx, by);
+            const f3 lp = (1.0f - bx - by) * a0 + bx * a1 + by * a2;
+            const f3 ln = tri_normal(a0, a1, a2);
+            float p_hat;
+            if (SHADOWED)
+            {
+                p_hat = target_function<true>(S, s_stack, sp, sn, lp, ln, L2.y);
+                ++nrays;
+            }
+            else { p_hat = target_unshadowed(sp, sn, lp, ln, L2.y); }
+            const float weight = p_hat / L2.z;
+            const float uu = st.rng.uniformf();
+            r.w_sum += weight;
+            r.M += 1;
+            if (uu < weight / r.w_sum)
+            {
+                r.hit_p = lp; r.hit_n = ln; r.lum = L2.y;
+                const float4 ke = S.light_ke[nth];
+                r.rad = F3(ke.x, ke.y, ke.z);
+            }
+        }
+        const f3 brdf = (1.0f / kPI) * kd;
+        const float G = geometry_term(sp, sn, r.hit_p, r.hit_n);
+        const float V = check_visibility_wide(S.wide, s_stack, sp, sn, r.hit_p) ? 1.0f : 0.0f;
+        ++nrays;
+        const float p_hat = target_function<SHADOWED>(S, s_stack, sp, sn, r.hit_p, r.hit_n, r.lum);
+        if (SHADOWED) ++nrays;
+        const float ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
+        st.radiance = st.radiance + st.throughput * brdf * G * V * r.rad * ucw;
+    }
+    /* next direction (07_pt.cu:61-70 / 09_ris.cu:128-137): common/core.hpp:216-235 */
+    const float r0 = st.rng.uniformf();
+    const float r1 = st.rng.uniformf();
+    const float r2 = st.rng.uniformf();
+    const f3 wl = sample_hemisphere(r0, r1, r2);
+    const f3 tg = normalize(v1 - v0);
+    const f3 bt = normalize(cross(tg, sn));
+    const f3 wo = wl.x * tg + wl.y * sn + wl.z * bt;
+    st.throughput = st.throughput * kd;
+    st.ro = sp + 0.001f * sn;
+    st.rd = wo;
+    return true;
+}
+RT_DEV void path_write(const FrameParams& P, float4* __restrict__ accum, size_t li, f3 radiance)
+{
+    if (P.accumulate)
+    {
+        const float4 a = accum[li];
+        accum[li] = make_float4(a.x + radiance.x, a.y + radiance.y, a.z + radiance.z, a.w + 1.0f);
+    }
+    else { accum[li] = make_float4(radiance.x, radiance.y, radiance.z, 1.0f); }
+}
+RT_DEV void count_rays(unsigned long long nrays, unsigned long long* __restrict__ rays)
+{
+    for (int off = 32; off > 0; off >>= 1) nrays += __shfl_down(nrays, off);
+    if ((threadIdx.x & 63) == 0 && nrays) atomicAdd(rays, nrays);
+}
+
+/* the reference's shape: one thread per pixel, whole path in one launch. rays[0] accumulates the
  * number of raytrace() calls (one atomic per wave). */
 template <int EXAMPLE, bool SHADOWED>
 __global__ __launch_bounds__(BLOCK) void k_path_trace(SceneView S, FrameParams P, int max_depth, f3 sky,
@@ -610,105 +730,83 @@ __global__ __launch_bounds__(BLOCK) void k_path_trace(SceneView S, FrameParams P
     unsigned long long nrays = 0;
     if (ok)
     {
-        const int yi = P.H - 1 - row;
-        const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
-        PCG rng = pcg_init(hashPCG3((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame), 0);
-        const float u = (float)x / (float)P.W, v = (float)yi / (float)P.H;
-        const f3 forward = normalize(cross(P.rg_up, P.rg_right));
-        const f3 to = P.rg_origin + forward + mix(-P.rg_right, P.rg_right, u) + mix(P.rg_up, -P.rg_up, v);
-        f3 ro = P.rg_origin;
-        f3 rd = normalize(to - P.rg_origin);
-        f3 radiance = F3(0.0f, 0.0f, 0.0f), throughput = F3(1.0f, 1.0f, 1.0f);
-        const float fL = (float)(size_t)P.n_lights;
+        PathState st;
+        path_begin(P, x, P.H - 1 - row, st);
         for (int depth = 0; depth < max_depth; ++depth)
-        {
-            Hit h;
-            ++nrays;
-            if (!trace_wide<false>(S.wide, s_stack, ro, rd, 0.0f, kFltMax, h))
-            {
-                if (EXAMPLE == 7) radiance = radiance + throughput * sky;
-                break;
-            }
-            const float4 kd4 = S.trimat[2 * (size_t)h.prim];
-            if (as_uint(kd4.w) != 0u)
-            {
-                const float4 ke4 = S.trimat[2 * (size_t)h.prim + 1];
-                if (EXAMPLE == 7 || depth == 0) radiance = radiance + throughput * F3(ke4.x, ke4.y, ke4.z);
-                break;
-            }
-            /* common/core.hpp:152-165 */
-            f3 v0, v1, v2;
-            load_tri(S.bvh.tv, h.prim, v0, v1, v2);
-            const f3 sp = ro + h.t * rd;
-            f3 sn = tri_normal(v0, v1, v2);
-            if (dot(-rd, sn) < 0.0f) sn = -sn;
-            const f3 kd = F3(kd4.x, kd4.y, kd4.z);
-
-            if (EXAMPLE == 9)
-            {
-                /* RIS over the lights (09_ris.cu:61-99), then the shaded contribution (:101-126) */
-                Res r = res_zero();
-                for (int i = 0; i < P.ris_sample_count; ++i)
-                {
-                    const float rv0 = rng.uniformf();
-                    float bx = rng.uniformf();
-                    float by = rng.uniformf();
-                    uint32_t nth = (uint32_t)(rv0 * fL);
-                    if (nth == (uint32_t)P.n_lights) nth = (uint32_t)P.n_lights - 1u;
-                    const float4* L = S.lights + 3 * (size_t)nth;
-                    const float4 L0 = L[0], L1 = L[1], L2 = L[2];
-                    const f3 a0 = F3(L0.x, L0.y, L0.z), a1 = F3(L0.w, L1.x, L1.y), a2 = F3(L1.z, L1.w, L2.x);
-                    warp_unit_triangle(bx, by);
-                    const f3 lp = (1.0f - bx - by) * a0 + bx * a1 + by * a2;
-                    const f3 ln = tri_normal(a0, a1, a2);
-                    float p_hat;
-                    if (SHADOWED)
-                    {
-                        p_hat = target_function<true>(S, s_stack, sp, sn, lp, ln, L2.y);
-                        ++nrays;
-                    }
-                    else { p_hat = target_unshadowed(sp, sn, lp, ln, L2.y); }
-                    const float weight = p_hat / L2.z;
-                    const float uu = rng.uniformf();
-                    r.w_sum += weight;
-                    r.M += 1;
-                    if (uu < weight / r.w_sum)
-                    {
-                        r.hit_p = lp; r.hit_n = ln; r.lum = L2.y;
-                        const float4 ke = S.light_ke[nth];
-                        r.rad = F3(ke.x, ke.y, ke.z);
-                    }
-                }
-                const f3 brdf = (1.0f / kPI) * kd;
-                const float G = geometry_term(sp, sn, r.hit_p, r.hit_n);
-                const float V = check_visibility_wide(S.wide, s_stack, sp, sn, r.hit_p) ? 1.0f : 0.0f;
-                ++nrays;
-                const float p_hat = target_function<SHADOWED>(S, s_stack, sp, sn, r.hit_p, r.hit_n, r.lum);
-                if (SHADOWED) ++nrays;
-                const float ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
-                radiance = radiance + throughput * brdf * G * V * r.rad * ucw;
-            }
-            /* next direction (07_pt.cu:61-70 / 09_ris.cu:128-137): common/core.hpp:216-235 */
-            const float r0 = rng.uniformf();
-            const float r1 = rng.uniformf();
-            const float r2 = rng.uniformf();
-            const f3 wl = sample_hemisphere(r0, r1, r2);
-            const f3 tg = normalize(v1 - v0);
-            const f3 bt = normalize(cross(tg, sn));
-            const f3 wo = wl.x * tg + wl.y * sn + wl.z * bt;
-            throughput = throughput * kd;
-            ro = sp + 0.001f * sn;
-            rd = wo;
-        }
-        if (P.accumulate)
-        {
-            const float4 a = accum[li];
-            accum[li] = make_float4(a.x + radiance.x, a.y + radiance.y, a.z + radiance.z, a.w + 1.0f);
-        }
-        else { accum[li] = make_float4(radiance.x, radiance.y, radiance.z, 1.0f); }
+            if (!path_bounce<EXAMPLE, SHADOWED>(S, s_stack, P, depth, sky, st, nrays)) break;
+        path_write(P, accum, (size_t)x + (size_t)(row - P.lrow0) * P.W, st.radiance);
     }
-    for (int off = 32; off > 0; off >>= 1) nrays += __shfl_down(nrays, off);
-    if ((threadIdx.x & 63) == 0 && nrays) atomicAdd(rays, nrays);
+    count_rays(nrays, rays);
+}
+
+/* Wavefront form of the same paths: one launch per bounce over the list of LIVE paths; survivors
+ * are appended to the next list by wave ballot + one aggregated atomic (compaction), so a wave of
+ * bounce d+1 is full again instead of carrying the lanes whose paths ended. 64-B path records:
+ *   {ro.xyz, rd.x} {rd.yz, thr.xy} {thr.z, rad.xyz} {rng.state lo/hi, bits(pixel), 0}
+ * counters[0] = rays, counters[2 + d] = number of paths alive when bounce d starts. */
+RT_DEV void path_store(float4* __restrict__ rec, size_t i, const PathState& st, uint32_t pixel)
+{
+    rec[4 * i + 0] = make_float4(st.ro.x, st.ro.y, st.ro.z, st.rd.x);
+    rec[4 * i + 1] = make_float4(st.rd.y, st.rd.z, st.throughput.x, st.throughput.y);
+    rec[4 * i + 2] = make_float4(st.throughput.z, st.radiance.x, st.radiance.y, st.radiance.z);
+    rec[4 * i + 3] = make_float4(as_float((uint32_t)(st.rng.state & 0xffffffffull)), as_float((uint32_t)(st.rng.state >> 32)),
+                                 as_float(pixel), 0.0f);
+}
+RT_DEV uint32_t path_load(const float4* __restrict__ rec, size_t i, PathState& st)
+{
+    const float4 a = rec[4 * i + 0], b = rec[4 * i + 1], c = rec[4 * i + 2], d = rec[4 * i + 3];
+    st.ro = F3(a.x, a.y, a.z); st.rd = F3(a.w, b.x, b.y);
+    st.throughput = F3(b.z, b.w, c.x); st.radiance = F3(c.y, c.z, c.w);
+    st.rng.state = (uint64_t)as_uint(d.x) | ((uint64_t)as_uint(d.y) << 32);
+    st.rng.inc = 1u; /* sequence 0 */
+    return as_uint(d.z);
+}
+__global__ __launch_bounds__(BLOCK) void k_pt_init(FrameParams P, float4* __restrict__ list, unsigned long long* __restrict__ counters)
+{
+    int x, row;
+    const bool ok = tile_pixel(P, x, row);
+    /* every owned pixel starts one path; list position = compacted order of this launch */
+    const unsigned long long m = __ballot(ok);
+    if (!m) return;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(&counters[2], (unsigned long long)__popcll(m));
+    base = __shfl(base, leader);
+    if (!ok) return;
+    PathState st;
+    path_begin(P, x, P.H - 1 - row, st);
+    const uint32_t li = (uint32_t)((size_t)x + (size_t)(row - P.lrow0) * P.W);
+    path_store(list, (size_t)(base + __popcll(m & ((1ull << lane) - 1ull))), st, li);
+}
+template <int EXAMPLE, bool SHADOWED>
+__global__ __launch_bounds__(BLOCK) void k_pt_bounce(SceneView S, FrameParams P, int depth, int max_depth, f3 sky,
+                                                      const float4* __restrict__ in, float4* __restrict__ out,
+                                                      float4* __restrict__ accum, unsigned long long* __restrict__ counters)
+{
+    __shared__ uint32_t s_stack[WIDE_LDS_STACK * BLOCK];
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool have = i < counters[2 + depth];
+    unsigned long long nrays = 0;
+    bool alive = false;
+    PathState st;
+    uint32_t pixel = 0;
+    if (have)
+    {
+        pixel = path_load(in, i, st);
+        alive = path_bounce<EXAMPLE, SHADOWED>(S, s_stack, P, depth, sky, st, nrays);
+        if (alive && depth + 1 >= max_depth) alive = false; /* the depth loop ends here */
+        if (!alive) path_write(P, accum, pixel, st.radiance);
+    }
+    const unsigned long long m = __ballot(alive);
+    if (m)
+    {
+        const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+        unsigned long long base = 0;
+        if (lane == leader) base = atomicAdd(&counters[3 + depth], (unsigned long long)__popcll(m));
+        base = __shfl(base, leader);
+        if (alive) path_store(out, (size_t)(base + __popcll(m & ((1ull << lane) - 1ull))), st, pixel);
+    }
+    count_rays(nrays, &counters[0]);
 }
 
 /* --------------------------------------------------------- clear / tone_mapping */

@@ -72,6 +72,9 @@ struct rt_ctx
     bool f_clear = false;
     bool halo_flags_ok[2] = {false, false}; /* neighbour shaded flags unpacked since the last raycast */ /* rt_frame_stage state */
     unsigned long long* d_counter = nullptr;
+    float4* d_paths[2] = {nullptr, nullptr}; /* wavefront path tracer: live-path lists (64 B per path) */
+    unsigned long long* d_pt_counters = nullptr;
+    int pt_wavefront = 2; /* rt_tuning key 6: 0 one launch per frame, 1 wavefront, 2 auto (wavefront for 09_ris) */
     void* d_stage = nullptr;
     size_t stage_bytes = 0;
 
@@ -210,7 +213,7 @@ int rt_destroy(rt_ctx* c)
     free_scene(c);
     hipFree(c->d_vis); hipFree(c->d_g0); hipFree(c->d_g1); hipFree(c->d_accum); hipFree(c->d_pixels);
     for (int k = 0; k < 3; ++k) { hipFree(c->d_rec[k]); hipFree(c->d_rad[k]); }
-    hipFree(c->d_counter); hipFree(c->d_stage);
+    hipFree(c->d_counter); hipFree(c->d_stage); hipFree(c->d_paths[0]); hipFree(c->d_paths[1]); hipFree(c->d_pt_counters);
     if (c->ev_created) for (auto& e : c->ev) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
@@ -785,9 +788,37 @@ int rt_path_trace(rt_ctx* c, int example, int frame)
     const f3 sky = F3(c->opt.sky_color[0], c->opt.sky_color[1], c->opt.sky_color[2]);
     const int g = launch_grid(c);
     const int md = c->opt.max_depth;
+    const bool sh = c->opt.use_shadowed_target_function != 0;
+    const bool wavefront = c->pt_wavefront == 1 || (c->pt_wavefront == 2 && example == 9);
+    if (wavefront && md > 0 && md <= 60)
+    {
+        /* one launch per bounce over the compacted list of live paths */
+        const size_t n = (size_t)c->W * (size_t)(c->row_end - c->row_begin);
+        if (!c->d_paths[0])
+        {
+            RT_HIP(c, hipMalloc(&c->d_paths[0], n * 64));
+            RT_HIP(c, hipMalloc(&c->d_paths[1], n * 64));
+            RT_HIP(c, hipMalloc(&c->d_pt_counters, 64 * 8));
+        }
+        RT_HIP(c, hipMemsetAsync(c->d_pt_counters, 0, 64 * 8, c->stream));
+        k_pt_init<<<g, BLOCK, 0, c->stream>>>(P, c->d_paths[0], c->d_pt_counters);
+        RT_HIP(c, hipGetLastError());
+        const int gb = (int)((n + BLOCK - 1) / BLOCK);
+        for (int d = 0; d < md; ++d)
+        {
+            const float4* in = c->d_paths[d & 1];
+            float4* out = c->d_paths[(d + 1) & 1];
+            if (example == 7) k_pt_bounce<7, false><<<gb, BLOCK, 0, c->stream>>>(S, P, d, md, sky, in, out, c->d_accum, c->d_pt_counters);
+            else if (sh) k_pt_bounce<9, true><<<gb, BLOCK, 0, c->stream>>>(S, P, d, md, sky, in, out, c->d_accum, c->d_pt_counters);
+            else k_pt_bounce<9, false><<<gb, BLOCK, 0, c->stream>>>(S, P, d, md, sky, in, out, c->d_accum, c->d_pt_counters);
+            RT_HIP(c, hipGetLastError());
+        }
+        RT_HIP(c, hipMemcpyAsync(c->d_counter, c->d_pt_counters, 8, hipMemcpyDeviceToDevice, c->stream));
+        return RT_OK;
+    }
     RT_HIP(c, hipMemsetAsync(c->d_counter, 0, 8, c->stream));
     if (example == 7) k_path_trace<7, false><<<g, BLOCK, 0, c->stream>>>(S, P, md, sky, c->d_accum, c->d_counter);
-    else if (c->opt.use_shadowed_target_function) k_path_trace<9, true><<<g, BLOCK, 0, c->stream>>>(S, P, md, sky, c->d_accum, c->d_counter);
+    else if (sh) k_path_trace<9, true><<<g, BLOCK, 0, c->stream>>>(S, P, md, sky, c->d_accum, c->d_counter);
     else k_path_trace<9, false><<<g, BLOCK, 0, c->stream>>>(S, P, md, sky, c->d_accum, c->d_counter);
     RT_HIP(c, hipGetLastError());
     return RT_OK;
@@ -1321,6 +1352,7 @@ int rt_tuning(rt_ctx* c, int key, int value)
     if (key >= 0 && key <= 3 && (value == 0 || value == 1)) c->tune_tile_mode[key] = value;
     else if (key == 4 && value >= 0 && value <= 160 * 1024) c->tune_spatial_lds = value;
     else if (key == 5 && (value == 0 || value == 1)) c->bvh_builder = value; /* before rt_scene_set */
+    else if (key == 6 && value >= 0 && value <= 2) c->pt_wavefront = value;
     else RT_FAIL(c, RT_ERR_ARG, "bad tuning key/value %d/%d", key, value);
     return RT_OK;
 }

@@ -223,7 +223,10 @@ int rt_trace_mode(rt_ctx* ctx, int mode);
  * i.e. the neighbour window that must stay in L2). Defaults: {1,0,1,0}, 32768.
  * key 5 (before rt_scene_set): binary-tree builder, 0 = device LBVH (Morton codes + Karras, fast),
  * 1 = host binned SAH (default; the reference requests HIPRT's high-quality build,
- * common/loader.hpp:98-99). Both feed the same wide-BVH collapse and both traversals. */
+ * common/loader.hpp:98-99). Both feed the same wide-BVH collapse and both traversals.
+ * key 6: rt_path_trace as 0 = one launch per frame (the reference's shape), 1 = wavefront (one launch
+ * per bounce over the list of live paths, compacted with wave ballots), 2 = auto (default: wavefront
+ * for 09_ris, whose per-bounce RIS makes compaction pay; one launch for 07_pt). Same results. */
 int rt_tuning(rt_ctx* ctx, int key, int value);
 /* elementwise device evaluation of the portable math / IEEE div & sqrt (parity tests);
  * fn ids as in tests/test_portable_math.py */

@@ -356,11 +356,12 @@ def test_path_tracers_07_and_09(api, oracle, scenes, golden_scenes, example, sce
     r.clear()
     for frame in range(1, frames + 1):
         cnt = oracle.new_counters()
+        r.tuning(6, frame % 2)  # alternate: one launch per frame / wavefront (one launch per bounce, compaction)
         r.path_trace(example, frame)
         sc.path_trace(example, W, H, frame, rg, opt, acc, cnt=cnt)
         got = r.download(api.RT_BUF_ACCUMULATION)
         nbad = int((got.view(np.uint32) != acc.view(np.uint32)).any(axis=1).sum())
-        assert nbad == 0, f"frame {frame}: {nbad} pixels differ, rel-L2 {_rel_l2(got[:, :3], acc[:, :3])}"
+        assert nbad == 0, f"frame {frame} (wavefront={frame % 2}): {nbad} pixels differ, rel-L2 {_rel_l2(got[:, :3], acc[:, :3])}"
         assert r.path_trace_rays() == int(cnt["rays"][0])
     assert acc[:, :3].max() > 0
     r.tone_mapping()
