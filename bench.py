@@ -39,7 +39,9 @@ def cpu_baseline(tris, eye, center, frames=2):
     from oracle import binding as ob
 
     ob.set_math_mode(ob.MATH_PORTABLE)
-    threads = ob.max_threads()
+    threads = ob.effective_cpus()  # cgroup CPU quota, not the 256 hardware threads the box shows
+    ob.set_threads(threads)
+    hw = os.cpu_count()
     sc = ob.Scene(tris, use_bvh=True)
     rg = ob.raygen_lookat(eye, center, (0, 1, 0), np.float32(np.pi) / np.float32(4), W, H)
     opt = ob.bench_options()
@@ -56,7 +58,8 @@ def cpu_baseline(tris, eye, center, frames=2):
     rays = int(cnt["rays"][0])
     return dict(value=rays / dt / 1e6, unit="Mray/s", cores=threads, kind="port",
                 sample=f"{frames} full frames of the same workload ({W}x{H}, frames 1..{frames}), "
-                       f"oracle/restir_oracle.c + its CPU BVH, OpenMP {threads} threads, {dt:.2f} s",
+                       f"oracle/restir_oracle.c + its CPU BVH, OpenMP {threads} threads (= the cgroup CPU quota; "
+                       f"the host shows {hw} hardware threads), {dt:.2f} s",
                 ms_per_frame=dt / frames * 1e3), st
 
 

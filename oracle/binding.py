@@ -87,6 +87,20 @@ def bench_options(**kw):
 _lib = None
 
 
+def effective_cpus():
+    """CPUs this process may actually use: scheduler affinity capped by the cgroup CPU quota
+    (the GPU boxes expose 256 hardware threads but grant a 16-CPU quota: 128 OpenMP threads run
+    the oracle 1.6x SLOWER than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(round(int(quota) / int(period)))))
+    except Exception:
+        pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -124,6 +138,7 @@ def lib():
         L.o_path_trace_07.argtypes = [vp, ci, ci, ci, vp, vp, vp, ci, ci, vp]
         L.o_path_trace_09.argtypes = [vp, ci, ci, ci, vp, vp, vp, ci, ci, vp]
         _lib = L
+        L.o_set_threads(effective_cpus())
     return _lib
 
 
