@@ -460,7 +460,7 @@ int rt_scene_set(rt_ctx* c, const rt_triangle* triangles, uint32_t count)
         uint32_t* d_ids = nullptr;
         RT_HIP(c, hipMalloc(&d_ids, lights.size() * 4));
         RT_HIP(c, hipMemcpyAsync(d_ids, lights.data(), lights.size() * 4, hipMemcpyHostToDevice, c->stream));
-        RT_HIP(c, hipMalloc(&c->d_lights, lights.size() * 48));
+        RT_HIP(c, hipMalloc(&c->d_lights, lights.size() * 16 * RT_LIGHT_STRIDE));
         RT_HIP(c, hipMalloc(&c->d_light_ke, lights.size() * 16));
         k_light_table<<<(c->n_lights + 255) / 256, 256, 0, c->stream>>>(c->n_lights, d_ids, c->d_tris, c->d_lights, c->d_light_ke);
         RT_HIP(c, hipGetLastError());
