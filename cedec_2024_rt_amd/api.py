@@ -27,7 +27,7 @@ EXPORTS = [
     "rt_spatial_resampling", "rt_resolve", "rt_tone_mapping", "rt_frame", "rt_frame_stage", "rt_frame_stage_input", "rt_frame_stage_begin", "rt_frame_stage_run", "rt_frame_stage_end", "rt_frame_stage_output", "rt_frame_stage_run_part", "rt_halo_bitmap_words", "rt_halo_flags_bytes",
     "rt_halo_flags_pack", "rt_halo_flags_unpack", "rt_halo_mark", "rt_halo_scan", "rt_halo_pack_sparse", "rt_halo_unpack_sparse", "rt_path_trace", "rt_path_trace_rays", "rt_local_rows", "rt_download",
     "rt_upload", "rt_halo_bytes", "rt_halo_pack", "rt_halo_unpack", "rt_ray_count", "rt_timing_enable",
-    "rt_timing", "rt_spatial_bytes", "rt_trace_closest", "rt_trace_stats", "rt_bvh_config", "rt_bvh_info", "rt_trace_mode", "rt_tuning", "rt_math_eval",
+    "rt_timing", "rt_spatial_bytes", "rt_trace_closest", "rt_trace_stats", "rt_bvh_config", "rt_bvh_info", "rt_trace_mode", "rt_trace_time", "rt_tuning", "rt_math_eval",
 ]
 
 
@@ -120,6 +120,7 @@ def load_library():
     L.rt_bvh_config.argtypes = [vp, cf]
     L.rt_bvh_info.argtypes = [vp, vp, vp]
     L.rt_trace_mode.argtypes = [vp, ci]
+    L.rt_trace_time.argtypes = [vp, vp]
     L.rt_tuning.argtypes = [vp, ci, ci]
     _lib = L
     return L
@@ -399,6 +400,11 @@ class Renderer:
 
     def trace_mode(self, mode):
         self._ck(self.L.rt_trace_mode(self.h, int(mode)))
+
+    def trace_time(self):
+        ms = C.c_float()
+        self._ck(self.L.rt_trace_time(self.h, C.byref(ms)))
+        return ms.value
 
     def tuning(self, key, value):
         self._ck(self.L.rt_tuning(self.h, int(key), int(value)))

@@ -190,7 +190,13 @@ struct WideView
 {
     const float4* __restrict__ rec; /* 3 per record */
     int n_tris;
+    int n_rec;
 };
+/* The first RT_LDS_NODES records (the top levels: collapse_wide emits them breadth-first) are
+ * staged in LDS behind the per-lane stack by wide_lds_fill(); 0 = every record from global. */
+#ifndef RT_LDS_NODES
+#define RT_LDS_NODES 0
+#endif
 constexpr int WIDE_LDS_STACK = 24;
 constexpr int WIDE_OVF_STACK = 40; /* total 64 >= 3 * wide height + 1 (checked at build) */
 constexpr uint32_t WIDE_LEAF_BIT = 0x80000000u;
@@ -198,8 +204,37 @@ constexpr uint32_t WIDE_LEAF_BIT = 0x80000000u;
 #define WIDE_ANY_SORTED 0 /* any-hit rays: visit children nearest-first (1) or in slot order (0) */
 #endif
 
+#define WIDE_LDS_WORDS (WIDE_LDS_STACK * BLOCK_THREADS + 12 * RT_LDS_NODES)
+/* every thread of the workgroup must call this before its first trace_wide (and before any return) */
+RT_DEV void wide_lds_fill(const WideView& bvh, uint32_t* __restrict__ lds_stack)
+{
+#if RT_LDS_NODES
+    float4* dst = (float4*)(lds_stack + WIDE_LDS_STACK * BLOCK_THREADS);
+    const int n = 3 * (bvh.n_rec < RT_LDS_NODES ? bvh.n_rec : RT_LDS_NODES);
+    for (int i = threadIdx.x; i < n; i += BLOCK_THREADS) dst[i] = bvh.rec[i];
+    __syncthreads();
+#else
+    (void)bvh; (void)lds_stack;
+#endif
+}
+
 RT_DEV float wide_byte(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }
 
+/* Leaf tests are DEFERRED: a lane that reaches a leaf parks it (one slot) and keeps walking inner
+ * records; the wave runs the triangle test only when at least RT_LEAF_NUM/RT_LEAF_DEN of its live
+ * lanes have one parked (or no lane has inner work left). With a leaf test per ~5 steps per lane,
+ * testing as soon as ANY lane holds a leaf executes the ~175-instruction leaf path at ~10 % lane
+ * utilisation on nearly every iteration; traversal is VALU-issue bound, so batching
+ * the leaf path is worth more than the few extra boxes visited because `best` shrinks later.
+ * Results do not depend on the order of the tests (closest hit with the index tie-break). */
+#ifndef RT_LEAF_NUM
+#define RT_LEAF_NUM 1
+#define RT_LEAF_DEN 2
+#endif
+#ifndef RT_LEAF_NUM_CLOSEST
+#define RT_LEAF_NUM_CLOSEST 1
+#define RT_LEAF_DEN_CLOSEST 4
+#endif
 template <bool ANY, bool STATS = false>
 RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3 ro, f3 rd, float tmin, float tmax,
                        Hit& hit, uint32_t* stats = nullptr)
@@ -210,6 +245,9 @@ RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3
     inv.x = fminf(fmaxf(inv.x, -1e30f), 1e30f);
     inv.y = fminf(fmaxf(inv.y, -1e30f), 1e30f);
     inv.z = fminf(fmaxf(inv.z, -1e30f), 1e30f);
+    /* t(q) = A + q*B is monotone in q with the sign of B = scale*inv: the entry plane of an axis is
+     * the low byte plane for inv >= 0 and the high one otherwise (same values as min/max of both) */
+    const bool px = inv.x >= 0.0f, py = inv.y >= 0.0f, pz = inv.z >= 0.0f;
     float best = tmax;
     int prim = -1;
     float bu = 0.0f, bv = 0.0f;
@@ -224,38 +262,61 @@ RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3
     };
     auto pop = [&]() -> uint32_t {
         --sp;
-        return sp < WIDE_LDS_STACK ? lds_stack[sp * BLOCK_THREADS + lane_slot] : ovf[sp - WIDE_LDS_STACK];
+        uint32_t e;
+        if (sp < WIDE_LDS_STACK) e = lds_stack[sp * BLOCK_THREADS + lane_slot];
+        else e = ovf[sp - WIDE_LDS_STACK];
+        return e;
     };
 
-    uint32_t cur = 0u; /* root is always an inner record */
+    constexpr uint32_t NONE = 0x7fffffffu;
+    /* share of live lanes with a parked leaf that triggers the leaf pass (A/B: 1/2 for shadow rays, 1/4 for closest hit) */
+    constexpr int LN = ANY ? RT_LEAF_NUM : RT_LEAF_NUM_CLOSEST, LD = ANY ? RT_LEAF_DEN : RT_LEAF_DEN_CLOSEST;
+    uint32_t cur = 0u;   /* root is always an inner record */
+    uint32_t pend = NONE; /* parked leaf */
     for (;;)
     {
-        const float4* r = bvh.rec + 3 * (size_t)(cur & ~WIDE_LEAF_BIT);
-        if (cur & WIDE_LEAF_BIT)
+        if ((int)cur < 0 && pend == NONE)
         {
-            if (STATS) stats[1]++;
-            const float4 t0 = r[0], t1 = r[1], t2 = r[2];
-            const f3 v0 = F3(t0.x, t0.y, t0.z), v1 = F3(t0.w, t1.x, t1.y), v2 = F3(t1.z, t1.w, t2.x);
-            const int pi = as_int(t2.y);
-            float t, u, v;
-            if (intersect_ray_triangle(t, u, v, ro, rd, tmin, tmax, v0, v1, v2))
+            pend = cur;
+            cur = sp ? pop() : NONE;
+        }
+        const bool has_inner = cur < NONE;
+        const bool has_pend = pend != NONE;
+        if (!has_inner && !has_pend) break;
+        const unsigned long long bi = __ballot(has_inner), bp = __ballot(has_pend), ba = __ballot(true);
+        if (bp != 0ull && (bi == 0ull || LD * __popcll(bp) >= LN * __popcll(ba)))
+        {
+            if (has_pend)
             {
-                if (prim < 0 || t < best || (t == best && pi > prim))
+                if (STATS) stats[1]++;
+                const float4* g = bvh.rec + 3 * (size_t)(pend & ~WIDE_LEAF_BIT);
+                const float4 t0 = g[0], t1 = g[1], t2 = g[2];
+                pend = NONE;
+                const f3 v0 = F3(t0.x, t0.y, t0.z), v1 = F3(t0.w, t1.x, t1.y), v2 = F3(t1.z, t1.w, t2.x);
+                const int pi = as_int(t2.y);
+                float t, u, v;
+                if (intersect_ray_triangle(t, u, v, ro, rd, tmin, tmax, v0, v1, v2))
                 {
-                    best = t; bu = u; bv = v; prim = pi;
-                    if (ANY) { hit.t = t; hit.u = u; hit.v = v; hit.prim = pi; return true; }
+                    if (prim < 0 || t < best || (t == best && pi > prim))
+                    {
+                        best = t; bu = u; bv = v; prim = pi;
+                        if (ANY) { hit.t = t; hit.u = u; hit.v = v; hit.prim = pi; return true; }
+                    }
                 }
             }
+            continue;
         }
-        else
+        if (has_inner)
         {
             if (STATS) stats[0]++;
-            const float4 q0 = r[0];
-            const float4 q1f = r[1], q2f = r[2];
+            const float4* g = bvh.rec + 3 * (size_t)cur;
+            const float4 q0 = g[0], q1f = g[1], q2f = g[2];
             const uint32_t e = as_uint(q0.w);
             const uint32_t base = as_uint(q1f.x), meta = as_uint(q1f.y);
             const uint32_t lx = as_uint(q1f.z), ly = as_uint(q1f.w), lz = as_uint(q2f.x);
             const uint32_t hx = as_uint(q2f.y), hy = as_uint(q2f.z), hz = as_uint(q2f.w);
+            const uint32_t nx = px ? lx : hx, ny = py ? ly : hy, nz = pz ? lz : hz;
+            const uint32_t fx = px ? hx : lx, fy = py ? hy : ly, fz = pz ? hz : lz;
             const float sx = as_float((e & 0xffu) << 23), sy = as_float(((e >> 8) & 0xffu) << 23),
                         sz = as_float(((e >> 16) & 0xffu) << 23);
             /* t(q) = (origin + q*scale - ro) * inv = A + q*B : one FMA per plane */
@@ -268,11 +329,10 @@ RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3
             for (int k = 0; k < 4; ++k)
             {
                 const uint32_t m = (meta >> (8 * k)) & 0xffu;
-                const float x0 = __builtin_fmaf(wide_byte(lx, k), Bx, Ax), x1 = __builtin_fmaf(wide_byte(hx, k), Bx, Ax);
-                const float y0 = __builtin_fmaf(wide_byte(ly, k), By, Ay), y1 = __builtin_fmaf(wide_byte(hy, k), By, Ay);
-                const float z0 = __builtin_fmaf(wide_byte(lz, k), Bz, Az), z1 = __builtin_fmaf(wide_byte(hz, k), Bz, Az);
-                float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-                float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+                float tn = fmaxf(fmaxf(__builtin_fmaf(wide_byte(nx, k), Bx, Ax), __builtin_fmaf(wide_byte(ny, k), By, Ay)),
+                                 __builtin_fmaf(wide_byte(nz, k), Bz, Az));
+                float tf = fminf(fminf(__builtin_fmaf(wide_byte(fx, k), Bx, Ax), __builtin_fmaf(wide_byte(fy, k), By, Ay)),
+                                 __builtin_fmaf(wide_byte(fz, k), Bz, Az));
                 tn = fmaxf(tn * (1.0f - 4e-7f), tmin);
                 tf = fminf(tf * (1.0f + 4e-7f), best);
                 const bool h = (m != 0u) && (tn <= tf);
@@ -282,9 +342,12 @@ RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3
             }
             if (nhit > 0)
             {
+                /* the scratch half of the stack is never reached in practice: one wave-uniform test
+                 * keeps its addressing out of the hot path */
+                const bool deep = __ballot(sp + 3 > WIDE_LDS_STACK) != 0ull;
                 if (!ANY || WIDE_ANY_SORTED)
                 {
-                    /* sort ascending by entry distance (5 compare-exchanges) */
+                    /* sort ascending by entry distance (5 compare-exchanges); misses (3e38) sink to the end */
 #define RT_CSWAP(i, j)                                                     \
     if (td[j] < td[i])                                                     \
     {                                                                      \
@@ -293,32 +356,45 @@ RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3
     }
                     RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
 #undef RT_CSWAP
-                    if (nhit > 3) push(ce[3]);
-                    if (nhit > 2) push(ce[2]);
-                    if (nhit > 1) push(ce[1]);
+                    /* ce[0] is visited next, ce[nhit-1] .. ce[1] go on the stack (ce[1] on top) */
+                    if (__builtin_expect(deep, 0))
+                    {
+                        if (nhit > 3) push(ce[3]);
+                        if (nhit > 2) push(ce[2]);
+                        if (nhit > 1) push(ce[1]);
+                    }
+                    else if (nhit > 1)
+                    {
+                        uint32_t* top = lds_stack + (sp + nhit - 2) * BLOCK_THREADS + lane_slot;
+                        top[0] = ce[1];
+                        if (nhit > 2) top[-BLOCK_THREADS] = ce[2];
+                        if (nhit > 3) top[-2 * BLOCK_THREADS] = ce[3];
+                        sp += nhit - 1;
+                    }
                     cur = ce[0];
                 }
                 else
                 {
-                    /* any-hit: order is irrelevant for the result; visit in slot order */
-                    bool first = true;
-                    uint32_t nxt = 0u;
-#pragma unroll
-                    for (int k = 3; k >= 0; --k)
+                    /* any-hit: the order is irrelevant for the result: visit the first hit child in
+                     * slot order next, push the others */
+                    const bool h0 = td[0] < 3.0e38f, h1 = td[1] < 3.0e38f, h2 = td[2] < 3.0e38f, h3 = td[3] < 3.0e38f;
+                    cur = h0 ? ce[0] : (h1 ? ce[1] : (h2 ? ce[2] : ce[3]));
+                    if (__builtin_expect(deep, 0))
                     {
-                        if (td[k] < 3.0e38f)
-                        {
-                            if (first) { nxt = ce[k]; first = false; }
-                            else { push(nxt); nxt = ce[k]; }
-                        }
+                        if (h1 && h0) push(ce[1]);
+                        if (h2 && (h0 || h1)) push(ce[2]);
+                        if (h3 && (h0 || h1 || h2)) push(ce[3]);
                     }
-                    cur = nxt;
+                    else
+                    {
+                        if (h1 && h0) { lds_stack[sp * BLOCK_THREADS + lane_slot] = ce[1]; ++sp; }
+                        if (h2 && (h0 || h1)) { lds_stack[sp * BLOCK_THREADS + lane_slot] = ce[2]; ++sp; }
+                        if (h3 && (h0 || h1 || h2)) { lds_stack[sp * BLOCK_THREADS + lane_slot] = ce[3]; ++sp; }
+                    }
                 }
-                continue;
             }
+            else cur = sp ? pop() : NONE;
         }
-        if (sp == 0) break;
-        cur = pop();
     }
     if (prim < 0) return false;
     hit.t = best; hit.u = bu; hit.v = bv; hit.prim = prim;

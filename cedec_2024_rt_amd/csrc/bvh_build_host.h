@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <deque>
 #include <vector>
 
 #include "../../include/restir_rt.h"
@@ -139,19 +140,22 @@ static void bin_children(const BvhNode& n, WideChild out[2])
     out[1].hi[0] = n.c.x; out[1].hi[1] = n.c.y; out[1].hi[2] = n.c.z;
 }
 /* returns the wide height, fills recs */
-static int collapse_wide(const std::vector<BvhNode>& bin, const rt_triangle* tris, std::vector<WideRec>& recs)
+static int collapse_wide(const std::vector<BvhNode>& bin, const rt_triangle* tris, std::vector<WideRec>& recs, int bfs_records)
 {
     struct Work { int bin; uint32_t out; int depth; };
     recs.clear();
     recs.reserve(bin.size() * 2 + 8);
     recs.push_back(WideRec());
-    std::vector<Work> stack;
+    /* the first bfs_records records are emitted breadth-first (top levels contiguous at the
+     * front: the traversal can stage them in LDS), the rest depth-first (subtrees contiguous) */
+    std::deque<Work> stack;
     stack.push_back({0, 0u, 1});
     int height = 1;
     while (!stack.empty())
     {
-        const Work wk = stack.back();
-        stack.pop_back();
+        Work wk;
+        if (recs.size() < (size_t)bfs_records) { wk = stack.front(); stack.pop_front(); }
+        else { wk = stack.back(); stack.pop_back(); }
         height = std::max(height, wk.depth);
         WideChild ch[4];
         int n = 2;

@@ -125,7 +125,8 @@ RT_DEV void gbuffer_write(const SceneView& S, const FrameParams& P, float4* __re
 __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_raycast(SceneView S, FrameParams P, float4* __restrict__ vis,
                                                     float4* __restrict__ g0, float4* __restrict__ g1)
 {
-    __shared__ uint32_t s_stack[WIDE_LDS_STACK * BLOCK];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_WORDS];
+    wide_lds_fill(S.wide, s_stack);
     int x, row;
     if (!tile_pixel(P, x, row)) return;
     const int yi = P.H - 1 - row;
@@ -205,7 +206,8 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_generate_candidate(
     const float4* __restrict__ prev_rec, const float4* __restrict__ prev_rad, float4* __restrict__ out_rec,
     float4* __restrict__ out_rad)
 {
-    __shared__ uint32_t s_stack[WIDE_LDS_STACK * BLOCK];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_WORDS];
+    wide_lds_fill(S.wide, s_stack);
     int x, row;
     if (!tile_pixel(P, x, row)) return;
     const int yi = P.H - 1 - row;
@@ -293,7 +295,8 @@ __global__ __launch_bounds__(BLOCK) void k_temporal(SceneView S, FrameParams P, 
                                                      const float4* __restrict__ prev_rad,
                                                      float4* __restrict__ rec, float4* __restrict__ radb)
 {
-    __shared__ uint32_t s_stack[WIDE_LDS_STACK * BLOCK];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_WORDS];
+    if (SHADOWED) wide_lds_fill(S.wide, s_stack);
     int x, row;
     if (!tile_pixel(P, x, row)) return;
     const int yi = P.H - 1 - row;
@@ -326,7 +329,8 @@ __global__ __launch_bounds__(BLOCK) void k_spatial(SceneView S, FrameParams P, c
                                                     const float4* __restrict__ in_rad,
                                                     float4* __restrict__ out_rec, float4* __restrict__ out_rad)
 {
-    __shared__ uint32_t s_stack[WIDE_LDS_STACK * BLOCK];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_WORDS];
+    if (SHADOWED) wide_lds_fill(S.wide, s_stack);
     int x, row;
     if (!tile_pixel(P, x, row)) return;
     const int yi = P.H - 1 - row;
@@ -562,7 +566,8 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_resolve(SceneView S, 
                                                     const float4* __restrict__ rec,
                                                     const float4* __restrict__ radb, float4* __restrict__ accum)
 {
-    __shared__ uint32_t s_stack[WIDE_LDS_STACK * BLOCK];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_WORDS];
+    wide_lds_fill(S.wide, s_stack);
     int x, row;
     if (!tile_pixel(P, x, row)) return;
     const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
@@ -732,7 +737,8 @@ __global__ __launch_bounds__(BLOCK) void k_path_trace(SceneView S, FrameParams P
                                                        float4* __restrict__ accum,
                                                        unsigned long long* __restrict__ rays)
 {
-    __shared__ uint32_t s_stack[WIDE_LDS_STACK * BLOCK];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_WORDS];
+    wide_lds_fill(S.wide, s_stack);
     int x, row;
     const bool ok = tile_pixel(P, x, row);
     unsigned long long nrays = 0;
@@ -791,7 +797,8 @@ __global__ __launch_bounds__(BLOCK) void k_pt_bounce(SceneView S, FrameParams P,
                                                       const float4* __restrict__ in, float4* __restrict__ out,
                                                       float4* __restrict__ accum, unsigned long long* __restrict__ counters)
 {
-    __shared__ uint32_t s_stack[WIDE_LDS_STACK * BLOCK];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_WORDS];
+    wide_lds_fill(S.wide, s_stack);
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool have = i < counters[2 + depth];
     unsigned long long nrays = 0;
@@ -935,24 +942,26 @@ __global__ void k_count_shaded(FrameParams P, const float4* __restrict__ g1, uns
     const unsigned long long m = __ballot(shaded);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
 }
-template <int MODE> /* 0 = wide (production), 1 = binary stackless */
+template <int MODE, bool ANY = false> /* 0 = wide (production), 1 = binary stackless; ANY = shadow-ray semantics */
 __global__ __launch_bounds__(BLOCK) void k_trace_closest(SceneView S, const float* __restrict__ rays, int n, float* __restrict__ hits)
 {
-    __shared__ uint32_t s_stack[MODE == 0 ? WIDE_LDS_STACK * BLOCK : 1];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[MODE == 0 ? WIDE_LDS_WORDS : 4];
+    if (MODE == 0) wide_lds_fill(S.wide, s_stack);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* r = rays + 8 * (size_t)i;
     Hit h;
     h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.prim = -1;
-    if (MODE == 0) trace_wide<false>(S.wide, s_stack, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7], h);
-    else trace<false>(S.bvh, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7], h);
+    if (MODE == 0) trace_wide<ANY>(S.wide, s_stack, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7], h);
+    else trace<ANY>(S.bvh, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7], h);
     float* o = hits + 4 * (size_t)i;
     o[0] = h.t; o[1] = h.u; o[2] = h.v; o[3] = as_float(h.prim);
 }
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void k_trace_stats(SceneView S, const float* __restrict__ rays, int n, uint32_t* __restrict__ stats)
 {
-    __shared__ uint32_t s_stack[MODE == 0 ? WIDE_LDS_STACK * BLOCK : 1];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[MODE == 0 ? WIDE_LDS_WORDS : 4];
+    if (MODE == 0) wide_lds_fill(S.wide, s_stack);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* r = rays + 8 * (size_t)i;

@@ -50,8 +50,10 @@ struct rt_ctx
      * pass's occupancy limiter (extra dynamic LDS). Defaults from the sweep in DESIGN.md §5. */
     int tune_tile_mode[5] = {1, 0, 1, 0, 0};
     int tune_spatial_lds = 32768;
+    float last_trace_ms = 0.0f;
     int trace_mode = 0; /* rt_trace_closest / rt_trace_stats: 0 = wide (what the frame kernels use), 1 = binary stackless */
     float bvh_split_factor = 8.0f; /* fragment length in median triangle extents; 0 = no pre-split */
+    int bvh_bfs_records = 2048; /* rt_tuning key 7: records emitted breadth-first (top of the tree contiguous) */
     int bvh_builder = 1; /* 0 = device LBVH (Morton/Karras), 1 = host binned SAH (high quality) */
     float* d_tris = nullptr;
     float4* d_tv = nullptr;
@@ -146,7 +148,7 @@ static SceneView make_scene(const rt_ctx* c)
 {
     SceneView S;
     S.bvh.nodes = c->d_nodes; S.bvh.tv = c->d_tv; S.bvh.n_tris = c->n_tris;
-    S.wide.rec = c->d_wide; S.wide.n_tris = c->n_tris;
+    S.wide.rec = c->d_wide; S.wide.n_tris = c->n_tris; S.wide.n_rec = c->n_wide;
     S.trimat = c->d_trimat; S.lights = c->d_lights; S.light_ke = c->d_light_ke;
     return S;
 }
@@ -259,7 +261,7 @@ static int build_wide(rt_ctx* c, const rt_triangle* tris, int n_refs)
     RT_HIP(c, hipMemcpyAsync(bin.data(), c->d_nodes, n_bin * sizeof(BvhNode), hipMemcpyDeviceToHost, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     std::vector<WideRec> recs;
-    c->wide_height = collapse_wide(bin, tris, recs);
+    c->wide_height = collapse_wide(bin, tris, recs, c->bvh_bfs_records);
     if (3 * c->wide_height + 1 > WIDE_LDS_STACK + WIDE_OVF_STACK)
         RT_FAIL(c, RT_ERR_BVH_DEPTH, "wide BVH height %d exceeds the traversal stack (%d entries)", c->wide_height,
                 WIDE_LDS_STACK + WIDE_OVF_STACK);
@@ -1298,6 +1300,10 @@ int rt_trace_closest(rt_ctx* c, const float* rays, uint32_t n, float* hits)
     RT_HIP(c, hipMalloc(&d_r, (size_t)n * 32));
     RT_HIP(c, hipMalloc(&d_h, (size_t)n * 16));
     RT_HIP(c, hipMemcpyAsync(d_r, rays, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
+    hipEvent_t e0, e1;
+    RT_HIP(c, hipEventCreate(&e0));
+    RT_HIP(c, hipEventCreate(&e1));
+    RT_HIP(c, hipEventRecord(e0, c->stream));
     if (c->trace_mode == 2 || c->trace_mode == 3)
     {
         unsigned int* d_head = (unsigned int*)c->d_counter;
@@ -1307,11 +1313,22 @@ int rt_trace_closest(rt_ctx* c, const float* rays, uint32_t n, float* hits)
         else k_trace_queue<true><<<grid, BLOCK, 0, c->stream>>>(make_scene(c).wide, d_r, (int)n, d_h, d_head);
     }
     else if (c->trace_mode == 0) k_trace_closest<0><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_h);
+    else if (c->trace_mode == 4) k_trace_closest<0, true><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_h);
     else k_trace_closest<1><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_h);
     RT_HIP(c, hipGetLastError());
+    RT_HIP(c, hipEventRecord(e1, c->stream));
     RT_HIP(c, hipMemcpyAsync(hits, d_h, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
+    hipEventElapsedTime(&c->last_trace_ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(d_r); hipFree(d_h);
+    return RT_OK;
+}
+/* device time of the traversal kernel of the last rt_trace_closest call */
+int rt_trace_time(rt_ctx* c, float* ms)
+{
+    RT_CHECK_CTX(c);
+    if (ms) *ms = c->last_trace_ms;
     return RT_OK;
 }
 
@@ -1353,6 +1370,7 @@ int rt_tuning(rt_ctx* c, int key, int value)
     else if (key == 4 && value >= 0 && value <= 160 * 1024) c->tune_spatial_lds = value;
     else if (key == 5 && (value == 0 || value == 1)) c->bvh_builder = value; /* before rt_scene_set */
     else if (key == 6 && value >= 0 && value <= 2) c->pt_wavefront = value;
+    else if (key == 7 && value >= 0) c->bvh_bfs_records = value; /* before rt_scene_set */
     else RT_FAIL(c, RT_ERR_ARG, "bad tuning key/value %d/%d", key, value);
     return RT_OK;
 }
@@ -1361,7 +1379,7 @@ int rt_tuning(rt_ctx* c, int key, int value)
 int rt_trace_mode(rt_ctx* c, int mode)
 {
     RT_CHECK_CTX(c);
-    if (mode < 0 || mode > 3) RT_FAIL(c, RT_ERR_ARG, "mode must be 0..3");
+    if (mode < 0 || mode > 4) RT_FAIL(c, RT_ERR_ARG, "mode must be 0..4");
     c->trace_mode = mode;
     return RT_OK;
 }

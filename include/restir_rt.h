@@ -98,7 +98,7 @@ int rt_sync(rt_ctx* ctx);
 /* ---- scene (replaces loadTrianglesFromObj + light list + buildHiprtGeometry, :184-220) ---- */
 /* Uploads the triangles, extracts the emissive-triangle list in index order (:196-205) and
  * builds the BVH (pre-split of large triangles, binary tree by the host SAH builder or the device
- * LBVH kernels, collapse to the 4-wide quantised structure the kernels traverse; rt_tuning key 5). */
+ * LBVH kernels, collapse to the 4-wide quantised structure the kernels traverse; rt_tuning keys 5, 7). */
 int rt_scene_set(rt_ctx* ctx, const rt_triangle* triangles, uint32_t count);
 int rt_scene_info(rt_ctx* ctx, uint32_t* n_triangles, uint32_t* n_lights, uint32_t* bvh_height);
 
@@ -215,8 +215,11 @@ int rt_trace_stats(rt_ctx* ctx, const float* rays, uint32_t n, uint32_t* stats);
 int rt_bvh_config(rt_ctx* ctx, float split_factor);
 int rt_bvh_info(rt_ctx* ctx, uint32_t* n_references, uint32_t* n_wide_records);
 /* which traversal rt_trace_closest / rt_trace_stats exercise: 0 = 4-wide quantised BVH + LDS stack
- * (what every frame kernel uses, default), 1 = binary LBVH + stackless trail (A/B measurements). */
+ * (what every frame kernel uses, default), 1 = binary LBVH + stackless trail (A/B measurements),
+ * 2/3 = persistent lane-refill queue (closest / any hit), 4 = mode 0 with any-hit (shadow-ray)
+ * semantics: hits[i].index >= 0 iff occluded. rt_trace_time: device ms of the last call's kernel. */
 int rt_trace_mode(rt_ctx* ctx, int mode);
+int rt_trace_time(rt_ctx* ctx, float* ms);
 /* performance knobs; results never depend on them. keys 0..3: workgroup->tile order inside an XCD
  * band for raycast / generate_candidate / spatial_resampling / resolve (0 row-major, 1 column-major);
  * key 4: extra LDS bytes per spatial_resampling workgroup (limits the workgroups resident per CU,
@@ -226,7 +229,9 @@ int rt_trace_mode(rt_ctx* ctx, int mode);
  * common/loader.hpp:98-99). Both feed the same wide-BVH collapse and both traversals.
  * key 6: rt_path_trace as 0 = one launch per frame (the reference's shape), 1 = wavefront (one launch
  * per bounce over the list of live paths, compacted with wave ballots), 2 = auto (default: wavefront
- * for 09_ris, whose per-bounce RIS makes compaction pay; one launch for 07_pt). Same results. */
+ * for 09_ris, whose per-bounce RIS makes compaction pay; one launch for 07_pt). Same results.
+ * key 7 (before rt_scene_set): number of wide-BVH records emitted breadth-first before the
+ * collapse switches to depth-first order (record order only; no measurable effect, default 2048). */
 int rt_tuning(rt_ctx* ctx, int key, int value);
 /* elementwise device evaluation of the portable math / IEEE div & sqrt (parity tests);
  * fn ids as in tests/test_portable_math.py */
