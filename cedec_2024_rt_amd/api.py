@@ -118,7 +118,7 @@ def load_library():
     L.rt_math_eval.argtypes = [vp, ci, vp, C.c_uint32, vp]
     L.rt_trace_stats.argtypes = [vp, vp, C.c_uint32, vp]
     L.rt_bvh_config.argtypes = [vp, cf]
-    L.rt_bvh_info.argtypes = [vp, vp, vp]
+    L.rt_bvh_info.argtypes = [vp, vp, vp, vp]
     L.rt_trace_mode.argtypes = [vp, ci]
     L.rt_trace_time.argtypes = [vp, vp]
     L.rt_tuning.argtypes = [vp, ci, ci]
@@ -393,7 +393,8 @@ class Renderer:
         r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
         st = np.zeros((len(r), 2), dtype=np.uint32)
         self._ck(self.L.rt_trace_stats(self.h, _p(r), len(r), _p(st)))
-        return st
+        self.last_wave_passes = st >> 16  # wide traversal: inner / leaf passes of the ray's wavefront
+        return st & 0xFFFF
 
     def bvh_config(self, split_factor):
         self._ck(self.L.rt_bvh_config(self.h, C.c_float(split_factor)))
@@ -410,9 +411,9 @@ class Renderer:
         self._ck(self.L.rt_tuning(self.h, int(key), int(value)))
 
     def bvh_info(self):
-        a, b = C.c_uint32(), C.c_uint32()
-        self._ck(self.L.rt_bvh_info(self.h, C.byref(a), C.byref(b)))
-        return dict(references=a.value, wide_records=b.value)
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._ck(self.L.rt_bvh_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(references=a.value, wide_records=b.value, wide_height=c.value)
 
     def math_eval(self, fn, x):
         x = np.ascontiguousarray(x, dtype=np.float32)

@@ -229,11 +229,14 @@ RT_DEV float wide_byte(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xff
  * Results do not depend on the order of the tests (closest hit with the index tie-break). */
 #ifndef RT_LEAF_NUM
 #define RT_LEAF_NUM 1
-#define RT_LEAF_DEN 2
+#define RT_LEAF_DEN 1
+#endif
+#ifndef RT_LEAF_SLOTS
+#define RT_LEAF_SLOTS 2
 #endif
 #ifndef RT_LEAF_NUM_CLOSEST
 #define RT_LEAF_NUM_CLOSEST 1
-#define RT_LEAF_DEN_CLOSEST 4
+#define RT_LEAF_DEN_CLOSEST 2
 #endif
 template <bool ANY, bool STATS = false>
 RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3 ro, f3 rd, float tmin, float tmax,
@@ -273,8 +276,25 @@ RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3
     constexpr int LN = ANY ? RT_LEAF_NUM : RT_LEAF_NUM_CLOSEST, LD = ANY ? RT_LEAF_DEN : RT_LEAF_DEN_CLOSEST;
     uint32_t cur = 0u;   /* root is always an inner record */
     uint32_t pend = NONE; /* parked leaf */
+#if RT_LEAF_SLOTS == 2
+    uint32_t pend2 = NONE;
+#endif
     for (;;)
     {
+#if RT_LEAF_SLOTS == 2
+        if ((int)cur < 0 && pend2 == NONE)
+        {
+            if (pend == NONE) pend = cur; else pend2 = cur;
+            cur = sp ? pop() : NONE;
+        }
+        const bool has_inner = cur < NONE;
+        const bool has_pend = pend != NONE;
+        if (!has_inner && !has_pend) break;
+        const unsigned long long bi = __ballot(has_inner), bp = __ballot(has_pend), ba = __ballot(true);
+        const int parked = __popcll(bp) + __popcll(__ballot(pend2 != NONE));
+        if (bp != 0ull && (bi == 0ull || LD * parked >= LN * __popcll(ba)))
+        {
+#else
         if ((int)cur < 0 && pend == NONE)
         {
             pend = cur;
@@ -286,12 +306,18 @@ RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3
         const unsigned long long bi = __ballot(has_inner), bp = __ballot(has_pend), ba = __ballot(true);
         if (bp != 0ull && (bi == 0ull || LD * __popcll(bp) >= LN * __popcll(ba)))
         {
+#endif
+            if (STATS) stats[1] += 0x10000u; /* leaf passes this lane's wave ran while the lane was live */
             if (has_pend)
             {
                 if (STATS) stats[1]++;
                 const float4* g = bvh.rec + 3 * (size_t)(pend & ~WIDE_LEAF_BIT);
                 const float4 t0 = g[0], t1 = g[1], t2 = g[2];
+#if RT_LEAF_SLOTS == 2
+                pend = pend2; pend2 = NONE;
+#else
                 pend = NONE;
+#endif
                 const f3 v0 = F3(t0.x, t0.y, t0.z), v1 = F3(t0.w, t1.x, t1.y), v2 = F3(t1.z, t1.w, t2.x);
                 const int pi = as_int(t2.y);
                 float t, u, v;
@@ -306,6 +332,7 @@ RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3
             }
             continue;
         }
+        if (STATS) stats[0] += 0x10000u; /* inner passes of the wave */
         if (has_inner)
         {
             if (STATS) stats[0]++;

@@ -957,7 +957,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest(SceneView S, const floa
     float* o = hits + 4 * (size_t)i;
     o[0] = h.t; o[1] = h.u; o[2] = h.v; o[3] = as_float(h.prim);
 }
-template <int MODE>
+template <int MODE, bool ANY = false>
 __global__ __launch_bounds__(BLOCK) void k_trace_stats(SceneView S, const float* __restrict__ rays, int n, uint32_t* __restrict__ stats)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_stack[MODE == 0 ? WIDE_LDS_WORDS : 4];
@@ -967,7 +967,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_stats(SceneView S, const float*
     const float* r = rays + 8 * (size_t)i;
     Hit h;
     uint32_t st[2] = {0u, 0u};
-    if (MODE == 0) trace_wide<false, true>(S.wide, s_stack, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7], h, st);
+    if (MODE == 0) trace_wide<ANY, true>(S.wide, s_stack, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7], h, st);
     else trace<false, true>(S.bvh, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7], h, st);
     stats[2 * (size_t)i] = st[0];
     stats[2 * (size_t)i + 1] = st[1];

@@ -483,9 +483,10 @@ int rt_scene_info(rt_ctx* c, uint32_t* n_triangles, uint32_t* n_lights, uint32_t
     if (bvh_height) *bvh_height = (uint32_t)c->bvh_height;
     return RT_OK;
 }
-int rt_bvh_info(rt_ctx* c, uint32_t* n_refs, uint32_t* n_nodes)
+int rt_bvh_info(rt_ctx* c, uint32_t* n_refs, uint32_t* n_nodes, uint32_t* wide_height)
 {
     RT_CHECK_CTX(c);
+    if (wide_height) *wide_height = (uint32_t)c->wide_height;
     if (n_refs) *n_refs = (uint32_t)c->n_refs;
     if (n_nodes) *n_nodes = (uint32_t)c->n_wide;
     return RT_OK;
@@ -1344,6 +1345,7 @@ int rt_trace_stats(rt_ctx* c, const float* rays, uint32_t n, uint32_t* stats)
     RT_HIP(c, hipMalloc(&d_s, (size_t)n * 8));
     RT_HIP(c, hipMemcpyAsync(d_r, rays, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
     if (c->trace_mode == 0) k_trace_stats<0><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_s);
+    else if (c->trace_mode == 4) k_trace_stats<0, true><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_s);
     else k_trace_stats<1><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_s);
     RT_HIP(c, hipGetLastError());
     RT_HIP(c, hipMemcpyAsync(stats, d_s, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));

@@ -208,12 +208,15 @@ int rt_spatial_bytes(rt_ctx* ctx, int frame, int pass, int in, uint64_t* bytes, 
 /* ---- BVH utilities (parity tests: BVH traversal == brute force) ----
  * rays: n x {ox,oy,oz, dx,dy,dz, tmin,tmax}; hits: n x {t,u,v, bits(index)}; host pointers. */
 int rt_trace_closest(rt_ctx* ctx, const float* rays, uint32_t n, float* hits);
-/* per ray {nodes visited, triangle tests} of the same traversal (BVH quality diagnostics) */
+/* per ray {nodes visited, triangle tests} of the same traversal (BVH quality diagnostics); for the
+ * wide traversal the upper 16 bits of each word count the inner / leaf passes the ray's wavefront
+ * executed while the ray was live (SIMT efficiency diagnostics) */
 int rt_trace_stats(rt_ctx* ctx, const float* rays, uint32_t n, uint32_t* stats);
 /* BVH build knob, call before rt_scene_set: large triangles are pre-split into fragments no
  * longer than split_factor x (median triangle extent); 0 = no pre-split. Default 8. */
 int rt_bvh_config(rt_ctx* ctx, float split_factor);
-int rt_bvh_info(rt_ctx* ctx, uint32_t* n_references, uint32_t* n_wide_records);
+/* wide_height: levels of the 4-wide tree the kernels walk; a walk holds at most 3 stack entries per level */
+int rt_bvh_info(rt_ctx* ctx, uint32_t* n_references, uint32_t* n_wide_records, uint32_t* wide_height);
 /* which traversal rt_trace_closest / rt_trace_stats exercise: 0 = 4-wide quantised BVH + LDS stack
  * (what every frame kernel uses, default), 1 = binary LBVH + stackless trail (A/B measurements),
  * 2/3 = persistent lane-refill queue (closest / any hit), 4 = mode 0 with any-hit (shadow-ray)

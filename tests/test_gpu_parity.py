@@ -128,8 +128,55 @@ def test_lbvh_equals_brute_force(api, oracle, scenes, golden_scenes):
                 r.trace_mode(mode)
                 dev = r.trace_closest(rays)
                 assert _eq_bits(dev, ref), f"{name} builder {builder} mode {mode}: {(dev.view(np.uint32) != ref.view(np.uint32)).any(axis=1).sum()} rays differ"
+            # shadow-ray semantics (3: persistent queue, 4: the frame kernels' any-hit walk): occluded <=> a closest hit exists
+            for mode in (3, 4):
+                r.trace_mode(mode)
+                occ = r.trace_closest(rays)[:, 3].view(np.int32) >= 0
+                assert (occ == (ref[:, 3].view(np.int32) >= 0)).all(), f"{name} builder {builder} any-hit mode {mode}"
             r.close()
         assert (ref[:, 3].view(np.int32) >= 0).mean() > 0.2
+
+
+def test_deep_traversal_stack_spills_past_lds(api, oracle):
+    """A deck of 1.1M parallel cards: a ray along the deck hits every box of the tree, so the
+    front-to-back walk holds ~3 entries per level and runs past the 24 LDS stack entries into the
+    scratch half (the wave-uniform `deep` path of trace_wide). Results == brute force."""
+    from cedec_2024_rt_amd.types import TRIANGLE as TRIANGLE_DTYPE
+
+    n = 1100000
+    tris = np.zeros(n, TRIANGLE_DTYPE)
+    z = (np.arange(n, dtype=np.float32) * np.float32(0.004)).astype(np.float32)
+    tris["v"][:, 0] = np.stack([np.zeros(n), np.zeros(n), z], 1)
+    tris["v"][:, 1] = np.stack([np.full(n, 2.0), np.zeros(n), z], 1)
+    tris["v"][:, 2] = np.stack([np.zeros(n), np.full(n, 2.0), z], 1)
+    tris["color"] = 0.5
+    rng = np.random.default_rng(5)
+    m = 192
+    rays = np.zeros((m, 8), np.float32)
+    rays[:, 0:2] = rng.random((m, 2), dtype=np.float32) * 0.9 + 0.02
+    rays[:, 2] = np.where(np.arange(m) % 2 == 0, -1.0, z[-1] + 1.0)
+    rays[:, 3:6] = rng.normal(size=(m, 3)).astype(np.float32) * 0.002
+    rays[:, 5] = np.where(np.arange(m) % 2 == 0, 1.0, -1.0)
+    rays[:, 6] = 0.0
+    rays[:, 7] = np.where(np.arange(m) % 3 == 0, 3.0e38, rng.random(m, dtype=np.float32) * 4000.0)
+    rays[::7, 6] = 500.0  # tmin inside the deck: the nearest cards are skipped
+    sc = oracle.Scene(tris, use_bvh=False)
+    ref = sc.trace_closest(rays, force_brute=True)
+    assert (ref[:, 3].view(np.int32) >= 0).mean() > 0.5
+    for builder in (0, 1):
+        r = api.Renderer(8, 8)
+        r.tuning(5, builder)
+        r.set_scene(tris)
+        assert 3 * (r.bvh_info()["wide_height"] - 1) >= 24 + 6, r.bvh_info()
+        for mode in (0, 2):
+            r.trace_mode(mode)
+            dev = r.trace_closest(rays)
+            assert _eq_bits(dev, ref), f"builder {builder} mode {mode}"
+        for mode in (3, 4):
+            r.trace_mode(mode)
+            occ = r.trace_closest(rays)[:, 3].view(np.int32) >= 0
+            assert (occ == (ref[:, 3].view(np.int32) >= 0)).all(), f"builder {builder} any-hit mode {mode}"
+        r.close()
 
 
 def test_lbvh_blocks_scene_vs_oracle_bvh(api, oracle, scenes):
