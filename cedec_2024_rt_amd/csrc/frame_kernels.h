@@ -80,8 +80,17 @@ RT_DEV bool tile_pixel(const FrameParams& P, int& x, int& row)
         ty = tile / tiles_x;
         tx = tile - ty * tiles_x;
     }
+#ifndef RT_WAVE_8X8
+#define RT_WAVE_8X8 1
+#endif
+#if RT_WAVE_8X8 && RT_TILE_W == 32
+    /* wavefront w of the workgroup covers the 8x8 sub-block w of the 32x8 tile */
+    x = tx * TILE_W + 8 * (threadIdx.x >> 6) + (threadIdx.x & 7);
+    row = P.row0 + ty * TILE_H + ((threadIdx.x >> 3) & 7);
+#else
     x = tx * TILE_W + (threadIdx.x & (TILE_W - 1));
     row = P.row0 + ty * TILE_H + (threadIdx.x >> TILE_W_LOG2);
+#endif
     return x < P.W && row < P.row1;
 }
 static inline int tile_grid(int W, int rows)

@@ -54,3 +54,24 @@ run("by direction morton", np.argsort(morton(dn) + np.where(sh, 0, 1 << 40), axi
 run("compact only (shaded first)", np.argsort(np.where(sh, 0, 1), axis=1, kind="stable"))
 rng = np.random.default_rng(1)
 run("random within tile", np.argsort(rng.random((ty * tx, 256)), axis=1))
+# upper bound for length-based regrouping: sort each tile's rays by their ACTUAL any-hit step count
+st = r.trace_stats(rays.reshape(-1, 8)).astype(np.int64).reshape(ty * tx, 256, 2)
+steps = st[..., 0] + st[..., 1]
+run("by actual step count", np.argsort(steps, axis=1, kind="stable"))
+# a realistic predictor: the step count of the same pixel's ray one frame earlier
+res_prev = res
+final = r.frame(4)
+res4 = r.download(api.RT_BUF_RES_0 + final).reshape(H, W)
+rs4 = tiled(res4)
+rays4 = np.zeros_like(rays)
+rays4[..., :3] = rs4["origin_position"] + np.float32(0.001) * rs4["origin_normal"]
+rays4[..., 3:6] = rs4["hit_position"] - rs4["origin_position"]
+rays4[..., 7] = np.where(sh, 0.99, -1.0).astype(np.float32)
+rays_keep = rays
+rays = rays4
+r.trace_mode(4)
+run("frame 4, tile order", ident)
+run("frame 4, by frame-3 step count", np.argsort(steps, axis=1, kind="stable"))
+st4 = r.trace_stats(rays.reshape(-1, 8)).astype(np.int64).reshape(ty * tx, 256, 2)
+run("frame 4, by own step count", np.argsort(st4[..., 0] + st4[..., 1], axis=1, kind="stable"))
+print("corr(frame3 steps, frame4 steps) = %.3f" % np.corrcoef(steps[sh].ravel(), (st4[..., 0] + st4[..., 1])[sh].ravel())[0, 1])

@@ -1,0 +1,91 @@
+"""Turns the rocprofv3 result databases of tools/profile_round.sh (gpurun_out/<tag>/) into the
+summaries committed under profiles/: <tag>_bench.json, <tag>_kernel_stats.csv,
+<tag>_pmc_fetch_write.json, <tag>_pmc_valu.json and spatial_pmc_latest.json (read by bench.py)."""
+import sys, os, json, sqlite3, collections, glob, shutil
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(ROOT, "profiles")
+
+
+def db(path):
+    f = glob.glob(os.path.join(src, path, "*.db"))
+    return sqlite3.connect(f[0]) if f else None
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "").strip()
+
+
+# kernel-trace stats: name, calls, total/avg/min/max duration (ns), share
+con = db("stats")
+rows = collections.defaultdict(list)
+for name, dur in con.execute("select name, duration from kernels"):
+    rows[short(name)].append(dur)
+total = sum(sum(v) for v in rows.values())
+with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
+    f.write("Name,Calls,TotalDurationNs,AverageNs,MinNs,MaxNs,Percentage\n")
+    for k, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
+        f.write(f'"{k}",{len(v)},{sum(v)},{sum(v)/len(v):.1f},{min(v)},{max(v)},{100.0*sum(v)/total:.3f}\n')
+stats_avg_ms = {k: sum(v) / len(v) * 1e-6 for k, v in rows.items()}
+
+
+def counters(path):
+    con = db(path)
+    if con is None:
+        return {}
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for k, c, v in con.execute("select kernel_name, counter_name, value from counters_collection"):
+        agg[short(k)][c].append(v)
+    return {k: {c: dict(launches=len(v), mean=sum(v) / len(v)) for c, v in cs.items()} for k, cs in agg.items()}
+
+
+fw = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    fw[c] = {k: dict(launches=v[c]["launches"], mean_KB=v[c]["mean"]) for k, v in counters("pmc_" + c).items() if c in v}
+json.dump(fw, open(os.path.join(dst, f"{tag}_pmc_fetch_write.json"), "w"), indent=1)
+
+valu = counters("pmc_valu")
+mix = counters("pmc_mix")
+out = {}
+for k, cs in valu.items():
+    if not k.startswith("k_") or "bvh" in k:
+        continue
+    e = {c: v["mean"] for c, v in cs.items()}
+    e.update({c: v["mean"] for c, v in mix.get(k, {}).items()})
+    if k in stats_avg_ms and e.get("SQ_INSTS_VALU"):
+        ms = stats_avg_ms[k]
+        # 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD (16 lanes) for 4 cycles
+        e["avg_ms_kernel_trace"] = ms
+        e["valu_issue_ms_at_2p4GHz"] = e["SQ_INSTS_VALU"] * 4 / 1024 / 2.4e6
+        e["valu_issue_fraction"] = e["valu_issue_ms_at_2p4GHz"] / ms
+        if e.get("SQ_WAVES"):
+            e["valu_insts_per_wave"] = e["SQ_INSTS_VALU"] / e["SQ_WAVES"]
+    out[k] = e
+json.dump(out, open(os.path.join(dst, f"{tag}_pmc_valu.json"), "w"), indent=1)
+
+shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
+
+# spatial kernel HBM traffic, corrected as calibrated in profiles/r01_fetch_calibration.json
+sp = [k for k in fw["FETCH_SIZE"] if k.startswith("k_spatial<")]
+if sp:
+    k = sp[0]
+    W, H = 1920, 1080
+    fetch = fw["FETCH_SIZE"][k]["mean_KB"] * 1024
+    write = fw["WRITE_SIZE"][k]["mean_KB"] * 1024
+    streamed = W * H * 112  # own G-buffer (32 B) + own record (64 B) + own radiance (16 B), read as 64-B-stride streams
+    corrected = fetch + streamed / 2
+    json.dump({
+        "kernel": k, "round": tag, "workload": "blocks_restir stand-in 1920x1080, bench options",
+        "FETCH_SIZE_KB_per_launch": fetch / 1024, "WRITE_SIZE_KB_per_launch": write / 1024,
+        "read_bytes_corrected": corrected, "streamed_read_bytes_known": streamed,
+        "hbm_bytes_per_launch": corrected + write,
+        "note": "MI355X_MICROARCH.md HBM section: FETCH_SIZE/WRITE_SIZE in KB, separate --pmc passes. Calibrated on this pool with "
+                "tools/fetch_calib.hip (profiles/r01_fetch_calibration.json): a 64-B-stride record stream read with 4 x dwordx4 per "
+                "lane reports exactly 1/2 of its bytes (the guide's gfx950 x2 correction), random 64-B record gathers report 1.00 of "
+                "their bytes. k_spatial streams 112 B/pixel and gathers the rest, so reads = FETCH_SIZE + streamed/2; WRITE_SIZE is exact.",
+        "source": f"profiles/{tag}_pmc_fetch_write.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)",
+    }, open(os.path.join(dst, "spatial_pmc_latest.json"), "w"), indent=1)
+print(open(os.path.join(dst, f"{tag}_kernel_stats.csv")).read())
+print(json.dumps({k: {c: (round(v, 3) if v < 100 else round(v)) for c, v in e.items()} for k, e in out.items()}, indent=0))

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Produces the raw material of one profiles/<tag>_* set on the GPU box (run from the repo root):
+#   bash tools/profile_round.sh r01_f
+# bench line, rocprofv3 kernel-trace stats, and separate PMC passes (never combined with traces).
+set -u
+TAG=${1:-rXX}
+export TMPDIR=/tmp
+OUT=gpurun_out/$TAG
+rm -rf $OUT; mkdir -p $OUT
+timeout 300 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o st -- python3 bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --pmc $c -d $OUT/pmc_$c -o pmc -- python3 bench.py --no-cpu-baseline --steps 16 --warmup 2 > $OUT/pmc_$c.log 2>&1
+done
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_valu -o pmc -- python3 bench.py --no-cpu-baseline --steps 16 --warmup 2 > $OUT/pmc_valu.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU -d $OUT/pmc_mix -o pmc -- python3 bench.py --no-cpu-baseline --steps 16 --warmup 2 > $OUT/pmc_mix.log 2>&1
+find $OUT -name "*.csv" | head -30
+cat $OUT/bench.json
