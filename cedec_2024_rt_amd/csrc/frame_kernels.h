@@ -244,9 +244,10 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_generate_candidate(
         /* common/core.hpp:261-285 */
         uint32_t nth = (uint32_t)(rv0 * fL);
         if (nth == (uint32_t)P.n_lights) nth = (uint32_t)P.n_lights - 1u;
-        /* 48-B light record = 3 lane-loads (the loop is bound by the number of divergent per-lane
-         * loads, not by ALU): vertices + luminance(Ke) + pdf; the normal is recomputed with the
-         * reference's exact expression (common/core.hpp:50-55), Ke is fetched once at the end. */
+        /* 64-B light record: vertices + luminance(Ke) + pdf + the geometric normal (the reference's
+         * exact expression, common/core.hpp:50-55, evaluated once at scene set: the loop is bound by
+         * vector-ALU issue and a normalize costs 3 IEEE divisions + a square root); Ke is fetched
+         * once at the end. */
         const float4* L = S.lights + RT_LIGHT_STRIDE * (size_t)nth;
         const float4 L0 = L[0], L1 = L[1], L2 = L[2];
         const f3 v0 = F3(L0.x, L0.y, L0.z), v1 = F3(L0.w, L1.x, L1.y), v2 = F3(L1.z, L1.w, L2.x);
