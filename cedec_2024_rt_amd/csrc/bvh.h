@@ -439,6 +439,150 @@ RT_DEV bool check_visibility_wide(const WideView& bvh, uint32_t* __restrict__ ld
     return !trace_wide<true>(bvh, lds_stack, org, dir, 0.0f, 0.99f, h);
 }
 
+/* Up to NR shadow rays of ONE lane from a common surface point, walked back to back: ray k is
+ * check_visibility(p0, n0, tgt[k]) (origin p0 + 0.001 n0, direction tgt[k] - p0, t in [0, 0.99]) and is
+ * traced iff bit k of `need` is set; returns the mask of occluded rays. A lane starts its next ray as
+ * soon as its current one is settled (refill pass, batched like the leaf pass: when at least
+ * RT_BATCH_REFILL lanes wait or nobody walks), so the lanes of a wavefront stay busy for the SUM of
+ * their ray lengths instead of 6 times the longest (used by the shadowed-target passes, where one
+ * pixel needs up to 6 independent rays). Per-ray steps and results are those of trace_wide<true>. */
+#ifndef RT_BATCH_REFILL
+#define RT_BATCH_REFILL 1
+#endif
+template <int NR>
+RT_DEV uint32_t occluded_batch(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3 p0, f3 n0, const f3 (&tgt)[NR],
+                               uint32_t need)
+{
+    if (bvh.n_tris <= 0) return 0u;
+    constexpr uint32_t NONE = 0x7fffffffu;
+    const f3 ro = p0 + 0.001f * n0;
+    const float tmin = 0.0f, tmax = 0.99f;
+    const int lane_slot = threadIdx.x;
+    uint32_t occluded = 0u;
+    uint32_t ovf[WIDE_OVF_STACK];
+    int sp = 0;
+    auto push = [&](uint32_t e) {
+        if (sp < WIDE_LDS_STACK) lds_stack[sp * BLOCK_THREADS + lane_slot] = e;
+        else ovf[sp - WIDE_LDS_STACK] = e;
+        ++sp;
+    };
+    auto pop = [&]() -> uint32_t {
+        --sp;
+        uint32_t e;
+        if (sp < WIDE_LDS_STACK) e = lds_stack[sp * BLOCK_THREADS + lane_slot];
+        else e = ovf[sp - WIDE_LDS_STACK];
+        return e;
+    };
+    f3 rd = F3(0.0f, 0.0f, 1.0f), inv = F3(0.0f, 0.0f, 1.0f);
+    bool px = true, py = true, pz = true;
+    uint32_t ray_bit = 0u;
+    uint32_t cur = NONE, pend = NONE, pend2 = NONE;
+    for (;;)
+    {
+        if ((int)cur < 0 && pend2 == NONE)
+        {
+            if (pend == NONE) pend = cur; else pend2 = cur;
+            cur = sp ? pop() : NONE;
+        }
+        const bool has_inner = cur < NONE;
+        const bool has_pend = pend != NONE;
+        const bool live = has_inner || has_pend;
+        const bool want = !live && need != 0u;
+        const unsigned long long bl = __ballot(live), bw = __ballot(want);
+        if (bl == 0ull && bw == 0ull) break; /* the whole wavefront is done */
+        if (bw != 0ull && (bl == 0ull || __popcll(bw) >= RT_BATCH_REFILL))
+        {
+            if (want)
+            {
+                const int k = __ffs((int)need) - 1;
+                ray_bit = 1u << k;
+                need &= ~ray_bit;
+                f3 t = tgt[0];
+#pragma unroll
+                for (int j = 1; j < NR; ++j)
+                    if (k == j) t = tgt[j];
+                rd = t - p0;
+                inv = F3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                inv.x = fminf(fmaxf(inv.x, -1e30f), 1e30f);
+                inv.y = fminf(fmaxf(inv.y, -1e30f), 1e30f);
+                inv.z = fminf(fmaxf(inv.z, -1e30f), 1e30f);
+                px = inv.x >= 0.0f; py = inv.y >= 0.0f; pz = inv.z >= 0.0f;
+                cur = 0u; sp = 0;
+            }
+            continue;
+        }
+        if (!live) continue; /* waits for the refill pass */
+        const unsigned long long bi = __ballot(has_inner), bp = __ballot(has_pend);
+        const int parked = __popcll(bp) + __popcll(__ballot(pend2 != NONE));
+        if (bp != 0ull && (bi == 0ull || RT_LEAF_DEN * parked >= RT_LEAF_NUM * __popcll(bl)))
+        {
+            if (has_pend)
+            {
+                const float4* g = bvh.rec + 3 * (size_t)(pend & ~WIDE_LEAF_BIT);
+                const float4 t0 = g[0], t1 = g[1], t2 = g[2];
+                pend = pend2; pend2 = NONE;
+                const f3 v0 = F3(t0.x, t0.y, t0.z), v1 = F3(t0.w, t1.x, t1.y), v2 = F3(t1.z, t1.w, t2.x);
+                float t, u, v;
+                if (intersect_ray_triangle(t, u, v, ro, rd, tmin, tmax, v0, v1, v2))
+                {
+                    occluded |= ray_bit; /* any hit settles a shadow ray */
+                    cur = NONE; pend = NONE; sp = 0;
+                }
+            }
+            continue;
+        }
+        if (has_inner)
+        {
+            const float4* g = bvh.rec + 3 * (size_t)cur;
+            const float4 q0 = g[0], q1f = g[1], q2f = g[2];
+            const uint32_t e = as_uint(q0.w);
+            const uint32_t base = as_uint(q1f.x), meta = as_uint(q1f.y);
+            const uint32_t lx = as_uint(q1f.z), ly = as_uint(q1f.w), lz = as_uint(q2f.x);
+            const uint32_t hx = as_uint(q2f.y), hy = as_uint(q2f.z), hz = as_uint(q2f.w);
+            const uint32_t nx = px ? lx : hx, ny = py ? ly : hy, nz = pz ? lz : hz;
+            const uint32_t fx = px ? hx : lx, fy = py ? hy : ly, fz = pz ? hz : lz;
+            const float sx = as_float((e & 0xffu) << 23), sy = as_float(((e >> 8) & 0xffu) << 23),
+                        sz = as_float(((e >> 16) & 0xffu) << 23);
+            const float Ax = (q0.x - ro.x) * inv.x, Ay = (q0.y - ro.y) * inv.y, Az = (q0.z - ro.z) * inv.z;
+            const float Bx = sx * inv.x, By = sy * inv.y, Bz = sz * inv.z;
+            bool h[4];
+            uint32_t ce[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+            {
+                const uint32_t m = (meta >> (8 * k)) & 0xffu;
+                float tn = fmaxf(fmaxf(__builtin_fmaf(wide_byte(nx, k), Bx, Ax), __builtin_fmaf(wide_byte(ny, k), By, Ay)),
+                                 __builtin_fmaf(wide_byte(nz, k), Bz, Az));
+                float tf = fminf(fminf(__builtin_fmaf(wide_byte(fx, k), Bx, Ax), __builtin_fmaf(wide_byte(fy, k), By, Ay)),
+                                 __builtin_fmaf(wide_byte(fz, k), Bz, Az));
+                tn = fmaxf(tn * (1.0f - 4e-7f), tmin);
+                tf = fminf(tf * (1.0f + 4e-7f), tmax);
+                h[k] = (m != 0u) && (tn <= tf);
+                ce[k] = (base + (uint32_t)k) | (m == 2u ? WIDE_LEAF_BIT : 0u);
+            }
+            if (h[0] || h[1] || h[2] || h[3])
+            {
+                const bool deep = __ballot(sp + 3 > WIDE_LDS_STACK) != 0ull;
+                cur = h[0] ? ce[0] : (h[1] ? ce[1] : (h[2] ? ce[2] : ce[3]));
+                if (__builtin_expect(deep, 0))
+                {
+                    if (h[1] && h[0]) push(ce[1]);
+                    if (h[2] && (h[0] || h[1])) push(ce[2]);
+                    if (h[3] && (h[0] || h[1] || h[2])) push(ce[3]);
+                }
+                else
+                {
+                    if (h[1] && h[0]) { lds_stack[sp * BLOCK_THREADS + lane_slot] = ce[1]; ++sp; }
+                    if (h[2] && (h[0] || h[1])) { lds_stack[sp * BLOCK_THREADS + lane_slot] = ce[2]; ++sp; }
+                    if (h[3] && (h[0] || h[1] || h[2])) { lds_stack[sp * BLOCK_THREADS + lane_slot] = ce[3]; ++sp; }
+                }
+            }
+            else cur = sp ? pop() : NONE;
+        }
+    }
+    return occluded;
+}
+
 /* common/core.hpp:32-36 + common/raytrace.hpp:45-52: 1 = visible, 0 = occluded */
 RT_DEV bool check_visibility(const BvhView& bvh, f3 p0, f3 n0, f3 p1)
 {

@@ -187,22 +187,49 @@ RT_DEV void res_take_sample(Res& r, const Res& o)
 }
 
 /* temporal merge of 10_restir_di.cu:177-233; r = current, pr = previous frame, same pixel */
+/* evaluate_target_function with the shadow term already known (common/reservoir.hpp:42-59) */
+RT_DEV float target_shadowed(f3 op, f3 on, f3 hp, f3 hn, float lum, float V)
+{
+    return (1.0f / kPI) * geometry_term(op, on, hp, hn) * V * lum;
+}
+
+/* The (<= 2) distinct shadow rays of a pixel's candidate + temporal step under the shadowed target
+ * function: surface -> current sample (p-hat of :115-123, the visibility-reuse ray of :127-131 and, if
+ * the current sample survives the merge, the p-hat of :225-229 are the same ray) and surface ->
+ * previous sample (:195-199; again :225-229 if it wins). The previous sample's ray is not walked
+ * when its weight is 0 whatever the answer. V = 1 visible, 0 occluded. */
+RT_DEV void temporal_rays(const SceneView& S, uint32_t* s_stack, const FrameParams& P, f3 sp, f3 sn, const Res& r,
+                          const Res& pr, bool with_prev, float& V_cur, float& V_prev)
+{
+    const f3 tgt[2] = {r.hit_p, pr.hit_p};
+    const bool moot = !with_prev || pr.ucw == 0.0f || (P.vis_reuse && !pr.vis);
+    const uint32_t occl = occluded_batch<2>(S.wide, s_stack, sp, sn, tgt, moot ? 1u : 3u);
+    V_cur = (occl & 1u) ? 0.0f : 1.0f;
+    V_prev = (occl & 2u) ? 0.0f : 1.0f;
+}
+
 template <bool SHADOWED>
-RT_DEV void temporal_merge(const SceneView& S, uint32_t* s_stack, const FrameParams& P, int x, int yi, f3 sp, f3 sn, Res& r,
-                           Res pr)
+RT_DEV void temporal_merge(const FrameParams& P, int x, int yi, f3 sp, f3 sn, Res& r, Res pr, float V_cur, float V_prev)
 {
     PCG rng = pcg_init(hashPCG4((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame, 1u), 0);
     const int cap = 20 * P.ris_sample_count;
     pr.M = pr.M < cap ? pr.M : cap;
-    float p_hat_y = target_function<SHADOWED>(S, s_stack, sp, sn, pr.hit_p, pr.hit_n, pr.lum);
+    float p_hat_y = SHADOWED ? target_shadowed(sp, sn, pr.hit_p, pr.hit_n, pr.lum, V_prev)
+                             : target_unshadowed(sp, sn, pr.hit_p, pr.hit_n, pr.lum);
     if (P.vis_reuse) p_hat_y *= pr.vis ? 1.0f : 0.0f;
     pr.M = scale_M(pr.M, rejection_heuristics(r.org_p, r.org_n, pr.org_p, pr.org_n, P.eye));
     const float weight = p_hat_y * pr.ucw * (float)pr.M;
     const float u = rng.uniformf();
     r.w_sum += weight;
     r.M += pr.M;
-    if (u < weight / r.w_sum) res_take_sample(r, pr);
-    const float p_hat = target_function<SHADOWED>(S, s_stack, sp, sn, r.hit_p, r.hit_n, r.lum);
+    float V = V_cur;
+    if (u < weight / r.w_sum)
+    {
+        res_take_sample(r, pr);
+        V = V_prev;
+    }
+    const float p_hat = SHADOWED ? target_shadowed(sp, sn, r.hit_p, r.hit_n, r.lum, V)
+                                 : target_unshadowed(sp, sn, r.hit_p, r.hit_n, r.lum);
     r.ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
 }
 
@@ -279,19 +306,28 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_generate_candidate(
         const float4 ke = S.light_ke[sel];
         r.rad = F3(ke.x, ke.y, ke.z);
     }
+    Res pr = res_zero();
+    auto load_prev = [&]() {
+        bool dummy;
+        pr = res_load(prev_rec, li, dummy);
+        const float4 pq = prev_rad[li];
+        pr.rad = F3(pq.x, pq.y, pq.z);
+    };
+    if (FUSE_TEMPORAL && SHADOWED) load_prev(); /* its sample is a ray target */
+    float V_cur = 1.0f, V_prev = 1.0f;
+    if (SHADOWED) temporal_rays(S, s_stack, P, sp, sn, r, pr, FUSE_TEMPORAL, V_cur, V_prev);
+    else if (P.vis_reuse) V_cur = check_visibility_wide(S.wide, s_stack, sp, sn, r.hit_p) ? 1.0f : 0.0f;
     {
-        const float p_hat = target_function<SHADOWED>(S, s_stack, sp, sn, r.hit_p, r.hit_n, r.lum);
+        const float p_hat = SHADOWED ? target_shadowed(sp, sn, r.hit_p, r.hit_n, r.lum, V_cur)
+                                     : target_unshadowed(sp, sn, r.hit_p, r.hit_n, r.lum);
         r.ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
     }
-    if (P.vis_reuse) r.vis = check_visibility_wide(S.wide, s_stack, sp, sn, r.hit_p);
+    if (P.vis_reuse) r.vis = V_cur != 0.0f; /* :127-131 */
 
     if (FUSE_TEMPORAL)
     {
-        bool dummy;
-        Res pr = res_load(prev_rec, li, dummy);
-        const float4 pq = prev_rad[li];
-        pr.rad = F3(pq.x, pq.y, pq.z);
-        temporal_merge<SHADOWED>(S, s_stack, P, x, yi, sp, sn, r, pr);
+        if (!SHADOWED) load_prev(); /* after the walk: not live across it */
+        temporal_merge<SHADOWED>(P, x, yi, sp, sn, r, pr, V_cur, V_prev);
     }
     res_store(out_rec, out_rad, li, r, true);
 }
@@ -322,7 +358,9 @@ __global__ __launch_bounds__(BLOCK) void k_temporal(SceneView S, FrameParams P, 
     Res pr = res_load(prev_rec, li, dummy);
     const float4 pq = prev_rad[li];
     pr.rad = F3(pq.x, pq.y, pq.z);
-    temporal_merge<SHADOWED>(S, s_stack, P, x, yi, sp, sn, r, pr);
+    float V_cur = 1.0f, V_prev = 1.0f;
+    if (SHADOWED) temporal_rays(S, s_stack, P, sp, sn, r, pr, true, V_cur, V_prev);
+    temporal_merge<SHADOWED>(P, x, yi, sp, sn, r, pr, V_cur, V_prev);
     res_store(rec, radb, li, r, true);
 }
 
@@ -359,7 +397,84 @@ __global__ __launch_bounds__(BLOCK) void k_spatial(SceneView S, FrameParams P, c
     Res r = res_load(in_rec, li, own_shaded);
     size_t rad_from = li;
 
-    if (P.use_spatial)
+    if (SHADOWED && P.use_spatial && P.spatial_count <= 5)
+    {
+        /* Shadowed target function (:346-350, :370-374): the reference traces one shadow ray per accepted
+         * neighbour (surface point -> the neighbour's light sample) and one for the finally selected
+         * sample. None of those rays depends on the merge chain, and the final one repeats the ray of
+         * whichever sample won, so: (1) draw all random numbers and pick the neighbours, (2) walk the
+         * <= 6 distinct rays of the pixel back to back (occluded_batch), (3) run the merge chain with
+         * the visibilities. A neighbour's ray is not traced when its weight is 0 whatever the answer
+         * (ucw == 0, or visibility reuse with an occluded sample). Same results, same reference ray
+         * count (rt_ray_count counts raytrace() calls of the reference, not walks). */
+        const float scale = P.spatial_radius / 1.96f;
+        long long pid[5];
+        float ud[5];
+        f3 tgt[6];
+        uint32_t need = 0u;
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+        {
+            pid[k] = -1; ud[k] = 0.0f; tgt[k] = F3(0.0f, 0.0f, 0.0f);
+            if (k < P.spatial_count)
+            {
+                const float rv0 = rng.uniformf();
+                const float rv1 = rng.uniformf();
+                const float radius = sqrtf(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
+                const float phi = 2.0f * kPI * rv1;
+                const float gx = radius * pm_cosf(phi), gy = radius * pm_sinf(phi);
+                const int nx = f2i_sat((float)x + scale * gx);
+                const int ny = f2i_sat((float)yi + scale * gy);
+                const int lr = P.H - 1 - ny - P.lrow0;
+                const bool ok = !(nx < 0 || nx >= P.W || ny < 0 || ny >= P.H) && !(nx == x && ny == yi) && !(lr < 0 || lr >= P.lrows);
+                if (ok)
+                {
+                    const size_t id = (size_t)nx + (size_t)lr * P.W;
+                    const float4 q0 = in_rec[4 * id + 0], q1 = in_rec[4 * id + 1];
+                    const uint32_t mb = as_uint(q1.w);
+                    if (mb & RES_SHADED_BIT)
+                    {
+                        pid[k] = (long long)id;
+                        ud[k] = rng.uniformf();
+                        tgt[k] = F3(q0.x, q0.y, q0.z);
+                        const bool moot = (q0.w == 0.0f) || (P.vis_reuse && !(mb & RES_VIS_BIT));
+                        if (!moot) need |= 1u << k;
+                    }
+                }
+            }
+        }
+        tgt[5] = r.hit_p;
+        need |= 1u << 5;
+        const uint32_t occl = occluded_batch<6>(S.wide, s_stack, sp, sn, tgt, need);
+        int sel = 5;
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+        {
+            if (pid[k] >= 0)
+            {
+                bool n_shaded;
+                Res nr = res_load(in_rec, (size_t)pid[k], n_shaded);
+                /* evaluate_target_function with the shadow term (common/reservoir.hpp:42-59) */
+                const float V = (occl >> k) & 1u ? 0.0f : 1.0f;
+                float p_hat_y = (1.0f / kPI) * geometry_term(sp, sn, nr.hit_p, nr.hit_n) * V * nr.lum;
+                if (P.vis_reuse) p_hat_y *= nr.vis ? 1.0f : 0.0f;
+                nr.M = scale_M(nr.M, rejection_heuristics(r.org_p, r.org_n, nr.org_p, nr.org_n, P.eye));
+                const float weight = p_hat_y * nr.ucw * (float)nr.M;
+                r.w_sum += weight;
+                r.M += nr.M;
+                if (ud[k] < weight / r.w_sum)
+                {
+                    res_take_sample(r, nr);
+                    rad_from = (size_t)pid[k];
+                    sel = k;
+                }
+            }
+        }
+        const float Vf = (occl >> sel) & 1u ? 0.0f : 1.0f;
+        const float p_hat = (1.0f / kPI) * geometry_term(sp, sn, r.hit_p, r.hit_n) * Vf * r.lum;
+        r.ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
+    }
+    else if (P.use_spatial)
     {
         const float scale = P.spatial_radius / 1.96f;
         for (int k = 0; k < P.spatial_count; ++k)
@@ -415,7 +530,7 @@ __global__ __launch_bounds__(BLOCK) void k_spatial_bytes(FrameParams P, const fl
 {
     int x, row;
     const bool ok = tile_pixel(P, x, row);
-    unsigned long long bytes = 0, accepted = 0;
+    unsigned long long bytes = 0, accepted = 0, merged = 0;
     if (ok)
     {
         const int yi = P.H - 1 - row;
@@ -445,6 +560,7 @@ __global__ __launch_bounds__(BLOCK) void k_spatial_bytes(FrameParams P, const fl
                     const uint32_t mb = as_uint(in_rec[4 * ((size_t)nx + (size_t)lr * P.W) + 1].w);
                     if (!(mb & RES_SHADED_BIT)) continue;
                     bytes += 76;
+                    merged += 1; /* neighbours that reach the target function (:346-350) */
                     rng.uniformf();
                 }
             }
@@ -454,11 +570,13 @@ __global__ __launch_bounds__(BLOCK) void k_spatial_bytes(FrameParams P, const fl
     {
         bytes += __shfl_down(bytes, off);
         accepted += __shfl_down(accepted, off);
+        merged += __shfl_down(merged, off);
     }
     if ((threadIdx.x & 63) == 0)
     {
         atomicAdd(&out[0], bytes);
         atomicAdd(&out[1], accepted);
+        atomicAdd(&out[2], merged);
     }
 }
 
@@ -707,7 +825,9 @@ RT_DEV bool path_bounce(const SceneView& S, uint32_t* s_stack, const FrameParams
         const float G = geometry_term(sp, sn, r.hit_p, r.hit_n);
         const float V = check_visibility_wide(S.wide, s_stack, sp, sn, r.hit_p) ? 1.0f : 0.0f;
         ++nrays;
-        const float p_hat = target_function<SHADOWED>(S, s_stack, sp, sn, r.hit_p, r.hit_n, r.lum);
+        /* the reference traces this ray again for the shadowed p-hat (09_ris.cu:110-118): same ray, same answer */
+        const float p_hat = SHADOWED ? target_shadowed(sp, sn, r.hit_p, r.hit_n, r.lum, V)
+                                     : target_unshadowed(sp, sn, r.hit_p, r.hit_n, r.lum);
         if (SHADOWED) ++nrays;
         const float ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
         st.radiance = st.radiance + st.throughput * brdf * G * V * r.rad * ucw;

@@ -51,6 +51,7 @@ struct rt_ctx
     int tune_tile_mode[5] = {1, 0, 1, 0, 0};
     int tune_spatial_lds = 32768;
     float last_trace_ms = 0.0f;
+    int last_frame = 0; /* frame number of the last rt_frame_stage / rt_spatial_resampling (ray counting) */
     int trace_mode = 0; /* rt_trace_closest / rt_trace_stats: 0 = wide (what the frame kernels use), 1 = binary stackless */
     float bvh_split_factor = 8.0f; /* fragment length in median triangle extents; 0 = no pre-split */
     int bvh_bfs_records = 2048; /* rt_tuning key 7: records emitted breadth-first (top of the tree contiguous) */
@@ -729,6 +730,9 @@ static int halo_rows_needed(const rt_options& o)
     if (!o.use_spatial_resampling || o.spatial_resampling_sample_count <= 0) return 0;
     return (int)ceilf(o.spatial_resampling_radius / 1.96f * 5.6471f);
 }
+#ifndef RT_SHADOWED_SPATIAL_LDS
+#define RT_SHADOWED_SPATIAL_LDS 0 /* the walk's own LDS stack already limits the shadowed variant to 6 workgroups per CU */
+#endif
 static int launch_spatial(rt_ctx* c, int frame, int pass, int in_phys, int out_phys)
 {
     const int need = halo_rows_needed(c->opt);
@@ -739,7 +743,7 @@ static int launch_spatial(rt_ctx* c, int frame, int pass, int in_phys, int out_p
     const SceneView S = make_scene(c);
     const FrameParams P = make_params(c, frame, pass, K_SPATIAL);
     if (c->opt.use_shadowed_target_function)
-        k_spatial<true><<<launch_grid(c), BLOCK, (size_t)c->tune_spatial_lds, c->stream>>>(S, P, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys]);
+        k_spatial<true><<<launch_grid(c), BLOCK, (size_t)(RT_SHADOWED_SPATIAL_LDS), c->stream>>>(S, P, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys]);
     else
         k_spatial<false><<<launch_grid(c), BLOCK, (size_t)c->tune_spatial_lds, c->stream>>>(S, P, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys]);
     RT_HIP(c, hipGetLastError());
@@ -753,6 +757,7 @@ int rt_spatial_resampling(rt_ctx* c, int frame, int pass, int in, int out)
     NEED_RES(c, in);
     NEED_RES(c, out);
     if (in == out) RT_FAIL(c, RT_ERR_ARG, "in and out must differ");
+    c->last_frame = frame;
     return launch_spatial(c, frame, pass, c->res_map[in], c->res_map[out]);
 }
 
@@ -863,7 +868,7 @@ int rt_frame_stage_begin(rt_ctx* c, int frame, int stage, int clear_first)
 {
     RT_CHECK_CTX(c);
     NEED_SCENE(c);
-    (void)frame;
+    c->last_frame = frame;
     const int passes = c->opt.spatial_resampling_passes;
     if (stage == 0)
     {
@@ -1261,14 +1266,32 @@ int rt_ray_count(rt_ctx* c, uint64_t* rays, uint64_t* shaded_pixels)
     const uint64_t n = (uint64_t)c->W * (uint64_t)(c->row_end - c->row_begin);
     uint64_t per_shaded = 1; /* resolve (10_restir_di.cu:443-444) */
     if (c->opt.use_visibility_reuse) per_shaded += 1; /* :129-130 */
+    uint64_t merged = 0;
     if (c->opt.use_shadowed_target_function)
     {
-        /* upper bound only: :115-118 (1), temporal :195-199,:224-227 (2), spatial per pass
-         * count+1 (:346-350, :375-378); exact counts come from the oracle's counters */
-        per_shaded += 1 + (c->opt.use_temporal_resampling ? 2 : 0) +
-                      (uint64_t)c->opt.spatial_resampling_passes * (c->opt.use_spatial_resampling ? (uint64_t)c->opt.spatial_resampling_sample_count + 1 : 0);
+        /* p-hat of the candidate (:115-118), two of the temporal step (:195-199, :224-227), and per
+         * spatial pass one per shaded pixel (:375-378) plus one per neighbour that reaches the target
+         * function (:346-350). The latter is counted by replaying the passes' RNG against the shaded
+         * bits of the last frame (any reservoir buffer of that frame carries them). */
+        per_shaded += 1 + (c->opt.use_temporal_resampling ? 2 : 0);
+        if (c->opt.use_spatial_resampling)
+        {
+            per_shaded += (uint64_t)c->opt.spatial_resampling_passes;
+            unsigned long long* d = nullptr;
+            RT_HIP(c, hipMalloc(&d, 24));
+            RT_HIP(c, hipMemsetAsync(d, 0, 24, c->stream));
+            for (int k = 0; k < c->opt.spatial_resampling_passes; ++k)
+                k_spatial_bytes<<<launch_grid(c), BLOCK, 0, c->stream>>>(make_params(c, c->last_frame, k), c->d_g1,
+                                                                        c->d_rec[c->res_map[RT_RES_TEMPORAL]], d);
+            RT_HIP(c, hipGetLastError());
+            unsigned long long h[3] = {0, 0, 0};
+            RT_HIP(c, hipMemcpyAsync(h, d, 24, hipMemcpyDeviceToHost, c->stream));
+            RT_HIP(c, hipStreamSynchronize(c->stream));
+            hipFree(d);
+            merged = h[2];
+        }
     }
-    if (rays) *rays = n + per_shaded * shaded;
+    if (rays) *rays = n + per_shaded * shaded + merged;
     if (shaded_pixels) *shaded_pixels = shaded;
     return RT_OK;
 }
@@ -1279,8 +1302,8 @@ int rt_spatial_bytes(rt_ctx* c, int frame, int pass, int in, uint64_t* bytes, ui
     NEED_RES(c, in);
     if (!c->has_gbuffer) RT_FAIL(c, RT_ERR_STATE, "no G-buffer yet");
     unsigned long long* d = nullptr;
-    RT_HIP(c, hipMalloc(&d, 16));
-    RT_HIP(c, hipMemsetAsync(d, 0, 16, c->stream));
+    RT_HIP(c, hipMalloc(&d, 24));
+    RT_HIP(c, hipMemsetAsync(d, 0, 24, c->stream));
     k_spatial_bytes<<<launch_grid(c), BLOCK, 0, c->stream>>>(make_params(c, frame, pass), c->d_g1, c->d_rec[c->res_map[in]], d);
     RT_HIP(c, hipGetLastError());
     unsigned long long h[2] = {0, 0};

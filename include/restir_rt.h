@@ -191,8 +191,12 @@ int rt_halo_pack_sparse(rt_ctx* ctx, int res, int row0, int n_rows, const void* 
 int rt_halo_unpack_sparse(rt_ctx* ctx, int res, int row0, int n_rows, const void* device_bitmap, const void* device_src);
 
 /* ---- measurement ---- */
-/* rays per frame for the current G-buffer and options: N primary + per shaded pixel the
- * visibility-reuse and resolve shadow rays; shaded = hit & not emissive. */
+/* raytrace() calls the REFERENCE makes for the last frame with the current G-buffer and options
+ * (the ray of BASELINE.md §3 / SURVEY §8d): N primary + per shaded pixel the visibility-reuse and
+ * resolve shadow rays; with use_shadowed_target_function also the target-function rays (candidate 1,
+ * temporal 2, per spatial pass 1 + one per neighbour that reaches the merge, counted by replaying
+ * the passes' RNG). The build walks fewer BVH rays than that where the reference repeats a ray or
+ * the answer cannot matter. shaded = hit & not emissive. */
 int rt_ray_count(rt_ctx* ctx, uint64_t* rays, uint64_t* shaded_pixels);
 /* time spent by the last `rt_frame` per kernel, HIP events on the context's stream.
  * ms[0..7] = clear, raycast, generate(+temporal), spatial pass 0,1,2, resolve, tone_mapping;

@@ -218,9 +218,12 @@ def _setup(api, oracle, tris, W, H, eye, center, **optkw):
     return r, sc, rg, oracle.bench_options(**optkw), np.asarray(eye, np.float32)
 
 
-@pytest.mark.parametrize("scene_name", ["cornellbox1", "quad_room", "cornellbox2"])
+@pytest.mark.parametrize("scene_name", ["cornellbox1", "quad_room", "cornellbox2", "quad_room_shadowed"])
 def test_kernel_by_kernel_parity(api, oracle, scenes, golden_scenes, scene_name):
-    """Every reference kernel, one at a time through its own entry point, two frames."""
+    """Every reference kernel, one at a time through its own entry point, two frames
+    (`_shadowed`: with use_shadowed_target_function, README key 3)."""
+    optkw = dict(use_shadowed_target_function=1) if scene_name.endswith("_shadowed") else {}
+    scene_name = scene_name.replace("_shadowed", "")
     if scene_name == "quad_room":
         tris, eye, center = scenes.make_quad_room(), (0.5, 2.5, 6.0), (0.0, 1.5, -1.0)
     elif scene_name == "cornellbox1":
@@ -228,7 +231,7 @@ def test_kernel_by_kernel_parity(api, oracle, scenes, golden_scenes, scene_name)
     else:
         tris, eye, center = golden_scenes["cornellbox2"], scenes.CORNELLBOX_EYE, scenes.CORNELLBOX_LOOKAT
     W, H = 96, 54
-    r, sc, rg, opt, eyev = _setup(api, oracle, tris, W, H, eye, center)
+    r, sc, rg, opt, eyev = _setup(api, oracle, tris, W, H, eye, center, **optkw)
     st = oracle.new_state(W, H)
     lights = set(sc.lights.tolist())
     for frame in (1, 2):
@@ -288,6 +291,13 @@ def test_kernel_by_kernel_parity(api, oracle, scenes, golden_scenes, scene_name)
     dict(spatial_resampling_passes=2),
     dict(spatial_resampling_passes=1, spatial_resampling_sample_count=3, ris_sample_count=8),
     dict(use_shadowed_target_function=1),
+    # shadowed target: the batched shadow walks (<= 6 distinct rays per pixel and pass) ...
+    dict(use_shadowed_target_function=1, use_visibility_reuse=0),
+    dict(use_shadowed_target_function=1, use_temporal_resampling=0, spatial_resampling_sample_count=3),
+    dict(use_shadowed_target_function=1, use_spatial_resampling=0),
+    # ... and the one-ray-at-a-time form kept for more than 5 neighbours
+    dict(use_shadowed_target_function=1, spatial_resampling_sample_count=7, spatial_resampling_passes=2),
+    dict(spatial_resampling_sample_count=7, spatial_resampling_passes=1),
 ])
 def test_fused_frame_equals_oracle_frame(api, oracle, scenes, optkw):
     """rt_frame (fused generate+temporal, rotating buffers) == the reference's 8-launch frame,
@@ -298,9 +308,12 @@ def test_fused_frame_equals_oracle_frame(api, oracle, scenes, optkw):
     st = oracle.new_state(W, H)
     for frame in (1, 2, 3):
         final = r.frame(frame)
-        sc.frame(W, H, frame, rg, eyev, opt, st)
+        cnt = oracle.new_counters()
+        sc.frame(W, H, frame, rg, eyev, opt, st, cnt)
         acc = r.download(api.RT_BUF_ACCUMULATION)
         assert _eq_bits(acc, st["accum"].reshape(acc.shape)), f"{optkw} frame {frame}: {(acc != st['accum'].reshape(acc.shape)).any(axis=1).sum()} pixels"
+        # rays = raytrace() calls of the reference for this frame, whatever the build really walks
+        assert r.ray_count()[0] == int(cnt["rays"][0]), f"{optkw} frame {frame}: ray count"
         # temporal history handed to the next frame
         shaded = (st["vis"]["index"] >= 0) & ~np.isin(st["vis"]["index"], sc.lights)
         bad = _res_fields_equal(r.download(api.RT_BUF_RES_TEMPORAL), st["temporal"], mask=shaded)
