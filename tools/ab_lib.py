@@ -11,6 +11,8 @@ r = api.Renderer(W, H)
 r.set_scene(scenes.make_blocks_restir())
 r.lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)
 r.set_options(bench_options())
+for kv in os.environ.get("RT_TUNE", "").split(","):
+    if kv: r.tuning(*[int(v) for v in kv.split("=")])
 r.timing_enable(True)
 acc = None
 for fr in range(1, 24):
