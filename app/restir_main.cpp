@@ -6,8 +6,10 @@
  *   restir_app [--obj scene.obj | --tris scene.tris] [--size W H] [--frames N]
  *              [--eye x y z] [--lookat x y z] [--temporal 0|1] [--spatial 0|1]
  *              [--shadowed 0|1] [--visreuse 0|1] [--accumulate 0|1] [--by-kernel]
- *              [--ppm out.ppm] [--pfm out.pfm] [--dump-tris out.tris]
+ *              [--example 10|7|8|9] [--ppm out.ppm] [--pfm out.pfm] [--dump-tris out.tris]
  *
+ * --example 7|8|9 runs the `path_trace` kernel of examples/07_pt, 08_nee or 09_ris instead of the
+ * ReSTIR DI frame (one sample per pixel and frame; use --accumulate 1 to average frames).
  * Keys 1,2,3,4,A of the example (10_restir_di.cpp:143-174) are the --temporal/--spatial/
  * --shadowed/--visreuse/--accumulate flags; key S (screenshot) is --ppm. `--tris` reads a raw
  * array of 60-byte Triangle records (cedec_2024_rt_amd.scenes can write one); `--obj` uses the
@@ -118,6 +120,7 @@ int main(int argc, char** argv)
     const float up[3] = {0, 1, 0};
     std::string obj, tris_path, ppm, pfm, dump;
     bool by_kernel = false;
+    int example = 10;
     rt_options opt;
     memset(&opt, 0, sizeof(opt));
     opt.max_depth = 6; opt.ris_sample_count = 32; opt.rejection_heuristics_threshold = 0.2f;
@@ -140,6 +143,7 @@ int main(int argc, char** argv)
         else if (a == "--visreuse") opt.use_visibility_reuse = (uint8_t)atoi(argv[++i]);
         else if (a == "--accumulate") opt.accumulate = (uint8_t)atoi(argv[++i]);
         else if (a == "--by-kernel") by_kernel = true;
+        else if (a == "--example") example = atoi(argv[++i]);
         else if (a == "--dump-tris") dump = argv[++i]; /* write the loaded triangle array and exit (no GPU needed) */
         else if (a == "--ppm") ppm = argv[++i];
         else if (a == "--pfm") pfm = argv[++i];
@@ -170,7 +174,13 @@ int main(int argc, char** argv)
 
     for (int frame = 1; frame <= frames; ++frame) /* frame++ before the first launch, :233-234 */
     {
-        if (!by_kernel) { CK(rt_frame(ctx, frame, 0, nullptr)); }
+        if (example != 10)
+        {
+            /* examples/07_pt/07_pt.cpp:206-222: path_trace, then tone_mapping */
+            CK(rt_path_trace(ctx, example, frame));
+            CK(rt_tone_mapping(ctx));
+        }
+        else if (!by_kernel) { CK(rt_frame(ctx, frame, 0, nullptr)); }
         else
         {
             /* the launch sequence of 10_restir_di.cpp:270-379, one C-ABI call per kernel */
@@ -188,7 +198,7 @@ int main(int argc, char** argv)
             CK(rt_tone_mapping(ctx));
         }
         CK(rt_sync(ctx));
-        if (!by_kernel)
+        if (!by_kernel && example == 10)
         {
             float ms[9];
             CK(rt_timing(ctx, ms));
@@ -197,8 +207,16 @@ int main(int argc, char** argv)
         }
     }
     uint64_t rays = 0, shaded = 0;
-    CK(rt_ray_count(ctx, &rays, &shaded));
-    printf("rays/frame: %llu (shaded pixels %llu)\n", (unsigned long long)rays, (unsigned long long)shaded);
+    if (example == 10)
+    {
+        CK(rt_ray_count(ctx, &rays, &shaded));
+        printf("rays/frame: %llu (shaded pixels %llu)\n", (unsigned long long)rays, (unsigned long long)shaded);
+    }
+    else
+    {
+        CK(rt_path_trace_rays(ctx, &rays));
+        printf("rays in the last frame: %llu\n", (unsigned long long)rays);
+    }
 
     if (!ppm.empty())
     {

@@ -758,7 +758,7 @@ RT_DEV void path_begin(const FrameParams& P, int x, int yi, PathState& st)
     st.radiance = F3(0.0f, 0.0f, 0.0f);
     st.throughput = F3(1.0f, 1.0f, 1.0f);
 }
-/* one iteration of the depth loop (07_pt.cu:39-79 / 09_ris.cu:39-155); false = the path ended */
+/* one iteration of the depth loop (07_pt.cu:39-79 / 08_nee.cu:39-118 / 09_ris.cu:39-155); false = the path ended */
 template <int EXAMPLE, bool SHADOWED>
 RT_DEV bool path_bounce(const SceneView& S, uint32_t* s_stack, const FrameParams& P, int depth, f3 sky, PathState& st,
                         unsigned long long& nrays)
@@ -785,6 +785,27 @@ RT_DEV bool path_bounce(const SceneView& S, uint32_t* s_stack, const FrameParams
     if (dot(-st.rd, sn) < 0.0f) sn = -sn;
     const f3 kd = F3(kd4.x, kd4.y, kd4.z);
 
+    if (EXAMPLE == 8)
+    {
+        /* next-event estimation (08_nee.cu:66-91): one uniformly picked light sample, one shadow ray */
+        const float rv0 = st.rng.uniformf();
+        float bx = st.rng.uniformf();
+        float by = st.rng.uniformf();
+        uint32_t nth = (uint32_t)(rv0 * (float)(size_t)P.n_lights);
+        if (nth == (uint32_t)P.n_lights) nth = (uint32_t)P.n_lights - 1u;
+        const float4* L = S.lights + RT_LIGHT_STRIDE * (size_t)nth;
+        const float4 L0 = L[0], L1 = L[1], L2 = L[2];
+        const f3 a0 = F3(L0.x, L0.y, L0.z), a1 = F3(L0.w, L1.x, L1.y), a2 = F3(L1.z, L1.w, L2.x);
+        warp_unit_triangle(bx, by);
+        const f3 lp = (1.0f - bx - by) * a0 + bx * a1 + by * a2;
+        const f3 ln = tri_normal(a0, a1, a2);
+        const float V = check_visibility_wide(S.wide, s_stack, sp, sn, lp) ? 1.0f : 0.0f;
+        ++nrays;
+        const f3 brdf = (1.0f / kPI) * kd;
+        const float G = geometry_term(sp, sn, lp, ln);
+        const float4 ke = S.light_ke[nth];
+        st.radiance = st.radiance + st.throughput * brdf * G * V * F3(ke.x, ke.y, ke.z) / L2.z; /* :89-90 */
+    }
     if (EXAMPLE == 9)
     {
         /* RIS over the lights (09_ris.cu:61-99), then the shaded contribution (:101-126) */

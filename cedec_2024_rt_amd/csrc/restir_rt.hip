@@ -784,13 +784,13 @@ int rt_tone_mapping(rt_ctx* c)
     return RT_OK;
 }
 
-/* examples/07_pt/07_pt.cu (example 7) or examples/09_ris/09_ris.cu (example 9) `path_trace` */
+/* `path_trace` of examples/07_pt/07_pt.cu (example 7), examples/08_nee/08_nee.cu (8) or examples/09_ris/09_ris.cu (9) */
 int rt_path_trace(rt_ctx* c, int example, int frame)
 {
     RT_CHECK_CTX(c);
     NEED_SCENE(c);
-    if (example != 7 && example != 9) RT_FAIL(c, RT_ERR_ARG, "example must be 7 (07_pt) or 9 (09_ris)");
-    if (example == 9 && c->n_lights == 0) RT_FAIL(c, RT_ERR_STATE, "09_ris needs at least one emissive triangle");
+    if (example != 7 && example != 8 && example != 9) RT_FAIL(c, RT_ERR_ARG, "example must be 7 (07_pt), 8 (08_nee) or 9 (09_ris)");
+    if (example != 7 && c->n_lights == 0) RT_FAIL(c, RT_ERR_STATE, "08_nee / 09_ris need at least one emissive triangle");
     const SceneView S = make_scene(c);
     const FrameParams P = make_params(c, frame, 0, K_RAYCAST);
     const f3 sky = F3(c->opt.sky_color[0], c->opt.sky_color[1], c->opt.sky_color[2]);
@@ -817,6 +817,7 @@ int rt_path_trace(rt_ctx* c, int example, int frame)
             const float4* in = c->d_paths[d & 1];
             float4* out = c->d_paths[(d + 1) & 1];
             if (example == 7) k_pt_bounce<7, false><<<gb, BLOCK, 0, c->stream>>>(S, P, d, md, sky, in, out, c->d_accum, c->d_pt_counters);
+            else if (example == 8) k_pt_bounce<8, false><<<gb, BLOCK, 0, c->stream>>>(S, P, d, md, sky, in, out, c->d_accum, c->d_pt_counters);
             else if (sh) k_pt_bounce<9, true><<<gb, BLOCK, 0, c->stream>>>(S, P, d, md, sky, in, out, c->d_accum, c->d_pt_counters);
             else k_pt_bounce<9, false><<<gb, BLOCK, 0, c->stream>>>(S, P, d, md, sky, in, out, c->d_accum, c->d_pt_counters);
             RT_HIP(c, hipGetLastError());
@@ -826,6 +827,7 @@ int rt_path_trace(rt_ctx* c, int example, int frame)
     }
     RT_HIP(c, hipMemsetAsync(c->d_counter, 0, 8, c->stream));
     if (example == 7) k_path_trace<7, false><<<g, BLOCK, 0, c->stream>>>(S, P, md, sky, c->d_accum, c->d_counter);
+    else if (example == 8) k_path_trace<8, false><<<g, BLOCK, 0, c->stream>>>(S, P, md, sky, c->d_accum, c->d_counter);
     else if (sh) k_path_trace<9, true><<<g, BLOCK, 0, c->stream>>>(S, P, md, sky, c->d_accum, c->d_counter);
     else k_path_trace<9, false><<<g, BLOCK, 0, c->stream>>>(S, P, md, sky, c->d_accum, c->d_counter);
     RT_HIP(c, hipGetLastError());

@@ -130,8 +130,9 @@ int rt_spatial_resampling(rt_ctx* ctx, int frame, int pass, int in, int out); /*
 int rt_resolve(rt_ctx* ctx, int res);                        /* resolve             .cu:390-459      */
 int rt_tone_mapping(rt_ctx* ctx);                            /* tone_mapping        common.cu:30-74  */
 
-/* ---- BASELINE configs #2 / #3: the `path_trace` kernels of examples/07_pt/07_pt.cu:11-90
- * (example = 7) and examples/09_ris/09_ris.cu:11-166 (example = 9); camera, Options (max_depth,
+/* ---- BASELINE configs #2 / #3 (+ 08_nee): the `path_trace` kernels of
+ * examples/07_pt/07_pt.cu:11-90 (example = 7), examples/08_nee/08_nee.cu:11-140 (example = 8) and
+ * examples/09_ris/09_ris.cu:11-166 (example = 9); camera, Options (max_depth,
  * sky_color, ris_sample_count, accumulate, use_shadowed_target_function) and the accumulation
  * buffer as for 10_restir_di; follow with rt_tone_mapping as 07_pt.cpp:222 does. ---- */
 int rt_path_trace(rt_ctx* ctx, int example, int frame);

@@ -136,6 +136,7 @@ def lib():
         L.o_frame.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.o_ao_04.argtypes = [vp, vp, vp, ci, ci]
         L.o_path_trace_07.argtypes = [vp, ci, ci, ci, vp, vp, vp, ci, ci, vp]
+        L.o_path_trace_08.argtypes = [vp, ci, ci, ci, vp, vp, vp, ci, ci, vp]
         L.o_path_trace_09.argtypes = [vp, ci, ci, ci, vp, vp, vp, ci, ci, vp]
         _lib = L
         L.o_set_threads(effective_cpus())
@@ -257,9 +258,9 @@ class Scene:
         return state
 
     def path_trace(self, example, W, H, frame, raygen, opt, accum, rows=None, cnt=None):
-        """examples/07_pt (example=7) or examples/09_ris (example=9) `path_trace` kernel."""
+        """examples/07_pt (example=7), examples/08_nee (8) or examples/09_ris (9) `path_trace` kernel."""
         r0, r1 = rows or (0, H)
-        fn = lib().o_path_trace_07 if example == 7 else lib().o_path_trace_09
+        fn = {7: lib().o_path_trace_07, 8: lib().o_path_trace_08, 9: lib().o_path_trace_09}[example]
         fn(self.h, W, H, frame, _p(raygen), _p(opt), _p(accum), r0, r1, _p(cnt))
         return accum
 

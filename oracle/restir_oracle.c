@@ -1330,6 +1330,74 @@ ORACLE_API void o_path_trace_07(const OScene* s, int W, int H, int frame, const 
     if (cnt) cnt->rays += rays;
 }
 
+/* examples/08_nee/08_nee.cu:11-140: path tracing with next-event estimation (one uniformly picked
+ * light sample and one shadow ray per bounce; emission counted at depth 0 only) */
+ORACLE_API void o_path_trace_08(const OScene* s, int W, int H, int frame, const ORayGen* rg,
+                                const OOptions* opt, v4* accum, int row0, int row1, OCounters* cnt)
+{
+    long rays = 0;
+#pragma omp parallel for schedule(dynamic, 2) reduction(+ : rays)
+    for (int row = row0; row < row1; ++row)
+    {
+        const int yi = H - 1 - row;
+        for (int xi = 0; xi < W; ++xi)
+        {
+            const int pixel_idx = xi + row * W;
+            PCG rng = pcg_init(hashPCG3((uint32_t)xi, (uint32_t)yi, (uint32_t)frame), 0); /* :27 */
+            v3 ro, rd;
+            raygen_shoot(rg, &ro, &rd, (float)xi / (float)W, (float)yi / (float)H);
+            v3 radiance = V3(0.0f, 0.0f, 0.0f), throughput = V3(1.0f, 1.0f, 1.0f);
+            for (int depth = 0; depth < opt->max_depth; ++depth)
+            {
+                OHit h;
+                ++rays;
+                if (!raytrace(s, ro, rd, 0.0f, O_FLT_MAX, &h)) break; /* :43-49, the sky is not a light here */
+                const OTriangle* tri = &s->tris[h.index];
+                if (has_emission(tri))
+                {
+                    if (depth == 0) radiance = add(radiance, mulv(throughput, tri->emissive)); /* :53-61 */
+                    break;
+                }
+                const Surf surf = make_surface_info_ray(tri, ro, rd, h.t);
+                /* :67-69: the three draws are function arguments, evaluated left to right (clang) */
+                const float rv0 = pcg_uniformf(&rng);
+                const float rv1 = pcg_uniformf(&rng);
+                const float rv2 = pcg_uniformf(&rng);
+                const LightSample ls = sample_light(s, rv0, rv1, rv2);
+                {
+                    const OTriangle* lt = &s->tris[ls.index];
+                    const float V = check_visibility(s, surf.p, surf.n, ls.p); /* :76-77 */
+                    ++rays;
+                    const v3 brdf = muls(tri->color, 1.0f / O_PI);
+                    const float G = geometry_term(surf.p, surf.n, ls.p, ls.n);
+                    const float light_pdf = 1.0f / (float)(size_t)s->n_lights * 1.0f / area_of(lt);
+                    /* :89-90: ((((throughput * brdf) * G) * V) * Le) / pdf */
+                    const v3 c = divs(mulv(muls(muls(mulv(throughput, brdf), G), V), lt->emissive), light_pdf);
+                    radiance = add(radiance, c);
+                }
+                const float r0 = pcg_uniformf(&rng);
+                const float r1 = pcg_uniformf(&rng);
+                const float r2 = pcg_uniformf(&rng);
+                const v3 wo = tangent_to_world(tri, surf.n, sample_hemisphere(r0, r1, r2));
+                throughput = mulv(throughput, tri->color);
+                ro = add(surf.p, muls(surf.n, 0.001f));
+                rd = wo;
+            }
+            if (opt->accumulate)
+            {
+                accum[pixel_idx].x += radiance.x; accum[pixel_idx].y += radiance.y;
+                accum[pixel_idx].z += radiance.z; accum[pixel_idx].w += 1.0f;
+            }
+            else
+            {
+                const v4 o = {radiance.x, radiance.y, radiance.z, 1.0f};
+                accum[pixel_idx] = o;
+            }
+        }
+    }
+    if (cnt) cnt->rays += rays;
+}
+
 /* examples/09_ris/09_ris.cu:11-166 */
 ORACLE_API void o_path_trace_09(const OScene* s, int W, int H, int frame, const ORayGen* rg,
                                 const OOptions* opt, v4* accum, int row0, int row1, OCounters* cnt)

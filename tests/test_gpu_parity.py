@@ -392,10 +392,13 @@ def test_strip_contexts_match_full_frame(api, oracle, scenes, n_strips, H, spars
     (9, "quad_room", 96, 54, 2, dict(accumulate=1)),
     (9, "quad_room", 64, 36, 1, dict(use_shadowed_target_function=1, ris_sample_count=8)),
     (9, "blocks", 320, 180, 1, dict()),                                        # config #3 at quarter res
+    (8, "quad_room", 96, 54, 2, dict(accumulate=1)),                           # 08_nee
+    (8, "cornellbox2", 256, 256, 2, dict(accumulate=1, max_depth=3)),
+    (8, "blocks", 320, 180, 1, dict()),
 ])
 def test_path_tracers_07_and_09(api, oracle, scenes, golden_scenes, example, scene_name, W, H, frames, optkw):
-    """Configs #2/#3: the `path_trace` kernels of 07_pt and 09_ris, bit-identical radiance and the
-    same number of raytrace() calls as the oracle."""
+    """Configs #2/#3 and 08_nee: the `path_trace` kernels of 07_pt, 08_nee and 09_ris, bit-identical
+    radiance and the same number of raytrace() calls as the oracle."""
     from cedec_2024_rt_amd.types import default_options
 
     if scene_name == "cornellbox2":

@@ -45,6 +45,16 @@ def pt9():
 ms = timed(pt9, 8); rays = r.path_trace_rays()
 out["config3_09_ris"] = dict(ms_per_frame=ms, rays=rays, mray_s=rays / ms / 1e3)
 r.close()
+# 08_nee and 07_pt at 1080p on the blocks stand-in (the reference's img/8.png, img/7.png settings)
+r = api.Renderer(1920, 1080); r.set_scene(tris); r.lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)
+r.set_options(default_options())
+for ex in (8, 7, 9):
+    fr = [0]
+    def pt():
+        fr[0] += 1; r.path_trace(ex, fr[0])
+    ms = timed(pt, 8); rays = r.path_trace_rays()
+    out["example_%02d_1080p" % ex] = dict(ms_per_frame=ms, rays=rays, mray_s=rays / ms / 1e3)
+r.close()
 # config #4 at 3840x2160 on ONE GPU (the 8-GPU config #5 is the driver's to run)
 r = api.Renderer(3840, 2160); r.set_scene(tris); r.lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)
 r.set_options(bench_options())
