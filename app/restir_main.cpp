@@ -6,12 +6,13 @@
  *   restir_app [--obj scene.obj | --tris scene.tris] [--size W H] [--frames N]
  *              [--eye x y z] [--lookat x y z] [--temporal 0|1] [--spatial 0|1]
  *              [--shadowed 0|1] [--visreuse 0|1] [--accumulate 0|1] [--by-kernel]
- *              [--example 10|7|8|9] [--ppm out.ppm] [--pfm out.pfm] [--dump-tris out.tris]
+ *              [--example 10|7|8|9] [--ppm out.ppm] [--png out.png] [--pfm out.pfm] [--dump-tris out.tris]
  *
  * --example 7|8|9 runs the `path_trace` kernel of examples/07_pt, 08_nee or 09_ris instead of the
  * ReSTIR DI frame (one sample per pixel and frame; use --accumulate 1 to average frames).
  * Keys 1,2,3,4,A of the example (10_restir_di.cpp:143-174) are the --temporal/--spatial/
- * --shadowed/--visreuse/--accumulate flags; key S (screenshot) is --ppm. `--tris` reads a raw
+ * --shadowed/--visreuse/--accumulate flags; key S (screenshot, an RGB PNG written top row first,
+ * common/misc.hpp:226-245) is --png (or --ppm). `--tris` reads a raw
  * array of 60-byte Triangle records (cedec_2024_rt_amd.scenes can write one); `--obj` uses the
  * OBJ/MTL subset the reference's loader consumes (common/loader.hpp:11-66: positions, faces as
  * triangle fans, per-face usemtl -> Kd/Ke).
@@ -27,6 +28,66 @@
 #include <vector>
 
 #include "../include/restir_rt.h"
+
+/* RGB8 PNG, top row first, as saveScreenshot writes it (common/misc.hpp:226-245 via stbi_write_png);
+ * the deflate stream uses stored blocks only (no compression: no zlib dependency). */
+static void write_png(const char* path, int W, int H, const uint8_t* rgb /* W*H*3, top-down */)
+{
+    static uint32_t crc_table[256];
+    if (!crc_table[1])
+        for (uint32_t n = 0; n < 256; ++n)
+        {
+            uint32_t c = n;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+            crc_table[n] = c;
+        }
+    auto crc = [&](const std::vector<uint8_t>& d, size_t from) {
+        uint32_t c = 0xffffffffu;
+        for (size_t i = from; i < d.size(); ++i) c = crc_table[(c ^ d[i]) & 0xffu] ^ (c >> 8);
+        return c ^ 0xffffffffu;
+    };
+    auto be32 = [](std::vector<uint8_t>& d, uint32_t v) { for (int s = 24; s >= 0; s -= 8) d.push_back((uint8_t)(v >> s)); };
+    std::vector<uint8_t> raw; /* filter byte 0 + RGB per scanline */
+    raw.reserve((size_t)H * (1 + 3 * (size_t)W));
+    for (int y = 0; y < H; ++y)
+    {
+        raw.push_back(0);
+        raw.insert(raw.end(), rgb + (size_t)y * W * 3, rgb + (size_t)(y + 1) * W * 3);
+    }
+    std::vector<uint8_t> z = {0x78, 0x01};
+    uint32_t a = 1, b = 0; /* adler32 */
+    for (size_t off = 0; off < raw.size() || off == 0; off += 65535)
+    {
+        const size_t n = raw.size() - off < 65535 ? raw.size() - off : 65535;
+        z.push_back(off + n >= raw.size() ? 1 : 0);
+        z.push_back((uint8_t)(n & 0xff)); z.push_back((uint8_t)(n >> 8));
+        z.push_back((uint8_t)(~n & 0xff)); z.push_back((uint8_t)((~n >> 8) & 0xff));
+        z.insert(z.end(), raw.begin() + (long)off, raw.begin() + (long)(off + n));
+        for (size_t i = off; i < off + n; ++i) { a = (a + raw[i]) % 65521u; b = (b + a) % 65521u; }
+        if (raw.empty()) break;
+    }
+    be32(z, (b << 16) | a);
+    FILE* f = fopen(path, "wb");
+    if (!f) { fprintf(stderr, "cannot write %s\n", path); exit(1); }
+    const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    fwrite(sig, 1, 8, f);
+    auto chunk = [&](const char* type, const std::vector<uint8_t>& payload) {
+        std::vector<uint8_t> d;
+        be32(d, (uint32_t)payload.size());
+        d.insert(d.end(), type, type + 4);
+        d.insert(d.end(), payload.begin(), payload.end());
+        be32(d, crc(d, 4));
+        fwrite(d.data(), 1, d.size(), f);
+    };
+    std::vector<uint8_t> ihdr;
+    be32(ihdr, (uint32_t)W); be32(ihdr, (uint32_t)H);
+    const uint8_t tail[5] = {8, 2, 0, 0, 0}; /* 8 bits, colour type 2 (RGB), deflate, no filter, no interlace */
+    ihdr.insert(ihdr.end(), tail, tail + 5);
+    chunk("IHDR", ihdr);
+    chunk("IDAT", z);
+    chunk("IEND", {});
+    fclose(f);
+}
 
 static void die(rt_ctx* c, const char* what, int rc)
 {
@@ -118,7 +179,7 @@ int main(int argc, char** argv)
     /* camera "blocks_restir.obj 1", 10_restir_di.cpp:188-189 */
     float eye[3] = {-0.579885f, 22.194597f, -6.567105f}, lookat[3] = {5.224952f, 20.847435f, 1.431192f};
     const float up[3] = {0, 1, 0};
-    std::string obj, tris_path, ppm, pfm, dump;
+    std::string obj, tris_path, ppm, png, pfm, dump;
     bool by_kernel = false;
     int example = 10;
     rt_options opt;
@@ -146,6 +207,7 @@ int main(int argc, char** argv)
         else if (a == "--example") example = atoi(argv[++i]);
         else if (a == "--dump-tris") dump = argv[++i]; /* write the loaded triangle array and exit (no GPU needed) */
         else if (a == "--ppm") ppm = argv[++i];
+        else if (a == "--png") png = argv[++i];
         else if (a == "--pfm") pfm = argv[++i];
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
@@ -227,6 +289,15 @@ int main(int argc, char** argv)
         for (int y = H - 1; y >= 0; --y) /* storage is bottom-up (pixel_idx = x + (H-yi-1)*W) */
             for (int x = 0; x < W; ++x) fwrite(&px[4 * ((size_t)y * W + x)], 1, 3, f);
         fclose(f);
+    }
+    if (!png.empty())
+    {
+        std::vector<uint8_t> px((size_t)W * H * 4), rgb((size_t)W * H * 3);
+        CK(rt_download(ctx, RT_BUF_PIXELS, px.data(), px.size()));
+        for (int y = 0; y < H; ++y) /* storage is bottom-up */
+            for (int x = 0; x < W; ++x)
+                memcpy(&rgb[3 * ((size_t)y * W + x)], &px[4 * ((size_t)(H - 1 - y) * W + x)], 3);
+        write_png(png.c_str(), W, H, rgb.data());
     }
     if (!pfm.empty())
     {

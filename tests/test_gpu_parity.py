@@ -4,10 +4,13 @@ Integer / index / decision data must be identical; float data is compared as raw
 portable math + -ffp-contract=off contract, DESIGN.md "Parity") — no tolerance anywhere except
 the north-star's 1e-4 relative L2 that is asserted on top for the radiance.
 """
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 FOVY = np.float32(np.pi) / np.float32(4)
 
@@ -658,3 +661,64 @@ def test_upload_download_round_trip_is_lossless(api, oracle, scenes):
     r.upload(api.RT_BUF_ACCUMULATION, acc)
     assert _eq_bits(r.download(api.RT_BUF_ACCUMULATION), acc)
     r.close()
+
+
+def test_headless_host_app_images(api, scenes, tmp_path):
+    """app/restir_app (the C++ mirror of the example's main(), written against the C-ABI only) renders
+    the same pixels as the ctypes host, and its PPM / PNG (key S of the example) / PFM files decode to
+    the downloaded buffers."""
+    import struct
+    import subprocess
+    import zlib
+
+    from cedec_2024_rt_amd.types import bench_options
+
+    app = os.path.join(ROOT, "app", "restir_app")
+    assert os.path.exists(app), "app/restir_app not built: run __graft_entry__.build()"
+    W, H, frames = 112, 63, 3
+    tris = scenes.make_quad_room()
+    tp = tmp_path / "q.tris"
+    tris.tofile(tp)
+    eye, at = (0.5, 2.5, 6.0), (0.0, 1.5, -1.0)
+    out = subprocess.run([app, "--tris", str(tp), "--size", str(W), str(H), "--frames", str(frames),
+                          "--eye", *map(str, eye), "--lookat", *map(str, at),
+                          "--ppm", str(tmp_path / "o.ppm"), "--png", str(tmp_path / "o.png"), "--pfm", str(tmp_path / "o.pfm")],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    r = api.Renderer(W, H)
+    r.set_scene(tris)
+    r.lookat(eye, at)
+    r.set_options(bench_options())
+    r.clear()
+    for f in range(1, frames + 1):
+        r.frame(f)
+    px = r.download(api.RT_BUF_PIXELS).reshape(H, W, 4)[::-1, :, :3]  # top row first
+    acc = r.download(api.RT_BUF_ACCUMULATION).reshape(H, W, 4)
+    assert f"rays/frame: {r.ray_count()[0]}" in out.stdout
+    r.close()
+    # PPM
+    raw = (tmp_path / "o.ppm").read_bytes()
+    head = f"P6\n{W} {H}\n255\n".encode()
+    assert raw.startswith(head)
+    assert np.array_equal(np.frombuffer(raw[len(head):], np.uint8).reshape(H, W, 3), px)
+    # PNG: signature, IHDR, one IDAT (zlib stream), IEND; CRCs checked
+    raw = (tmp_path / "o.png").read_bytes()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(raw):
+        n, typ = struct.unpack(">I4s", raw[pos:pos + 8])
+        body = raw[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(typ + body)
+        chunks.append((typ, body))
+        pos += 12 + n
+    assert [c[0] for c in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    assert struct.unpack(">IIBBBBB", chunks[0][1]) == (W, H, 8, 2, 0, 0, 0)
+    rows = np.frombuffer(zlib.decompress(chunks[1][1]), np.uint8).reshape(H, 1 + 3 * W)
+    assert not rows[:, 0].any()
+    assert np.array_equal(rows[:, 1:].reshape(H, W, 3), px)
+    # PFM: bottom-up little-endian RGB = accumulation / spp
+    raw = (tmp_path / "o.pfm").read_bytes()
+    head = f"PF\n{W} {H}\n-1.0\n".encode()
+    assert raw.startswith(head)
+    rgb = np.frombuffer(raw[len(head):], np.float32).reshape(H, W, 3)
+    assert np.array_equal(rgb.view(np.uint32), (acc[:, :, :3] / acc[:, :, 3:4]).astype(np.float32).view(np.uint32))
