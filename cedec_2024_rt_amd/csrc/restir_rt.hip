@@ -43,6 +43,10 @@ struct rt_ctx
     int device = 0, W = 0, H = 0, row_begin = 0, row_end = 0, halo = 0;
     int lrow0 = 0, lrows = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    /* second lane of a frame stage (rt_frame_stage_run_async): interior rows run beside the boundary rows */
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_stage = nullptr, ev_aux = nullptr;
+    bool aux_used = false;
     std::string err;
 
     int n_tris = 0, n_lights = 0, bvh_height = 0, n_refs = 0;
@@ -174,6 +178,10 @@ int rt_create(int device, int width, int height, int row_begin, int row_end, int
     memset(&c->rg, 0, sizeof(c->rg));
     RT_HIP(c, hipSetDevice(device));
     RT_HIP(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    /* default priority: with the lowest priority the lane was starved in some exchanges (A/B in DESIGN.md §7) */
+    RT_HIP(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    RT_HIP(c, hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming));
+    RT_HIP(c, hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming));
     c->stream = c->own_stream;
     const size_t n = local_pixels(c);
     RT_HIP(c, hipMalloc(&c->d_vis, n * 16));
@@ -213,6 +221,9 @@ int rt_destroy(rt_ctx* c)
     RT_CHECK_CTX(c);
     hipSetDevice(c->device);
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
+    if (c->aux_stream) { hipStreamSynchronize(c->aux_stream); hipStreamDestroy(c->aux_stream); }
+    if (c->ev_stage) hipEventDestroy(c->ev_stage);
+    if (c->ev_aux) hipEventDestroy(c->ev_aux);
     free_scene(c);
     hipFree(c->d_vis); hipFree(c->d_g0); hipFree(c->d_g1); hipFree(c->d_accum); hipFree(c->d_pixels);
     for (int k = 0; k < 3; ++k) { hipFree(c->d_rec[k]); hipFree(c->d_rad[k]); }
@@ -871,6 +882,8 @@ int rt_frame_stage_begin(rt_ctx* c, int frame, int stage, int clear_first)
     RT_CHECK_CTX(c);
     NEED_SCENE(c);
     c->last_frame = frame;
+    RT_HIP(c, hipEventRecord(c->ev_stage, c->stream)); /* everything the stage reads is complete here */
+    c->aux_used = false;
     const int passes = c->opt.spatial_resampling_passes;
     if (stage == 0)
     {
@@ -930,6 +943,35 @@ int rt_frame_stage_run_part(rt_ctx* c, int frame, int stage, int part, int row0,
     return rc;
 }
 
+/* The same rows on the context's second stream: they run beside whatever the main stream is doing
+ * for this stage (a strip computes its boundary rows first, posts their halo exchange, and lets the
+ * interior rows fill the rest of the GPU meanwhile).
+ * The lane starts after everything that was enqueued on the main stream when rt_frame_stage_begin
+ * or, later, rt_frame_stage_fork was called (fork after a part the lane depends on, e.g. the
+ * raycast part of stage 0), and rt_frame_stage_end joins it back into the main stream. Rows of the
+ * two lanes must not overlap, and the lane must not read halo rows still in flight. */
+int rt_frame_stage_fork(rt_ctx* c)
+{
+    RT_CHECK_CTX(c);
+    if (c->aux_used) RT_FAIL(c, RT_ERR_STATE, "rt_frame_stage_fork after the stage's second lane has started");
+    RT_HIP(c, hipEventRecord(c->ev_stage, c->stream));
+    return RT_OK;
+}
+int rt_frame_stage_run_async(rt_ctx* c, int frame, int stage, int part, int row0, int row1)
+{
+    RT_CHECK_CTX(c);
+    if (!c->aux_used) RT_HIP(c, hipStreamWaitEvent(c->aux_stream, c->ev_stage, 0));
+    c->aux_used = true;
+    hipStream_t main_stream = c->stream;
+    const bool timing = c->timing;
+    c->stream = c->aux_stream;
+    c->timing = false; /* the per-kernel events belong to the main lane */
+    const int rc = rt_frame_stage_run_part(c, frame, stage, part, row0, row1);
+    c->stream = main_stream;
+    c->timing = timing;
+    return rc;
+}
+
 /* all parts of the stage (part 0); stage 0 can be split: part 1 = [clear,] raycast, part 2 = generate */
 int rt_frame_stage_run(rt_ctx* c, int frame, int stage, int row0, int row1)
 {
@@ -940,6 +982,12 @@ int rt_frame_stage_end(rt_ctx* c, int stage)
 {
     RT_CHECK_CTX(c);
     if (stage != c->f_stage) RT_FAIL(c, RT_ERR_STATE, "rt_frame_stage_end: expected stage %d, got %d", c->f_stage, stage);
+    if (c->aux_used)
+    {
+        RT_HIP(c, hipEventRecord(c->ev_aux, c->aux_stream));
+        RT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_aux, 0));
+        c->aux_used = false;
+    }
     const int passes = c->opt.spatial_resampling_passes;
     if (stage <= passes) { c->f_stage = stage + 1; return RT_OK; }
     const int X = c->fX, Y = c->fY, Z = c->fZ;

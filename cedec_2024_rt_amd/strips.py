@@ -13,6 +13,7 @@ the critical path.
 backend over gloo.
 """
 import math
+import os
 
 HALO_ROWS = 87  # ceil(86.43)
 
@@ -208,18 +209,28 @@ class StripFrame:
         b, P = self.b, self.b.passes
         pending = None
         sparse = self.sparse and self.plan and P > 0
+        two_lanes = bool(self.plan) and hasattr(b, "stage_run_async") and not os.environ.get("RT_ONE_LANE")
         for s in range(0, P + 1):
-            if pending is not None:
-                self._finish(pending)
-                pending = None
             b.stage_begin(frame, s, clear_first if s == 0 else False)
             part = 0
             if s == 0 and sparse:
                 a0, e0 = self.bounds[self.rank]
                 b.stage_run_part(frame, 0, 1, a0, e0)  # [clear,] raycast of all owned rows
+                part = 2  # only generate_candidate(+temporal) is left
+                if two_lanes:
+                    b.stage_fork()  # the second lane needs the G-buffer
+            if two_lanes:
+                # interior rows never read halo rows (they are >= halo rows away from the neighbours):
+                # they start at once on the second lane and fill the GPU while the main
+                # lane waits for halos, computes the boundary rows and packs them
+                for r0, r1 in self.interior:
+                    b.stage_run_async(frame, s, part, r0, r1)
+            if pending is not None:
+                self._finish(pending)
+                pending = None
+            if s == 0 and sparse:
                 for tag in self._sparse_setup_gen(frame):
                     yield tag
-                part = 2  # only generate_candidate(+temporal) is left
             for r0, r1 in self.boundary:
                 b.stage_run_part(frame, s, part, r0, r1) if part else b.stage_run(frame, s, r0, r1)
             if s < P and self.plan:
@@ -227,9 +238,12 @@ class StripFrame:
                     self._sparse_setup_finish()
                 pending = self._post(b.stage_output(s), s)
                 yield s
-            for r0, r1 in self.interior:
-                b.stage_run_part(frame, s, part, r0, r1) if part else b.stage_run(frame, s, r0, r1)
+            if not two_lanes:
+                for r0, r1 in self.interior:
+                    b.stage_run_part(frame, s, part, r0, r1) if part else b.stage_run(frame, s, r0, r1)
             b.stage_end(frame, s)
+        if pending is not None:  # (P == 0: nothing was posted)
+            self._finish(pending)
         a, e = self.bounds[self.rank]
         b.stage_begin(frame, P + 1, False)
         b.stage_run(frame, P + 1, a, e)
@@ -267,6 +281,12 @@ class HipStripBackend:
 
     def stage_run_part(self, frame, s, part, r0, r1):
         self.r.frame_stage_run_part(frame, s, part, r0, r1)
+
+    def stage_fork(self):
+        self.r.frame_stage_fork()
+
+    def stage_run_async(self, frame, s, part, r0, r1):
+        self.r.frame_stage_run_async(frame, s, part, r0, r1)
 
     # ---- sparse halos (receiver-marked bitmaps, see include/restir_rt.h)
     sparse_supported = True
@@ -429,6 +449,11 @@ def run_frame_local(renderers, bounds, frame, device, halo=HALO_ROWS, sparse=Fal
             self.r.sync()
 
     tr = LocalTransport()
+    # as in the product path, the contexts enqueue on torch's current stream: the torch ops of the
+    # backend (message assembly, zero-fills, copies) and the contexts' kernels are then ordered
+    for r in renderers:
+        r.sync()
+        r.set_stream(torch.cuda.current_stream().cuda_stream)
     frames = [StripFrame(_Sync(r, device), bounds, k, tr, halo, sparse=sparse) for k, r in enumerate(renderers)]
     gens = [f.frame_gen(frame) for f in frames]
     live = list(range(len(gens)))
@@ -440,3 +465,4 @@ def run_frame_local(renderers, bounds, frame, device, halo=HALO_ROWS, sparse=Fal
                 live.remove(k)
     for r in renderers:
         r.sync()
+        r.set_stream_own()

@@ -157,6 +157,12 @@ int rt_frame_stage_input(rt_ctx* ctx, int stage, int* physical_buffer);
 int rt_frame_stage_begin(rt_ctx* ctx, int frame, int stage, int clear_first);
 int rt_frame_stage_run(rt_ctx* ctx, int frame, int stage, int row0, int row1);
 int rt_frame_stage_run_part(rt_ctx* ctx, int frame, int stage, int part, int row0, int row1); /* stage 0: part 1 = [clear,] raycast, 2 = generate, 0 = both */
+/* Second lane: the same as _run_part, on the context's second stream, beside what the
+ * main stream does for this stage (interior rows next to boundary rows). It starts after all work
+ * enqueued on the main stream at _begin or at the last _fork; _end joins it. The two lanes' rows must
+ * be disjoint and the lane must not read halo rows that are still being received. */
+int rt_frame_stage_fork(rt_ctx* ctx);
+int rt_frame_stage_run_async(rt_ctx* ctx, int frame, int stage, int part, int row0, int row1);
 int rt_frame_stage_end(rt_ctx* ctx, int stage);
 int rt_frame_stage_output(rt_ctx* ctx, int stage, int* physical_buffer);
 
