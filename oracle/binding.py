@@ -12,7 +12,7 @@ import tempfile
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liboracle.so")
+LIB_PATH = os.environ.get("ORACLE_LIB") or os.path.join(HERE, "liboracle.so")  # ORACLE_LIB: e.g. the sanitizer build
 REF_BIN = os.path.join(HERE, "_ref", "ref_kernels")
 
 MATH_LIBM = 0
