@@ -279,7 +279,7 @@ struct SahBuilder
         bounds(first, count, lo, hi, clo, chi);
         if (depth > height) height = depth;
         if (count == 1) return ~refs[(size_t)order[first]].tri;
-        constexpr int NB = 16;
+        constexpr int NB = 32; /* 16 -> 32 bins: -3 % on the resolve shadow rays, nothing elsewhere; an exact sweep below 64/512 references: +-0 */
         int best_axis = -1, best_split = -1;
         float best_cost = INFINITY;
         for (int a = 0; a < 3; ++a)
