@@ -573,11 +573,12 @@ def test_interactive_camera_and_accumulation_reset(api, oracle, scenes):
     r2.close()
 
 
-def test_full_size_properties_1080p(api, scenes):
-    """At BASELINE.json's full size (blocks_restir stand-in, 1920x1080, bench options) the oracle is too
+@pytest.mark.parametrize("W,H", [(1920, 1080), (3840, 2160)])  # BASELINE configs #4 and #5
+def test_full_size_properties_1080p(api, scenes, W, H):
+    """At BASELINE.json's full sizes (blocks_restir stand-in, 1920x1080 and 3840x2160, bench options) the oracle is too
     slow for a per-pixel check in a test, so size-independent properties are asserted instead:
     (1) the fused rt_frame == the reference's kernel-by-kernel launch sequence, bit for bit;
-    (2) 8 row strips (135 rows, 87-row halos, the 8-GPU partition) == the single-context frame;
+    (2) 8 row strips (135 / 270 rows, 87-row halos, the 8-GPU partition) == the single-context frame;
     (3) ray count = pixels + 2 x shaded pixels; the spatial pass's algorithmic bytes are bounded by
         16 + 152 + 5 x 92 per pixel and are the same for every pass input that shares the G-buffer."""
     import torch
@@ -585,7 +586,6 @@ def test_full_size_properties_1080p(api, scenes):
     from cedec_2024_rt_amd import strips
     from cedec_2024_rt_amd.types import bench_options
 
-    W, H = 1920, 1080
     tris = scenes.make_blocks_restir()
     eye, at = scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT
 
