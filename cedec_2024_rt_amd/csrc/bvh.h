@@ -192,11 +192,6 @@ struct WideView
     int n_tris;
     int n_rec;
 };
-/* The first RT_LDS_NODES records (the top levels: collapse_wide emits them breadth-first) are
- * staged in LDS behind the per-lane stack by wide_lds_fill(); 0 = every record from global. */
-#ifndef RT_LDS_NODES
-#define RT_LDS_NODES 0
-#endif
 #ifndef RT_WIDE_LDS_STACK
 #define RT_WIDE_LDS_STACK 24
 #endif
@@ -207,35 +202,20 @@ constexpr uint32_t WIDE_LEAF_BIT = 0x80000000u;
 #define WIDE_ANY_SORTED 0 /* any-hit rays: visit children nearest-first (1) or in slot order (0) */
 #endif
 
-#define WIDE_LDS_WORDS (WIDE_LDS_STACK * BLOCK_THREADS + 12 * RT_LDS_NODES)
-/* every thread of the workgroup must call this before its first trace_wide (and before any return) */
-RT_DEV void wide_lds_fill(const WideView& bvh, uint32_t* __restrict__ lds_stack)
-{
-#if RT_LDS_NODES
-    float4* dst = (float4*)(lds_stack + WIDE_LDS_STACK * BLOCK_THREADS);
-    const int n = 3 * (bvh.n_rec < RT_LDS_NODES ? bvh.n_rec : RT_LDS_NODES);
-    for (int i = threadIdx.x; i < n; i += BLOCK_THREADS) dst[i] = bvh.rec[i];
-    __syncthreads();
-#else
-    (void)bvh; (void)lds_stack;
-#endif
-}
+#define WIDE_LDS_WORDS (WIDE_LDS_STACK * BLOCK_THREADS)
 
 RT_DEV float wide_byte(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }
 
-/* Leaf tests are DEFERRED: a lane that reaches a leaf parks it (one slot) and keeps walking inner
- * records; the wave runs the triangle test only when at least RT_LEAF_NUM/RT_LEAF_DEN of its live
- * lanes have one parked (or no lane has inner work left). With a leaf test per ~5 steps per lane,
- * testing as soon as ANY lane holds a leaf executes the ~175-instruction leaf path at ~10 % lane
- * utilisation on nearly every iteration; traversal is VALU-issue bound, so batching
- * the leaf path is worth more than the few extra boxes visited because `best` shrinks later.
+/* Leaf tests are DEFERRED: a lane that reaches a leaf parks it (two slots) and keeps walking inner
+ * records; the wave runs the triangle test only when the parked leaves number at least
+ * RT_LEAF_NUM/RT_LEAF_DEN of its live lanes (or no lane has inner work left). With a leaf test per ~5
+ * steps per lane, testing as soon as ANY lane holds a leaf executes the ~150-instruction leaf path at
+ * ~10 % lane utilisation on nearly every iteration; traversal is VALU-issue bound, so
+ * batching the leaf path is worth more than the few extra boxes visited because `best` shrinks later.
  * Results do not depend on the order of the tests (closest hit with the index tie-break). */
 #ifndef RT_LEAF_NUM
 #define RT_LEAF_NUM 1
 #define RT_LEAF_DEN 1
-#endif
-#ifndef RT_LEAF_SLOTS
-#define RT_LEAF_SLOTS 2
 #endif
 #ifndef RT_LEAF_NUM_CLOSEST
 #define RT_LEAF_NUM_CLOSEST 1
@@ -279,12 +259,9 @@ RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3
     constexpr int LN = ANY ? RT_LEAF_NUM : RT_LEAF_NUM_CLOSEST, LD = ANY ? RT_LEAF_DEN : RT_LEAF_DEN_CLOSEST;
     uint32_t cur = 0u;   /* root is always an inner record */
     uint32_t pend = NONE; /* parked leaf */
-#if RT_LEAF_SLOTS == 2
     uint32_t pend2 = NONE;
-#endif
     for (;;)
     {
-#if RT_LEAF_SLOTS == 2
         if ((int)cur < 0 && pend2 == NONE)
         {
             if (pend == NONE) pend = cur; else pend2 = cur;
@@ -297,30 +274,13 @@ RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3
         const int parked = __popcll(bp) + __popcll(__ballot(pend2 != NONE));
         if (bp != 0ull && (bi == 0ull || LD * parked >= LN * __popcll(ba)))
         {
-#else
-        if ((int)cur < 0 && pend == NONE)
-        {
-            pend = cur;
-            cur = sp ? pop() : NONE;
-        }
-        const bool has_inner = cur < NONE;
-        const bool has_pend = pend != NONE;
-        if (!has_inner && !has_pend) break;
-        const unsigned long long bi = __ballot(has_inner), bp = __ballot(has_pend), ba = __ballot(true);
-        if (bp != 0ull && (bi == 0ull || LD * __popcll(bp) >= LN * __popcll(ba)))
-        {
-#endif
             if (STATS) stats[1] += 0x10000u; /* leaf passes this lane's wave ran while the lane was live */
             if (has_pend)
             {
                 if (STATS) stats[1]++;
                 const float4* g = bvh.rec + 3 * (size_t)(pend & ~WIDE_LEAF_BIT);
                 const float4 t0 = g[0], t1 = g[1], t2 = g[2];
-#if RT_LEAF_SLOTS == 2
                 pend = pend2; pend2 = NONE;
-#else
-                pend = NONE;
-#endif
                 const f3 v0 = F3(t0.x, t0.y, t0.z), v1 = F3(t0.w, t1.x, t1.y), v2 = F3(t1.z, t1.w, t2.x);
                 const int pi = as_int(t2.y);
                 float t, u, v;

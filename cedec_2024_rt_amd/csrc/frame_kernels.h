@@ -135,7 +135,6 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_raycast(SceneView S, 
                                                     float4* __restrict__ g0, float4* __restrict__ g1)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_WORDS];
-    wide_lds_fill(S.wide, s_stack);
     int x, row;
     if (!tile_pixel(P, x, row)) return;
     const int yi = P.H - 1 - row;
@@ -243,7 +242,6 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_generate_candidate(
     float4* __restrict__ out_rad)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_WORDS];
-    wide_lds_fill(S.wide, s_stack);
     int x, row;
     if (!tile_pixel(P, x, row)) return;
     const int yi = P.H - 1 - row;
@@ -342,7 +340,6 @@ __global__ __launch_bounds__(BLOCK) void k_temporal(SceneView S, FrameParams P, 
                                                      float4* __restrict__ rec, float4* __restrict__ radb)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_WORDS];
-    if (SHADOWED) wide_lds_fill(S.wide, s_stack);
     int x, row;
     if (!tile_pixel(P, x, row)) return;
     const int yi = P.H - 1 - row;
@@ -378,7 +375,6 @@ __global__ __launch_bounds__(BLOCK) void k_spatial(SceneView S, FrameParams P, c
                                                     float4* __restrict__ out_rec, float4* __restrict__ out_rad)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_WORDS];
-    if (SHADOWED) wide_lds_fill(S.wide, s_stack);
     int x, row;
     if (!tile_pixel(P, x, row)) return;
     const int yi = P.H - 1 - row;
@@ -695,7 +691,6 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_resolve(SceneView S, 
                                                     const float4* __restrict__ radb, float4* __restrict__ accum)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_WORDS];
-    wide_lds_fill(S.wide, s_stack);
     int x, row;
     if (!tile_pixel(P, x, row)) return;
     const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
@@ -889,7 +884,6 @@ __global__ __launch_bounds__(BLOCK) void k_path_trace(SceneView S, FrameParams P
                                                        unsigned long long* __restrict__ rays)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_WORDS];
-    wide_lds_fill(S.wide, s_stack);
     int x, row;
     const bool ok = tile_pixel(P, x, row);
     unsigned long long nrays = 0;
@@ -949,7 +943,6 @@ __global__ __launch_bounds__(BLOCK) void k_pt_bounce(SceneView S, FrameParams P,
                                                       float4* __restrict__ accum, unsigned long long* __restrict__ counters)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_WORDS];
-    wide_lds_fill(S.wide, s_stack);
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool have = i < counters[2 + depth];
     unsigned long long nrays = 0;
@@ -1097,7 +1090,6 @@ template <int MODE, bool ANY = false> /* 0 = wide (production), 1 = binary stack
 __global__ __launch_bounds__(BLOCK) void k_trace_closest(SceneView S, const float* __restrict__ rays, int n, float* __restrict__ hits)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_stack[MODE == 0 ? WIDE_LDS_WORDS : 4];
-    if (MODE == 0) wide_lds_fill(S.wide, s_stack);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* r = rays + 8 * (size_t)i;
@@ -1112,7 +1104,6 @@ template <int MODE, bool ANY = false>
 __global__ __launch_bounds__(BLOCK) void k_trace_stats(SceneView S, const float* __restrict__ rays, int n, uint32_t* __restrict__ stats)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_stack[MODE == 0 ? WIDE_LDS_WORDS : 4];
-    if (MODE == 0) wide_lds_fill(S.wide, s_stack);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* r = rays + 8 * (size_t)i;
