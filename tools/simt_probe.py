@@ -6,6 +6,8 @@ import numpy as np
 from cedec_2024_rt_amd import api, scenes
 from cedec_2024_rt_amd.types import bench_options
 W, H = 1920, 1080
+if os.environ.get("RT_LIB"):
+    api.LIB_PATH = os.path.join(ROOT, "cedec_2024_rt_amd", os.environ["RT_LIB"])
 tris = scenes.make_blocks_restir()
 r = api.Renderer(W, H)
 r.set_scene(tris)
@@ -34,3 +36,4 @@ for mode, name in ((4, "any-hit (shadow)"), (0, "closest")):
         name, n_in.sum() / sh.sum(), n_lf.sum() / sh.sum(), w_in.mean(), w_lf.mean(),
         n_in.sum() / (64.0 * w_in.sum()), n_lf.sum() / (64.0 * max(w_lf.sum(), 1))), flush=True)
     hits = r.trace_closest(rays); print("   kernel %.3f ms" % r.trace_time())
+
