@@ -330,11 +330,12 @@ def test_fused_frame_equals_oracle_frame(api, oracle, scenes, optkw):
     r.close()
 
 
-def test_frame_parity_blocks_restir_quarter_res(api, oracle, scenes):
-    """The benchmark stand-in at 480x270, benchmark options, 2 frames: bit-identical radiance,
+@pytest.mark.parametrize("W,H", [(480, 270), (1920, 1080)])
+def test_frame_parity_blocks_restir_quarter_res(api, oracle, scenes, W, H):
+    """The benchmark stand-in at 480x270 and at the BASELINE size 1920x1080 (the bench.py workload:
+    benchmark options, 2 frames): bit-identical radiance, reservoirs and pixels against the oracle,
     identical ray count (rays counted by the CPU restatement)."""
     tris = scenes.make_blocks_restir()
-    W, H = 480, 270
     r, sc, rg, opt, eyev = _setup(api, oracle, tris, W, H, scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)
     st = oracle.new_state(W, H)
     for frame in (1, 2):
@@ -347,6 +348,10 @@ def test_frame_parity_blocks_restir_quarter_res(api, oracle, scenes):
         assert nbad == 0, f"frame {frame}: {nbad} pixels differ, rel-L2 {_rel_l2(acc[:, :3], ref[:, :3])}"
         rays, shaded_n = r.ray_count()
         assert rays == int(cnt["rays"][0]) and shaded_n == int(cnt["shaded_pixels"][0])
+    shaded = (st["vis"]["index"] >= 0) & ~np.isin(st["vis"]["index"], sc.lights)
+    bad = _res_fields_equal(r.download(api.RT_BUF_RES_TEMPORAL), st["temporal"], mask=shaded)
+    assert not bad, f"temporal history: {bad}"
+    assert np.array_equal(r.download(api.RT_BUF_PIXELS).reshape(H, W, 4), st["pixels"])
     r.close()
 
 
