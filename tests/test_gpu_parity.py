@@ -330,7 +330,7 @@ def test_fused_frame_equals_oracle_frame(api, oracle, scenes, optkw):
     r.close()
 
 
-@pytest.mark.parametrize("W,H", [(480, 270), (1920, 1080)])
+@pytest.mark.parametrize("W,H", [(480, 270), (1920, 1080), (3840, 2160)])  # quarter res, BASELINE configs #4 and #5
 def test_frame_parity_blocks_restir_quarter_res(api, oracle, scenes, W, H):
     """The benchmark stand-in at 480x270 and at the BASELINE size 1920x1080 (the bench.py workload:
     benchmark options, 2 frames): bit-identical radiance, reservoirs and pixels against the oracle,
@@ -400,6 +400,7 @@ def test_strip_contexts_match_full_frame(api, oracle, scenes, n_strips, H, spars
     (9, "quad_room", 96, 54, 2, dict(accumulate=1)),
     (9, "quad_room", 64, 36, 1, dict(use_shadowed_target_function=1, ris_sample_count=8)),
     (9, "blocks", 320, 180, 1, dict()),                                        # config #3 at quarter res
+    (9, "blocks", 1280, 720, 1, dict()),                                       # BASELINE config #3 at full size
     (8, "quad_room", 96, 54, 2, dict(accumulate=1)),                           # 08_nee
     (8, "cornellbox2", 256, 256, 2, dict(accumulate=1, max_depth=3)),
     (8, "blocks", 320, 180, 1, dict()),
