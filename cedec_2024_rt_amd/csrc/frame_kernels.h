@@ -260,6 +260,7 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_generate_candidate(
     PCG rng = pcg_init(hashPCG4((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame, 0u), 0);
     const float fL = (float)(size_t)P.n_lights;
     int sel = -1;
+    float sel_bx = 0.0f, sel_by = 0.0f; /* warped barycentrics of the selected candidate */
     for (int i = 0; i < P.ris_sample_count; ++i)
     {
         /* draw order rv0, rv1, rv2, u: left-to-right argument evaluation (hipcc) */
@@ -278,12 +279,8 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_generate_candidate(
         const f3 v0 = F3(L0.x, L0.y, L0.z), v1 = F3(L0.w, L1.x, L1.y), v2 = F3(L1.z, L1.w, L2.x);
         warp_unit_triangle(bx, by);
         const f3 lp = (1.0f - bx - by) * v0 + bx * v1 + by * v2;
-#if RT_LIGHT_STRIDE == 4
         const float4 L3n = L[3];
         const f3 ln = F3(L3n.x, L3n.y, L3n.z);
-#else
-        const f3 ln = tri_normal(v0, v1, v2);
-#endif
         const float lum = L2.y;
         const float light_pdf = L2.z; /* 1/L * 1/area (:98-99) */
         const float p_hat = target_unshadowed(sp, sn, lp, ln, lum); /* unshadowed always (:104) */
@@ -292,15 +289,22 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_generate_candidate(
         /* common/reservoir.hpp:22-29 */
         r.w_sum += weight;
         r.M += 1;
+        /* only what identifies the winner is carried through the loop (3 registers instead of the
+         * 8 of position, normal, luminance): its sample is rebuilt once below, bit for bit */
         if (u < weight / r.w_sum)
         {
-            r.hit_p = lp; r.hit_n = ln; r.lum = lum;
-            r.org_p = sp; r.org_n = sn; r.vis = false;
-            sel = (int)nth;
+            sel = (int)nth; sel_bx = bx; sel_by = by;
         }
     }
     if (sel >= 0)
     {
+        const float4* L = S.lights + RT_LIGHT_STRIDE * (size_t)sel;
+        const float4 L0 = L[0], L1 = L[1], L2 = L[2], L3n = L[3];
+        const f3 v0 = F3(L0.x, L0.y, L0.z), v1 = F3(L0.w, L1.x, L1.y), v2 = F3(L1.z, L1.w, L2.x);
+        r.hit_p = (1.0f - sel_bx - sel_by) * v0 + sel_bx * v1 + sel_by * v2;
+        r.hit_n = F3(L3n.x, L3n.y, L3n.z);
+        r.lum = L2.y;
+        r.org_p = sp; r.org_n = sn; r.vis = false;
         const float4 ke = S.light_ke[sel];
         r.rad = F3(ke.x, ke.y, ke.z);
     }
