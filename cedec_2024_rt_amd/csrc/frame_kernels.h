@@ -422,7 +422,9 @@ __global__ __launch_bounds__(BLOCK) void k_spatial(SceneView S, FrameParams P, c
                 const float rv1 = rng.uniformf();
                 const float radius = sqrtf(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
                 const float phi = 2.0f * kPI * rv1;
-                const float gx = radius * pm_cosf(phi), gy = radius * pm_sinf(phi);
+                float sn_phi, cs_phi;
+                pm_sincosf(phi, &sn_phi, &cs_phi);
+                const float gx = radius * cs_phi, gy = radius * sn_phi;
                 const int nx = f2i_sat((float)x + scale * gx);
                 const int ny = f2i_sat((float)yi + scale * gy);
                 const int lr = P.H - 1 - ny - P.lrow0;
@@ -484,7 +486,9 @@ __global__ __launch_bounds__(BLOCK) void k_spatial(SceneView S, FrameParams P, c
             /* common/reservoir.hpp:89-95 with portable log/cos/sin */
             const float radius = sqrtf(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
             const float phi = 2.0f * kPI * rv1;
-            const float gx = radius * pm_cosf(phi), gy = radius * pm_sinf(phi);
+            float sn_phi, cs_phi;
+            pm_sincosf(phi, &sn_phi, &cs_phi);
+            const float gx = radius * cs_phi, gy = radius * sn_phi;
             const int nx = f2i_sat((float)x + scale * gx);
             const int ny = f2i_sat((float)yi + scale * gy);
             if (nx < 0 || nx >= P.W || ny < 0 || ny >= P.H) continue;
@@ -549,8 +553,10 @@ __global__ __launch_bounds__(BLOCK) void k_spatial_bytes(FrameParams P, const fl
                     const float rv1 = rng.uniformf();
                     const float radius = sqrtf(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
                     const float phi = 2.0f * kPI * rv1;
-                    const int nx = f2i_sat((float)x + scale * (radius * pm_cosf(phi)));
-                    const int ny = f2i_sat((float)yi + scale * (radius * pm_sinf(phi)));
+                    float sn_phi, cs_phi;
+                    pm_sincosf(phi, &sn_phi, &cs_phi);
+                    const int nx = f2i_sat((float)x + scale * (radius * cs_phi));
+                    const int ny = f2i_sat((float)yi + scale * (radius * sn_phi));
                     if (nx < 0 || nx >= P.W || ny < 0 || ny >= P.H) continue;
                     if (nx == x && ny == yi) continue;
                     const int lr = P.H - 1 - ny - P.lrow0;
@@ -608,8 +614,10 @@ __global__ __launch_bounds__(BLOCK) void k_halo_mark(FrameParams P, const float4
             const float rv1 = rng.uniformf();
             const float radius = sqrtf(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
             const float phi = 2.0f * kPI * rv1;
-            const int nx = f2i_sat((float)x + scale * (radius * pm_cosf(phi)));
-            const int ny = f2i_sat((float)yi + scale * (radius * pm_sinf(phi)));
+            float sn_phi, cs_phi;
+            pm_sincosf(phi, &sn_phi, &cs_phi);
+            const int nx = f2i_sat((float)x + scale * (radius * cs_phi));
+            const int ny = f2i_sat((float)yi + scale * (radius * sn_phi));
             if (nx < 0 || nx >= P.W || ny < 0 || ny >= P.H) continue;
             if (nx == x && ny == yi) continue;
             const int nrow = P.H - 1 - ny;
@@ -733,8 +741,10 @@ RT_DEV f3 sample_hemisphere(float r0, float r1, float r2)
     const float theta = r0 * 2.0f * kPI;
     float radius = r1 + r2;
     if (1.0f < radius) radius = 2.0f - radius;
-    const float x = pm_cosf(theta) * radius;
-    const float z = pm_sinf(theta) * radius;
+    float sn_t, cs_t;
+    pm_sincosf(theta, &sn_t, &cs_t);
+    const float x = cs_t * radius;
+    const float z = sn_t * radius;
     const float a = 1.0f - radius * radius;
     const float y = sqrtf((a < 0.0f) ? 0.0f : a);
     return F3(x, y, z);
@@ -1275,6 +1285,8 @@ __global__ void k_math_eval(int fn, const float* __restrict__ in, int n, float* 
         case 20: r = pm_logf(in[i]); break;
         case 21: r = pm_cosf(in[i]); break;
         case 22: r = pm_sinf(in[i]); break;
+        case 28: { float sn, cs; pm_sincosf(in[i], &sn, &cs); r = sn; break; } /* the fused form the kernels use */
+        case 29: { float sn, cs; pm_sincosf(in[i], &sn, &cs); r = cs; break; }
         case 23: r = pm_expf(in[i]); break;
         case 24: r = pm_pow8f(in[i]); break;
         case 25: r = pm_powf_pos(in[i], 1.0f / 2.2f); break;

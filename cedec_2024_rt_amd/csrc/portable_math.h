@@ -226,6 +226,24 @@ PM_FN float pm_cosf(float x)
     }
 }
 
+/* pm_sinf(x) and pm_cosf(x) at once: one reduction and one evaluation of each kernel instead of two
+ * of each (callers always need both of the same angle, and on a wavefront the quadrants of the lanes
+ * differ, so the separate functions evaluate both kernels twice). Bit-identical to the two calls:
+ * same reduced argument, same kernels, and (float)(-k) == -(float)k. */
+PM_FN void pm_sincosf(float x, float* sn, float* cs)
+{
+    const uint32_t ax = pm_f2u(x) & 0x7fffffffu;
+    if (ax >= 0x7f800000u) { *sn = pm_u2f(0x7fc00000u); *cs = pm_u2f(0x7fc00000u); return; }
+    if (ax > 0x4e000000u) { *sn = 0.0f; *cs = 1.0f; return; }
+    double y;
+    const int n = pm_rem_pio2(x, &y);
+    const float s = (float)pm_sin_kernel(y), c = (float)pm_cos_kernel(y);
+    const float a = (n & 1) ? c : s;  /* |sin| source */
+    const float b = (n & 1) ? s : c;  /* |cos| source */
+    *sn = (n & 2) ? -a : a;
+    *cs = ((n + 1) & 2) ? -b : b;
+}
+
 /* x^8 by three squarings: the portable definition of powf(x, 8.0f)
  * (common/reservoir.hpp:61-65). */
 PM_FN float pm_pow8f(float x)

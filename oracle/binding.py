@@ -164,7 +164,8 @@ FN = dict(warp_unit_triangle=(0, 2, 2), sample_hemisphere=(1, 3, 3), sample_2d_g
           normal_rejection=(6, 6, 1), depth_rejection=(7, 9, 1), triangle_props=(8, 9, 7), aces=(9, 1, 1),
           surface_ray=(10, 16, 6), tangent_world=(11, 15, 3),
           logf=(20, 1, 1), cosf=(21, 1, 1), sinf=(22, 1, 1), expf=(23, 1, 1), pow8=(24, 1, 1),
-          pow_gamma=(25, 1, 1), div=(26, 2, 1), sqrt=(27, 1, 1))
+          pow_gamma=(25, 1, 1), div=(26, 2, 1), sqrt=(27, 1, 1),
+          sincos_sin=(28, 1, 1), sincos_cos=(29, 1, 1))  # portable_math.h pm_sincosf (always the portable form)
 
 
 def fn_bulk(name, x):

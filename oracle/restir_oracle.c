@@ -864,6 +864,8 @@ ORACLE_API void o_fn_bulk(int fn, const float* in, float* out, int n)
             case 20: out[i] = m_log(in[i]); break;
             case 21: out[i] = m_cos(in[i]); break;
             case 22: out[i] = m_sin(in[i]); break;
+            case 28: { float sn, cs; pm_sincosf(in[i], &sn, &cs); out[i] = sn; break; } /* fused form of the device kernels */
+            case 29: { float sn, cs; pm_sincosf(in[i], &sn, &cs); out[i] = cs; break; }
             case 23: out[i] = m_exp(in[i]); break;
             case 24: out[i] = m_pow8(in[i]); break;
             case 25: out[i] = m_pow(in[i], 1.0f / 2.2f); break;

@@ -77,6 +77,8 @@ def test_portable_math_and_ieee_on_device(api, oracle):
         "logf": np.concatenate([u, (u * 2.0 ** -20).astype(np.float32), np.float32([0.0, 1.0, 2.0 ** -23, 1e-38, 1e-45])]),
         "cosf": np.concatenate([(u * 6.2831855).astype(np.float32), (u * 40 - 20).astype(np.float32)]),
         "sinf": np.concatenate([(u * 6.2831855).astype(np.float32), (u * 40 - 20).astype(np.float32)]),
+        "sincos_sin": np.concatenate([(u * 6.2831855).astype(np.float32), (u * 40 - 20).astype(np.float32)]),
+        "sincos_cos": np.concatenate([(u * 6.2831855).astype(np.float32), (u * 40 - 20).astype(np.float32)]),
         "expf": np.concatenate([(-u * 100).astype(np.float32), (u * 4 - 2).astype(np.float32), np.float32([-103.0, -104.5, 0.0, 88.0, 89.0])]),
         "pow8": np.concatenate([u, np.float32([0.0, 1.0, 1.0000001])]),
         "pow_gamma": np.concatenate([u, (u * 8).astype(np.float32), np.float32([0.0, 1.0])]),

@@ -40,6 +40,24 @@ def test_accuracy_vs_glibc(oracle):
     assert _ulp_err(p, l).max() <= 16.0  # display-only path (tone mapping)
 
 
+def test_fused_sincos_equals_the_two_functions(oracle):
+    """pm_sincosf (what the device kernels call) == (pm_sinf, pm_cosf) bit for bit: in [0, 2 pi) where
+    the spatial pass uses it, over a wide range, and on the special values."""
+    oracle.set_math_mode(oracle.MATH_PORTABLE)
+    rng = np.random.default_rng(7)
+    x = np.concatenate([
+        (rng.random(500000, dtype=np.float32) * np.float32(6.2831855)).astype(np.float32),
+        ((rng.random(300000, dtype=np.float32) - np.float32(0.5)) * np.float32(2000.0)).astype(np.float32),
+        np.float32([0.0, -0.0, 1e-30, -1e-30, 1.5707964, 3.1415927, 4.712389, 6.2831855, 5e8, 6e8, -7e8, np.inf, -np.inf, np.nan]),
+        (np.arange(-64, 65, dtype=np.float32) * np.float32(np.pi / 4)).astype(np.float32),
+    ])
+    f = oracle.fn_bulk
+    s1, c1 = f("sinf", x).reshape(-1), f("cosf", x).reshape(-1)
+    s2, c2 = f("sincos_sin", x).reshape(-1), f("sincos_cos", x).reshape(-1)
+    assert np.array_equal(s1.view(np.uint32), s2.view(np.uint32))
+    assert np.array_equal(c1.view(np.uint32), c2.view(np.uint32))
+
+
 def test_special_values(oracle):
     oracle.set_math_mode(oracle.MATH_PORTABLE)
     f = oracle.fn_bulk
