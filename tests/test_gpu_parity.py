@@ -730,3 +730,81 @@ def test_headless_host_app_images(api, scenes, tmp_path):
     assert raw.startswith(head)
     rgb = np.frombuffer(raw[len(head):], np.float32).reshape(H, W, 3)
     assert np.array_equal(rgb.view(np.uint32), (acc[:, :, :3] / acc[:, :, 3:4]).astype(np.float32).view(np.uint32))
+
+
+_SOUP_STATS = []
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("RT_SOUP_SEEDS", "10")))))
+def test_random_triangle_soups_differential(api, oracle, seed):
+    """Differential test on random triangle soups (sliver and degenerate triangles, coplanar overlaps,
+    zero-area lights, lights facing away, camera inside the soup) with random option sets: the fused
+    frame on the device == the oracle's frame, bit for bit, two frames."""
+    from cedec_2024_rt_amd.types import TRIANGLE, bench_options
+
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(8, 400))
+    tris = np.zeros(n, TRIANGLE)
+    c = rng.normal(size=(n, 1, 3)).astype(np.float32) * np.float32(3.0)
+    size = np.float32(10.0) ** rng.uniform(-2.0, 0.7, size=(n, 1, 1)).astype(np.float32)
+    tris["v"] = (c + rng.normal(size=(n, 3, 3)).astype(np.float32) * size).astype(np.float32)
+    # special shapes: degenerate (two equal vertices), collinear, exact duplicates, axis-aligned quads' halves
+    k = n // 8
+    tris["v"][:k, 1] = tris["v"][:k, 0]
+    tris["v"][k:2 * k, 2] = (tris["v"][k:2 * k, 0] + (tris["v"][k:2 * k, 1] - tris["v"][k:2 * k, 0]) * np.float32(0.5)).astype(np.float32)
+    tris["v"][2 * k:3 * k] = tris["v"][3 * k:4 * k]
+    tris["v"][4 * k:5 * k, :, 1] = np.float32(-2.0)  # a coplanar patch (floor-like, many exact t ties)
+    tris["color"] = rng.random((n, 3), dtype=np.float32)
+    lights = rng.random(n) < 0.3
+    lights[0] = True
+    tris["emissive"][lights] = (rng.random((int(lights.sum()), 3), dtype=np.float32) * np.float32(20.0)).astype(np.float32)
+    optkw = dict(
+        use_temporal_resampling=int(rng.integers(0, 2)), use_spatial_resampling=int(rng.integers(0, 2)),
+        use_visibility_reuse=int(rng.integers(0, 2)), use_shadowed_target_function=int(rng.integers(0, 2)),
+        ris_sample_count=int(rng.integers(1, 12)), spatial_resampling_passes=int(rng.integers(0, 4)),
+        spatial_resampling_sample_count=int(rng.integers(1, 7)), spatial_resampling_radius=float(rng.uniform(2.0, 30.0)),
+        accumulate=int(rng.integers(0, 2)))
+    W, H = int(rng.integers(20, 90)), int(rng.integers(12, 60))
+    eye = tuple(float(v) for v in rng.normal(size=3) * 6.0)
+    at = tuple(float(v) for v in rng.normal(size=3))
+    r, sc, rg, opt, eyev = _setup(api, oracle, tris, W, H, eye, at, **optkw)
+    st = oracle.new_state(W, H)
+    for frame in (1, 2):
+        cnt = oracle.new_counters()
+        r.frame(frame)
+        sc.frame(W, H, frame, rg, eyev, opt, st, cnt)
+        vis = r.download(api.RT_BUF_VISIBILITY)
+        assert _eq_bits(vis, st["vis"].reshape(vis.shape)), f"seed {seed} {optkw}: visibility frame {frame}"
+        acc = r.download(api.RT_BUF_ACCUMULATION)
+        ref = st["accum"].reshape(acc.shape)
+        bad = (acc.view(np.uint32) != ref.view(np.uint32)).any(axis=1)
+        assert not bad.any(), f"seed {seed} {optkw} frame {frame}: {int(bad.sum())} pixels, first {np.flatnonzero(bad)[:5]}: {acc[bad][:3]} vs {ref[bad][:3]}"
+        assert r.ray_count()[0] == int(cnt["rays"][0])
+    assert np.array_equal(r.download(api.RT_BUF_PIXELS).reshape(H, W, 4), st["pixels"])
+    _SOUP_STATS.append((seed, int(r.ray_count()[1]), W * H))
+    # the path tracers of 07_pt / 08_nee / 09_ris on the same soup (one launch and wavefront form)
+    from cedec_2024_rt_amd.types import default_options
+
+    ptkw = dict(max_depth=int(rng.integers(1, 7)), ris_sample_count=int(rng.integers(1, 9)),
+                use_shadowed_target_function=int(rng.integers(0, 2)), sky_color=tuple(float(v) for v in rng.random(3)))
+    r.set_options(default_options(**ptkw))
+    popt = oracle.default_options(**ptkw)
+    for example in (7, 8, 9):
+        for mode in (0, 1):
+            acc = np.zeros((W * H, 4), np.float32)
+            cnt = oracle.new_counters()
+            r.tuning(6, mode)
+            r.path_trace(example, 3)
+            sc.path_trace(example, W, H, 3, rg, popt, acc, cnt=cnt)
+            got = r.download(api.RT_BUF_ACCUMULATION)
+            assert _eq_bits(got, acc), f"seed {seed} example {example} mode {mode} {ptkw}: {(got.view(np.uint32) != acc.view(np.uint32)).any(axis=1).sum()} pixels"
+            assert r.path_trace_rays() == int(cnt["rays"][0])
+    r.close()
+
+
+def test_random_triangle_soups_are_not_trivial():
+    """(runs after the soups, same module order) most of them put shaded pixels on screen"""
+    if not _SOUP_STATS:
+        pytest.skip("soup tests did not run")
+    frac = [s / n for _, s, n in _SOUP_STATS]
+    assert np.mean(np.array(frac) > 0.05) > 0.5, _SOUP_STATS
