@@ -530,7 +530,7 @@ __global__ __launch_bounds__(BLOCK) void k_spatial(SceneView S, FrameParams P, c
  * the RNG and the shaded bits, not on reservoir contents). Measurement aid, not on the hot path. */
 __global__ __launch_bounds__(BLOCK) void k_spatial_bytes(FrameParams P, const float4* __restrict__ g1,
                                                           const float4* __restrict__ in_rec,
-                                                          unsigned long long* __restrict__ out)
+                                                          unsigned long long* __restrict__ out, bool flags_from_g1 = false)
 {
     int x, row;
     const bool ok = tile_pixel(P, x, row);
@@ -563,8 +563,12 @@ __global__ __launch_bounds__(BLOCK) void k_spatial_bytes(FrameParams P, const fl
                     if (lr < 0 || lr >= P.lrows) continue;
                     bytes += 16;
                     accepted += 1;
-                    const uint32_t mb = as_uint(in_rec[4 * ((size_t)nx + (size_t)lr * P.W) + 1].w);
-                    if (!(mb & RES_SHADED_BIT)) continue;
+                    /* the neighbour's shaded flag: from its record, or (strips with sparse halos, where
+                     * only the records that will be gathered travel) from the exchanged G-buffer flags */
+                    const size_t nid = (size_t)nx + (size_t)lr * P.W;
+                    const bool n_shaded = flags_from_g1 ? (as_uint(g1[nid].w) & GB_SHADED) != 0u
+                                                        : (as_uint(in_rec[4 * nid + 1].w) & RES_SHADED_BIT) != 0u;
+                    if (!n_shaded) continue;
                     bytes += 76;
                     merged += 1; /* neighbours that reach the target function (:346-350) */
                     rng.uniformf();

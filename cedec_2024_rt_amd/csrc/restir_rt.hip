@@ -1331,8 +1331,12 @@ int rt_ray_count(rt_ctx* c, uint64_t* rays, uint64_t* shaded_pixels)
             RT_HIP(c, hipMalloc(&d, 24));
             RT_HIP(c, hipMemsetAsync(d, 0, 24, c->stream));
             for (int k = 0; k < c->opt.spatial_resampling_passes; ++k)
+            {
+                /* halo rows: G-buffer flags if the neighbours' were exchanged for this frame, else the records */
+                const bool g1_ok = (c->row_begin == c->lrow0 || c->halo_flags_ok[0]) && (c->row_end == c->lrow0 + c->lrows || c->halo_flags_ok[1]);
                 k_spatial_bytes<<<launch_grid(c), BLOCK, 0, c->stream>>>(make_params(c, c->last_frame, k), c->d_g1,
-                                                                        c->d_rec[c->res_map[RT_RES_TEMPORAL]], d);
+                                                                        c->d_rec[c->res_map[RT_RES_TEMPORAL]], d, g1_ok);
+            }
             RT_HIP(c, hipGetLastError());
             unsigned long long h[3] = {0, 0, 0};
             RT_HIP(c, hipMemcpyAsync(h, d, 24, hipMemcpyDeviceToHost, c->stream));

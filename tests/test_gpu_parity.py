@@ -396,6 +396,52 @@ def test_strip_contexts_match_full_frame(api, oracle, scenes, n_strips, H, spars
     full.close()
 
 
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("RT_STRIP_SEEDS", "8")))))
+def test_random_strip_partitions_match_single_context(api, scenes, seed):
+    """Random image sizes, 2-5 strips, random option sets, dense or sparse halos: the strip contexts driven
+    through StripFrame (two lanes where a strip has interior rows) reproduce the single context, 2 frames."""
+    import torch
+
+    from cedec_2024_rt_amd import strips
+    from cedec_2024_rt_amd.types import bench_options
+
+    rng = np.random.default_rng(500 + seed)
+    n_strips = int(rng.integers(2, 6))
+    H = int(rng.integers(n_strips * strips.HALO_ROWS, n_strips * 260))
+    W = int(rng.integers(33, 150))
+    sparse = bool(rng.integers(0, 2))
+    optkw = dict(use_temporal_resampling=int(rng.integers(0, 2)), use_visibility_reuse=int(rng.integers(0, 2)),
+                 use_shadowed_target_function=int(rng.integers(0, 4) == 0), ris_sample_count=int(rng.integers(1, 9)),
+                 spatial_resampling_passes=int(rng.integers(1, 4)), spatial_resampling_sample_count=int(rng.integers(1, 7)),
+                 accumulate=int(rng.integers(0, 2)))
+    tris = scenes.make_quad_room()
+    eye, at = (0.5 + float(rng.normal()) * 0.5, 2.5, 6.0), (0.0, 1.5 + float(rng.normal()) * 0.3, -1.0)
+
+    def make(rows=None, halo=0):
+        c = api.Renderer(W, H, rows=rows, halo=halo)
+        c.set_scene(tris)
+        c.lookat(eye, at)
+        c.set_options(bench_options(**optkw))
+        return c
+
+    full = make()
+    bounds = strips.partition_rows(H, n_strips)
+    ctxs = [make(rows=b, halo=strips.HALO_ROWS) for b in bounds]
+    for frame in (1, 2):
+        full.frame(frame)
+        ref = full.download(api.RT_BUF_ACCUMULATION).reshape(H, W, 4)
+        refpx = full.download(api.RT_BUF_PIXELS).reshape(H, W, 4)
+        strips.run_frame_local(ctxs, bounds, frame, torch.device("cuda:0"), sparse=sparse)
+        for c, (a, b) in zip(ctxs, bounds):
+            acc = c.download(api.RT_BUF_ACCUMULATION).reshape(c.local_rows, W, 4)
+            assert _eq_bits(acc[a - c.local_row0: b - c.local_row0], ref[a:b]), f"seed {seed}: {n_strips} strips of {W}x{H}, sparse={sparse}, {optkw}, rows {a}:{b}, frame {frame}"
+            px = c.download(api.RT_BUF_PIXELS).reshape(c.local_rows, W, 4)
+            assert np.array_equal(px[a - c.local_row0: b - c.local_row0], refpx[a:b])
+    assert sum(c.ray_count()[0] for c in ctxs) == full.ray_count()[0]
+    for c in ctxs + [full]:
+        c.close()
+
+
 @pytest.mark.parametrize("example,scene_name,W,H,frames,optkw", [
     (7, "cornellbox2", 512, 512, 4, dict(accumulate=1)),                       # BASELINE config #2
     (7, "quad_room", 96, 54, 2, dict(accumulate=1, sky_color=(0.3, 0.4, 0.5))),
