@@ -131,7 +131,10 @@ RT_DEV void gbuffer_write(const SceneView& S, const FrameParams& P, float4* __re
 
 /* -------------------------------------------------------------------- raycast */
 /* examples/10_restir_di/10_restir_di.cu:9-34 (+ common/camera.hpp:27-35) */
-__global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_raycast(SceneView S, FrameParams P, float4* __restrict__ vis,
+#ifndef RT_RAYCAST_WAVES
+#define RT_RAYCAST_WAVES RT_TRACE_WAVES
+#endif
+__global__ __launch_bounds__(BLOCK, RT_RAYCAST_WAVES) void k_raycast(SceneView S, FrameParams P, float4* __restrict__ vis,
                                                     float4* __restrict__ g0, float4* __restrict__ g1)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_WORDS];
@@ -703,7 +706,10 @@ __global__ void k_halo_flags(float4* __restrict__ g1, size_t off, int n_pix, uin
 /* examples/10_restir_di/10_restir_di.cu:390-459 */
 /* 6 wavefronts per SIMD (what the 24 KB LDS stack allows): 86 -> 80 VGPRs, -3 % (A/B); the same bound
  * makes the candidate kernel spill (+6 %), so it is set here only */
-__global__ __launch_bounds__(BLOCK, 6) void k_resolve(SceneView S, FrameParams P, const float4* __restrict__ g0,
+#ifndef RT_RESOLVE_WAVES
+#define RT_RESOLVE_WAVES 6
+#endif
+__global__ __launch_bounds__(BLOCK, RT_RESOLVE_WAVES) void k_resolve(SceneView S, FrameParams P, const float4* __restrict__ g0,
                                                     const float4* __restrict__ g1,
                                                     const float4* __restrict__ rec,
                                                     const float4* __restrict__ radb, float4* __restrict__ accum)

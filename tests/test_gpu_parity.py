@@ -566,7 +566,32 @@ def test_edge_cases_and_error_codes(api, oracle, scenes):
     t = torch.empty(r3.halo_bitmap_words(40) * 4, dtype=torch.uint8, device="cuda")
     with pytest.raises(api.RtError, match="shaded flags"):
         r3.halo_mark(1, 0, 3, 1, t.data_ptr())  # neighbour flags not exchanged since the raycast
+    # the staged frame's two lanes: misuse is reported, a split stage equals the one-call stage
+    r3.set_options(bench_options(spatial_resampling_radius=10.0, spatial_resampling_passes=1))
+    with pytest.raises(api.RtError, match="expected stage"):
+        r3.frame_stage_run(2, 1, 0, 100)
+    r3.frame_stage_begin(2, 0, False)
+    r3.frame_stage_run_async(2, 0, 0, 40, 100)  # rows 40..99 on the second stream ...
+    with pytest.raises(api.RtError, match="second lane"):
+        r3.frame_stage_fork()
+    r3.frame_stage_run(2, 0, 0, 40)             # ... rows 0..39 on the main stream
+    r3.frame_stage_end(0)
+    r3.frame_stage_begin(2, 1, False)
+    r3.frame_stage_run(2, 1, 0, 100)
+    r3.frame_stage_end(1)
+    r3.frame_stage_begin(2, 2, False)
+    r3.frame_stage_run(2, 2, 0, 100)
+    r3.frame_stage_end(2)
+    split = r3.download(api.RT_BUF_ACCUMULATION).copy()
+    r4 = api.Renderer(32, 200, rows=(0, 100), halo=40)
+    r4.set_scene(tris)
+    r4.lookat(eye, center)
+    r4.set_options(bench_options(spatial_resampling_radius=10.0, spatial_resampling_passes=1))
+    for st in range(3):
+        r4.frame_stage(2, st, False)
+    assert _eq_bits(split, r4.download(api.RT_BUF_ACCUMULATION))
     r3.close()
+    r4.close()
 
 
 def test_interactive_camera_and_accumulation_reset(api, oracle, scenes):
