@@ -176,6 +176,10 @@ static int collapse_wide(const std::vector<BvhNode>& bin, const rt_triangle* tri
             ch[pick] = two[0];
             ch[n++] = two[1];
         }
+        /* any-hit walks visit hit children in slot order: smallest box first (A/B on the bench frame:
+         * ascending area -1 % frame, descending +1 %, leaves first/last = ascending; closest-hit walks
+         * sort by entry distance and do not care) */
+        std::sort(ch, ch + n, [](const WideChild& x, const WideChild& y) { return box_area6(x.lo, x.hi) < box_area6(y.lo, y.hi); });
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (int k = 0; k < n; ++k)
             for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], ch[k].lo[a]); hi[a] = fmaxf(hi[a], ch[k].hi[a]); }
