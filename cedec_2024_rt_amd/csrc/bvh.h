@@ -365,8 +365,8 @@ RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3
                 }
                 else
                 {
-                    /* any-hit: the order is irrelevant for the result: visit the first hit child in
-                     * slot order next, push the others */
+                    /* any-hit: the order is irrelevant for the result: visit the hit children in slot order
+                     * (= ascending box area, see collapse_wide): the first one next, the others pushed last-first */
                     const bool h0 = td[0] < 3.0e38f, h1 = td[1] < 3.0e38f, h2 = td[2] < 3.0e38f, h3 = td[3] < 3.0e38f;
                     cur = h0 ? ce[0] : (h1 ? ce[1] : (h2 ? ce[2] : ce[3]));
                     if (__builtin_expect(deep, 0))
@@ -377,9 +377,9 @@ RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3
                     }
                     else
                     {
-                        if (h1 && h0) { lds_stack[sp * BLOCK_THREADS + lane_slot] = ce[1]; ++sp; }
-                        if (h2 && (h0 || h1)) { lds_stack[sp * BLOCK_THREADS + lane_slot] = ce[2]; ++sp; }
                         if (h3 && (h0 || h1 || h2)) { lds_stack[sp * BLOCK_THREADS + lane_slot] = ce[3]; ++sp; }
+                        if (h2 && (h0 || h1)) { lds_stack[sp * BLOCK_THREADS + lane_slot] = ce[2]; ++sp; }
+                        if (h1 && h0) { lds_stack[sp * BLOCK_THREADS + lane_slot] = ce[1]; ++sp; }
                     }
                 }
             }
@@ -532,9 +532,9 @@ RT_DEV uint32_t occluded_batch(const WideView& bvh, uint32_t* __restrict__ lds_s
                 }
                 else
                 {
-                    if (h[1] && h[0]) { lds_stack[sp * BLOCK_THREADS + lane_slot] = ce[1]; ++sp; }
-                    if (h[2] && (h[0] || h[1])) { lds_stack[sp * BLOCK_THREADS + lane_slot] = ce[2]; ++sp; }
                     if (h[3] && (h[0] || h[1] || h[2])) { lds_stack[sp * BLOCK_THREADS + lane_slot] = ce[3]; ++sp; }
+                    if (h[2] && (h[0] || h[1])) { lds_stack[sp * BLOCK_THREADS + lane_slot] = ce[2]; ++sp; }
+                    if (h[1] && h[0]) { lds_stack[sp * BLOCK_THREADS + lane_slot] = ce[1]; ++sp; }
                 }
             }
             else cur = sp ? pop() : NONE;
