@@ -814,7 +814,8 @@ def test_random_triangle_soups_differential(api, oracle, seed):
     from cedec_2024_rt_amd.types import TRIANGLE, bench_options
 
     rng = np.random.default_rng(1000 + seed)
-    n = int(rng.integers(8, 400))
+    big = int(os.environ.get("RT_SOUP_SCALE", "1"))  # ad-hoc soak runs: more triangles, larger images
+    n = int(rng.integers(8, 400 * big * big))
     tris = np.zeros(n, TRIANGLE)
     c = rng.normal(size=(n, 1, 3)).astype(np.float32) * np.float32(3.0)
     size = np.float32(10.0) ** rng.uniform(-2.0, 0.7, size=(n, 1, 1)).astype(np.float32)
@@ -835,7 +836,7 @@ def test_random_triangle_soups_differential(api, oracle, seed):
         ris_sample_count=int(rng.integers(1, 12)), spatial_resampling_passes=int(rng.integers(0, 4)),
         spatial_resampling_sample_count=int(rng.integers(1, 7)), spatial_resampling_radius=float(rng.uniform(2.0, 30.0)),
         accumulate=int(rng.integers(0, 2)))
-    W, H = int(rng.integers(20, 90)), int(rng.integers(12, 60))
+    W, H = int(rng.integers(20, 90 * big)), int(rng.integers(12, 60 * big))
     eye = tuple(float(v) for v in rng.normal(size=3) * 6.0)
     at = tuple(float(v) for v in rng.normal(size=3))
     r, sc, rg, opt, eyev = _setup(api, oracle, tris, W, H, eye, at, **optkw)
