@@ -221,7 +221,8 @@ RT_DEV float wide_byte(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xff
 #define RT_LEAF_NUM_CLOSEST 1
 #define RT_LEAF_DEN_CLOSEST 2
 #endif
-template <bool ANY, bool STATS = false>
+/* STRIDE = threads of the calling workgroup = row pitch of the LDS stack (entry i of thread t at word i*STRIDE + t) */
+template <bool ANY, bool STATS = false, int STRIDE = BLOCK_THREADS>
 RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3 ro, f3 rd, float tmin, float tmax,
                        Hit& hit, uint32_t* stats = nullptr)
 {
@@ -242,14 +243,14 @@ RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3
     int sp = 0;
     const int lane_slot = threadIdx.x;
     auto push = [&](uint32_t e) {
-        if (sp < WIDE_LDS_STACK) lds_stack[sp * BLOCK_THREADS + lane_slot] = e;
+        if (sp < WIDE_LDS_STACK) lds_stack[sp * STRIDE + lane_slot] = e;
         else ovf[sp - WIDE_LDS_STACK] = e;
         ++sp;
     };
     auto pop = [&]() -> uint32_t {
         --sp;
         uint32_t e;
-        if (sp < WIDE_LDS_STACK) e = lds_stack[sp * BLOCK_THREADS + lane_slot];
+        if (sp < WIDE_LDS_STACK) e = lds_stack[sp * STRIDE + lane_slot];
         else e = ovf[sp - WIDE_LDS_STACK];
         return e;
     };
@@ -355,10 +356,10 @@ RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3
                     }
                     else if (nhit > 1)
                     {
-                        uint32_t* top = lds_stack + (sp + nhit - 2) * BLOCK_THREADS + lane_slot;
+                        uint32_t* top = lds_stack + (sp + nhit - 2) * STRIDE + lane_slot;
                         top[0] = ce[1];
-                        if (nhit > 2) top[-BLOCK_THREADS] = ce[2];
-                        if (nhit > 3) top[-2 * BLOCK_THREADS] = ce[3];
+                        if (nhit > 2) top[-STRIDE] = ce[2];
+                        if (nhit > 3) top[-2 * STRIDE] = ce[3];
                         sp += nhit - 1;
                     }
                     cur = ce[0];
@@ -377,9 +378,9 @@ RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3
                     }
                     else
                     {
-                        if (h3 && (h0 || h1 || h2)) { lds_stack[sp * BLOCK_THREADS + lane_slot] = ce[3]; ++sp; }
-                        if (h2 && (h0 || h1)) { lds_stack[sp * BLOCK_THREADS + lane_slot] = ce[2]; ++sp; }
-                        if (h1 && h0) { lds_stack[sp * BLOCK_THREADS + lane_slot] = ce[1]; ++sp; }
+                        if (h3 && (h0 || h1 || h2)) { lds_stack[sp * STRIDE + lane_slot] = ce[3]; ++sp; }
+                        if (h2 && (h0 || h1)) { lds_stack[sp * STRIDE + lane_slot] = ce[2]; ++sp; }
+                        if (h1 && h0) { lds_stack[sp * STRIDE + lane_slot] = ce[1]; ++sp; }
                     }
                 }
             }
@@ -391,12 +392,13 @@ RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3
     return true;
 }
 
+template <int STRIDE = BLOCK_THREADS>
 RT_DEV bool check_visibility_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3 p0, f3 n0, f3 p1)
 {
     const f3 org = p0 + 0.001f * n0;
     const f3 dir = p1 - p0;
     Hit h;
-    return !trace_wide<true>(bvh, lds_stack, org, dir, 0.0f, 0.99f, h);
+    return !trace_wide<true, false, STRIDE>(bvh, lds_stack, org, dir, 0.0f, 0.99f, h);
 }
 
 /* Up to NR shadow rays of ONE lane from a common surface point, walked back to back: ray k is
@@ -409,7 +411,7 @@ RT_DEV bool check_visibility_wide(const WideView& bvh, uint32_t* __restrict__ ld
 #ifndef RT_BATCH_REFILL
 #define RT_BATCH_REFILL 1
 #endif
-template <int NR>
+template <int NR, int STRIDE = BLOCK_THREADS>
 RT_DEV uint32_t occluded_batch(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3 p0, f3 n0, const f3 (&tgt)[NR],
                                uint32_t need)
 {
@@ -422,14 +424,14 @@ RT_DEV uint32_t occluded_batch(const WideView& bvh, uint32_t* __restrict__ lds_s
     uint32_t ovf[WIDE_OVF_STACK];
     int sp = 0;
     auto push = [&](uint32_t e) {
-        if (sp < WIDE_LDS_STACK) lds_stack[sp * BLOCK_THREADS + lane_slot] = e;
+        if (sp < WIDE_LDS_STACK) lds_stack[sp * STRIDE + lane_slot] = e;
         else ovf[sp - WIDE_LDS_STACK] = e;
         ++sp;
     };
     auto pop = [&]() -> uint32_t {
         --sp;
         uint32_t e;
-        if (sp < WIDE_LDS_STACK) e = lds_stack[sp * BLOCK_THREADS + lane_slot];
+        if (sp < WIDE_LDS_STACK) e = lds_stack[sp * STRIDE + lane_slot];
         else e = ovf[sp - WIDE_LDS_STACK];
         return e;
     };
@@ -532,9 +534,9 @@ RT_DEV uint32_t occluded_batch(const WideView& bvh, uint32_t* __restrict__ lds_s
                 }
                 else
                 {
-                    if (h[3] && (h[0] || h[1] || h[2])) { lds_stack[sp * BLOCK_THREADS + lane_slot] = ce[3]; ++sp; }
-                    if (h[2] && (h[0] || h[1])) { lds_stack[sp * BLOCK_THREADS + lane_slot] = ce[2]; ++sp; }
-                    if (h[1] && h[0]) { lds_stack[sp * BLOCK_THREADS + lane_slot] = ce[1]; ++sp; }
+                    if (h[3] && (h[0] || h[1] || h[2])) { lds_stack[sp * STRIDE + lane_slot] = ce[3]; ++sp; }
+                    if (h[2] && (h[0] || h[1])) { lds_stack[sp * STRIDE + lane_slot] = ce[2]; ++sp; }
+                    if (h[1] && h[0]) { lds_stack[sp * STRIDE + lane_slot] = ce[1]; ++sp; }
                 }
             }
             else cur = sp ? pop() : NONE;

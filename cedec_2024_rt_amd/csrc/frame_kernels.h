@@ -55,8 +55,22 @@ constexpr int TILE_W_LOG2 = RT_TILE_W == 32 ? 5 : (RT_TILE_W == 16 ? 4 : 3);
  * tile rows either row by row (mode 0) or column by column (mode 1: the set of tiles in flight
  * on an XCD is then ~13 tiles wide x the band height instead of full-width x 4 rows, which is
  * what keeps the spatial pass's neighbour window inside the 4 MiB L2). */
+/* The tracing kernels (raycast, generate_candidate, resolve) run 64-thread workgroups = one wavefront
+ * on an 8x8 tile: a wavefront that finishes gives its LDS stack (6 KB) and its slot back at once,
+ * whereas the four wavefronts of a 256-thread workgroup hold 24 KB until the slowest is done
+ * (A/B: raycast -3 %, candidates -3 %, resolve -1 %). The spatial pass keeps 256 threads on 32x8
+ * tiles (its L2 window and occupancy limiter were tuned for them; 64-thread groups: +4 %). */
+#ifndef RT_TRACE_BLOCK
+#define RT_TRACE_BLOCK 64
+#endif
+constexpr int TRACE_BLOCK = RT_TRACE_BLOCK;
+template <int TB> struct TileShape { static constexpr int W = TILE_W, H = TILE_H; };
+template <> struct TileShape<64> { static constexpr int W = 8, H = 8; };
+
+template <int TB = BLOCK>
 RT_DEV bool tile_pixel(const FrameParams& P, int& x, int& row)
 {
+    constexpr int TILE_W = TileShape<TB>::W, TILE_H = TileShape<TB>::H;
     const int tiles_x = (P.W + TILE_W - 1) / TILE_W;
     const int tiles_y = (P.row1 - P.row0 + TILE_H - 1) / TILE_H;
     const int b = blockIdx.x;
@@ -83,20 +97,28 @@ RT_DEV bool tile_pixel(const FrameParams& P, int& x, int& row)
 #ifndef RT_WAVE_8X8
 #define RT_WAVE_8X8 1
 #endif
+    if (TB == 64)
+    {
+        x = tx * 8 + (threadIdx.x & 7);
+        row = P.row0 + ty * 8 + (threadIdx.x >> 3);
+    }
+    else
+    {
 #if RT_WAVE_8X8 && RT_TILE_W == 32
-    /* wavefront w of the workgroup covers the 8x8 sub-block w of the 32x8 tile */
-    x = tx * TILE_W + 8 * (threadIdx.x >> 6) + (threadIdx.x & 7);
-    row = P.row0 + ty * TILE_H + ((threadIdx.x >> 3) & 7);
+        /* wavefront w of the workgroup covers the 8x8 sub-block w of the 32x8 tile */
+        x = tx * TILE_W + 8 * (threadIdx.x >> 6) + (threadIdx.x & 7);
+        row = P.row0 + ty * TILE_H + ((threadIdx.x >> 3) & 7);
 #else
-    x = tx * TILE_W + (threadIdx.x & (TILE_W - 1));
-    row = P.row0 + ty * TILE_H + (threadIdx.x >> TILE_W_LOG2);
+        x = tx * TILE_W + (threadIdx.x & (TILE_W - 1));
+        row = P.row0 + ty * TILE_H + (threadIdx.x >> TILE_W_LOG2);
 #endif
+    }
     return x < P.W && row < P.row1;
 }
-static inline int tile_grid(int W, int rows)
+static inline int tile_grid(int W, int rows, int tile_w = TILE_W, int tile_h = TILE_H)
 {
     /* covers both orders: mode 1 needs 8 * ceil(tiles_y/8) * tiles_x workgroups */
-    const int tx = (W + TILE_W - 1) / TILE_W, ty = (rows + TILE_H - 1) / TILE_H;
+    const int tx = (W + tile_w - 1) / tile_w, ty = (rows + tile_h - 1) / tile_h;
     const int a = ((tx * ty + 7) / 8) * 8, b = 8 * ((ty + 7) / 8) * tx;
     return a > b ? a : b;
 }
@@ -134,12 +156,12 @@ RT_DEV void gbuffer_write(const SceneView& S, const FrameParams& P, float4* __re
 #ifndef RT_RAYCAST_WAVES
 #define RT_RAYCAST_WAVES RT_TRACE_WAVES
 #endif
-__global__ __launch_bounds__(BLOCK, RT_RAYCAST_WAVES) void k_raycast(SceneView S, FrameParams P, float4* __restrict__ vis,
+__global__ __launch_bounds__(TRACE_BLOCK, RT_RAYCAST_WAVES) void k_raycast(SceneView S, FrameParams P, float4* __restrict__ vis,
                                                     float4* __restrict__ g0, float4* __restrict__ g1)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_STACK * TRACE_BLOCK];
     int x, row;
-    if (!tile_pixel(P, x, row)) return;
+    if (!tile_pixel<TRACE_BLOCK>(P, x, row)) return;
     const int yi = P.H - 1 - row;
     const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
 
@@ -150,7 +172,7 @@ __global__ __launch_bounds__(BLOCK, RT_RAYCAST_WAVES) void k_raycast(SceneView S
 
     Hit h;
     h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.prim = -1;
-    trace_wide<false>(S.wide, s_stack, P.rg_origin, rd, 0.0f, kFltMax, h);
+    trace_wide<false, false, TRACE_BLOCK>(S.wide, s_stack, P.rg_origin, rd, 0.0f, kFltMax, h);
     vis[li] = make_float4(h.u, h.v, as_float(h.prim), as_float(0));
     gbuffer_write(S, P, g0, g1, li, h.u, h.v, h.prim);
 }
@@ -200,12 +222,13 @@ RT_DEV float target_shadowed(f3 op, f3 on, f3 hp, f3 hn, float lum, float V)
  * the current sample survives the merge, the p-hat of :225-229 are the same ray) and surface ->
  * previous sample (:195-199; again :225-229 if it wins). The previous sample's ray is not walked
  * when its weight is 0 whatever the answer. V = 1 visible, 0 occluded. */
+template <int STRIDE = BLOCK>
 RT_DEV void temporal_rays(const SceneView& S, uint32_t* s_stack, const FrameParams& P, f3 sp, f3 sn, const Res& r,
                           const Res& pr, bool with_prev, float& V_cur, float& V_prev)
 {
     const f3 tgt[2] = {r.hit_p, pr.hit_p};
     const bool moot = !with_prev || pr.ucw == 0.0f || (P.vis_reuse && !pr.vis);
-    const uint32_t occl = occluded_batch<2>(S.wide, s_stack, sp, sn, tgt, moot ? 1u : 3u);
+    const uint32_t occl = occluded_batch<2, STRIDE>(S.wide, s_stack, sp, sn, tgt, moot ? 1u : 3u);
     V_cur = (occl & 1u) ? 0.0f : 1.0f;
     V_prev = (occl & 2u) ? 0.0f : 1.0f;
 }
@@ -239,14 +262,14 @@ RT_DEV void temporal_merge(const FrameParams& P, int x, int yi, f3 sp, f3 sn, Re
 /* examples/10_restir_di/10_restir_di.cu:36-135; with FUSE_TEMPORAL also :137-237 on the
  * value still in registers (the reference round-trips it through reservoir_buffer0). */
 template <bool FUSE_TEMPORAL, bool SHADOWED>
-__global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_generate_candidate(
+__global__ __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_generate_candidate(
     SceneView S, FrameParams P, const float4* __restrict__ g0, const float4* __restrict__ g1,
     const float4* __restrict__ prev_rec, const float4* __restrict__ prev_rad, float4* __restrict__ out_rec,
     float4* __restrict__ out_rad)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_STACK * TRACE_BLOCK];
     int x, row;
-    if (!tile_pixel(P, x, row)) return;
+    if (!tile_pixel<TRACE_BLOCK>(P, x, row)) return;
     const int yi = P.H - 1 - row;
     const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
 
@@ -320,8 +343,8 @@ __global__ __launch_bounds__(BLOCK, RT_TRACE_WAVES) void k_generate_candidate(
     };
     if (FUSE_TEMPORAL && SHADOWED) load_prev(); /* its sample is a ray target */
     float V_cur = 1.0f, V_prev = 1.0f;
-    if (SHADOWED) temporal_rays(S, s_stack, P, sp, sn, r, pr, FUSE_TEMPORAL, V_cur, V_prev);
-    else if (P.vis_reuse) V_cur = check_visibility_wide(S.wide, s_stack, sp, sn, r.hit_p) ? 1.0f : 0.0f;
+    if (SHADOWED) temporal_rays<TRACE_BLOCK>(S, s_stack, P, sp, sn, r, pr, FUSE_TEMPORAL, V_cur, V_prev);
+    else if (P.vis_reuse) V_cur = check_visibility_wide<TRACE_BLOCK>(S.wide, s_stack, sp, sn, r.hit_p) ? 1.0f : 0.0f;
     {
         const float p_hat = SHADOWED ? target_shadowed(sp, sn, r.hit_p, r.hit_n, r.lum, V_cur)
                                      : target_unshadowed(sp, sn, r.hit_p, r.hit_n, r.lum);
@@ -709,14 +732,14 @@ __global__ void k_halo_flags(float4* __restrict__ g1, size_t off, int n_pix, uin
 #ifndef RT_RESOLVE_WAVES
 #define RT_RESOLVE_WAVES 6
 #endif
-__global__ __launch_bounds__(BLOCK, RT_RESOLVE_WAVES) void k_resolve(SceneView S, FrameParams P, const float4* __restrict__ g0,
+__global__ __launch_bounds__(TRACE_BLOCK, RT_RESOLVE_WAVES) void k_resolve(SceneView S, FrameParams P, const float4* __restrict__ g0,
                                                     const float4* __restrict__ g1,
                                                     const float4* __restrict__ rec,
                                                     const float4* __restrict__ radb, float4* __restrict__ accum)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_STACK * TRACE_BLOCK];
     int x, row;
-    if (!tile_pixel(P, x, row)) return;
+    if (!tile_pixel<TRACE_BLOCK>(P, x, row)) return;
     const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
     const float4 G0 = g0[li], G1 = g1[li];
     const int tri = as_int(G0.w);
@@ -735,7 +758,7 @@ __global__ __launch_bounds__(BLOCK, RT_RESOLVE_WAVES) void k_resolve(SceneView S
     const f3 hp = F3(q0.x, q0.y, q0.z), hn = F3(q1.x, q1.y, q1.z);
     const f3 brdf = (1.0f / kPI) * F3(kd.x, kd.y, kd.z);
     const float G = geometry_term(sp, sn, hp, hn);
-    const float V = check_visibility_wide(S.wide, s_stack, sp, sn, hp) ? 1.0f : 0.0f;
+    const float V = check_visibility_wide<TRACE_BLOCK>(S.wide, s_stack, sp, sn, hp) ? 1.0f : 0.0f;
     const f3 radiance = brdf * G * V * F3(rq.x, rq.y, rq.z) * q0.w;
     if (P.accumulate)
     {

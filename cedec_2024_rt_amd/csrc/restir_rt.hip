@@ -654,6 +654,12 @@ static int launch_grid(const rt_ctx* c)
 {
     return c->sub0 >= 0 ? tile_grid(c->W, c->sub1 - c->sub0) : tile_grid(c->W, c->row_end - c->row_begin);
 }
+/* grid of the tracing kernels: TRACE_BLOCK threads on TileShape<TRACE_BLOCK> tiles */
+static int trace_grid(const rt_ctx* c)
+{
+    const int rows = c->sub0 >= 0 ? c->sub1 - c->sub0 : c->row_end - c->row_begin;
+    return tile_grid(c->W, rows, TileShape<TRACE_BLOCK>::W, TileShape<TRACE_BLOCK>::H);
+}
 
 int rt_clear(rt_ctx* c)
 {
@@ -667,7 +673,7 @@ int rt_raycast(rt_ctx* c)
 {
     RT_CHECK_CTX(c);
     NEED_SCENE(c);
-    k_raycast<<<launch_grid(c), BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_vis, c->d_g0, c->d_g1);
+    k_raycast<<<trace_grid(c), TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_vis, c->d_g0, c->d_g1);
     RT_HIP(c, hipGetLastError());
     c->has_gbuffer = true;
     c->halo_flags_ok[0] = c->halo_flags_ok[1] = false; /* the neighbours' G-buffers are new as well */
@@ -683,11 +689,11 @@ static int launch_generate(rt_ctx* c, int frame, int dst_phys, int prev_phys, bo
     const bool sh = c->opt.use_shadowed_target_function;
     float4 *orec = c->d_rec[dst_phys], *orad = c->d_rad[dst_phys];
     const float4 *prec = fuse ? c->d_rec[prev_phys] : nullptr, *prad = fuse ? c->d_rad[prev_phys] : nullptr;
-    const int g = launch_grid(c);
-    if (fuse && sh) k_generate_candidate<true, true><<<g, BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
-    else if (fuse) k_generate_candidate<true, false><<<g, BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
-    else if (sh) k_generate_candidate<false, true><<<g, BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
-    else k_generate_candidate<false, false><<<g, BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
+    const int g = trace_grid(c);
+    if (fuse && sh) k_generate_candidate<true, true><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
+    else if (fuse) k_generate_candidate<true, false><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
+    else if (sh) k_generate_candidate<false, true><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
+    else k_generate_candidate<false, false><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }
@@ -774,7 +780,7 @@ int rt_spatial_resampling(rt_ctx* c, int frame, int pass, int in, int out)
 
 static int launch_resolve(rt_ctx* c, int phys)
 {
-    k_resolve<<<launch_grid(c), BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RESOLVE), c->d_g0, c->d_g1,
+    k_resolve<<<trace_grid(c), TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RESOLVE), c->d_g0, c->d_g1,
                                                         c->d_rec[phys], c->d_rad[phys], c->d_accum);
     RT_HIP(c, hipGetLastError());
     return RT_OK;
