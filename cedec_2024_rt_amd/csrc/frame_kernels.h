@@ -191,14 +191,14 @@ __global__ __launch_bounds__(BLOCK) void k_gbuffer_from_vis(SceneView S, FramePa
 
 /* ------------------------------------------------------- target function helper */
 /* common/reservoir.hpp:42-59 */
-template <bool SHADOWED>
+template <bool SHADOWED, int STRIDE = BLOCK>
 RT_DEV float target_function(const SceneView& S, uint32_t* s_stack, f3 op, f3 on, f3 hp, f3 hn, float lum)
 {
     if (SHADOWED)
     {
         const float brdf = 1.0f / kPI;
         const float G = geometry_term(op, on, hp, hn);
-        const float V = check_visibility_wide(S.wide, s_stack, op, on, hp) ? 1.0f : 0.0f;
+        const float V = check_visibility_wide<STRIDE>(S.wide, s_stack, op, on, hp) ? 1.0f : 0.0f;
         return brdf * G * V * lum;
     }
     return target_unshadowed(op, on, hp, hn, lum);
@@ -398,15 +398,16 @@ __global__ __launch_bounds__(BLOCK) void k_temporal(SceneView S, FrameParams P, 
  * shaded bit kept inside the record; radiance (side record) is fetched once, for the sample
  * that survived. */
 template <bool SHADOWED>
-__global__ __launch_bounds__(BLOCK) void k_spatial(SceneView S, FrameParams P, const float4* __restrict__ g0,
+__global__ __launch_bounds__(SHADOWED ? TRACE_BLOCK : BLOCK) void k_spatial(SceneView S, FrameParams P, const float4* __restrict__ g0,
                                                     const float4* __restrict__ g1,
                                                     const float4* __restrict__ in_rec,
                                                     const float4* __restrict__ in_rad,
                                                     float4* __restrict__ out_rec, float4* __restrict__ out_rad)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_WORDS];
+    constexpr int TB = SHADOWED ? TRACE_BLOCK : BLOCK; /* the shadowed variant is a tracing kernel */
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[SHADOWED ? WIDE_LDS_STACK * TB : 4];
     int x, row;
-    if (!tile_pixel(P, x, row)) return;
+    if (!tile_pixel<TB>(P, x, row)) return;
     const int yi = P.H - 1 - row;
     const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
     const float4 G0 = g0[li], G1 = g1[li];
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(BLOCK) void k_spatial(SceneView S, FrameParams P, c
         }
         tgt[5] = r.hit_p;
         need |= 1u << 5;
-        const uint32_t occl = occluded_batch<6>(S.wide, s_stack, sp, sn, tgt, need);
+        const uint32_t occl = occluded_batch<6, TB>(S.wide, s_stack, sp, sn, tgt, need);
         int sel = 5;
 #pragma unroll
         for (int k = 0; k < 5; ++k)
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(BLOCK) void k_spatial(SceneView S, FrameParams P, c
             Res nr = res_load(in_rec, pid, n_shaded);
             if (!n_shaded) continue; /* sky or emissive neighbour (:326-338) */
 
-            float p_hat_y = target_function<SHADOWED>(S, s_stack, sp, sn, nr.hit_p, nr.hit_n, nr.lum);
+            float p_hat_y = target_function<SHADOWED, TB>(S, s_stack, sp, sn, nr.hit_p, nr.hit_n, nr.lum);
             if (P.vis_reuse) p_hat_y *= nr.vis ? 1.0f : 0.0f;
             nr.M = scale_M(nr.M, rejection_heuristics(r.org_p, r.org_n, nr.org_p, nr.org_n, P.eye));
             const float weight = p_hat_y * nr.ucw * (float)nr.M;
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(BLOCK) void k_spatial(SceneView S, FrameParams P, c
                 rad_from = pid;
             }
         }
-        const float p_hat = target_function<SHADOWED>(S, s_stack, sp, sn, r.hit_p, r.hit_n, r.lum);
+        const float p_hat = target_function<SHADOWED, TB>(S, s_stack, sp, sn, r.hit_p, r.hit_n, r.lum);
         r.ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
     }
     const float4 rq = in_rad[rad_from];
