@@ -804,13 +804,13 @@ RT_DEV void path_begin(const FrameParams& P, int x, int yi, PathState& st)
     st.throughput = F3(1.0f, 1.0f, 1.0f);
 }
 /* one iteration of the depth loop (07_pt.cu:39-79 / 08_nee.cu:39-118 / 09_ris.cu:39-155); false = the path ended */
-template <int EXAMPLE, bool SHADOWED>
+template <int EXAMPLE, bool SHADOWED, int STRIDE = TRACE_BLOCK>
 RT_DEV bool path_bounce(const SceneView& S, uint32_t* s_stack, const FrameParams& P, int depth, f3 sky, PathState& st,
                         unsigned long long& nrays)
 {
     Hit h;
     ++nrays;
-    if (!trace_wide<false>(S.wide, s_stack, st.ro, st.rd, 0.0f, kFltMax, h))
+    if (!trace_wide<false, false, STRIDE>(S.wide, s_stack, st.ro, st.rd, 0.0f, kFltMax, h))
     {
         if (EXAMPLE == 7) st.radiance = st.radiance + st.throughput * sky;
         return false;
@@ -844,7 +844,7 @@ RT_DEV bool path_bounce(const SceneView& S, uint32_t* s_stack, const FrameParams
         warp_unit_triangle(bx, by);
         const f3 lp = (1.0f - bx - by) * a0 + bx * a1 + by * a2;
         const f3 ln = tri_normal(a0, a1, a2);
-        const float V = check_visibility_wide(S.wide, s_stack, sp, sn, lp) ? 1.0f : 0.0f;
+        const float V = check_visibility_wide<STRIDE>(S.wide, s_stack, sp, sn, lp) ? 1.0f : 0.0f;
         ++nrays;
         const f3 brdf = (1.0f / kPI) * kd;
         const float G = geometry_term(sp, sn, lp, ln);
@@ -872,7 +872,7 @@ RT_DEV bool path_bounce(const SceneView& S, uint32_t* s_stack, const FrameParams
             float p_hat;
             if (SHADOWED)
             {
-                p_hat = target_function<true>(S, s_stack, sp, sn, lp, ln, L2.y);
+                p_hat = target_function<true, STRIDE>(S, s_stack, sp, sn, lp, ln, L2.y);
                 ++nrays;
             }
             else { p_hat = target_unshadowed(sp, sn, lp, ln, L2.y); }
@@ -889,7 +889,7 @@ RT_DEV bool path_bounce(const SceneView& S, uint32_t* s_stack, const FrameParams
         }
         const f3 brdf = (1.0f / kPI) * kd;
         const float G = geometry_term(sp, sn, r.hit_p, r.hit_n);
-        const float V = check_visibility_wide(S.wide, s_stack, sp, sn, r.hit_p) ? 1.0f : 0.0f;
+        const float V = check_visibility_wide<STRIDE>(S.wide, s_stack, sp, sn, r.hit_p) ? 1.0f : 0.0f;
         ++nrays;
         /* the reference traces this ray again for the shadowed p-hat (09_ris.cu:110-118): same ray, same answer */
         const float p_hat = SHADOWED ? target_shadowed(sp, sn, r.hit_p, r.hit_n, r.lum, V)
@@ -929,13 +929,13 @@ RT_DEV void count_rays(unsigned long long nrays, unsigned long long* __restrict_
 /* the reference's shape: one thread per pixel, whole path in one launch. rays[0] accumulates the
  * number of raytrace() calls (one atomic per wave). */
 template <int EXAMPLE, bool SHADOWED>
-__global__ __launch_bounds__(BLOCK) void k_path_trace(SceneView S, FrameParams P, int max_depth, f3 sky,
+__global__ __launch_bounds__(TRACE_BLOCK) void k_path_trace(SceneView S, FrameParams P, int max_depth, f3 sky,
                                                        float4* __restrict__ accum,
                                                        unsigned long long* __restrict__ rays)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_STACK * TRACE_BLOCK];
     int x, row;
-    const bool ok = tile_pixel(P, x, row);
+    const bool ok = tile_pixel<TRACE_BLOCK>(P, x, row);
     unsigned long long nrays = 0;
     if (ok)
     {
@@ -970,10 +970,10 @@ RT_DEV uint32_t path_load(const float4* __restrict__ rec, size_t i, PathState& s
     st.rng.inc = 1u; /* sequence 0 */
     return as_uint(d.z);
 }
-__global__ __launch_bounds__(BLOCK) void k_pt_init(FrameParams P, float4* __restrict__ list, unsigned long long* __restrict__ counters)
+__global__ __launch_bounds__(TRACE_BLOCK) void k_pt_init(FrameParams P, float4* __restrict__ list, unsigned long long* __restrict__ counters)
 {
     int x, row;
-    const bool ok = tile_pixel(P, x, row);
+    const bool ok = tile_pixel<TRACE_BLOCK>(P, x, row);
     /* every owned pixel starts one path; list position = compacted order of this launch */
     const unsigned long long m = __ballot(ok);
     if (!m) return;
@@ -988,12 +988,12 @@ __global__ __launch_bounds__(BLOCK) void k_pt_init(FrameParams P, float4* __rest
     path_store(list, (size_t)(base + __popcll(m & ((1ull << lane) - 1ull))), st, li);
 }
 template <int EXAMPLE, bool SHADOWED>
-__global__ __launch_bounds__(BLOCK) void k_pt_bounce(SceneView S, FrameParams P, int depth, int max_depth, f3 sky,
+__global__ __launch_bounds__(TRACE_BLOCK) void k_pt_bounce(SceneView S, FrameParams P, int depth, int max_depth, f3 sky,
                                                       const float4* __restrict__ in, float4* __restrict__ out,
                                                       float4* __restrict__ accum, unsigned long long* __restrict__ counters)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_WORDS];
-    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_STACK * TRACE_BLOCK];
+    const size_t i = (size_t)blockIdx.x * TRACE_BLOCK + threadIdx.x;
     const bool have = i < counters[2 + depth];
     unsigned long long nrays = 0;
     bool alive = false;

@@ -811,7 +811,7 @@ int rt_path_trace(rt_ctx* c, int example, int frame)
     const SceneView S = make_scene(c);
     const FrameParams P = make_params(c, frame, 0, K_RAYCAST);
     const f3 sky = F3(c->opt.sky_color[0], c->opt.sky_color[1], c->opt.sky_color[2]);
-    const int g = launch_grid(c);
+    const int g = trace_grid(c);
     const int md = c->opt.max_depth;
     const bool sh = c->opt.use_shadowed_target_function != 0;
     const bool wavefront = c->pt_wavefront == 1 || (c->pt_wavefront == 2 && example == 9);
@@ -826,27 +826,27 @@ int rt_path_trace(rt_ctx* c, int example, int frame)
             RT_HIP(c, hipMalloc(&c->d_pt_counters, 64 * 8));
         }
         RT_HIP(c, hipMemsetAsync(c->d_pt_counters, 0, 64 * 8, c->stream));
-        k_pt_init<<<g, BLOCK, 0, c->stream>>>(P, c->d_paths[0], c->d_pt_counters);
+        k_pt_init<<<g, TRACE_BLOCK, 0, c->stream>>>(P, c->d_paths[0], c->d_pt_counters);
         RT_HIP(c, hipGetLastError());
-        const int gb = (int)((n + BLOCK - 1) / BLOCK);
+        const int gb = (int)((n + TRACE_BLOCK - 1) / TRACE_BLOCK);
         for (int d = 0; d < md; ++d)
         {
             const float4* in = c->d_paths[d & 1];
             float4* out = c->d_paths[(d + 1) & 1];
-            if (example == 7) k_pt_bounce<7, false><<<gb, BLOCK, 0, c->stream>>>(S, P, d, md, sky, in, out, c->d_accum, c->d_pt_counters);
-            else if (example == 8) k_pt_bounce<8, false><<<gb, BLOCK, 0, c->stream>>>(S, P, d, md, sky, in, out, c->d_accum, c->d_pt_counters);
-            else if (sh) k_pt_bounce<9, true><<<gb, BLOCK, 0, c->stream>>>(S, P, d, md, sky, in, out, c->d_accum, c->d_pt_counters);
-            else k_pt_bounce<9, false><<<gb, BLOCK, 0, c->stream>>>(S, P, d, md, sky, in, out, c->d_accum, c->d_pt_counters);
+            if (example == 7) k_pt_bounce<7, false><<<gb, TRACE_BLOCK, 0, c->stream>>>(S, P, d, md, sky, in, out, c->d_accum, c->d_pt_counters);
+            else if (example == 8) k_pt_bounce<8, false><<<gb, TRACE_BLOCK, 0, c->stream>>>(S, P, d, md, sky, in, out, c->d_accum, c->d_pt_counters);
+            else if (sh) k_pt_bounce<9, true><<<gb, TRACE_BLOCK, 0, c->stream>>>(S, P, d, md, sky, in, out, c->d_accum, c->d_pt_counters);
+            else k_pt_bounce<9, false><<<gb, TRACE_BLOCK, 0, c->stream>>>(S, P, d, md, sky, in, out, c->d_accum, c->d_pt_counters);
             RT_HIP(c, hipGetLastError());
         }
         RT_HIP(c, hipMemcpyAsync(c->d_counter, c->d_pt_counters, 8, hipMemcpyDeviceToDevice, c->stream));
         return RT_OK;
     }
     RT_HIP(c, hipMemsetAsync(c->d_counter, 0, 8, c->stream));
-    if (example == 7) k_path_trace<7, false><<<g, BLOCK, 0, c->stream>>>(S, P, md, sky, c->d_accum, c->d_counter);
-    else if (example == 8) k_path_trace<8, false><<<g, BLOCK, 0, c->stream>>>(S, P, md, sky, c->d_accum, c->d_counter);
-    else if (sh) k_path_trace<9, true><<<g, BLOCK, 0, c->stream>>>(S, P, md, sky, c->d_accum, c->d_counter);
-    else k_path_trace<9, false><<<g, BLOCK, 0, c->stream>>>(S, P, md, sky, c->d_accum, c->d_counter);
+    if (example == 7) k_path_trace<7, false><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, md, sky, c->d_accum, c->d_counter);
+    else if (example == 8) k_path_trace<8, false><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, md, sky, c->d_accum, c->d_counter);
+    else if (sh) k_path_trace<9, true><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, md, sky, c->d_accum, c->d_counter);
+    else k_path_trace<9, false><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, md, sky, c->d_accum, c->d_counter);
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }
