@@ -57,7 +57,7 @@ struct rt_ctx
     float last_trace_ms = 0.0f;
     int last_frame = 0; /* frame number of the last rt_frame_stage / rt_spatial_resampling (ray counting) */
     int trace_mode = 0; /* rt_trace_closest / rt_trace_stats: 0 = wide (what the frame kernels use), 1 = binary stackless */
-    float bvh_split_factor = 12.0f; /* fragment length in median triangle extents; 0 = no pre-split */
+    float bvh_split_factor = 10.0f; /* fragment length in median triangle extents; 0 = no pre-split */
     int bvh_bfs_records = 2048; /* rt_tuning key 7: records emitted breadth-first (top of the tree contiguous) */
     int bvh_builder = 1; /* 0 = device LBVH (Morton/Karras), 1 = host binned SAH (high quality) */
     float* d_tris = nullptr;
@@ -843,7 +843,7 @@ int rt_path_trace(rt_ctx* c, int example, int frame)
         return RT_OK;
     }
     RT_HIP(c, hipMemsetAsync(c->d_counter, 0, 8, c->stream));
-    if (example == 7) k_path_trace<7, false><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, md, sky, c->d_accum, c->d_counter);
+    if (example == 7) k_path_trace<7, false><<<launch_grid(c), BLOCK, 0, c->stream>>>(S, P, md, sky, c->d_accum, c->d_counter);
     else if (example == 8) k_path_trace<8, false><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, md, sky, c->d_accum, c->d_counter);
     else if (sh) k_path_trace<9, true><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, md, sky, c->d_accum, c->d_counter);
     else k_path_trace<9, false><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, md, sky, c->d_accum, c->d_counter);

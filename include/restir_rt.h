@@ -224,7 +224,7 @@ int rt_trace_closest(rt_ctx* ctx, const float* rays, uint32_t n, float* hits);
  * executed while the ray was live (SIMT efficiency diagnostics) */
 int rt_trace_stats(rt_ctx* ctx, const float* rays, uint32_t n, uint32_t* stats);
 /* BVH build knob, call before rt_scene_set: large triangles are pre-split into fragments no
- * longer than split_factor x (median triangle extent); 0 = no pre-split. Default 12. */
+ * longer than split_factor x (median triangle extent); 0 = no pre-split. Default 10. */
 int rt_bvh_config(rt_ctx* ctx, float split_factor);
 /* wide_height: levels of the 4-wide tree the kernels walk; a walk holds at most 3 stack entries per level */
 int rt_bvh_info(rt_ctx* ctx, uint32_t* n_references, uint32_t* n_wide_records, uint32_t* wide_height);
