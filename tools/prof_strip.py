@@ -1,5 +1,8 @@
+"""Dev tool: one middle strip of the 8-way partition alone on the GPU (transport that answers instantly): cProfile of
+the host loop; run it under rocprofv3 --kernel-trace for the per-kernel times of a strip."""
 import sys, os, time, cProfile, pstats
-sys.path.insert(0, "/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import torch
 from cedec_2024_rt_amd import api, scenes, strips
 from cedec_2024_rt_amd.types import bench_options
