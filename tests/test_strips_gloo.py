@@ -81,6 +81,16 @@ class OracleBackend:
         else:
             self.sc.resolve(self.accum, W, H, self.vis, self.eye, self.opt, self.res[self.dst], rows=rows)
 
+    # the two-lane protocol of StripFrame: interior rows are computed BEFORE the halos of the stage are
+    # imported (on the device: on a second stream); here simply earlier, which checks the claim that
+    # interior rows never read a halo row (the halo rows still hold the previous stage's data / poison)
+    def stage_fork(self):
+        pass
+
+    def stage_run_async(self, frame, s, part, r0, r1):
+        assert part == 0
+        self.stage_run(frame, s, r0, r1)
+
     def stage_end(self, frame, s):
         if s == 0:
             for sl in self.staged_temporal:
