@@ -216,6 +216,47 @@ def main():
                 verified = bool(np.array_equal(np.concatenate(parts, axis=0).view(np.uint32), ref.view(np.uint32)))
                 full.close()
 
+    # Secondary line, reported next to the headline and never instead of it: the 3840x2160 frame of BASELINE
+    # config #5 on the same N GPUs (4x the pixels: a strip is then large enough to amortise the per-kernel
+    # latency floor that bounds strong scaling of the 2.3 ms 1080p frame).
+    also_4k = None
+    if (width, height) == (W, H) and not os.environ.get("BENCH_NO_4K"):
+        r.close()
+        w4, h4, k4, wm4 = 3840, 2160, 10, 3
+        if world == 1:
+            r4 = api.Renderer(w4, h4, device=local_rank)
+            r4.set_scene(tris)
+            r4.lookat(eye, center)
+            r4.set_options(opt)
+            step4 = r4.frame
+        else:
+            r4, sf4 = strips.make_hip_strip(w4, h4, rank, world, tris, eye, center, opt, device_index=local_rank)
+            step4 = sf4.frame
+        f4 = 0
+        for _ in range(wm4):
+            f4 += 1
+            step4(f4)
+        torch.cuda.synchronize()
+        rays4, _ = r4.ray_count()
+        barrier()
+        t4 = time.perf_counter()
+        for _ in range(k4):
+            f4 += 1
+            step4(f4)
+        barrier()
+        dt4 = time.perf_counter() - t4
+        if world > 1:
+            cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+            t = torch.tensor([dt4], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt4 = float(t.item())
+            rr = torch.tensor([rays4], dtype=torch.int64, device=cdev)
+            dist.all_reduce(rr, op=dist.ReduceOp.SUM)
+            rays4 = int(rr.item())
+        also_4k = {"workload": "same scene and options at 3840x2160 (the frame of BASELINE config #5)", "steps": k4, "warmup": wm4,
+                   "ms_per_step": dt4 / k4 * 1e3, "value": rays4 * k4 / dt4 / 1e6, "unit": "Mray/s", "rays_per_frame": rays4}
+        r4.close()
+
     if rank == 0:
         ms = elapsed / K * 1e3
         out = {
@@ -232,6 +273,8 @@ def main():
         }
         if world > 1 and verified is not None:
             out["verified_vs_single_context"] = verified
+        if also_4k is not None:
+            out["also_3840x2160"] = also_4k
         if world == 1:
             ach = algo_bytes / (spatial_ms * 1e-3) / 1e9
             traffic = None

@@ -20,9 +20,18 @@ def short(name):
 
 # kernel-trace stats: name, calls, total/avg/min/max duration (ns), share
 con = db("stats")
+# bench.py also renders a few 3840x2160 frames (its secondary line): launches are keyed by kernel AND grid,
+# so the 1920x1080 rows are exactly the launches the bench line's numbers are about
+raw = collections.defaultdict(list)
+for name, dur, gx, gy in con.execute("select name, duration, grid_x, grid_y from kernels"):
+    raw[(short(name), gx * max(gy, 1))].append(dur)
+grids = collections.defaultdict(set)
+for (k, g) in raw:
+    grids[k].add(g)
 rows = collections.defaultdict(list)
-for name, dur in con.execute("select name, duration from kernels"):
-    rows[short(name)].append(dur)
+for (k, g), v in raw.items():
+    # the smallest grid of a frame kernel is the 1080p launch and keeps the plain name
+    rows[k if g == min(grids[k]) or not k.startswith("k_") else f"{k} [grid {g}, 3840x2160 frames]"] += v
 total = sum(sum(v) for v in rows.values())
 with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
     f.write("Name,Calls,TotalDurationNs,AverageNs,MinNs,MaxNs,Percentage\n")
@@ -36,8 +45,13 @@ def counters(path):
     if con is None:
         return {}
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for k, c, v in con.execute("select kernel_name, counter_name, value from counters_collection"):
-        agg[short(k)][c].append(v)
+    rows_ = list(con.execute("select kernel_name, counter_name, value, grid_size from counters_collection"))
+    gmin = {}
+    for k, c, v, g in rows_:
+        gmin[short(k)] = min(gmin.get(short(k), g), g)
+    for k, c, v, g in rows_:
+        if g == gmin[short(k)] or not short(k).startswith("k_"):  # frame kernels: the 1920x1080 launches only (see above)
+            agg[short(k)][c].append(v)
     return {k: {c: dict(launches=len(v), mean=sum(v) / len(v)) for c, v in cs.items()} for k, cs in agg.items()}
 
 
