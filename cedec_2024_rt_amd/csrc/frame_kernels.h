@@ -397,8 +397,11 @@ __global__ __launch_bounds__(BLOCK) void k_temporal(SceneView S, FrameParams P, 
  * a Triangle and a 76-B Reservoir); the "sky / emissive neighbour" test of :326-338 reads the
  * shaded bit kept inside the record; radiance (side record) is fetched once, for the sample
  * that survived. */
+#ifndef RT_SHSPATIAL_WAVES
+#define RT_SHSPATIAL_WAVES 4 /* <= 128 VGPRs: 4 wavefronts per SIMD instead of 3 (shadowed frame 10.0 -> 9.2 ms; 5 and 6 spill: 14.5, 11.8 ms) */
+#endif
 template <bool SHADOWED>
-__global__ __launch_bounds__(SHADOWED ? TRACE_BLOCK : BLOCK) void k_spatial(SceneView S, FrameParams P, const float4* __restrict__ g0,
+__global__ __launch_bounds__(SHADOWED ? TRACE_BLOCK : BLOCK, SHADOWED ? RT_SHSPATIAL_WAVES : 1) void k_spatial(SceneView S, FrameParams P, const float4* __restrict__ g0,
                                                     const float4* __restrict__ g1,
                                                     const float4* __restrict__ in_rec,
                                                     const float4* __restrict__ in_rad,
