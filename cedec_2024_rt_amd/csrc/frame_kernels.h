@@ -806,6 +806,7 @@ RT_DEV void path_begin(const FrameParams& P, int x, int yi, PathState& st)
     st.radiance = F3(0.0f, 0.0f, 0.0f);
     st.throughput = F3(1.0f, 1.0f, 1.0f);
 }
+/* register budgets of the path tracers (A/B at 1080p): 08_nee at 6 wavefronts per SIMD -6.5 %, 09_ris at 5 -2 % */
 /* one iteration of the depth loop (07_pt.cu:39-79 / 08_nee.cu:39-118 / 09_ris.cu:39-155); false = the path ended */
 template <int EXAMPLE, bool SHADOWED, int STRIDE = TRACE_BLOCK>
 RT_DEV bool path_bounce(const SceneView& S, uint32_t* s_stack, const FrameParams& P, int depth, f3 sky, PathState& st,
@@ -932,7 +933,7 @@ RT_DEV void count_rays(unsigned long long nrays, unsigned long long* __restrict_
 /* the reference's shape: one thread per pixel, whole path in one launch. rays[0] accumulates the
  * number of raytrace() calls (one atomic per wave). */
 template <int EXAMPLE, bool SHADOWED>
-__global__ __launch_bounds__(EXAMPLE == 7 ? BLOCK : TRACE_BLOCK) void k_path_trace(SceneView S, FrameParams P, int max_depth, f3 sky,
+__global__ __launch_bounds__(EXAMPLE == 7 ? BLOCK : TRACE_BLOCK, EXAMPLE == 7 ? 1 : (EXAMPLE == 8 ? 6 : 5)) void k_path_trace(SceneView S, FrameParams P, int max_depth, f3 sky,
                                                        float4* __restrict__ accum,
                                                        unsigned long long* __restrict__ rays)
 {
@@ -993,7 +994,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_pt_init(FrameParams P, float4* 
     path_store(list, (size_t)(base + __popcll(m & ((1ull << lane) - 1ull))), st, li);
 }
 template <int EXAMPLE, bool SHADOWED>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_pt_bounce(SceneView S, FrameParams P, int depth, int max_depth, f3 sky,
+__global__ __launch_bounds__(TRACE_BLOCK, EXAMPLE == 7 ? 1 : (EXAMPLE == 8 ? 6 : 5)) void k_pt_bounce(SceneView S, FrameParams P, int depth, int max_depth, f3 sky,
                                                       const float4* __restrict__ in, float4* __restrict__ out,
                                                       float4* __restrict__ accum, unsigned long long* __restrict__ counters)
 {
