@@ -634,6 +634,16 @@ int rt_options_set(rt_ctx* c, const rt_options* o)
     if (!o) RT_FAIL(c, RT_ERR_ARG, "null options");
     if (o->ris_sample_count < 0 || o->spatial_resampling_sample_count < 0 || o->spatial_resampling_passes < 0)
         RT_FAIL(c, RT_ERR_ARG, "negative counts in options");
+    {
+        /* The 64-B record keeps M in 30 bits (rt_device.h; the reference's int M has 31). The largest M a
+         * frame can reach is 21 * ris (candidates + the temporal cap of 20 * ris, 10_restir_di.cu:185-187)
+         * times (1 + neighbours) per spatial pass: refuse option sets that could wrap instead of wrapping. */
+        double m = 21.0 * (double)(o->ris_sample_count > 0 ? o->ris_sample_count : 1);
+        for (int k = 0; k < o->spatial_resampling_passes && m < 4e9; ++k) m *= 1.0 + (double)o->spatial_resampling_sample_count;
+        if (m >= 1073741824.0)
+            RT_FAIL(c, RT_ERR_UNSUPPORTED, "options let the reservoir count M reach %.3g >= 2^30 (ris_sample_count %d, %d neighbours, %d passes)",
+                    m, o->ris_sample_count, o->spatial_resampling_sample_count, o->spatial_resampling_passes);
+    }
     c->opt = *o;
     return RT_OK;
 }
@@ -901,8 +911,16 @@ int rt_frame_stage_begin(rt_ctx* c, int frame, int stage, int clear_first)
         return RT_OK;
     }
     if (stage != c->f_stage) RT_FAIL(c, RT_ERR_STATE, "rt_frame_stage: expected stage %d, got %d", c->f_stage, stage);
-    if (stage >= 2 && stage <= passes) { c->f_in = c->f_out; c->f_out = (c->f_in == c->fZ) ? c->fX : c->fZ; }
     if (stage > passes + 1) RT_FAIL(c, RT_ERR_ARG, "bad stage %d", stage);
+    /* buffer roles are a pure function of the stage index, so a repeated _begin (retry after a failed
+     * _run) cannot swap the ping-pong pair twice: pass k reads what pass k-1 wrote (Y for k = 0) and
+     * writes Z for even k, X for odd k */
+    if (stage >= 1 && stage <= passes)
+    {
+        const int k = stage - 1;
+        c->f_in = (k == 0) ? c->fY : ((k & 1) ? c->fZ : c->fX);
+        c->f_out = (k & 1) ? c->fX : c->fZ;
+    }
     return RT_OK;
 }
 
@@ -939,6 +957,11 @@ int rt_frame_stage_run_part(rt_ctx* c, int frame, int stage, int part, int row0,
     else
     {
         for (int k = passes; k < 3; ++k) mark(4 + k);
+        /* passes == 0: the reference resolves reservoir_buffer1, which no kernel of that frame wrote
+         * (10_restir_di.cpp:324-368): zeros after start-up, else what an earlier frame's last odd pass
+         * left there. Logical RT_RES_1 (physical Z) holds exactly that content here, frame by frame
+         * (rt_frame_stage_end keeps the logical names on the reference's buffers), so the result is the
+         * reference's, stale data included. */
         const int final_phys = passes > 0 ? c->f_out : c->fZ;
         rc = launch_resolve(c, final_phys);
         mark(7);
@@ -1152,6 +1175,12 @@ int rt_upload(rt_ctx* c, int buf, const void* src, size_t bytes)
             if (bytes != n * 76) RT_FAIL(c, RT_ERR_ARG, "size mismatch: want %zu", n * 76);
             if (!c->has_gbuffer) RT_FAIL(c, RT_ERR_STATE, "upload RT_BUF_VISIBILITY (or rt_raycast) before reservoirs");
             const int phys = c->res_map[buf - RT_BUF_RES_0];
+            /* the record keeps M in 30 bits: refuse what it cannot hold rather than truncate */
+            for (size_t i = 0; i < n; ++i)
+            {
+                const int32_t M = ((const rt_reservoir*)src)[i].M;
+                if (M < 0 || M >= (1 << 30)) RT_FAIL(c, RT_ERR_UNSUPPORTED, "reservoir %zu has M = %d outside [0, 2^30)", i, M);
+            }
             int rc = ensure_stage(c, n * 76);
             if (rc != RT_OK) return rc;
             RT_HIP(c, hipMemcpyAsync(c->d_stage, src, bytes, hipMemcpyHostToDevice, c->stream));

@@ -117,6 +117,10 @@ int rt_camera_zoom(rt_ctx* ctx, float dy);
 int rt_camera_pan(rt_ctx* ctx, float dx, float dy);
 int rt_camera_updated(rt_ctx* ctx, int* updated);
 int rt_camera_pose(rt_ctx* ctx, float eye[3], float lookat[3]);
+/* Refuses (RT_ERR_UNSUPPORTED) option sets whose reservoir count M could reach 2^30 =
+ * 21 * ris_sample_count * (1 + spatial_resampling_sample_count)^spatial_resampling_passes: the 64-B
+ * device record keeps M in 30 bits (the reference's int has 31). spatial_resampling_passes == 0 is
+ * accepted and behaves as the reference does: resolve reads reservoir_buffer1, which that frame did not write. */
 int rt_options_set(rt_ctx* ctx, const rt_options* options);
 int rt_options_get(rt_ctx* ctx, rt_options* options);
 
@@ -207,7 +211,8 @@ int rt_halo_unpack_sparse(rt_ctx* ctx, int res, int row0, int n_rows, const void
 int rt_ray_count(rt_ctx* ctx, uint64_t* rays, uint64_t* shaded_pixels);
 /* time spent by the last `rt_frame` per kernel, HIP events on the context's stream.
  * ms[0..7] = clear, raycast, generate(+temporal), spatial pass 0,1,2, resolve, tone_mapping;
- * ms[8] = whole frame. Enabled by rt_timing_enable(ctx, 1). */
+ * ms[8] = whole frame. Enabled by rt_timing_enable(ctx, 1). With more than 3 spatial passes the
+ * passes beyond the third are attributed to ms[6] (resolve); ms[8] stays the whole frame. */
 int rt_timing_enable(rt_ctx* ctx, int on);
 int rt_timing(rt_ctx* ctx, float ms[9]);
 

@@ -1,6 +1,6 @@
 """Dev tool: A/B two builds of librestir_rt (env RT_LIB selects the .so) on the bench frame."""
 import sys, os, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from cedec_2024_rt_amd import api, scenes
 if os.environ.get("RT_LIB"):

@@ -1,14 +1,14 @@
-"""Dev tool: frame time vs the triangle pre-split factor (rt_bvh_config) on the bench frame."""
+"""Dev tool: sweep rt_tuning key 7 (wide-BVH records emitted breadth-first) on the bench frame."""
 import sys, os, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from cedec_2024_rt_amd import api, scenes
 from cedec_2024_rt_amd.types import bench_options
 W, H = 1920, 1080
 tris = scenes.make_blocks_restir()
-for f in [float(a) for a in sys.argv[1:]] or [0, 3, 4, 6, 8, 12, 16]:
+for bfs in [int(a) for a in sys.argv[1:]] or [0, 256, 2048, 16384, 131072, 1 << 30]:
     r = api.Renderer(W, H)
-    r.bvh_config(f)
+    r.tuning(7, bfs)
     r.set_scene(tris)
     r.lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)
     r.set_options(bench_options())
@@ -17,5 +17,5 @@ for f in [float(a) for a in sys.argv[1:]] or [0, 3, 4, 6, 8, 12, 16]:
     for fr in range(1, 24):
         r.frame(fr); t = r.timing()
         if fr > 3: acc = {k: acc[k] + v for k, v in t.items()} if acc else dict(t)
-    print(f, r.bvh_info(), json.dumps({k: round(v / 20, 4) for k, v in acc.items() if k in ("raycast", "generate_candidate", "resolve", "frame")}), flush=True)
-    r.close()
+    print(bfs, json.dumps({k: round(v / 20, 4) for k, v in acc.items() if k in ("raycast", "generate_candidate", "resolve", "frame")}), flush=True)
+    del r

@@ -2,7 +2,7 @@
 shadow rays of a bench frame in kernel order (32x8 tiles = one 256-thread workgroup each) and
 times the any-hit traversal (trace mode 4) for several lane assignments."""
 import sys, os, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from cedec_2024_rt_amd import api, scenes

@@ -1,5 +1,5 @@
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cedec_2024_rt_amd import api, scenes
 from cedec_2024_rt_amd.types import default_options
 if os.environ.get("RT_LIB"): api.LIB_PATH = os.path.join(os.path.dirname(api.__file__), os.environ["RT_LIB"])

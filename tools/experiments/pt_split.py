@@ -1,6 +1,6 @@
 """Dev tool: path tracers (07_pt, 08_nee) vs the triangle pre-split factor, on cornellbox2 and the blocks stand-in."""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from cedec_2024_rt_amd import api, scenes

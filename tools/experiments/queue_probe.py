@@ -1,6 +1,6 @@
 """Dev tool: shadow-ray batch traced by (0) one-thread-per-ray wide kernel vs (2/3) persistent queue."""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from cedec_2024_rt_amd import api, scenes

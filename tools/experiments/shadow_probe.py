@@ -1,6 +1,6 @@
 """Dev tool: traversal work of the resolve-pass shadow rays (closest-hit stats as a proxy)."""
 import sys, os, time, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from cedec_2024_rt_amd import api, scenes

@@ -1,6 +1,6 @@
 """Dev tool: SIMT efficiency of the shadow-ray traversal: per-lane steps vs passes the wavefront ran."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from cedec_2024_rt_amd import api, scenes

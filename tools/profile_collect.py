@@ -62,6 +62,9 @@ json.dump(fw, open(os.path.join(dst, f"{tag}_pmc_fetch_write.json"), "w"), inden
 
 valu = counters("pmc_valu")
 mix = counters("pmc_mix")
+stall = counters("pmc_stall")
+for k, cs in stall.items():
+    mix.setdefault(k, {}).update({c: v for c, v in cs.items() if c not in mix.get(k, {})})
 out = {}
 for k, cs in valu.items():
     if not k.startswith("k_") or "bvh" in k:

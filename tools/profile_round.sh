@@ -14,5 +14,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_valu -o pmc -- python3 bench.py --no-cpu-baseline --steps 16 --warmup 2 > $OUT/pmc_valu.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU -d $OUT/pmc_mix -o pmc -- python3 bench.py --no-cpu-baseline --steps 16 --warmup 2 > $OUT/pmc_mix.log 2>&1
+# where a wavefront's cycles go (quad-cycles; WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES, MI355X_MICROARCH.md PMC slots)
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS -d $OUT/pmc_stall -o pmc -- python3 bench.py --no-cpu-baseline --steps 16 --warmup 2 > $OUT/pmc_stall.log 2>&1
+sha256sum cedec_2024_rt_amd/librestir_rt.so > $OUT/lib.sha256
 find $OUT -name "*.csv" | head -30
 cat $OUT/bench.json
