@@ -49,6 +49,9 @@
 #define OP_CMP(i) "v_cmp_lt_f32 vcc, %" #i ", %8\n"
 #define OP_BFE(i) "v_bfe_u32 %" #i ", %" #i ", 8, 8\n"
 #define OP_CVTUB(i) "v_cvt_f32_ubyte1 %" #i ", %" #i "\n"
+#define OP_CND64(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %8, vcc\n"
+#define OP_CMPCND(i) "v_cmp_lt_f32 vcc, %" #i ", %9\nv_cndmask_b32 %" #i ", %" #i ", %8, vcc\n"
+#define OP_CMPCNDS(i) "v_cmp_lt_f32 s[10:11], %" #i ", %9\nv_cndmask_b32 %" #i ", %" #i ", %8, s[10:11]\n"
 #define OP_CNDS(i) "v_cndmask_b32 %" #i ", %" #i ", %8, s[10:11]\n"
 #define OP_MIN(i) "v_min_f32 %" #i ", %" #i ", %8\n"
 #define OP_MED3(i) "v_med3_f32 %" #i ", %" #i ", %8, %9\n"
@@ -123,6 +126,9 @@ __global__ __launch_bounds__(256) void k_rate(float* out, uint64_t* cycles, floa
         if (OP == 43) CHAIN8(OP_LDEXP);
         if (OP == 44) CHAIN8(OP_FREXPM);
         if (OP == 45) CHAIN8(OP_RNDNE);
+        if (OP == 46) CHAIN8(OP_CND64);
+        if (OP == 47) CHAIN8(OP_CMPCND);
+        if (OP == 48) CHAIN8(OP_CMPCNDS);
     }
     uint64_t t1 = __builtin_amdgcn_s_memtime();
     float s = 0.0f;
@@ -188,7 +194,8 @@ static const char* NAMES[] = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_add_u32"
                               "v_cndmask_b32 (sgpr mask)", "v_min_f32", "v_med3_f32", "v_and_b32", "v_or_b32", "v_sub_f32", "v_fmac_f32",
                               "v_perm_b32", "v_lshl_or_b32", "v_mov_b32", "v_fma_f32 (neg mod)", "v_mul_f32 (abs mod)",
                               "v_cmp_lt_f32 (sgpr dst)", "v_mad_u32_u24", "v_subrev_u32", "v_ashrrev_i32", "v_ldexp_f32",
-                              "v_frexp_mant_f32", "v_rndne_f32"};
+                              "v_frexp_mant_f32", "v_rndne_f32", "v_cndmask_b32_e64 (vcc)", "v_cmp+v_cndmask via vcc (per pair)",
+                              "v_cmp+v_cndmask via sgpr pair (per pair)"};
 
 template <int OP> static void launch(int grid, float* out, uint64_t* cyc) { k_rate<OP><<<grid, 256>>>(out, cyc, 1.0001f, 0.5f); }
 typedef void (*launch_fn)(int, float*, uint64_t*);
@@ -204,7 +211,8 @@ int main()
                        launch<10>, launch<11>, launch<12>, launch<13>, launch<14>, launch<15>, launch<16>, launch<17>, launch<18>,
                        launch<19>, launch<20>, launch<21>, launch<22>, launch<23>, launch<24>, launch<25>, launch<26>, launch<27>,
                        launch<28>, launch<29>, launch<30>, launch<31>, launch<32>, launch<33>, launch<34>, launch<35>, launch<36>,
-                       launch<37>, launch<38>, launch<39>, launch<40>, launch<41>, launch<42>, launch<43>, launch<44>, launch<45>};
+                       launch<37>, launch<38>, launch<39>, launch<40>, launch<41>, launch<42>, launch<43>, launch<44>, launch<45>,
+                       launch<46>, launch<47>, launch<48>};
     const int nfn = sizeof(fns) / sizeof(fns[0]);
     printf("{\n");
     auto measure = [&](const char* name, auto&& go, bool last) {
@@ -214,15 +222,24 @@ int main()
         {
             const int W = Ws[wi];
             const int grid = CUS * W; // 256-thread workgroups = one wavefront per SIMD each; W workgroups per CU
-            for (int rep = 0; rep < 2; ++rep) go(grid);
+            go(grid);
             hipDeviceSynchronize();
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0); hipEventCreate(&e1);
+            hipEventRecord(e0);
+            go(grid);
+            hipEventRecord(e1);
+            hipDeviceSynchronize();
+            float ms = 0.0f;
+            hipEventElapsedTime(&ms, e0, e1);
+            hipEventDestroy(e0); hipEventDestroy(e1);
             hipMemcpy(h.data(), cyc, (size_t)grid * 4 * 8, hipMemcpyDeviceToHost);
             std::vector<uint64_t> v(h.begin(), h.begin() + (size_t)grid * 4);
             std::sort(v.begin(), v.end());
             const double med = (double)v[v.size() / 2];
             const double per_wave = med / (double)(REP * UNR);
             printf("\"w%d\": %.2f, ", W, per_wave);
-            if (W == 8) printf("\"simd_w8\": %.2f", per_wave / 8.0);
+            if (W == 8) printf("\"w8_wall_ns_per_instr_per_simd\": %.3f", (double)ms * 1e6 / ((double)REP * UNR * 8.0));
         }
         printf("}%s\n", last ? "" : ",");
     };
