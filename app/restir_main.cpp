@@ -7,7 +7,14 @@
  *              [--eye x y z] [--lookat x y z] [--temporal 0|1] [--spatial 0|1]
  *              [--shadowed 0|1] [--visreuse 0|1] [--accumulate 0|1] [--by-kernel]
  *              [--example 10|7|8|9] [--ppm out.ppm] [--png out.png] [--pfm out.pfm] [--dump-tris out.tris]
+ *              [--ranks N [--mirror] [--equal-strips]]
  *
+ * --ranks N: the multi-GPU frame loop: N processes, forked before anything touches a GPU,
+ * rank r on device r, each rendering one row strip through the native strip driver (rt_mg_*: sparse
+ * reservoir halos over RCCL send/recv with rank +-1). Strip heights are cost-weighted from the shaded
+ * pixels per row unless --equal-strips. --pfm then receives every rank's rows (one file, written in
+ * place). --mirror: all ranks on device 0 with the MIRROR transport (1-GPU boxes; timing/launch smoke
+ * run, the image is not a frame).
  * --example 7|8|9 runs the `path_trace` kernel of examples/07_pt, 08_nee or 09_ris instead of the
  * ReSTIR DI frame (one sample per pixel and frame; use --accumulate 1 to average frames).
  * Keys 1,2,3,4,A of the example (10_restir_di.cpp:143-174) are the --temporal/--spatial/
@@ -17,6 +24,7 @@
  * OBJ/MTL subset the reference's loader consumes (common/loader.hpp:11-66: positions, faces as
  * triangle fans, per-face usemtl -> Kd/Ke).
  */
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -26,6 +34,11 @@
 #include <sstream>
 #include <string>
 #include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include "../include/restir_rt.h"
 
@@ -173,6 +186,122 @@ static std::vector<rt_triangle> load_tris(const std::string& path)
     return t;
 }
 
+/* ---- --ranks N: one process per GPU over the native strip driver ---- */
+struct Shared /* anonymous shared mapping made by the parent before fork */
+{
+    std::atomic<int> arrived[8];
+    char uid[128];
+    std::atomic<int> uid_ready;
+    double ms_per_frame[64];
+    unsigned long long rays[64];
+    uint32_t row_cost[1]; /* H entries */
+};
+static void shared_barrier(Shared* sh, int which, int ranks)
+{
+    sh->arrived[which].fetch_add(1);
+    for (long spins = 0; sh->arrived[which].load() < ranks; ++spins)
+    {
+        if (spins > 1500000L) { fprintf(stderr, "a rank did not reach barrier %d within 300 s\n", which); _exit(3); }
+        usleep(200);
+    }
+}
+static int rank_main(int rank, int ranks, bool mirror, bool equal_strips, Shared* sh, const std::vector<rt_triangle>& triangles, int W,
+                     int H, int frames, const float* eye, const float* lookat, const rt_options& opt, const std::string& pfm)
+{
+    const float up[3] = {0, 1, 0};
+    const int halo = 87, device = mirror ? 0 : rank;
+    if (rank == 0 && !mirror)
+    {
+        if (rt_mg_unique_id(sh->uid) != RT_OK) { fprintf(stderr, "rank 0: %s\n", rt_mg_load_error()); return 1; }
+    }
+    if (rank == 0) sh->uid_ready.store(1);
+    while (!sh->uid_ready.load()) usleep(200);
+    std::vector<int> bounds((size_t)ranks + 1);
+    if (rt_mg_partition(H, ranks, halo, nullptr, bounds.data()) != RT_OK) { fprintf(stderr, "%d rows cannot be cut into %d strips of >= %d rows\n", H, ranks, halo); return 1; }
+    rt_ctx* ctx = nullptr;
+    auto make_ctx = [&]() -> int {
+        int rc = rt_create(device, W, H, bounds[(size_t)rank], bounds[(size_t)rank + 1], halo, &ctx);
+        if (rc != RT_OK) return rc;
+        rc = rt_scene_set(ctx, triangles.data(), (uint32_t)triangles.size());
+        if (rc == RT_OK) rc = rt_camera_lookat(ctx, eye, lookat, up, 3.14159265358979323846f / 4.0f);
+        if (rc == RT_OK) rc = rt_options_set(ctx, &opt);
+        return rc;
+    };
+    int rc = make_ctx();
+    if (rc != RT_OK) die(ctx, "strip context", rc);
+    if (!equal_strips)
+    {
+        /* cost-weighted heights: shaded pixels per row from one raycast of the equal partition */
+        CK(rt_raycast(ctx));
+        CK(rt_row_shaded(ctx, sh->row_cost + bounds[(size_t)rank]));
+        shared_barrier(sh, 0, ranks);
+        std::vector<uint32_t> cost((size_t)H);
+        for (int i = 0; i < H; ++i) cost[(size_t)i] = sh->row_cost[i] * 7u + (uint32_t)W;
+        std::vector<int> nb((size_t)ranks + 1);
+        if (rt_mg_partition(H, ranks, halo, cost.data(), nb.data()) == RT_OK && nb != bounds)
+        {
+            CK(rt_destroy(ctx));
+            bounds = nb;
+            rc = make_ctx();
+            if (rc != RT_OK) die(ctx, "strip context", rc);
+        }
+    }
+    rt_mg* mg = nullptr;
+    rc = rt_mg_create(ctx, rank, ranks, bounds.data(), mirror ? RT_MG_TRANSPORT_MIRROR : RT_MG_TRANSPORT_RCCL, mirror ? nullptr : sh->uid, 0, &mg);
+    if (rc != RT_OK) { fprintf(stderr, "rank %d: rt_mg_create failed (%d): %s\n", rank, rc, mg ? rt_mg_last_error(mg) : ""); return 1; }
+    CK(rt_clear(ctx));
+    const int warm = frames > 4 ? 2 : 0;
+    struct timespec t0, t1;
+    for (int frame = 1; frame <= frames; ++frame)
+    {
+        if (frame == warm + 1) { CK(rt_sync(ctx)); shared_barrier(sh, 1, ranks); clock_gettime(CLOCK_MONOTONIC, &t0); }
+        rc = rt_mg_frame(mg, frame, 0);
+        if (rc != RT_OK) { fprintf(stderr, "rank %d frame %d: %s\n", rank, frame, rt_mg_last_error(mg)); return 1; }
+    }
+    CK(rt_sync(ctx));
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    sh->ms_per_frame[rank] = ((double)(t1.tv_sec - t0.tv_sec) * 1e3 + (double)(t1.tv_nsec - t0.tv_nsec) * 1e-6) / (double)(frames - warm);
+    uint64_t rays = 0, shaded = 0;
+    CK(rt_ray_count(ctx, &rays, &shaded));
+    sh->rays[rank] = rays;
+    rt_mg_stats st;
+    rt_mg_get_stats(mg, &st);
+    printf("rank %d: rows [%d,%d) %.3f ms/frame, host %.0f us/frame, %llu cold frame(s), %.2f MB sent/frame\n", rank, bounds[(size_t)rank],
+           bounds[(size_t)rank + 1], sh->ms_per_frame[rank], (double)st.host_ns / 1e3 / (double)st.frames, st.cold_frames,
+           (double)st.bytes_sent / 1e6 / (double)st.frames);
+    if (!pfm.empty())
+    {
+        int l0 = 0, ln = 0;
+        CK(rt_local_rows(ctx, &l0, &ln));
+        std::vector<float> acc((size_t)W * (size_t)ln * 4);
+        CK(rt_download(ctx, RT_BUF_ACCUMULATION, acc.data(), acc.size() * 4));
+        char hdr[64];
+        const int hl = snprintf(hdr, sizeof(hdr), "PF\n%d %d\n-1.0\n", W, H);
+        const int fd = open(pfm.c_str(), O_WRONLY);
+        if (fd < 0) { fprintf(stderr, "cannot write %s\n", pfm.c_str()); return 1; }
+        std::vector<float> rgb((size_t)W * 3);
+        for (int row = bounds[(size_t)rank]; row < bounds[(size_t)rank + 1]; ++row)
+        {
+            const float* a = &acc[(size_t)(row - l0) * W * 4];
+            for (int x = 0; x < W; ++x)
+                for (int c = 0; c < 3; ++c) rgb[3 * (size_t)x + c] = a[4 * (size_t)x + c] / a[4 * (size_t)x + 3];
+            if (pwrite(fd, rgb.data(), rgb.size() * 4, (off_t)hl + (off_t)row * W * 12) < 0) return 1;
+        }
+        close(fd);
+    }
+    shared_barrier(sh, 2, ranks);
+    if (rank == 0)
+    {
+        double worst = 0.0;
+        unsigned long long total = 0;
+        for (int r = 0; r < ranks; ++r) { worst = sh->ms_per_frame[r] > worst ? sh->ms_per_frame[r] : worst; total += sh->rays[r]; }
+        printf("%d ranks: %.3f ms/frame (slowest rank), %llu rays/frame, %.0f Mray/s\n", ranks, worst, total, (double)total / worst / 1e3);
+    }
+    rt_mg_destroy(mg);
+    CK(rt_destroy(ctx));
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     int W = 1920, H = 1080, frames = 8; /* 10_restir_di.cpp:26-27 */
@@ -180,8 +309,8 @@ int main(int argc, char** argv)
     float eye[3] = {-0.579885f, 22.194597f, -6.567105f}, lookat[3] = {5.224952f, 20.847435f, 1.431192f};
     const float up[3] = {0, 1, 0};
     std::string obj, tris_path, ppm, png, pfm, dump;
-    bool by_kernel = false;
-    int example = 10;
+    bool by_kernel = false, mirror = false, equal_strips = false;
+    int example = 10, ranks = 1;
     rt_options opt;
     memset(&opt, 0, sizeof(opt));
     opt.max_depth = 6; opt.ris_sample_count = 32; opt.rejection_heuristics_threshold = 0.2f;
@@ -205,6 +334,9 @@ int main(int argc, char** argv)
         else if (a == "--accumulate") opt.accumulate = (uint8_t)atoi(argv[++i]);
         else if (a == "--by-kernel") by_kernel = true;
         else if (a == "--example") example = atoi(argv[++i]);
+        else if (a == "--ranks") ranks = atoi(argv[++i]);
+        else if (a == "--mirror") mirror = true;
+        else if (a == "--equal-strips") equal_strips = true;
         else if (a == "--dump-tris") dump = argv[++i]; /* write the loaded triangle array and exit (no GPU needed) */
         else if (a == "--ppm") ppm = argv[++i];
         else if (a == "--png") png = argv[++i];
@@ -220,6 +352,40 @@ int main(int argc, char** argv)
         fclose(f);
         printf("triangles: %zu\n", triangles.size());
         return 0;
+    }
+
+    if (ranks > 1)
+    {
+        /* one process per GPU, forked BEFORE any HIP call (a process that has initialised the GPU must not fork) */
+        if (ranks > 64 || example != 10) { fprintf(stderr, "--ranks: 2..64 ranks of the ReSTIR DI frame\n"); return 2; }
+        const size_t bytes = sizeof(Shared) + (size_t)H * 4;
+        Shared* sh = (Shared*)mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+        if (sh == MAP_FAILED) { perror("mmap"); return 1; }
+        memset((void*)sh, 0, bytes);
+        if (!pfm.empty())
+        {
+            FILE* f = fopen(pfm.c_str(), "wb");
+            if (!f) { fprintf(stderr, "cannot write %s\n", pfm.c_str()); return 1; }
+            const int hl = fprintf(f, "PF\n%d %d\n-1.0\n", W, H);
+            fclose(f);
+            if (truncate(pfm.c_str(), (off_t)hl + (off_t)W * H * 12) != 0) { perror("truncate"); return 1; }
+        }
+        std::vector<pid_t> kids;
+        for (int r = 0; r < ranks; ++r)
+        {
+            const pid_t pid = fork();
+            if (pid == 0) _exit(rank_main(r, ranks, mirror, equal_strips, sh, triangles, W, H, frames, eye, lookat, opt, pfm));
+            kids.push_back(pid);
+        }
+        int worst = 0;
+        for (pid_t k : kids)
+        {
+            int status = 0;
+            waitpid(k, &status, 0);
+            const int code = WIFEXITED(status) ? WEXITSTATUS(status) : 1;
+            worst = code > worst ? code : worst;
+        }
+        return worst;
     }
 
     rt_ctx* ctx = nullptr;

@@ -28,7 +28,14 @@ EXPORTS = [
     "rt_halo_flags_pack", "rt_halo_flags_unpack", "rt_halo_mark", "rt_halo_scan", "rt_halo_pack_sparse", "rt_halo_unpack_sparse", "rt_path_trace", "rt_path_trace_rays", "rt_local_rows", "rt_download",
     "rt_upload", "rt_halo_bytes", "rt_halo_pack", "rt_halo_unpack", "rt_ray_count", "rt_timing_enable",
     "rt_timing", "rt_spatial_bytes", "rt_trace_closest", "rt_trace_stats", "rt_bvh_config", "rt_bvh_info", "rt_trace_mode", "rt_trace_time", "rt_tuning", "rt_math_eval",
+    "rt_row_shaded", "rt_state_epoch", "rt_get_stream", "rt_geometry", "rt_res_region", "rt_lane",
+    "rt_mg_partition", "rt_mg_bands", "rt_mg_unique_id", "rt_mg_load_error", "rt_mg_hub_create", "rt_mg_hub_destroy", "rt_mg_create",
+    "rt_mg_destroy", "rt_mg_last_error", "rt_mg_frame", "rt_mg_frame_begin", "rt_mg_frame_step", "rt_mg_get_stats", "rt_mg_reset_stats",
+    "rt_mg_selftest_rccl",
 ]
+
+RT_MG_TRANSPORT_RCCL, RT_MG_TRANSPORT_LOCAL, RT_MG_TRANSPORT_MIRROR = 0, 1, 2
+RT_MG_DENSE, RT_MG_ONE_LANE = 1, 2
 
 
 class RtError(RuntimeError):
@@ -124,8 +131,154 @@ def load_library():
     L.rt_trace_mode.argtypes = [vp, ci]
     L.rt_trace_time.argtypes = [vp, vp]
     L.rt_tuning.argtypes = [vp, ci, ci]
+    L.rt_row_shaded.argtypes = [vp, vp]
+    L.rt_state_epoch.argtypes = [vp, vp]
+    L.rt_get_stream.argtypes = [vp, vp]
+    L.rt_geometry.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.rt_res_region.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp]
+    L.rt_lane.argtypes = [vp, ci]
+    L.rt_mg_partition.argtypes = [ci, ci, ci, vp, vp]
+    L.rt_mg_bands.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp]
+    L.rt_mg_unique_id.argtypes = [vp]
+    L.rt_mg_load_error.restype = C.c_char_p
+    L.rt_mg_hub_create.argtypes = [ci, C.POINTER(vp)]
+    L.rt_mg_hub_destroy.argtypes = [vp]
+    L.rt_mg_create.argtypes = [vp, ci, ci, vp, ci, vp, ci, C.POINTER(vp)]
+    L.rt_mg_destroy.argtypes = [vp]
+    L.rt_mg_last_error.argtypes = [vp]
+    L.rt_mg_last_error.restype = C.c_char_p
+    L.rt_mg_frame.argtypes = [vp, ci, ci]
+    L.rt_mg_frame_begin.argtypes = [vp, ci, ci]
+    L.rt_mg_frame_step.argtypes = [vp, vp]
+    L.rt_mg_get_stats.argtypes = [vp, vp]
+    L.rt_mg_reset_stats.argtypes = [vp]
+    L.rt_mg_selftest_rccl.argtypes = [C.c_size_t]
     _lib = L
     return L
+
+
+# ---- native multi-GPU strip driver (csrc/strip_mg.cpp) -------------------------------------------
+def mg_partition(height, world, halo=87, row_cost=None):
+    """[(a, b)] per rank: near-equal strips, or cost-weighted if row_cost (uint32 per storage row) is given."""
+    L = load_library()
+    b = np.zeros(world + 1, dtype=np.int32)
+    rc_ptr = None
+    if row_cost is not None:
+        rc_arr = np.ascontiguousarray(row_cost, dtype=np.uint32)
+        assert rc_arr.size == height
+        rc_ptr = _p(rc_arr)
+    rc = L.rt_mg_partition(int(height), int(world), int(halo), rc_ptr, _p(b))
+    if rc != 0:
+        raise ValueError(f"{height} rows over {world} ranks gives strips thinner than the {halo}-row halo")
+    return [(int(b[i]), int(b[i + 1])) for i in range(world)]
+
+
+def mg_bands(bounds, rank, halo=87):
+    """(boundary, interior) row ranges of a strip, as lists of (row0, row1)."""
+    L = load_library()
+    world = len(bounds)
+    flat = np.array([bounds[0][0]] + [e for _, e in bounds], dtype=np.int32)
+    bl, il = np.zeros(4, np.int32), np.zeros(4, np.int32)
+    nb, ni = C.c_int(), C.c_int()
+    rc = L.rt_mg_bands(_p(flat), world, int(rank), int(halo), _p(bl), C.byref(nb), _p(il), C.byref(ni))
+    if rc != 0:
+        raise RtError(f"rt_mg_bands -> {rc}")
+    return ([(int(bl[2 * i]), int(bl[2 * i + 1])) for i in range(nb.value)],
+            [(int(il[2 * i]), int(il[2 * i + 1])) for i in range(ni.value)])
+
+
+def mg_unique_id():
+    """128-byte RCCL unique id (bytes); make it on one rank and hand it to the others."""
+    L = load_library()
+    buf = (C.c_char * 128)()
+    rc = L.rt_mg_unique_id(buf)
+    if rc != 0:
+        raise RtError(f"rt_mg_unique_id -> {rc}: {L.rt_mg_load_error().decode()}")
+    return bytes(buf)
+
+
+class MgHub:
+    """Mailbox of the LOCAL transport: several strip contexts of one process on one GPU (tests)."""
+
+    def __init__(self, world):
+        self.L = load_library()
+        self.h = C.c_void_p()
+        if self.L.rt_mg_hub_create(int(world), C.byref(self.h)) != 0:
+            raise RtError("rt_mg_hub_create failed")
+
+    def close(self):
+        if self.h:
+            self.L.rt_mg_hub_destroy(self.h)
+            self.h = None
+
+
+class _MgStats(C.Structure):
+    _fields_ = [(n, C.c_ulonglong) for n in ("frames", "cold_frames", "host_ns", "plan_wait_ns", "bytes_sent", "messages", "records_sent")]
+
+
+class MultiGpu:
+    """One rank of the native strip driver: rt_mg_* over this rank's strip Renderer."""
+
+    def __init__(self, renderer, rank, bounds, transport=RT_MG_TRANSPORT_RCCL, unique_id=None, hub=None, flags=0):
+        self.L, self.r, self.rank, self.bounds = renderer.L, renderer, int(rank), list(bounds)
+        world = len(bounds)
+        flat = np.array([bounds[0][0]] + [e for _, e in bounds], dtype=np.int32)
+        arg = None
+        if world > 1:
+            if transport == RT_MG_TRANSPORT_RCCL:
+                self._id = C.create_string_buffer(bytes(unique_id), 128)
+                arg = C.cast(self._id, C.c_void_p)
+            elif transport == RT_MG_TRANSPORT_LOCAL:
+                arg = hub.h
+        h = C.c_void_p()
+        rc = self.L.rt_mg_create(renderer.h, self.rank, world, _p(flat), int(transport), arg, int(flags), C.byref(h))
+        self.h = h
+        if rc != 0:
+            msg = self.L.rt_mg_last_error(h).decode() if h else "rt_mg_create failed"
+            raise RtError(f"rt_mg_create -> {rc}: {msg}")
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RtError(f"strip driver error {rc}: {self.L.rt_mg_last_error(self.h).decode()}")
+
+    def frame(self, frame, clear_first=False):
+        self._ck(self.L.rt_mg_frame(self.h, int(frame), int(bool(clear_first))))
+
+    def frame_begin(self, frame, clear_first=False):
+        self._ck(self.L.rt_mg_frame_begin(self.h, int(frame), int(bool(clear_first))))
+
+    def frame_step(self):
+        more = C.c_int(0)
+        self._ck(self.L.rt_mg_frame_step(self.h, C.byref(more)))
+        return bool(more.value)
+
+    def stats(self):
+        st = _MgStats()
+        self._ck(self.L.rt_mg_get_stats(self.h, C.byref(st)))
+        return {n: int(getattr(st, n)) for n, _ in _MgStats._fields_}
+
+    def reset_stats(self):
+        self._ck(self.L.rt_mg_reset_stats(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rt_mg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def mg_frame_lockstep(ranks, frame, clear_first=False):
+    """Drive several LOCAL-transport ranks of one process through one frame in lock-step."""
+    for m in ranks:
+        m.frame_begin(frame, clear_first)
+    live = list(ranks)
+    while live:
+        live = [m for m in live if m.frame_step()]
 
 
 def _p(a):
@@ -382,6 +535,12 @@ class Renderer:
         a, b = C.c_uint64(), C.c_uint64()
         self._ck(self.L.rt_ray_count(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def row_shaded(self):
+        """shaded pixels per owned storage row (uint32)"""
+        out = np.zeros(self.rows[1] - self.rows[0], dtype=np.uint32)
+        self._ck(self.L.rt_row_shaded(self.h, _p(out)))
+        return out
 
     def timing_enable(self, on=True):
         self._ck(self.L.rt_timing_enable(self.h, int(on)))

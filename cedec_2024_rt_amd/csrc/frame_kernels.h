@@ -1142,6 +1142,15 @@ __global__ void k_count_shaded(FrameParams P, const float4* __restrict__ g1, uns
     const unsigned long long m = __ballot(shaded);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
 }
+/* shaded pixels per storage row (one workgroup per row): the cost model of the strip partition */
+__global__ __launch_bounds__(BLOCK) void k_row_shaded(int W, int row0_local, const float4* __restrict__ g1, uint32_t* __restrict__ out)
+{
+    const size_t base = (size_t)(row0_local + (int)blockIdx.x) * W;
+    uint32_t n = 0;
+    for (int x = threadIdx.x; x < W; x += BLOCK) n += (as_uint(g1[base + x].w) & GB_SHADED) ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off);
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(&out[blockIdx.x], n);
+}
 template <int MODE, bool ANY = false> /* 0 = wide (production), 1 = binary stackless; ANY = shadow-ray semantics */
 __global__ __launch_bounds__(BLOCK) void k_trace_closest(SceneView S, const float* __restrict__ rays, int n, float* __restrict__ hits)
 {

@@ -47,6 +47,8 @@ struct rt_ctx
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_stage = nullptr, ev_aux = nullptr;
     bool aux_used = false;
+    bool lane_saved = false, lane_timing = false; /* rt_lane */
+    hipStream_t lane_main = nullptr;
     std::string err;
 
     int n_tris = 0, n_lights = 0, bvh_height = 0, n_refs = 0;
@@ -77,7 +79,7 @@ struct rt_ctx
     int sub0 = -1, sub1 = -1; /* row sub-range of the running rt_frame_stage_run (-1: all owned rows) */
     int fX = 0, fY = 1, fZ = 2, f_in = 0, f_out = 1, f_stage = 0, f_final = RT_RES_1;
     bool f_clear = false;
-    bool halo_flags_ok[2] = {false, false}; /* neighbour shaded flags unpacked since the last raycast */ /* rt_frame_stage state */
+    uint64_t halo_flags_epoch[2] = {0, 0}; /* epoch at which the neighbour's shaded flags were unpacked (valid while it is the current one) */
     unsigned long long* d_counter = nullptr;
     float4* d_paths[2] = {nullptr, nullptr}; /* wavefront path tracer: live-path lists (64 B per path) */
     unsigned long long* d_pt_counters = nullptr;
@@ -91,6 +93,9 @@ struct rt_ctx
     bool has_camera = false, has_scene = false, has_gbuffer = false;
     float cam_eye[3] = {8.0f, 8.0f, 8.0f}, cam_at[3] = {0.0f, 0.0f, 0.0f}, cam_fovy = 0.78539816339f; /* misc.hpp:217-218 */
     bool cam_updated = false;
+    /* bumped by everything that can change the G-buffer or the spatial pass's neighbour choice (camera,
+     * options, scene, rows, uploads): the strip driver keys its cached halo plans on it */
+    uint64_t epoch = 1;
 
     bool timing = false;
     hipEvent_t ev[10] = {};
@@ -454,6 +459,7 @@ int rt_scene_set(rt_ctx* c, const rt_triangle* triangles, uint32_t count)
     RT_HIP(c, hipSetDevice(c->device));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     free_scene(c);
+    ++c->epoch;
     const int n = (int)count;
     c->n_tris = n;
     /* light list in index order (10_restir_di.cpp:196-205) */
@@ -524,6 +530,7 @@ int rt_camera_lookat(rt_ctx* c, const float eye[3], const float center[3], const
     memcpy(c->cam_at, center, 12);
     c->cam_fovy = fovy;
     c->has_camera = true;
+    ++c->epoch;
     return RT_OK;
 }
 /* ---- interactive camera of the examples (common/misc.hpp:108-224 CameraControl): the mouse
@@ -619,6 +626,7 @@ int rt_camera_set(rt_ctx* c, const rt_raygen* rg, const float eye[3])
     c->rg = *rg;
     c->eye[0] = eye[0]; c->eye[1] = eye[1]; c->eye[2] = eye[2];
     c->has_camera = true;
+    ++c->epoch;
     return RT_OK;
 }
 int rt_camera_get(rt_ctx* c, rt_raygen* rg)
@@ -645,6 +653,7 @@ int rt_options_set(rt_ctx* c, const rt_options* o)
                     m, o->ris_sample_count, o->spatial_resampling_sample_count, o->spatial_resampling_passes);
     }
     c->opt = *o;
+    ++c->epoch;
     return RT_OK;
 }
 int rt_options_get(rt_ctx* c, rt_options* o)
@@ -686,7 +695,8 @@ int rt_raycast(rt_ctx* c)
     k_raycast<<<trace_grid(c), TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_vis, c->d_g0, c->d_g1);
     RT_HIP(c, hipGetLastError());
     c->has_gbuffer = true;
-    c->halo_flags_ok[0] = c->halo_flags_ok[1] = false; /* the neighbours' G-buffers are new as well */
+    /* halo rows of the G-buffer keep the neighbours' shaded flags: they stay valid until the camera,
+     * the scene or the options change (halo_flags_epoch), which is when the neighbours' G-buffers change */
     return RT_OK;
 }
 
@@ -1162,6 +1172,7 @@ int rt_upload(rt_ctx* c, int buf, const void* src, size_t bytes)
             k_gbuffer_from_vis<<<tile_grid(c->W, c->lrows), BLOCK, 0, c->stream>>>(make_scene(c), P, c->d_vis, c->d_g0, c->d_g1);
             RT_HIP(c, hipGetLastError());
             c->has_gbuffer = true;
+            ++c->epoch;
             break;
         }
         case RT_BUF_ACCUMULATION:
@@ -1271,8 +1282,8 @@ int rt_halo_flags_unpack(rt_ctx* c, int row0, int n_rows, const void* device_src
     const int n = n_rows * c->W;
     k_halo_flags<false><<<(n + 255) / 256, 256, 0, c->stream>>>(c->d_g1, (size_t)(row0 - c->lrow0) * c->W, n, (uint8_t*)const_cast<void*>(device_src));
     RT_HIP(c, hipGetLastError());
-    if (row0 == c->lrow0 && row0 + n_rows == c->row_begin) c->halo_flags_ok[0] = true;
-    if (row0 == c->row_end && row0 + n_rows == c->lrow0 + c->lrows) c->halo_flags_ok[1] = true;
+    if (row0 == c->lrow0 && row0 + n_rows == c->row_begin) c->halo_flags_epoch[0] = c->epoch;
+    if (row0 == c->row_end && row0 + n_rows == c->lrow0 + c->lrows) c->halo_flags_epoch[1] = c->epoch;
     return RT_OK;
 }
 /* records of the neighbour on `side` that spatial passes [pass, pass + n_pass) of `frame` will
@@ -1285,9 +1296,9 @@ int rt_halo_mark(rt_ctx* c, int frame, int pass, int n_pass, int side, void* dev
     int r0, n;
     int rc = halo_side_region(c, side, &r0, &n);
     if (rc != RT_OK) return rc;
-    if (!c->halo_flags_ok[side])
+    if (c->halo_flags_epoch[side] != c->epoch)
         RT_FAIL(c, RT_ERR_STATE, "rt_halo_mark: the neighbour's shaded flags (rt_halo_flags_unpack of all %d halo rows on side %d) "
-                                 "must be refreshed after every rt_raycast", n, side);
+                                 "must be refreshed after a camera, scene or option change", n, side);
     const size_t words = rt_halo_bitmap_words(c, n);
     const int nw = (int)((words - 1) / 2);
     RT_HIP(c, hipMemsetAsync(device_bitmaps, 0, words * 4 * (size_t)n_pass, c->stream));
@@ -1338,6 +1349,73 @@ int rt_halo_unpack_sparse(rt_ctx* c, int res, int row0, int n_rows, const void* 
     return halo_sparse(c, false, res, row0, n_rows, device_bitmap, const_cast<void*>(device_src));
 }
 
+/* ---- hooks of the native strip driver (strip_mg.cpp), plain C-ABI like everything else ---- */
+int rt_state_epoch(rt_ctx* c, uint64_t* epoch)
+{
+    RT_CHECK_CTX(c);
+    if (!epoch) return RT_ERR_ARG;
+    *epoch = c->epoch;
+    return RT_OK;
+}
+int rt_get_stream(rt_ctx* c, void** hip_stream)
+{
+    RT_CHECK_CTX(c);
+    if (!hip_stream) return RT_ERR_ARG;
+    *hip_stream = (void*)c->stream;
+    return RT_OK;
+}
+int rt_geometry(rt_ctx* c, int* width, int* height, int* row_begin, int* row_end, int* halo)
+{
+    RT_CHECK_CTX(c);
+    if (width) *width = c->W;
+    if (height) *height = c->H;
+    if (row_begin) *row_begin = c->row_begin;
+    if (row_end) *row_end = c->row_end;
+    if (halo) *halo = c->halo;
+    return RT_OK;
+}
+/* device addresses of `n_rows` storage rows of a reservoir buffer (64-B records, 16-B radiance side
+ * records): dense halos are sent from and received into the buffers themselves, no staging copy */
+int rt_res_region(rt_ctx* c, int res, int row0, int n_rows, void** rec, size_t* rec_bytes, void** rad, size_t* rad_bytes)
+{
+    RT_CHECK_CTX(c);
+    const int phys = halo_phys(c, res);
+    if (phys < 0) RT_FAIL(c, RT_ERR_ARG, "bad reservoir buffer id %d", res);
+    int rc = halo_range(c, row0, n_rows);
+    if (rc != RT_OK) return rc;
+    const size_t off = (size_t)(row0 - c->lrow0) * c->W, n = (size_t)n_rows * c->W;
+    if (rec) *rec = (void*)(c->d_rec[phys] + 4 * off);
+    if (rec_bytes) *rec_bytes = n * 64;
+    if (rad) *rad = (void*)(c->d_rad[phys] + off);
+    if (rad_bytes) *rad_bytes = n * 16;
+    return RT_OK;
+}
+/* Second lane for arbitrary calls: between rt_lane(ctx, 1) and rt_lane(ctx, 0) every enqueue of this
+ * context goes to the second stream (ordered after rt_frame_stage_begin / _fork, joined by
+ * rt_frame_stage_end) — e.g. the halo marks of the NEXT frame beside this frame's passes. */
+int rt_lane(rt_ctx* c, int second)
+{
+    RT_CHECK_CTX(c);
+    if (second)
+    {
+        if (c->lane_saved) RT_FAIL(c, RT_ERR_STATE, "rt_lane(1) twice");
+        if (!c->aux_used) RT_HIP(c, hipStreamWaitEvent(c->aux_stream, c->ev_stage, 0));
+        c->aux_used = true;
+        c->lane_main = c->stream;
+        c->lane_timing = c->timing;
+        c->stream = c->aux_stream;
+        c->timing = false;
+        c->lane_saved = true;
+    }
+    else if (c->lane_saved)
+    {
+        c->stream = c->lane_main;
+        c->timing = c->lane_timing;
+        c->lane_saved = false;
+    }
+    return RT_OK;
+}
+
 int rt_ray_count(rt_ctx* c, uint64_t* rays, uint64_t* shaded_pixels)
 {
     RT_CHECK_CTX(c);
@@ -1368,7 +1446,7 @@ int rt_ray_count(rt_ctx* c, uint64_t* rays, uint64_t* shaded_pixels)
             for (int k = 0; k < c->opt.spatial_resampling_passes; ++k)
             {
                 /* halo rows: G-buffer flags if the neighbours' were exchanged for this frame, else the records */
-                const bool g1_ok = (c->row_begin == c->lrow0 || c->halo_flags_ok[0]) && (c->row_end == c->lrow0 + c->lrows || c->halo_flags_ok[1]);
+                const bool g1_ok = (c->row_begin == c->lrow0 || c->halo_flags_epoch[0] == c->epoch) && (c->row_end == c->lrow0 + c->lrows || c->halo_flags_epoch[1] == c->epoch);
                 k_spatial_bytes<<<launch_grid(c), BLOCK, 0, c->stream>>>(make_params(c, c->last_frame, k), c->d_g1,
                                                                         c->d_rec[c->res_map[RT_RES_TEMPORAL]], d, g1_ok);
             }
@@ -1382,6 +1460,25 @@ int rt_ray_count(rt_ctx* c, uint64_t* rays, uint64_t* shaded_pixels)
     }
     if (rays) *rays = n + per_shaded * shaded + merged;
     if (shaded_pixels) *shaded_pixels = shaded;
+    return RT_OK;
+}
+
+/* shaded pixels (hit and not emissive: the ones that run RIS, reuse and shadow rays) of each owned
+ * storage row of the current G-buffer, row_end - row_begin host counters */
+int rt_row_shaded(rt_ctx* c, uint32_t* counts)
+{
+    RT_CHECK_CTX(c);
+    if (!counts) return RT_ERR_ARG;
+    if (!c->has_gbuffer) RT_FAIL(c, RT_ERR_STATE, "no G-buffer yet");
+    const int rows = c->row_end - c->row_begin;
+    uint32_t* d = nullptr;
+    RT_HIP(c, hipMalloc(&d, (size_t)rows * 4));
+    RT_HIP(c, hipMemsetAsync(d, 0, (size_t)rows * 4, c->stream));
+    k_row_shaded<<<rows, BLOCK, 0, c->stream>>>(c->W, c->row_begin - c->lrow0, c->d_g1, d);
+    RT_HIP(c, hipGetLastError());
+    RT_HIP(c, hipMemcpyAsync(counts, d, (size_t)rows * 4, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    hipFree(d);
     return RT_OK;
 }
 

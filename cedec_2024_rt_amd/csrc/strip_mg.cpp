@@ -1,0 +1,881 @@
+/*
+ * strip_mg.cpp — native multi-GPU driver of the frame: one process (or, in tests, one context) per
+ * GPU, the image cut into row strips, reservoir halos exchanged with rank +-1 between the spatial
+ * passes. The reference is single-GPU (examples/10_restir_di/10_restir_di.cpp:35,
+ * 231-383): this file is the frame loop of :257-379 for one strip, built on the C-ABI of
+ * include/restir_rt.h only (it is a client of rt_frame_stage_* / rt_halo_*), plus HIP streams/events
+ * and RCCL point-to-point over xGMI.
+ *
+ * What it adds over the Python StripFrame of round 1 (cedec_2024_rt_amd/strips.py):
+ *   - no host wait in a steady frame: the sparse-halo plan of frame f+1 (which neighbour records
+ *     each rank will gather = a pure function of the RNG and the shaded flags) is marked during frame
+ *     f on the second lane, its bitmaps ride along with frame f's last halo message, and the record
+ *     counts (= the message sizes of frame f+1) reach the host by an asynchronous copy that frame f+1
+ *     finds finished. A frame whose plan is not there (first frame, camera / option / scene change,
+ *     non-consecutive frame number) builds it on the spot with one synchronisation ("cold" frame);
+ *   - dense halos are sent from and received into the reservoir buffers themselves (no staging);
+ *   - RCCL is called directly (ncclSend/ncclRecv grouped per exchange on a communication stream),
+ *     loaded with dlopen so that librestir_rt.so has no link-time dependency on it;
+ *   - cost-weighted strip heights (rt_mg_partition) and the boundary/interior row bands.
+ *
+ * Transports: RCCL (product) and LOCAL (several contexts of ONE process on one GPU, driven in
+ * lock-step by rt_mg_frame_step; device-to-device copies ordered by events) — the latter exists
+ * because the development boxes have one GPU and RCCL refuses two ranks on one device.
+ */
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include "../../include/restir_rt.h"
+
+/* ------------------------------------------------------------------ RCCL, resolved at run time */
+namespace
+{
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId; /* NCCL_UNIQUE_ID_BYTES, rccl.h:40-43 */
+enum { ncclSuccess = 0 };
+enum { ncclUint8 = 1 }; /* rccl.h:459-460 */
+
+struct Rccl
+{
+    void* lib = nullptr;
+    int (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string err;
+
+    bool load()
+    {
+        if (lib) return true;
+        /* torch ships its own librccl.so (same SONAME): if it is already mapped the loader returns it */
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names)
+            if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!lib) { err = std::string("cannot load RCCL: ") + dlerror(); return false; }
+#define RCCL_SYM(field, name)                                                       \
+    field = reinterpret_cast<decltype(field)>(dlsym(lib, name));                    \
+    if (!field) { err = std::string("RCCL lacks ") + name; lib = nullptr; return false; }
+        RCCL_SYM(GetUniqueId, "ncclGetUniqueId")
+        RCCL_SYM(CommInitRank, "ncclCommInitRank")
+        RCCL_SYM(CommDestroy, "ncclCommDestroy")
+        RCCL_SYM(GroupStart, "ncclGroupStart")
+        RCCL_SYM(GroupEnd, "ncclGroupEnd")
+        RCCL_SYM(Send, "ncclSend")
+        RCCL_SYM(Recv, "ncclRecv")
+        RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef RCCL_SYM
+        return true;
+    }
+};
+Rccl g_rccl;
+
+/* ------------------------------------------------------------------ transports */
+struct Part { const void* send; size_t send_bytes; void* recv; size_t recv_bytes; };
+struct Exchange { int peer; std::vector<Part> parts; };
+
+/* LOCAL transport: mailbox shared by the contexts of one process */
+struct LocalMsg
+{
+    std::vector<std::pair<const void*, size_t>> parts;
+    hipEvent_t ready = nullptr, consumed = nullptr;
+    bool consumed_recorded = false;
+    ~LocalMsg()
+    {
+        if (ready) hipEventDestroy(ready);
+        if (consumed) hipEventDestroy(consumed);
+    }
+};
+struct LocalHub
+{
+    int world = 0;
+    std::map<std::pair<int, int>, std::deque<std::shared_ptr<LocalMsg>>> box; /* (src, dst) -> FIFO */
+};
+}  // namespace
+
+struct rt_mg
+{
+    rt_ctx* ctx = nullptr;
+    int rank = 0, world = 1, W = 0, H = 0, halo = 0, a = 0, b = 0;
+    std::vector<int> bounds;
+    int transport = RT_MG_TRANSPORT_RCCL;
+    bool sparse = true, two_lanes = true;
+    std::string err;
+
+    /* neighbours: side 0 = the strip below (rank - 1, smaller rows), side 1 = the strip above */
+    struct Side
+    {
+        int peer = -1, side = 0;
+        int send_row0 = 0, recv_row0 = 0, n_rows = 0;
+        size_t bm_words = 0;                                /* rt_halo_bitmap_words(n_rows): count, bits, prefix */
+        uint32_t* need_bm[2] = {nullptr, nullptr};          /* [plan slot] passes x bm_words: what I gather from the peer */
+        uint32_t* give_bm[2] = {nullptr, nullptr};          /* what the peer gathers from me */
+        uint32_t* cnt_h[2] = {nullptr, nullptr};            /* pinned host, [slot][0..P) need counts, [P..2P) give counts */
+        char* send_buf[2] = {nullptr, nullptr};             /* sparse record lists, by exchange parity */
+        char* recv_buf = nullptr;
+        uint8_t *flags_send = nullptr, *flags_recv = nullptr;
+        std::shared_ptr<LocalMsg> last_send[2], last_bm[2], last_flags; /* LOCAL: who may still be reading a buffer */
+    };
+    std::vector<Side> sides;
+    int bnd[2][2] = {{0, 0}, {0, 0}}, n_bnd = 0;   /* boundary row ranges (needed by a neighbour), computed first */
+    int itr[2][2] = {{0, 0}, {0, 0}}, n_itr = 0;   /* interior row ranges, computed while halos travel */
+
+    hipStream_t comm = nullptr;
+    hipEvent_t ev_packed = nullptr, ev_arrived = nullptr, ev_plan[2] = {nullptr, nullptr};
+    ncclComm_t nccl = nullptr;
+    LocalHub* hub = nullptr;
+
+    /* cached halo plans, slot = frame & 1 */
+    int plan_passes = 0, max_passes = 0;
+    long long plan_frame[2] = {-1, -1};
+    uint64_t plan_epoch[2] = {0, 0}, flags_epoch = 0;
+
+    /* frame state machine (rt_mg_frame_begin / _step) */
+    enum Seg { SEG_IDLE, SEG_RAYCAST, SEG_COLD_FLAGS, SEG_COLD_MARK, SEG_COLD_BITMAPS, SEG_GENERATE, SEG_PASS, SEG_FINAL };
+    Seg seg = SEG_IDLE;
+    int frame = 0, clear_first = 0, stage = 0, passes = 0;
+    bool warm = false, use_sparse = false, pending = false, pending_carries_plan = false;
+    int pending_buf = 0, pending_k = 0;
+    std::vector<Exchange> pending_x;
+    std::vector<std::shared_ptr<LocalMsg>> pending_local;
+
+    rt_mg_stats stats;
+};
+
+#define MG_FAIL(m, code, ...)                     \
+    do                                            \
+    {                                             \
+        char _b[512];                             \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);    \
+        (m)->err = _b;                            \
+        return (code);                            \
+    } while (0)
+#define MG_HIP(m, call)                                                                             \
+    do                                                                                              \
+    {                                                                                               \
+        hipError_t _e = (call);                                                                     \
+        if (_e != hipSuccess) MG_FAIL(m, RT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(_e)); \
+    } while (0)
+#define MG_RT(m, call)                                                                    \
+    do                                                                                    \
+    {                                                                                     \
+        int _rc = (call);                                                                 \
+        if (_rc != RT_OK) MG_FAIL(m, _rc, "%s: %s", #call, rt_last_error((m)->ctx));      \
+    } while (0)
+#define MG_NCCL(m, call)                                                                                   \
+    do                                                                                                     \
+    {                                                                                                      \
+        int _r = (call);                                                                                   \
+        if (_r != ncclSuccess) MG_FAIL(m, RT_ERR_COMM, "%s failed: %s", #call, g_rccl.GetErrorString(_r)); \
+    } while (0)
+
+static hipStream_t main_stream(rt_mg* m)
+{
+    void* s = nullptr;
+    rt_get_stream(m->ctx, &s);
+    return (hipStream_t)s;
+}
+
+/* ------------------------------------------------------------------ partition / bands (pure host) */
+extern "C" {
+
+/* Contiguous strips of at least `halo` rows each (a halo must not reach beyond the adjacent strip).
+ * row_cost == NULL: near-equal heights, the first H % world strips one row taller. Otherwise the
+ * partition that minimises the largest strip cost (binary search on the bound, greedy fill). */
+int rt_mg_partition(int height, int world, int halo, const uint32_t* row_cost, int* bounds)
+{
+    if (height <= 0 || world <= 0 || !bounds || halo < 0) return RT_ERR_ARG;
+    if (world > 1 && height / world < halo) return RT_ERR_ARG;
+    if (!row_cost || world == 1)
+    {
+        const int base = height / world, extra = height % world;
+        bounds[0] = 0;
+        for (int r = 0; r < world; ++r) bounds[r + 1] = bounds[r] + base + (r < extra ? 1 : 0);
+        return RT_OK;
+    }
+    std::vector<unsigned long long> pre((size_t)height + 1, 0);
+    for (int i = 0; i < height; ++i) pre[(size_t)i + 1] = pre[(size_t)i] + (unsigned long long)row_cost[i] + 1ull; /* +1: every row costs something */
+    const int min_rows = halo > 1 ? halo : 1;
+    auto fill = [&](unsigned long long T, int* out) -> bool {
+        int at = 0;
+        out[0] = 0;
+        for (int r = 0; r < world; ++r)
+        {
+            const int left = world - 1 - r;               /* strips still to place after this one */
+            int lo = at + min_rows, hi = height - left * min_rows;
+            if (lo > hi) return false;
+            if (left == 0) { if (pre[(size_t)height] - pre[(size_t)at] > T) return false; out[r + 1] = height; return true; }
+            /* the largest end <= hi with cost <= T, but at least lo rows */
+            int end = lo;
+            if (pre[(size_t)lo] - pre[(size_t)at] > T) return false;
+            int l = lo, h = hi;
+            while (l <= h)
+            {
+                const int mid = (l + h) / 2;
+                if (pre[(size_t)mid] - pre[(size_t)at] <= T) { end = mid; l = mid + 1; }
+                else h = mid - 1;
+            }
+            out[r + 1] = end;
+            at = end;
+        }
+        return true;
+    };
+    unsigned long long lo = 0, hi = pre[(size_t)height];
+    std::vector<int> tmp((size_t)world + 1);
+    while (lo < hi)
+    {
+        const unsigned long long mid = lo + (hi - lo) / 2;
+        if (fill(mid, tmp.data())) hi = mid; else lo = mid + 1;
+    }
+    if (!fill(lo, bounds)) return RT_ERR_ARG;
+    return RT_OK;
+}
+
+/* Row bands of one strip: `boundary` = owned rows a neighbour's spatial pass can reach (within `halo`
+ * rows of a strip edge that has a neighbour) — computed and sent first; `interior` = the rest,
+ * computed while the halos travel. Each list holds up to two [row0,row1) pairs. */
+int rt_mg_bands(const int* bounds, int world, int rank, int halo, int* boundary, int* n_boundary, int* interior, int* n_interior)
+{
+    if (!bounds || rank < 0 || rank >= world || !boundary || !n_boundary || !interior || !n_interior) return RT_ERR_ARG;
+    const int a = bounds[rank], b = bounds[rank + 1];
+    int nb = 0, ni = 0;
+    int c[2][2];
+    int nc = 0;
+    if (rank > 0) { c[nc][0] = a; c[nc][1] = a + halo < b ? a + halo : b; ++nc; }
+    if (rank + 1 < world) { c[nc][0] = b - halo > a ? b - halo : a; c[nc][1] = b; ++nc; }
+    if (nc == 2 && c[1][0] <= c[0][1]) { c[0][1] = c[1][1] > c[0][1] ? c[1][1] : c[0][1]; nc = 1; }
+    int cur = a;
+    for (int i = 0; i < nc; ++i)
+    {
+        boundary[2 * nb] = c[i][0]; boundary[2 * nb + 1] = c[i][1]; ++nb;
+        if (cur < c[i][0]) { interior[2 * ni] = cur; interior[2 * ni + 1] = c[i][0]; ++ni; }
+        cur = c[i][1];
+    }
+    if (cur < b) { interior[2 * ni] = cur; interior[2 * ni + 1] = b; ++ni; }
+    *n_boundary = nb;
+    *n_interior = ni;
+    return RT_OK;
+}
+
+/* ------------------------------------------------------------------ creation */
+int rt_mg_unique_id(void* id128)
+{
+    if (!id128) return RT_ERR_ARG;
+    if (!g_rccl.load()) return RT_ERR_COMM;
+    ncclUniqueId id;
+    if (g_rccl.GetUniqueId(&id) != ncclSuccess) return RT_ERR_COMM;
+    memcpy(id128, &id, sizeof(id));
+    return RT_OK;
+}
+const char* rt_mg_load_error(void) { return g_rccl.err.c_str(); }
+
+int rt_mg_hub_create(int world, void** hub)
+{
+    if (!hub || world <= 0) return RT_ERR_ARG;
+    LocalHub* h = new LocalHub();
+    h->world = world;
+    *hub = h;
+    return RT_OK;
+}
+int rt_mg_hub_destroy(void* hub)
+{
+    delete (LocalHub*)hub;
+    return RT_OK;
+}
+
+const char* rt_mg_last_error(rt_mg* m) { return m ? m->err.c_str() : "null rt_mg"; }
+
+static int alloc_sides(rt_mg* m)
+{
+    for (auto& s : m->sides)
+    {
+        s.bm_words = rt_halo_bitmap_words(m->ctx, s.n_rows);
+        const size_t bm_bytes = s.bm_words * 4 * (size_t)m->max_passes;
+        const size_t list_bytes = rt_halo_bytes(m->ctx, s.n_rows) + 256;
+        for (int k = 0; k < 2; ++k)
+        {
+            MG_HIP(m, hipMalloc(&s.need_bm[k], bm_bytes));
+            MG_HIP(m, hipMalloc(&s.give_bm[k], bm_bytes));
+            MG_HIP(m, hipMemset(s.need_bm[k], 0, bm_bytes));
+            MG_HIP(m, hipMemset(s.give_bm[k], 0, bm_bytes));
+            MG_HIP(m, hipHostMalloc(&s.cnt_h[k], (size_t)m->max_passes * 2 * 4, hipHostMallocDefault));
+            MG_HIP(m, hipMalloc(&s.send_buf[k], list_bytes));
+        }
+        MG_HIP(m, hipMalloc(&s.recv_buf, list_bytes));
+        MG_HIP(m, hipMalloc(&s.flags_send, rt_halo_flags_bytes(m->ctx, s.n_rows) + 16));
+        MG_HIP(m, hipMalloc(&s.flags_recv, rt_halo_flags_bytes(m->ctx, s.n_rows) + 16));
+    }
+    return RT_OK;
+}
+
+/* ctx: the strip context of this rank, created with rows bounds[rank]..bounds[rank+1] and a halo of at
+ * least the reach of the spatial pass (87 rows for the default radius). `arg`: RCCL: the 128-byte unique
+ * id of rt_mg_unique_id (made by one rank, distributed by the caller); LOCAL: the hub. */
+int rt_mg_create(rt_ctx* ctx, int rank, int world, const int* bounds, int transport, const void* arg, int flags, rt_mg** out)
+{
+    if (!ctx || !out || !bounds || world <= 0 || rank < 0 || rank >= world) return RT_ERR_ARG;
+    rt_mg* m = new rt_mg();
+    *out = m;
+    m->ctx = ctx; m->rank = rank; m->world = world; m->transport = transport;
+    m->bounds.assign(bounds, bounds + world + 1);
+    m->sparse = !(flags & RT_MG_DENSE);
+    m->two_lanes = !(flags & RT_MG_ONE_LANE);
+    memset(&m->stats, 0, sizeof(m->stats));
+    int ra = 0, rb = 0;
+    MG_RT(m, rt_geometry(ctx, &m->W, &m->H, &ra, &rb, &m->halo));
+    m->a = bounds[rank]; m->b = bounds[rank + 1];
+    if (ra != m->a || rb != m->b) MG_FAIL(m, RT_ERR_ARG, "context owns rows [%d,%d), the partition gives rank %d [%d,%d)", ra, rb, rank, m->a, m->b);
+    if (bounds[0] != 0 || bounds[world] != m->H) MG_FAIL(m, RT_ERR_ARG, "bounds must cover rows 0..%d", m->H);
+    for (int r = 0; r < world; ++r)
+        if (world > 1 && bounds[r + 1] - bounds[r] < m->halo)
+            MG_FAIL(m, RT_ERR_ARG, "strip %d has %d rows, fewer than the %d-row halo", r, bounds[r + 1] - bounds[r], m->halo);
+    if (world > 1 && m->halo <= 0) MG_FAIL(m, RT_ERR_ARG, "strip contexts of a multi-rank frame need halo rows");
+    int bl[4], il[4];
+    rt_mg_bands(bounds, world, rank, m->halo, bl, &m->n_bnd, il, &m->n_itr);
+    for (int i = 0; i < m->n_bnd; ++i) { m->bnd[i][0] = bl[2 * i]; m->bnd[i][1] = bl[2 * i + 1]; }
+    for (int i = 0; i < m->n_itr; ++i) { m->itr[i][0] = il[2 * i]; m->itr[i][1] = il[2 * i + 1]; }
+    if (rank > 0)
+    {
+        rt_mg::Side s;
+        s.peer = rank - 1; s.side = 0; s.n_rows = m->halo;
+        s.send_row0 = m->a; s.recv_row0 = m->a - m->halo;
+        m->sides.push_back(s);
+    }
+    if (rank + 1 < world)
+    {
+        rt_mg::Side s;
+        s.peer = rank + 1; s.side = 1; s.n_rows = m->halo;
+        s.send_row0 = m->b - m->halo; s.recv_row0 = m->b;
+        m->sides.push_back(s);
+    }
+    m->max_passes = 8;
+    int dev = 0;
+    MG_HIP(m, hipGetDevice(&dev));
+    MG_HIP(m, hipStreamCreateWithFlags(&m->comm, hipStreamNonBlocking));
+    MG_HIP(m, hipEventCreateWithFlags(&m->ev_packed, hipEventDisableTiming));
+    MG_HIP(m, hipEventCreateWithFlags(&m->ev_arrived, hipEventDisableTiming));
+    for (auto& e : m->ev_plan) MG_HIP(m, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    int rc = alloc_sides(m);
+    if (rc != RT_OK) return rc;
+    if (world > 1 && transport == RT_MG_TRANSPORT_RCCL)
+    {
+        if (!arg) MG_FAIL(m, RT_ERR_ARG, "RCCL transport needs the 128-byte unique id");
+        if (!g_rccl.load()) MG_FAIL(m, RT_ERR_COMM, "%s", g_rccl.err.c_str());
+        ncclUniqueId id;
+        memcpy(&id, arg, sizeof(id));
+        MG_NCCL(m, g_rccl.CommInitRank(&m->nccl, world, id, rank));
+    }
+    else if (world > 1 && transport == RT_MG_TRANSPORT_LOCAL)
+    {
+        if (!arg) MG_FAIL(m, RT_ERR_ARG, "LOCAL transport needs a hub (rt_mg_hub_create)");
+        m->hub = (LocalHub*)arg;
+        if (m->hub->world != world) MG_FAIL(m, RT_ERR_ARG, "hub was created for %d ranks", m->hub->world);
+    }
+    else if (world > 1 && transport != RT_MG_TRANSPORT_MIRROR) MG_FAIL(m, RT_ERR_ARG, "unknown transport %d", transport);
+    return RT_OK;
+}
+
+int rt_mg_destroy(rt_mg* m)
+{
+    if (!m) return RT_ERR_ARG;
+    if (m->ctx) rt_sync(m->ctx);
+    if (m->comm) hipStreamSynchronize(m->comm);
+    m->pending_local.clear();
+    for (auto& s : m->sides)
+    {
+        for (int k = 0; k < 2; ++k)
+        {
+            hipFree(s.need_bm[k]); hipFree(s.give_bm[k]); hipFree(s.send_buf[k]);
+            if (s.cnt_h[k]) hipHostFree(s.cnt_h[k]);
+            s.last_send[k].reset(); s.last_bm[k].reset();
+        }
+        s.last_flags.reset();
+        hipFree(s.recv_buf); hipFree(s.flags_send); hipFree(s.flags_recv);
+    }
+    if (m->nccl) g_rccl.CommDestroy(m->nccl);
+    if (m->ev_packed) hipEventDestroy(m->ev_packed);
+    if (m->ev_arrived) hipEventDestroy(m->ev_arrived);
+    for (auto& e : m->ev_plan) if (e) hipEventDestroy(e);
+    if (m->comm) hipStreamDestroy(m->comm);
+    delete m;
+    return RT_OK;
+}
+
+int rt_mg_get_stats(rt_mg* m, rt_mg_stats* out)
+{
+    if (!m || !out) return RT_ERR_ARG;
+    *out = m->stats;
+    return RT_OK;
+}
+int rt_mg_reset_stats(rt_mg* m)
+{
+    if (!m) return RT_ERR_ARG;
+    memset(&m->stats, 0, sizeof(m->stats));
+    return RT_OK;
+}
+
+}  // extern "C"
+
+/* ------------------------------------------------------------------ exchange = post + complete */
+/* LOCAL: before a buffer that a peer may still be copying from is overwritten */
+static int local_guard(rt_mg* m, std::shared_ptr<LocalMsg>& last, hipStream_t writer)
+{
+    if (last && last->consumed_recorded) MG_HIP(m, hipStreamWaitEvent(writer, last->consumed, 0));
+    last.reset();
+    return RT_OK;
+}
+
+/* post: everything the sends read has been enqueued on the main stream (or lanes joined into it) */
+static int post(rt_mg* m, std::vector<Exchange>&& xs)
+{
+    hipStream_t ms = main_stream(m);
+    m->pending_x = std::move(xs);
+    m->pending = true;
+    for (auto& x : m->pending_x)
+        for (auto& p : x.parts) { m->stats.bytes_sent += p.send_bytes; m->stats.messages += 1; }
+    if (m->transport == RT_MG_TRANSPORT_MIRROR) return RT_OK;
+    if (m->transport == RT_MG_TRANSPORT_RCCL)
+    {
+        MG_HIP(m, hipEventRecord(m->ev_packed, ms));
+        MG_HIP(m, hipStreamWaitEvent(m->comm, m->ev_packed, 0));
+        MG_NCCL(m, g_rccl.GroupStart());
+        for (auto& x : m->pending_x)
+            for (auto& p : x.parts)
+            {
+                MG_NCCL(m, g_rccl.Send(p.send, p.send_bytes, ncclUint8, x.peer, m->nccl, m->comm));
+                MG_NCCL(m, g_rccl.Recv(p.recv, p.recv_bytes, ncclUint8, x.peer, m->nccl, m->comm));
+            }
+        MG_NCCL(m, g_rccl.GroupEnd());
+        MG_HIP(m, hipEventRecord(m->ev_arrived, m->comm));
+        return RT_OK;
+    }
+    m->pending_local.clear();
+    for (auto& x : m->pending_x)
+    {
+        auto msg = std::make_shared<LocalMsg>();
+        for (auto& p : x.parts) msg->parts.push_back({p.send, p.send_bytes});
+        MG_HIP(m, hipEventCreateWithFlags(&msg->ready, hipEventDisableTiming));
+        MG_HIP(m, hipEventCreateWithFlags(&msg->consumed, hipEventDisableTiming));
+        MG_HIP(m, hipEventRecord(msg->ready, ms));
+        m->hub->box[{m->rank, x.peer}].push_back(msg);
+        m->pending_local.push_back(msg);
+    }
+    return RT_OK;
+}
+
+/* complete: after it, the received bytes are visible to work enqueued on the main stream */
+static int complete(rt_mg* m)
+{
+    if (!m->pending) return RT_OK;
+    hipStream_t ms = main_stream(m);
+    m->pending = false;
+    if (m->transport == RT_MG_TRANSPORT_RCCL)
+    {
+        MG_HIP(m, hipStreamWaitEvent(ms, m->ev_arrived, 0));
+        return RT_OK;
+    }
+    if (m->transport == RT_MG_TRANSPORT_MIRROR)
+    {
+        /* every rank receives what it sent (a neighbour that mirrors it): same launches and bytes as a
+         * real exchange with no peer to wait for — the overhead measurements of tools/strip_overhead.py */
+        for (auto& x : m->pending_x)
+            for (auto& p : x.parts)
+            {
+                if (p.send_bytes != p.recv_bytes) MG_FAIL(m, RT_ERR_STATE, "MIRROR transport: %zu bytes out, %zu in", p.send_bytes, p.recv_bytes);
+                MG_HIP(m, hipMemcpyAsync(p.recv, p.send, p.recv_bytes, hipMemcpyDeviceToDevice, ms));
+            }
+        return RT_OK;
+    }
+    for (auto& x : m->pending_x)
+    {
+        auto& q = m->hub->box[{x.peer, m->rank}];
+        if (q.empty()) MG_FAIL(m, RT_ERR_STATE, "LOCAL transport: rank %d has not posted to rank %d yet (drive all ranks in lock-step)", x.peer, m->rank);
+        auto msg = q.front();
+        q.pop_front();
+        if (msg->parts.size() != x.parts.size()) MG_FAIL(m, RT_ERR_STATE, "LOCAL transport: message shape mismatch between ranks %d and %d", x.peer, m->rank);
+        MG_HIP(m, hipStreamWaitEvent(ms, msg->ready, 0));
+        for (size_t i = 0; i < x.parts.size(); ++i)
+        {
+            if (msg->parts[i].second != x.parts[i].recv_bytes)
+                MG_FAIL(m, RT_ERR_STATE, "LOCAL transport: rank %d sends %zu bytes, rank %d expects %zu", x.peer, msg->parts[i].second, m->rank, x.parts[i].recv_bytes);
+            MG_HIP(m, hipMemcpyAsync(x.parts[i].recv, msg->parts[i].first, x.parts[i].recv_bytes, hipMemcpyDeviceToDevice, ms));
+        }
+        MG_HIP(m, hipEventRecord(msg->consumed, ms));
+        msg->consumed_recorded = true;
+    }
+    return RT_OK;
+}
+
+/* ------------------------------------------------------------------ the frame */
+static size_t list_bytes(uint32_t count) { return (size_t)(count > 0 ? count : 1) * 80; }
+
+/* record counts of the plan in `slot`: device bitmaps word 0 of each pass -> pinned host (async) */
+static int fetch_counts(rt_mg* m, int slot, hipStream_t st)
+{
+    for (auto& s : m->sides)
+    {
+        MG_HIP(m, hipMemcpy2DAsync(s.cnt_h[slot], 4, s.need_bm[slot], s.bm_words * 4, 4, (size_t)m->passes, hipMemcpyDeviceToHost, st));
+        MG_HIP(m, hipMemcpy2DAsync(s.cnt_h[slot] + m->passes, 4, s.give_bm[slot], s.bm_words * 4, 4, (size_t)m->passes, hipMemcpyDeviceToHost, st));
+    }
+    return RT_OK;
+}
+
+/* need-bitmaps of `frame` for both neighbours (RNG replay on the device, rt_halo_mark) */
+static int mark_plan(rt_mg* m, int frame, int slot, hipStream_t writer)
+{
+    for (auto& s : m->sides)
+    {
+        if (m->transport == RT_MG_TRANSPORT_LOCAL) { int rc = local_guard(m, s.last_bm[slot], writer); if (rc != RT_OK) return rc; }
+        MG_RT(m, rt_halo_mark(m->ctx, frame, 0, m->passes, s.side, s.need_bm[slot]));
+    }
+    return RT_OK;
+}
+
+/* the bitmap part of an exchange: my need-bitmaps go to the owner of those rows, its need-bitmaps
+ * (= what I must give) come back */
+static void add_bitmap_parts(rt_mg* m, int slot, std::vector<Exchange>& xs)
+{
+    for (size_t i = 0; i < m->sides.size(); ++i)
+    {
+        auto& s = m->sides[i];
+        const size_t bytes = s.bm_words * 4 * (size_t)m->passes;
+        xs[i].parts.push_back({s.need_bm[slot], bytes, s.give_bm[slot], bytes});
+    }
+}
+
+static int run_rows(rt_mg* m, int stage, int part, const int (*ranges)[2], int n, bool second_lane)
+{
+    for (int i = 0; i < n; ++i)
+    {
+        if (second_lane) MG_RT(m, rt_frame_stage_run_async(m->ctx, m->frame, stage, part, ranges[i][0], ranges[i][1]));
+        else MG_RT(m, rt_frame_stage_run_part(m->ctx, m->frame, stage, part, ranges[i][0], ranges[i][1]));
+    }
+    return RT_OK;
+}
+
+/* halo exchange of the buffer stage `stage` has just written on the boundary rows (input of spatial
+ * pass `stage`); with_plan: the bitmaps of the next frame's plan ride along */
+static int post_halo(rt_mg* m, int stage, int buf, bool with_plan)
+{
+    hipStream_t ms = main_stream(m);
+    const int slot = m->frame & 1, nslot = slot ^ 1, k = stage;
+    std::vector<Exchange> xs(m->sides.size());
+    for (size_t i = 0; i < m->sides.size(); ++i)
+    {
+        auto& s = m->sides[i];
+        xs[i].peer = s.peer;
+        if (m->use_sparse)
+        {
+            const uint32_t give = s.cnt_h[slot][m->passes + k], need = s.cnt_h[slot][k];
+            char* sb = s.send_buf[k & 1];
+            if (m->transport == RT_MG_TRANSPORT_LOCAL) { int rc = local_guard(m, s.last_send[k & 1], ms); if (rc != RT_OK) return rc; }
+            MG_RT(m, rt_halo_pack_sparse(m->ctx, buf, s.send_row0, s.n_rows, s.give_bm[slot] + (size_t)k * s.bm_words, sb));
+            xs[i].parts.push_back({sb, list_bytes(give), s.recv_buf, list_bytes(need)});
+            m->stats.records_sent += give;
+        }
+        else
+        {
+            void *srec, *srad, *rrec, *rrad;
+            size_t nrec, nrad;
+            MG_RT(m, rt_res_region(m->ctx, buf, s.send_row0, s.n_rows, &srec, &nrec, &srad, &nrad));
+            MG_RT(m, rt_res_region(m->ctx, buf, s.recv_row0, s.n_rows, &rrec, &nrec, &rrad, &nrad));
+            xs[i].parts.push_back({srec, nrec, rrec, nrec});
+            xs[i].parts.push_back({srad, nrad, rrad, nrad});
+            m->stats.records_sent += (unsigned long long)s.n_rows * m->W;
+        }
+    }
+    if (with_plan) add_bitmap_parts(m, nslot, xs);
+    int rc = post(m, std::move(xs));
+    if (rc != RT_OK) return rc;
+    if (m->transport == RT_MG_TRANSPORT_LOCAL)
+        for (size_t i = 0; i < m->sides.size(); ++i)
+        {
+            if (m->use_sparse) m->sides[i].last_send[k & 1] = m->pending_local[i];
+            if (with_plan) m->sides[i].last_bm[nslot] = m->pending_local[i];
+        }
+    m->pending_buf = buf; m->pending_k = k; m->pending_carries_plan = with_plan;
+    return RT_OK;
+}
+
+static int finish_halo(rt_mg* m)
+{
+    hipStream_t ms = main_stream(m);
+    const bool carried = m->pending_carries_plan;
+    int rc = complete(m);
+    if (rc != RT_OK) return rc;
+    const int slot = m->frame & 1, nslot = slot ^ 1, k = m->pending_k;
+    if (m->use_sparse)
+        for (auto& s : m->sides)
+            MG_RT(m, rt_halo_unpack_sparse(m->ctx, m->pending_buf, s.recv_row0, s.n_rows, s.need_bm[slot] + (size_t)k * s.bm_words, s.recv_buf));
+    if (carried)
+    {
+        /* the plan of frame + 1 is complete on the device: its counts travel to the host behind it */
+        rc = fetch_counts(m, nslot, ms);
+        if (rc != RT_OK) return rc;
+        MG_HIP(m, hipEventRecord(m->ev_plan[nslot], ms));
+        m->plan_frame[nslot] = (long long)m->frame + 1;
+        rt_state_epoch(m->ctx, &m->plan_epoch[nslot]);
+        m->plan_passes = m->passes;
+        m->pending_carries_plan = false;
+    }
+    return RT_OK;
+}
+
+extern "C" {
+
+int rt_mg_frame_begin(rt_mg* m, int frame, int clear_first)
+{
+    if (!m) return RT_ERR_ARG;
+    if (m->seg != rt_mg::SEG_IDLE) MG_FAIL(m, RT_ERR_STATE, "the previous frame has not been stepped to its end");
+    rt_options o;
+    MG_RT(m, rt_options_get(m->ctx, &o));
+    m->passes = o.spatial_resampling_passes;
+    if (m->passes > m->max_passes) MG_FAIL(m, RT_ERR_UNSUPPORTED, "more than %d spatial passes", m->max_passes);
+    m->frame = frame; m->clear_first = clear_first;
+    const bool exchanges = !m->sides.empty() && m->passes > 0;
+    m->use_sparse = exchanges && m->sparse && o.use_spatial_resampling;
+    m->warm = false;
+    if (m->use_sparse)
+    {
+        uint64_t epoch = 0;
+        rt_state_epoch(m->ctx, &epoch);
+        const int slot = frame & 1;
+        if (m->plan_frame[slot] == (long long)frame && m->plan_epoch[slot] == epoch && m->plan_passes == m->passes)
+        {
+            /* recorded in the middle of the previous frame: in a steady loop this returns at once */
+            const auto t0 = std::chrono::steady_clock::now();
+            MG_HIP(m, hipEventSynchronize(m->ev_plan[slot]));
+            m->stats.plan_wait_ns += (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            m->warm = true;
+        }
+    }
+    m->seg = rt_mg::SEG_RAYCAST;
+    m->stats.frames += 1;
+    if (m->use_sparse && !m->warm) m->stats.cold_frames += 1;
+    return RT_OK;
+}
+
+/* one segment of the frame: [finish the exchange posted by the previous segment,] compute, [post the
+ * next exchange]. *more = 0 after the last one. All ranks take the same sequence of segments. */
+static int frame_step(rt_mg* m, int* more);
+int rt_mg_frame_step(rt_mg* m, int* more)
+{
+    if (!m || !more) return RT_ERR_ARG;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = frame_step(m, more);
+    m->stats.host_ns += (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+static int frame_step(rt_mg* m, int* more)
+{
+    hipStream_t ms = main_stream(m);
+    const int slot = m->frame & 1, nslot = slot ^ 1, P = m->passes;
+    const bool exchanges = !m->sides.empty() && P > 0;
+    const int all[1][2] = {{m->a, m->b}};
+    *more = 1;
+    int rc = RT_OK;
+    switch (m->seg)
+    {
+        case rt_mg::SEG_IDLE: MG_FAIL(m, RT_ERR_STATE, "rt_mg_frame_begin first");
+        case rt_mg::SEG_RAYCAST:
+        {
+            MG_RT(m, rt_frame_stage_begin(m->ctx, m->frame, 0, m->clear_first));
+            /* [clear,] raycast of all owned rows: the marks and the second lane need the G-buffer */
+            MG_RT(m, rt_frame_stage_run_part(m->ctx, m->frame, 0, 1, m->a, m->b));
+            if (!m->use_sparse || m->warm) { m->seg = rt_mg::SEG_GENERATE; return frame_step(m, more); }
+            uint64_t epoch = 0;
+            rt_state_epoch(m->ctx, &epoch);
+            if (m->flags_epoch == epoch) { m->seg = rt_mg::SEG_COLD_MARK; return frame_step(m, more); }
+            /* cold frame, 1: shaded flags of the neighbours' boundary rows (valid until the camera moves) */
+            std::vector<Exchange> xs(m->sides.size());
+            for (size_t i = 0; i < m->sides.size(); ++i)
+            {
+                auto& s = m->sides[i];
+                if (m->transport == RT_MG_TRANSPORT_LOCAL) { rc = local_guard(m, s.last_flags, ms); if (rc != RT_OK) return rc; }
+                MG_RT(m, rt_halo_flags_pack(m->ctx, s.send_row0, s.n_rows, s.flags_send));
+                const size_t fb = rt_halo_flags_bytes(m->ctx, s.n_rows);
+                xs[i].peer = s.peer;
+                xs[i].parts.push_back({s.flags_send, fb, s.flags_recv, fb});
+            }
+            rc = post(m, std::move(xs));
+            if (rc != RT_OK) return rc;
+            if (m->transport == RT_MG_TRANSPORT_LOCAL)
+                for (size_t i = 0; i < m->sides.size(); ++i) m->sides[i].last_flags = m->pending_local[i];
+            m->seg = rt_mg::SEG_COLD_FLAGS;
+            return RT_OK;
+        }
+        case rt_mg::SEG_COLD_FLAGS:
+        {
+            rc = complete(m);
+            if (rc != RT_OK) return rc;
+            for (auto& s : m->sides) MG_RT(m, rt_halo_flags_unpack(m->ctx, s.recv_row0, s.n_rows, s.flags_recv));
+            rt_state_epoch(m->ctx, &m->flags_epoch);
+            m->seg = rt_mg::SEG_COLD_MARK;
+            return frame_step(m, more);
+        }
+        case rt_mg::SEG_COLD_MARK:
+        {
+            /* cold frame, 2: what I will gather from each neighbour in every pass of THIS frame */
+            rc = mark_plan(m, m->frame, slot, ms);
+            if (rc != RT_OK) return rc;
+            std::vector<Exchange> xs(m->sides.size());
+            for (size_t i = 0; i < m->sides.size(); ++i) xs[i].peer = m->sides[i].peer;
+            add_bitmap_parts(m, slot, xs);
+            rc = post(m, std::move(xs));
+            if (rc != RT_OK) return rc;
+            if (m->transport == RT_MG_TRANSPORT_LOCAL)
+                for (size_t i = 0; i < m->sides.size(); ++i) m->sides[i].last_bm[slot] = m->pending_local[i];
+            m->seg = rt_mg::SEG_COLD_BITMAPS;
+            return RT_OK;
+        }
+        case rt_mg::SEG_COLD_BITMAPS:
+        {
+            rc = complete(m);
+            if (rc != RT_OK) return rc;
+            rc = fetch_counts(m, slot, ms);
+            if (rc != RT_OK) return rc;
+            MG_HIP(m, hipStreamSynchronize(ms)); /* the one host wait of a cold frame: message sizes */
+            m->plan_frame[slot] = m->frame;
+            rt_state_epoch(m->ctx, &m->plan_epoch[slot]);
+            m->plan_passes = P;
+            m->seg = rt_mg::SEG_GENERATE;
+            return frame_step(m, more);
+        }
+        case rt_mg::SEG_GENERATE:
+        {
+            const bool lanes = m->two_lanes && exchanges && m->n_itr > 0;
+            if (lanes)
+            {
+                MG_RT(m, rt_frame_stage_fork(m->ctx)); /* the second lane starts behind the raycast */
+                rc = run_rows(m, 0, 2, m->itr, m->n_itr, true);
+                if (rc != RT_OK) return rc;
+            }
+            if (m->use_sparse)
+            {
+                /* the plan of the NEXT frame, beside this frame's work (valid if the camera stays) */
+                if (m->two_lanes) { if (!lanes) MG_RT(m, rt_frame_stage_fork(m->ctx)); MG_RT(m, rt_lane(m->ctx, 1)); }
+                void* ws = nullptr;
+                rt_get_stream(m->ctx, &ws);
+                rc = mark_plan(m, m->frame + 1, nslot, (hipStream_t)ws);
+                if (m->two_lanes) rt_lane(m->ctx, 0);
+                if (rc != RT_OK) return rc;
+            }
+            if (exchanges)
+            {
+                rc = run_rows(m, 0, 2, m->bnd, m->n_bnd, false);
+                if (rc != RT_OK) return rc;
+                if (!lanes) { rc = run_rows(m, 0, 2, m->itr, m->n_itr, false); if (rc != RT_OK) return rc; }
+            }
+            else { rc = run_rows(m, 0, 2, all, 1, false); if (rc != RT_OK) return rc; }
+            if (exchanges)
+            {
+                /* joins the second lane first when the next frame's bitmaps ride on this message */
+                const bool carry = m->use_sparse && P == 1;
+                int buf = 0;
+                MG_RT(m, rt_frame_stage_output(m->ctx, 0, &buf));
+                if (carry) { MG_RT(m, rt_frame_stage_end(m->ctx, 0)); }
+                rc = post_halo(m, 0, RT_RES_PHYS + buf, carry);
+                if (rc != RT_OK) return rc;
+                if (!carry) MG_RT(m, rt_frame_stage_end(m->ctx, 0));
+            }
+            else MG_RT(m, rt_frame_stage_end(m->ctx, 0));
+            m->stage = 1;
+            m->seg = P > 0 ? rt_mg::SEG_PASS : rt_mg::SEG_FINAL;
+            return exchanges ? RT_OK : frame_step(m, more);
+        }
+        case rt_mg::SEG_PASS:
+        {
+            const int s = m->stage; /* spatial pass s - 1 */
+            const bool lanes = m->two_lanes && exchanges && m->n_itr > 0;
+            MG_RT(m, rt_frame_stage_begin(m->ctx, m->frame, s, 0));
+            if (lanes) { rc = run_rows(m, s, 0, m->itr, m->n_itr, true); if (rc != RT_OK) return rc; }
+            if (exchanges) { rc = finish_halo(m); if (rc != RT_OK) return rc; }
+            if (exchanges)
+            {
+                rc = run_rows(m, s, 0, m->bnd, m->n_bnd, false);
+                if (rc != RT_OK) return rc;
+                if (!lanes) { rc = run_rows(m, s, 0, m->itr, m->n_itr, false); if (rc != RT_OK) return rc; }
+            }
+            else { rc = run_rows(m, s, 0, all, 1, false); if (rc != RT_OK) return rc; }
+            bool posted = false;
+            if (exchanges && s < P)
+            {
+                const bool carry = m->use_sparse && s == P - 1;
+                int buf = 0;
+                MG_RT(m, rt_frame_stage_output(m->ctx, s, &buf));
+                rc = post_halo(m, s, RT_RES_PHYS + buf, carry);
+                if (rc != RT_OK) return rc;
+                posted = true;
+            }
+            MG_RT(m, rt_frame_stage_end(m->ctx, s));
+            m->stage = s + 1;
+            if (s == P) m->seg = rt_mg::SEG_FINAL;
+            return posted ? RT_OK : frame_step(m, more);
+        }
+        case rt_mg::SEG_FINAL:
+        {
+            MG_RT(m, rt_frame_stage_begin(m->ctx, m->frame, P + 1, 0));
+            MG_RT(m, rt_frame_stage_run(m->ctx, m->frame, P + 1, m->a, m->b));
+            MG_RT(m, rt_frame_stage_end(m->ctx, P + 1));
+            m->seg = rt_mg::SEG_IDLE;
+            *more = 0;
+            return RT_OK;
+        }
+    }
+    return RT_OK;
+}
+
+int rt_mg_frame(rt_mg* m, int frame, int clear_first)
+{
+    int rc = rt_mg_frame_begin(m, frame, clear_first);
+    int more = 1;
+    while (rc == RT_OK && more) rc = rt_mg_frame_step(m, &more);
+    if (rc != RT_OK && m) m->seg = rt_mg::SEG_IDLE;
+    return rc;
+}
+
+/* RCCL smoke test for boxes with one GPU: a communicator of ONE rank sends a buffer to itself through
+ * the same grouped ncclSend/ncclRecv path the halos use (dlopen, types, stream ordering). */
+int rt_mg_selftest_rccl(size_t bytes)
+{
+    if (!g_rccl.load()) return RT_ERR_COMM;
+    ncclUniqueId id;
+    if (g_rccl.GetUniqueId(&id) != ncclSuccess) return RT_ERR_COMM;
+    ncclComm_t comm = nullptr;
+    if (g_rccl.CommInitRank(&comm, 1, id, 0) != ncclSuccess) return RT_ERR_COMM;
+    unsigned char *a = nullptr, *b = nullptr;
+    hipStream_t st = nullptr;
+    int rc = RT_ERR_HIP;
+    if (hipMalloc(&a, bytes) == hipSuccess && hipMalloc(&b, bytes) == hipSuccess && hipStreamCreate(&st) == hipSuccess)
+    {
+        std::vector<unsigned char> h(bytes), g(bytes);
+        for (size_t i = 0; i < bytes; ++i) h[i] = (unsigned char)(i * 131u + 7u);
+        hipMemcpyAsync(a, h.data(), bytes, hipMemcpyHostToDevice, st);
+        hipMemsetAsync(b, 0, bytes, st);
+        bool ok = g_rccl.GroupStart() == ncclSuccess;
+        ok = ok && g_rccl.Send(a, bytes, ncclUint8, 0, comm, st) == ncclSuccess;
+        ok = ok && g_rccl.Recv(b, bytes, ncclUint8, 0, comm, st) == ncclSuccess;
+        ok = ok && g_rccl.GroupEnd() == ncclSuccess;
+        hipMemcpyAsync(g.data(), b, bytes, hipMemcpyDeviceToHost, st);
+        ok = ok && hipStreamSynchronize(st) == hipSuccess;
+        rc = ok ? (memcmp(h.data(), g.data(), bytes) == 0 ? RT_OK : RT_ERR_STATE) : RT_ERR_COMM;
+    }
+    if (st) hipStreamDestroy(st);
+    hipFree(a); hipFree(b);
+    g_rccl.CommDestroy(comm);
+    return rc;
+}
+
+}  // extern "C"

@@ -67,7 +67,8 @@ enum
     RT_ERR_STATE = 3,       /* call order (e.g. no scene) */
     RT_ERR_BVH_DEPTH = 4,   /* BVH deeper than the traversal stack / trail word can follow */
     RT_ERR_UNSUPPORTED = 5, /* option combination not built yet */
-    RT_ERR_NO_DEVICE = 6
+    RT_ERR_NO_DEVICE = 6,
+    RT_ERR_COMM = 7         /* RCCL could not be loaded or a collective call failed */
 };
 
 /* reservoir buffers of 10_restir_di.cpp:113-122 */
@@ -201,6 +202,58 @@ int rt_halo_scan(rt_ctx* ctx, int n_rows, int n_bitmaps, void* device_bitmaps);
 int rt_halo_pack_sparse(rt_ctx* ctx, int res, int row0, int n_rows, const void* device_bitmap, void* device_dst);
 int rt_halo_unpack_sparse(rt_ctx* ctx, int res, int row0, int n_rows, const void* device_bitmap, const void* device_src);
 
+/* ---- hooks used by the native strip driver below (and usable by any other driver) ---- */
+int rt_state_epoch(rt_ctx* ctx, uint64_t* epoch);   /* changes whenever camera, options, scene or an uploaded G-buffer change */
+int rt_get_stream(rt_ctx* ctx, void** hip_stream);  /* the stream calls are enqueued on right now */
+int rt_geometry(rt_ctx* ctx, int* width, int* height, int* row_begin, int* row_end, int* halo);
+/* device addresses of n_rows storage rows of a reservoir buffer: 64-B records and 16-B radiance side
+ * records; dense halos travel from / into the buffers themselves */
+int rt_res_region(rt_ctx* ctx, int res, int row0, int n_rows, void** rec, size_t* rec_bytes, void** rad, size_t* rad_bytes);
+/* rt_lane(ctx, 1) .. rt_lane(ctx, 0): calls in between are enqueued on the context's second stream
+ * (the lane of rt_frame_stage_run_async; joined by rt_frame_stage_end) */
+int rt_lane(rt_ctx* ctx, int second);
+
+/* ---- multi-GPU: the frame of 10_restir_di.cpp:257-379 on a row strip per GPU (the
+ * reference is single-GPU). One process per GPU; each creates its strip context with rt_create(device,
+ * W, H, bounds[rank], bounds[rank+1], 87, &ctx), sets scene / camera / options on it as usual, and
+ * drives frames with rt_mg_frame instead of rt_frame. Before each spatial pass the strips exchange the
+ * reservoir records their neighbours will gather (RCCL send/recv with rank +-1 over xGMI), boundary rows
+ * first, interior rows on a second stream meanwhile. N-rank results are bit-identical to one context.
+ * Sparse halos (default): only the records a neighbour's RNG will select travel (about 1/5 of the
+ * 87-row band); which ones is known one frame ahead while the camera is static, so a steady frame
+ * needs no host synchronisation; a frame after a camera / option change synchronises once. ---- */
+typedef struct rt_mg rt_mg;
+enum { RT_MG_TRANSPORT_RCCL = 0, RT_MG_TRANSPORT_LOCAL = 1, RT_MG_TRANSPORT_MIRROR = 2 /* a rank receives what it sent: one rank alone, for overhead measurements (results are not a frame) */ };
+enum { RT_MG_DENSE = 1 /* whole 87-row bands, sent from the buffers in place */, RT_MG_ONE_LANE = 2 /* no second stream */ };
+typedef struct
+{
+    unsigned long long frames, cold_frames; /* cold = built its halo plan on the spot (one host wait) */
+    unsigned long long host_ns;             /* host time spent inside rt_mg_frame_step (enqueueing) */
+    unsigned long long plan_wait_ns;        /* host time waiting for the next frame's plan counts (0 in a steady loop) */
+    unsigned long long bytes_sent, messages, records_sent;
+} rt_mg_stats;
+/* strips of >= halo rows; row_cost NULL: near-equal heights; else minimise the most expensive strip
+ * (row_cost[r] = e.g. shaded pixels of storage row r). bounds: world + 1 entries. */
+int rt_mg_partition(int height, int world, int halo, const uint32_t* row_cost, int* bounds);
+/* rows of a strip its neighbours can reach (computed and sent first) and the rest; up to 2 ranges each */
+int rt_mg_bands(const int* bounds, int world, int rank, int halo, int* boundary, int* n_boundary, int* interior, int* n_interior);
+int rt_mg_unique_id(void* id128);        /* ncclGetUniqueId: one rank makes it, the caller distributes the 128 bytes */
+const char* rt_mg_load_error(void);
+int rt_mg_hub_create(int world, void** hub); /* LOCAL transport: mailbox of `world` contexts in ONE process (tests) */
+int rt_mg_hub_destroy(void* hub);
+int rt_mg_create(rt_ctx* ctx, int rank, int world, const int* bounds, int transport, const void* unique_id_or_hub, int flags, rt_mg** out);
+int rt_mg_destroy(rt_mg* mg);
+const char* rt_mg_last_error(rt_mg* mg);
+int rt_mg_frame(rt_mg* mg, int frame, int clear_first);
+/* the same frame in segments that end where an exchange was posted: LOCAL contexts are stepped in
+ * lock-step (every rank's segment i before any rank's segment i+1); *more = 0 after the last one */
+int rt_mg_frame_begin(rt_mg* mg, int frame, int clear_first);
+int rt_mg_frame_step(rt_mg* mg, int* more);
+int rt_mg_get_stats(rt_mg* mg, rt_mg_stats* out);
+int rt_mg_reset_stats(rt_mg* mg);
+/* one-rank RCCL communicator sending `bytes` to itself through the grouped send/recv path (1-GPU boxes) */
+int rt_mg_selftest_rccl(size_t bytes);
+
 /* ---- measurement ---- */
 /* raytrace() calls the REFERENCE makes for the last frame with the current G-buffer and options
  * (the ray of BASELINE.md §3 / SURVEY §8d): N primary + per shaded pixel the visibility-reuse and
@@ -209,6 +262,8 @@ int rt_halo_unpack_sparse(rt_ctx* ctx, int res, int row0, int n_rows, const void
  * the passes' RNG). The build walks fewer BVH rays than that where the reference repeats a ray or
  * the answer cannot matter. shaded = hit & not emissive. */
 int rt_ray_count(rt_ctx* ctx, uint64_t* rays, uint64_t* shaded_pixels);
+/* shaded pixels of each owned storage row (row_end - row_begin counters): the row cost of rt_mg_partition */
+int rt_row_shaded(rt_ctx* ctx, uint32_t* counts);
 /* time spent by the last `rt_frame` per kernel, HIP events on the context's stream.
  * ms[0..7] = clear, raycast, generate(+temporal), spatial pass 0,1,2, resolve, tone_mapping;
  * ms[8] = whole frame. Enabled by rt_timing_enable(ctx, 1). With more than 3 spatial passes the

@@ -1,0 +1,268 @@
+"""Native multi-GPU strip driver (cedec_2024_rt_amd/csrc/strip_mg.cpp, C-ABI rt_mg_*).
+
+CPU (`-m "not gpu"`): the partition / band logic against the Python model of round 1 and a brute-force
+optimum for the cost-weighted partition. GPU: N strip contexts of ONE process driven in lock-step
+through the LOCAL transport (the development boxes have one GPU; RCCL refuses two ranks on one
+device) must reproduce the single-context frame bit for bit — warm frames (halo plan prepared one frame
+ahead, no host wait), cold frames (first frame, camera move, option change, frame-number jump), dense
+and sparse halos, one and two lanes, BASELINE sizes 1920x1080 and 3840x2160 over 8 strips. The RCCL
+code path itself is exercised by a one-rank communicator sending to itself.
+"""
+import itertools
+import os
+
+import numpy as np
+import pytest
+
+
+def _api():
+    from cedec_2024_rt_amd import api
+
+    return api
+
+
+def test_partition_matches_python_model_and_bands():
+    api = _api()
+    from cedec_2024_rt_amd import strips
+
+    for H, N in ((1080, 1), (1080, 2), (1080, 4), (1080, 8), (2160, 8), (1083, 5), (435, 5), (100, 1)):
+        b = api.mg_partition(H, N)
+        assert b == strips.partition_rows(H, N)
+        for r in range(N):
+            assert api.mg_bands(b, r) == strips.row_bands(b, r)
+    with pytest.raises(ValueError):
+        api.mg_partition(1080, 16)  # 67-row strips < 87-row halo
+    # irregular (cost-weighted) bounds: bands still follow the halo rule
+    b = [(0, 493), (493, 689), (689, 885), (885, 1080)]
+    assert api.mg_bands(b, 0) == ([(406, 493)], [(0, 406)])
+    assert api.mg_bands(b, 1) == ([(493, 580), (602, 689)], [(580, 602)])
+    assert api.mg_bands(b, 3) == ([(885, 972)], [(972, 1080)])
+
+
+def test_cost_weighted_partition_is_optimal():
+    """rt_mg_partition(row_cost) minimises the most expensive strip subject to >= halo rows per strip:
+    checked against brute force over all admissible cuts on small problems."""
+    api = _api()
+    rng = np.random.default_rng(7)
+    for trial in range(40):
+        H, N, halo = int(rng.integers(12, 40)), int(rng.integers(2, 5)), int(rng.integers(1, 4))
+        if H // N < halo:
+            continue
+        cost = rng.integers(0, 50, H).astype(np.uint32)
+        if trial % 3 == 0:
+            cost[: H // 3] = 0  # a sky band
+        b = api.mg_partition(H, N, halo, cost)
+        assert b[0][0] == 0 and b[-1][1] == H and all(e - a >= halo for a, e in b)
+        assert all(b[i][1] == b[i + 1][0] for i in range(N - 1))
+        c1 = cost.astype(np.int64) + 1
+        got = max(int(c1[a:e].sum()) for a, e in b)
+        best = None
+        for cuts in itertools.combinations(range(1, H), N - 1):
+            edges = (0,) + cuts + (H,)
+            if min(edges[i + 1] - edges[i] for i in range(N)) < halo:
+                continue
+            worst = max(int(c1[edges[i]:edges[i + 1]].sum()) for i in range(N))
+            best = worst if best is None else min(best, worst)
+        assert got == best, (H, N, halo, b, got, best)
+    # a sky band of cheap rows makes the first strip taller at the benchmark size
+    cost = np.full(1080, 1920, np.uint32)
+    cost[:300] = 0
+    b = api.mg_partition(1080, 4, 87, cost)
+    assert b[0][1] - b[0][0] > 400 and all(e - a >= 87 for a, e in b)
+
+
+def test_library_exports_strip_driver_symbols():
+    api = _api()
+    L = api.load_library()
+    for sym in ("rt_mg_partition", "rt_mg_bands", "rt_mg_unique_id", "rt_mg_create", "rt_mg_frame", "rt_mg_frame_begin",
+                "rt_mg_frame_step", "rt_mg_destroy", "rt_mg_get_stats", "rt_mg_selftest_rccl", "rt_lane", "rt_res_region"):
+        assert hasattr(L, sym), sym
+
+
+# ------------------------------------------------------------------------------------------ GPU
+def _eq_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
+
+
+class _Rig:
+    """A single full-frame context and N strip contexts + native drivers over the LOCAL transport."""
+
+    def __init__(self, api, tris, W, H, n, eye, at, optkw, flags=0, bounds=None):
+        from cedec_2024_rt_amd.types import bench_options
+
+        self.api, self.W, self.H = api, W, H
+        self.bounds = bounds or api.mg_partition(H, n)
+        self.opt = bench_options(**optkw)
+
+        def make(rows=None, halo=0):
+            r = api.Renderer(W, H, rows=rows, halo=halo)
+            r.set_scene(tris)
+            r.lookat(eye, at)
+            r.set_options(self.opt)
+            return r
+
+        self.full = make()
+        self.ctxs = [make(rows=b, halo=87) for b in self.bounds]
+        self.hub = api.MgHub(len(self.bounds))
+        self.mgs = [api.MultiGpu(c, k, self.bounds, transport=api.RT_MG_TRANSPORT_LOCAL, hub=self.hub, flags=flags)
+                    for k, c in enumerate(self.ctxs)]
+
+    def everyone(self):
+        return [self.full] + self.ctxs
+
+    def frame(self, frame, clear_first=False):
+        self.full.frame(frame, clear_first)
+        self.api.mg_frame_lockstep(self.mgs, frame, clear_first)
+
+    def check(self, what):
+        api, W, H = self.api, self.W, self.H
+        ref = self.full.download(api.RT_BUF_ACCUMULATION).reshape(H, W, 4)
+        refpx = self.full.download(api.RT_BUF_PIXELS).reshape(H, W, 4)
+        for c, (a, b) in zip(self.ctxs, self.bounds):
+            acc = c.download(api.RT_BUF_ACCUMULATION).reshape(c.local_rows, W, 4)[a - c.local_row0: b - c.local_row0]
+            assert _eq_bits(acc, ref[a:b]), f"{what}: rows {a}:{b}: {int((acc != ref[a:b]).any(axis=2).sum())} pixels differ"
+            px = c.download(api.RT_BUF_PIXELS).reshape(c.local_rows, W, 4)[a - c.local_row0: b - c.local_row0]
+            assert np.array_equal(px, refpx[a:b]), f"{what}: pixels of rows {a}:{b}"
+
+    def check_history(self, what):
+        """temporal history of the owned rows (what the next frame starts from)"""
+        api, W, H = self.api, self.W, self.H
+        ref = self.full.download(api.RT_BUF_RES_TEMPORAL).reshape(H, W)
+        for c, (a, b) in zip(self.ctxs, self.bounds):
+            mine = c.download(api.RT_BUF_RES_TEMPORAL).reshape(c.local_rows, W)[a - c.local_row0: b - c.local_row0]
+            assert _eq_bits(mine, ref[a:b]), f"{what}: temporal history of rows {a}:{b}"
+
+    def close(self):
+        for m in self.mgs:
+            m.close()
+        self.hub.close()
+        for c in self.everyone():
+            c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,H,flags,optkw", [
+    (2, 240, 0, dict()),
+    (3, 300, 0, dict()),
+    (3, 600, 0, dict()),                                         # strips with interior rows: two lanes
+    (3, 600, 2, dict()),                                         # one lane
+    (2, 400, 1, dict()),                                         # dense halos, in place
+    (3, 600, 1, dict(spatial_resampling_passes=2)),
+    (2, 240, 0, dict(spatial_resampling_passes=1)),              # the only exchange carries the next plan
+    (2, 240, 0, dict(spatial_resampling_passes=0)),              # nothing to exchange
+    (3, 330, 0, dict(use_shadowed_target_function=1, spatial_resampling_passes=2)),
+    (2, 240, 0, dict(use_spatial_resampling=0)),
+    (4, 700, 0, dict(accumulate=1, use_visibility_reuse=0, spatial_resampling_sample_count=3)),
+])
+def test_native_strips_match_single_context(n, H, flags, optkw):
+    """Frames 1..6 with a camera move before frame 4 (cold frame + clear) and a frame-number jump after
+    frame 5: accumulation, pixels and temporal history of every strip == the single context, bit for bit."""
+    api = _api()
+    from cedec_2024_rt_amd import scenes
+
+    tris = scenes.make_quad_room()
+    W = 96
+    rig = _Rig(api, tris, W, H, n, (0.5, 2.5, 6.0), (0.0, 1.5, -1.0), optkw, flags)
+    seq = [1, 2, 3, 4, 5, 9]
+    for i, frame in enumerate(seq):
+        clear = False
+        if frame == 4:
+            for r in rig.everyone():
+                r.orbit(35.0, -12.0)
+                assert r.camera_updated()
+            clear = True
+        rig.frame(frame, clear)
+        rig.check(f"frame {frame}")
+        rig.check_history(f"frame {frame}")
+    st = rig.mgs[0].stats()
+    assert st["frames"] == len(seq)
+    sparse = not (flags & 1) and rig.opt["spatial_resampling_passes"][0] > 0 and rig.opt["use_spatial_resampling"][0]
+    if sparse:
+        # cold: frame 1 (no plan), frame 4 (camera moved), frame 9 (not the frame the plan was made for)
+        assert st["cold_frames"] == 3, st
+        assert st["records_sent"] > 0
+    else:
+        assert st["cold_frames"] == 0
+    assert sum(c.ray_count()[0] for c in rig.ctxs) == rig.full.ray_count()[0]
+    rig.close()
+
+
+@pytest.mark.gpu
+def test_native_strips_option_change_and_irregular_bounds():
+    """Cost-weighted (irregular) strip heights and an option change between frames (new plan)."""
+    api = _api()
+    from cedec_2024_rt_amd import scenes
+    from cedec_2024_rt_amd.types import bench_options
+
+    tris = scenes.make_quad_room()
+    W, H = 80, 520
+    bounds = [(0, 200), (200, 300), (300, 520)]
+    rig = _Rig(api, tris, W, H, 3, (0.5, 2.5, 6.0), (0.0, 1.5, -1.0), dict(), 0, bounds=bounds)
+    for frame in (1, 2, 3):
+        rig.frame(frame)
+        rig.check(f"frame {frame}")
+    new = bench_options(spatial_resampling_passes=2, spatial_resampling_radius=20.0)
+    for r in rig.everyone():
+        r.set_options(new)
+    for frame in (4, 5):
+        rig.frame(frame)
+        rig.check(f"frame {frame} after the option change")
+    assert rig.mgs[1].stats()["cold_frames"] == 2
+    rig.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H", [(1920, 1080), (3840, 2160)])  # BASELINE configs #4 and #5, the 8-GPU partition
+def test_native_strips_full_size(W, H):
+    api = _api()
+    from cedec_2024_rt_amd import scenes
+
+    tris = scenes.make_blocks_restir()
+    rig = _Rig(api, tris, W, H, 8, scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT, dict())
+    for frame in (1, 2, 3):
+        rig.frame(frame)
+        rig.check(f"{W}x{H} frame {frame}")
+    st = [m.stats() for m in rig.mgs]
+    assert all(s["cold_frames"] == 1 for s in st)
+    dense = 87 * W * 3 * 3  # records of a dense exchange per side, 3 passes, 3 frames
+    mid = st[3]
+    frac = mid["records_sent"] / (2 * dense)
+    print(f"{W}x{H}: sparse halos move {frac:.3f} of the dense band; host {mid['host_ns'] / mid['frames'] / 1e3:.0f} us/frame (lock-step, 8 ranks in one process)")
+    assert 0.05 < frac < 0.5
+    assert sum(c.ray_count()[0] for c in rig.ctxs) == rig.full.ray_count()[0]
+    rig.close()
+
+
+@pytest.mark.gpu
+def test_rccl_path_one_rank_selftest():
+    """dlopen(RCCL) + ncclCommInitRank + grouped ncclSend/ncclRecv on a stream, on a communicator of one rank."""
+    api = _api()
+    L = api.load_library()
+    assert len(api.mg_unique_id()) == 128
+    for nbytes in (80, 4096, 5 * 1024 * 1024):
+        rc = L.rt_mg_selftest_rccl(nbytes)
+        assert rc == 0, (nbytes, rc, L.rt_mg_load_error())
+
+
+@pytest.mark.gpu
+def test_native_single_rank_driver_equals_rt_frame():
+    """world = 1: rt_mg_frame is rt_frame."""
+    api = _api()
+    from cedec_2024_rt_amd import scenes
+    from cedec_2024_rt_amd.types import bench_options
+
+    tris = scenes.make_quad_room()
+    W, H = 64, 48
+    a, b = api.Renderer(W, H), api.Renderer(W, H)
+    for r in (a, b):
+        r.set_scene(tris)
+        r.lookat((0.5, 2.5, 6.0), (0.0, 1.5, -1.0))
+        r.set_options(bench_options())
+    mg = api.MultiGpu(b, 0, [(0, H)])
+    for frame in (1, 2, 3):
+        a.frame(frame)
+        mg.frame(frame)
+        assert _eq_bits(a.download(api.RT_BUF_ACCUMULATION), b.download(api.RT_BUF_ACCUMULATION))
+    mg.close()
+    a.close()
+    b.close()

@@ -93,8 +93,15 @@ if sp:
     write = fw["WRITE_SIZE"][k]["mean_KB"] * 1024
     streamed = W * H * 112  # own G-buffer (32 B) + own record (64 B) + own radiance (16 B), read as 64-B-stride streams
     corrected = fetch + streamed / 2
+    sha = None
+    shaf = os.path.join(src, "lib.sha256")
+    if os.path.exists(shaf):
+        sha = open(shaf).read().split()[0]
+    vfrac = {kk: round(e["valu_issue_fraction"], 3) for kk, e in out.items()
+             if "valu_issue_fraction" in e and kk.split("<")[0] in ("k_raycast", "k_generate_candidate", "k_resolve", "k_spatial")}
     json.dump({
-        "kernel": k, "round": tag, "workload": "blocks_restir stand-in 1920x1080, bench options",
+        "kernel": k, "round": tag, "lib_sha256": sha, "valu_issue_frac": vfrac,
+        "workload": "blocks_restir stand-in 1920x1080, bench options",
         "FETCH_SIZE_KB_per_launch": fetch / 1024, "WRITE_SIZE_KB_per_launch": write / 1024,
         "read_bytes_corrected": corrected, "streamed_read_bytes_known": streamed,
         "hbm_bytes_per_launch": corrected + write,

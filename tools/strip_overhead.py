@@ -1,47 +1,80 @@
-"""Dev tool: what one rank's frame costs in the N-strip decomposition when nothing has to wait for a
-neighbour (transport = drop sends, zero-fill receives): host orchestration + the extra launches of
-the halo machinery + the strip's kernels. N strip contexts live in this process; each rank's frame
-loop runs to completion one after the other, so wall/N = per-rank frame time on an otherwise idle GPU."""
-import sys, os, time, json
+"""What ONE rank of an N-strip frame costs when it never waits for a neighbour: the native strip
+driver (rt_mg_*, csrc/strip_mg.cpp) with the MIRROR transport (a rank receives the bytes it sent, by a
+device copy), alone on the GPU. Same launches, same pack/unpack work and message sizes as a real
+exchange; only the xGMI hop and the peers' skew are missing. Reported per N and image size:
+
+  ms_per_frame    wall time per frame of the rank in a steady loop (GPU-bound)
+  host_us         host time spent enqueueing one frame (rt_mg_stats.host_ns / frames)
+  plan_wait_us    host time waiting for the next frame's halo plan (0 = the plan was ready)
+  speedup_bound   single-GPU ms / this rank's ms: the scaling the compute side allows
+
+  python tools/strip_overhead.py [--out profiles/r02_strip_overhead.json]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import torch
-from cedec_2024_rt_amd import api, scenes, strips
-from cedec_2024_rt_amd.types import bench_options
 
-class NullTransport:
-    def post(self, rank, items): return None
-    def finish(self, rank, handle, items):
-        for _, _, tr in items: tr.zero_()
+from cedec_2024_rt_amd import api, scenes  # noqa: E402
+from cedec_2024_rt_amd.types import bench_options  # noqa: E402
 
-W, H = int(os.environ.get("W", 1920)), int(os.environ.get("H", 1080))
-tris = scenes.make_blocks_restir()
-dev = torch.device("cuda", 0)
-stream = torch.cuda.current_stream().cuda_stream
-out = {}
-for N in (1, 2, 4, 8):
-    bounds = strips.partition_rows(H, N)
-    for sparse in ((False,) if N == 1 else (False, True)):
-        rs, fs = [], []
-        for k, (a, b) in enumerate(bounds):
-            r = api.Renderer(W, H, device=0, rows=(a, b), halo=strips.HALO_ROWS if N > 1 else 0, stream=stream)
-            r.set_scene(tris); r.lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT); r.set_options(bench_options())
-            rs.append(r)
-            fs.append(strips.StripFrame(strips.HipStripBackend(r, dev), bounds, k, NullTransport() if N > 1 else None, sparse=sparse))
-        def run(frames):
-            for fr in frames:
-                for f in fs: f.frame(fr)
-            torch.cuda.synchronize()
-        run(range(1, 4))
-        t0 = time.perf_counter(); run(range(4, 24)); wall = (time.perf_counter() - t0) / 20 * 1e3
-        # one rank alone on the GPU (what a rank of a real N-GPU job sees), and the host time of its loop
-        mid = fs[len(fs) // 2]
-        t0 = time.perf_counter()
-        for fr in range(24, 44): mid.frame(fr)
-        host = (time.perf_counter() - t0) / 20 * 1e3
-        torch.cuda.synchronize()
-        alone = (time.perf_counter() - t0) / 20 * 1e3
-        out["N=%d %s" % (N, "sparse" if sparse else "dense")] = dict(ms_all_ranks=round(wall, 3), ms_per_rank=round(wall / N, 3),
-                                                                      ms_middle_rank_alone=round(alone, 3), host_ms_middle_rank=round(host, 3))
-        print(json.dumps({k: v for k, v in out.items() if k.startswith("N=%d" % N)}), flush=True)
-        for r in rs: r.close()
+
+def measure(W, H, N, flags, tris, frames=40, warm=6, rank=None):
+    bounds = api.mg_partition(H, N)
+    rank = N // 2 if rank is None else rank
+    a, b = bounds[rank]
+    r = api.Renderer(W, H, rows=(a, b), halo=87 if N > 1 else 0)
+    r.set_scene(tris)
+    r.lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)
+    r.set_options(bench_options())
+    mg = api.MultiGpu(r, rank, bounds, transport=api.RT_MG_TRANSPORT_MIRROR, flags=flags)
+    f = 0
+    for _ in range(warm):
+        f += 1
+        mg.frame(f)
+    r.sync()
+    mg.reset_stats()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        f += 1
+        mg.frame(f)
+    t_host = time.perf_counter() - t0
+    r.sync()
+    wall = time.perf_counter() - t0
+    st = mg.stats()
+    out = dict(rows=b - a, ms_per_frame=round(wall / frames * 1e3, 4), host_us=round(st["host_ns"] / frames / 1e3, 1),
+               host_loop_us=round(t_host / frames * 1e6, 1), plan_wait_us=round(st["plan_wait_ns"] / frames / 1e3, 1),
+               cold_frames=st["cold_frames"], MB_sent_per_frame=round(st["bytes_sent"] / frames / 1e6, 3),
+               messages_per_frame=st["messages"] / frames)
+    mg.close()
+    r.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    tris = scenes.make_blocks_restir()
+    res = {}
+    for (W, H) in ((1920, 1080), (3840, 2160)):
+        single = None
+        for N in (1, 2, 4, 8):
+            for name, flags in (("sparse", 0), ("dense", api.RT_MG_DENSE)) if N > 1 else (("single", 0),):
+                m = measure(W, H, N, flags, tris)
+                if N == 1:
+                    single = m["ms_per_frame"]
+                m["speedup_bound"] = round(single / m["ms_per_frame"], 2)
+                res[f"{W}x{H} N={N} {name}"] = m
+                print(json.dumps({f"{W}x{H} N={N} {name}": m}), flush=True)
+    if args.out:
+        with open(args.out, "w") as f:
+            json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
