@@ -113,6 +113,12 @@ def main():
     ap.add_argument("--height", type=int, default=H)
     args = ap.parse_args()
 
+    # the contract is ONE JSON line on stdout: libraries that print banners to fd 1 (RCCL's version block,
+    # gloo's connection messages) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
 
@@ -367,7 +373,8 @@ def main():
                 out["cpu_baseline"] = cb
             else:
                 out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

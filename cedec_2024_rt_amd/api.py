@@ -24,7 +24,7 @@ EXPORTS = [
     "rt_camera_lookat", "rt_camera_set", "rt_camera_get", "rt_camera_orbit", "rt_camera_zoom", "rt_camera_pan",
     "rt_camera_updated", "rt_camera_pose", "rt_options_set", "rt_options_get", "rt_clear",
     "rt_raycast", "rt_generate_candidate", "rt_temporal_resampling", "rt_save_temporal_reservoir",
-    "rt_spatial_resampling", "rt_resolve", "rt_tone_mapping", "rt_frame", "rt_frame_stage", "rt_frame_stage_input", "rt_frame_stage_begin", "rt_frame_stage_run", "rt_frame_stage_end", "rt_frame_stage_output", "rt_frame_stage_run_part", "rt_frame_stage_fork", "rt_frame_stage_run_async", "rt_halo_bitmap_words", "rt_halo_flags_bytes",
+    "rt_spatial_resampling", "rt_resolve", "rt_tone_mapping", "rt_frame", "rt_frame_stage", "rt_frame_stage_input", "rt_frame_stage_begin", "rt_frame_stage_run", "rt_frame_stage_end", "rt_frame_stage_output", "rt_frame_stage_run_part", "rt_frame_stage_fork", "rt_frame_stage_run_async", "rt_frame_stage_run_ranges", "rt_halo_bitmap_words", "rt_halo_flags_bytes",
     "rt_halo_flags_pack", "rt_halo_flags_unpack", "rt_halo_mark", "rt_halo_scan", "rt_halo_pack_sparse", "rt_halo_unpack_sparse", "rt_path_trace", "rt_path_trace_rays", "rt_local_rows", "rt_download",
     "rt_upload", "rt_halo_bytes", "rt_halo_pack", "rt_halo_unpack", "rt_ray_count", "rt_timing_enable",
     "rt_timing", "rt_spatial_bytes", "rt_trace_closest", "rt_trace_stats", "rt_bvh_config", "rt_bvh_info", "rt_trace_mode", "rt_trace_time", "rt_tuning", "rt_math_eval",
@@ -100,6 +100,7 @@ def load_library():
     L.rt_frame_stage_end.argtypes = [vp, ci]
     L.rt_frame_stage_run_part.argtypes = [vp, ci, ci, ci, ci, ci]
     L.rt_frame_stage_fork.argtypes = [vp]
+    L.rt_frame_stage_run_ranges.argtypes = [vp, ci, ci, ci, ci, vp, ci]
     L.rt_frame_stage_run_async.argtypes = [vp, ci, ci, ci, ci, ci]
     L.rt_halo_bitmap_words.argtypes = [vp, ci]
     L.rt_halo_bitmap_words.restype = C.c_size_t

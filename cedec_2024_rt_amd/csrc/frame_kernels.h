@@ -18,6 +18,9 @@ struct FrameParams
 {
     int W, H;           /* full image */
     int row0, row1;     /* global storage rows processed by this launch */
+    int rowb0, rowb1;   /* optional second row range of the same launch (rowb0 >= rowb1: none): a strip's two
+                           boundary bands run as ONE launch — a launch that fits the GPU in one round lasts as
+                           long as its slowest wavefront, so two of them back to back cost twice that */
     int lrow0, lrows;   /* global row of local buffer row 0, local rows held */
     int frame, pass;
     f3 eye;
@@ -72,7 +75,8 @@ RT_DEV bool tile_pixel(const FrameParams& P, int& x, int& row)
 {
     constexpr int TILE_W = TileShape<TB>::W, TILE_H = TileShape<TB>::H;
     const int tiles_x = (P.W + TILE_W - 1) / TILE_W;
-    const int tiles_y = (P.row1 - P.row0 + TILE_H - 1) / TILE_H;
+    const int tiles_ya = (P.row1 - P.row0 + TILE_H - 1) / TILE_H;
+    const int tiles_y = tiles_ya + (P.rowb1 > P.rowb0 ? (P.rowb1 - P.rowb0 + TILE_H - 1) / TILE_H : 0);
     const int b = blockIdx.x;
     int tx, ty;
     if (P.tile_mode == 1)
@@ -97,28 +101,32 @@ RT_DEV bool tile_pixel(const FrameParams& P, int& x, int& row)
 #ifndef RT_WAVE_8X8
 #define RT_WAVE_8X8 1
 #endif
+    /* tile rows 0 .. tiles_ya-1 belong to the first row range, the rest to the second */
+    const bool second = ty >= tiles_ya;
+    const int base = second ? P.rowb0 + (ty - tiles_ya) * TILE_H : P.row0 + ty * TILE_H;
+    const int end = second ? P.rowb1 : P.row1;
     if (TB == 64)
     {
         x = tx * 8 + (threadIdx.x & 7);
-        row = P.row0 + ty * 8 + (threadIdx.x >> 3);
+        row = base + (threadIdx.x >> 3);
     }
     else
     {
 #if RT_WAVE_8X8 && RT_TILE_W == 32
         /* wavefront w of the workgroup covers the 8x8 sub-block w of the 32x8 tile */
         x = tx * TILE_W + 8 * (threadIdx.x >> 6) + (threadIdx.x & 7);
-        row = P.row0 + ty * TILE_H + ((threadIdx.x >> 3) & 7);
+        row = base + ((threadIdx.x >> 3) & 7);
 #else
         x = tx * TILE_W + (threadIdx.x & (TILE_W - 1));
-        row = P.row0 + ty * TILE_H + (threadIdx.x >> TILE_W_LOG2);
+        row = base + (threadIdx.x >> TILE_W_LOG2);
 #endif
     }
-    return x < P.W && row < P.row1;
+    return x < P.W && row < end;
 }
-static inline int tile_grid(int W, int rows, int tile_w = TILE_W, int tile_h = TILE_H)
+static inline int tile_grid(int W, int rows, int tile_w = TILE_W, int tile_h = TILE_H, int rows_b = 0)
 {
     /* covers both orders: mode 1 needs 8 * ceil(tiles_y/8) * tiles_x workgroups */
-    const int tx = (W + tile_w - 1) / tile_w, ty = (rows + tile_h - 1) / tile_h;
+    const int tx = (W + tile_w - 1) / tile_w, ty = (rows + tile_h - 1) / tile_h + (rows_b > 0 ? (rows_b + tile_h - 1) / tile_h : 0);
     const int a = ((tx * ty + 7) / 8) * 8, b = 8 * ((ty + 7) / 8) * tx;
     return a > b ? a : b;
 }

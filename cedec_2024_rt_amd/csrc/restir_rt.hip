@@ -77,6 +77,7 @@ struct rt_ctx
     float4* d_rad[3] = {nullptr, nullptr, nullptr};
     int res_map[3] = {0, 1, 2};
     int sub0 = -1, sub1 = -1; /* row sub-range of the running rt_frame_stage_run (-1: all owned rows) */
+    int subb0 = 0, subb1 = 0; /* optional second row range of the same launches (rt_frame_stage_run_ranges) */
     int fX = 0, fY = 1, fZ = 2, f_in = 0, f_out = 1, f_stage = 0, f_final = RT_RES_1;
     bool f_clear = false;
     uint64_t halo_flags_epoch[2] = {0, 0}; /* epoch at which the neighbour's shaded flags were unpacked (valid while it is the current one) */
@@ -140,6 +141,8 @@ static FrameParams make_params(const rt_ctx* c, int frame, int pass, int kernel 
     P.W = c->W; P.H = c->H;
     P.row0 = c->sub0 >= 0 ? c->sub0 : c->row_begin;
     P.row1 = c->sub0 >= 0 ? c->sub1 : c->row_end;
+    P.rowb0 = c->sub0 >= 0 ? c->subb0 : 0;
+    P.rowb1 = c->sub0 >= 0 ? c->subb1 : 0;
     P.lrow0 = c->lrow0; P.lrows = c->lrows;
     P.frame = frame; P.pass = pass;
     P.eye = F3(c->eye[0], c->eye[1], c->eye[2]);
@@ -671,13 +674,13 @@ int rt_options_get(rt_ctx* c, rt_options* o)
 
 static int launch_grid(const rt_ctx* c)
 {
-    return c->sub0 >= 0 ? tile_grid(c->W, c->sub1 - c->sub0) : tile_grid(c->W, c->row_end - c->row_begin);
+    return c->sub0 >= 0 ? tile_grid(c->W, c->sub1 - c->sub0, TILE_W, TILE_H, c->subb1 - c->subb0) : tile_grid(c->W, c->row_end - c->row_begin);
 }
 /* grid of the tracing kernels: TRACE_BLOCK threads on TileShape<TRACE_BLOCK> tiles */
 static int trace_grid(const rt_ctx* c)
 {
     const int rows = c->sub0 >= 0 ? c->sub1 - c->sub0 : c->row_end - c->row_begin;
-    return tile_grid(c->W, rows, TileShape<TRACE_BLOCK>::W, TileShape<TRACE_BLOCK>::H);
+    return tile_grid(c->W, rows, TileShape<TRACE_BLOCK>::W, TileShape<TRACE_BLOCK>::H, c->sub0 >= 0 ? c->subb1 - c->subb0 : 0);
 }
 
 int rt_clear(rt_ctx* c)
@@ -934,16 +937,45 @@ int rt_frame_stage_begin(rt_ctx* c, int frame, int stage, int clear_first)
     return RT_OK;
 }
 
+static int stage_run_ranges(rt_ctx* c, int frame, int stage, int part, int row0, int row1, int rowb0, int rowb1);
 int rt_frame_stage_run_part(rt_ctx* c, int frame, int stage, int part, int row0, int row1)
+{
+    return stage_run_ranges(c, frame, stage, part, row0, row1, 0, 0);
+}
+/* the stage's kernels over up to two disjoint row ranges in ONE launch each (a strip's two boundary bands);
+ * ranges: n x {row0, row1}, n = 1 or 2; lane 1 = the second stream (as rt_frame_stage_run_async) */
+int rt_frame_stage_run_ranges(rt_ctx* c, int frame, int stage, int part, int n, const int* ranges, int lane)
+{
+    RT_CHECK_CTX(c);
+    if (!ranges || n < 1 || n > 2) RT_FAIL(c, RT_ERR_ARG, "1 or 2 row ranges");
+    if (n == 2 && !(ranges[1] <= ranges[2] || ranges[3] <= ranges[0])) RT_FAIL(c, RT_ERR_ARG, "row ranges overlap");
+    if (!lane) return stage_run_ranges(c, frame, stage, part, ranges[0], ranges[1], n == 2 ? ranges[2] : 0, n == 2 ? ranges[3] : 0);
+    if (!c->aux_used) RT_HIP(c, hipStreamWaitEvent(c->aux_stream, c->ev_stage, 0));
+    c->aux_used = true;
+    hipStream_t main_stream = c->stream;
+    const bool timing = c->timing;
+    c->stream = c->aux_stream;
+    c->timing = false;
+    const int rc = stage_run_ranges(c, frame, stage, part, ranges[0], ranges[1], n == 2 ? ranges[2] : 0, n == 2 ? ranges[3] : 0);
+    c->stream = main_stream;
+    c->timing = timing;
+    return rc;
+}
+static int stage_run_ranges(rt_ctx* c, int frame, int stage, int part, int row0, int row1, int rowb0, int rowb1)
 {
     RT_CHECK_CTX(c);
     NEED_SCENE(c);
     if (stage != c->f_stage) RT_FAIL(c, RT_ERR_STATE, "rt_frame_stage_run: expected stage %d, got %d", c->f_stage, stage);
     if (row0 < c->row_begin) row0 = c->row_begin;
     if (row1 > c->row_end) row1 = c->row_end;
+    if (rowb0 < c->row_begin) rowb0 = c->row_begin;
+    if (rowb1 > c->row_end) rowb1 = c->row_end;
+    if (rowb0 >= rowb1) rowb0 = rowb1 = 0;
+    if (row0 >= row1) { row0 = rowb0; row1 = rowb1; rowb0 = rowb1 = 0; }
     if (row0 >= row1) return RT_OK;
+    c->subb0 = rowb0; c->subb1 = rowb1;
     const int passes = c->opt.spatial_resampling_passes;
-    const bool whole = row0 == c->row_begin && row1 == c->row_end;
+    const bool whole = row0 == c->row_begin && row1 == c->row_end && rowb0 >= rowb1;
     const bool T = c->timing && whole;
     auto mark = [&](int i) { if (T && i <= 8) hipEventRecord(c->ev[i], c->stream); };
     c->sub0 = row0; c->sub1 = row1;
@@ -979,6 +1011,7 @@ int rt_frame_stage_run_part(rt_ctx* c, int frame, int stage, int part, int row0,
         mark(8);
     }
     c->sub0 = c->sub1 = -1;
+    c->subb0 = c->subb1 = 0;
     return rc;
 }
 

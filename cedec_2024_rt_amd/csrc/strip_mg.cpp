@@ -132,8 +132,8 @@ struct rt_mg
     int bnd[2][2] = {{0, 0}, {0, 0}}, n_bnd = 0;   /* boundary row ranges (needed by a neighbour), computed first */
     int itr[2][2] = {{0, 0}, {0, 0}}, n_itr = 0;   /* interior row ranges, computed while halos travel */
 
-    hipStream_t comm = nullptr;
-    hipEvent_t ev_packed = nullptr, ev_arrived = nullptr, ev_plan[2] = {nullptr, nullptr};
+    hipStream_t comm = nullptr, prep = nullptr; /* prep: the next frame's halo marks, beside this frame's passes */
+    hipEvent_t ev_packed = nullptr, ev_arrived = nullptr, ev_plan[2] = {nullptr, nullptr}, ev_gbuf = nullptr, ev_marked = nullptr;
     ncclComm_t nccl = nullptr;
     LocalHub* hub = nullptr;
 
@@ -364,6 +364,9 @@ int rt_mg_create(rt_ctx* ctx, int rank, int world, const int* bounds, int transp
     int dev = 0;
     MG_HIP(m, hipGetDevice(&dev));
     MG_HIP(m, hipStreamCreateWithFlags(&m->comm, hipStreamNonBlocking));
+    MG_HIP(m, hipStreamCreateWithFlags(&m->prep, hipStreamNonBlocking));
+    MG_HIP(m, hipEventCreateWithFlags(&m->ev_gbuf, hipEventDisableTiming));
+    MG_HIP(m, hipEventCreateWithFlags(&m->ev_marked, hipEventDisableTiming));
     MG_HIP(m, hipEventCreateWithFlags(&m->ev_packed, hipEventDisableTiming));
     MG_HIP(m, hipEventCreateWithFlags(&m->ev_arrived, hipEventDisableTiming));
     for (auto& e : m->ev_plan) MG_HIP(m, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -392,6 +395,7 @@ int rt_mg_destroy(rt_mg* m)
     if (!m) return RT_ERR_ARG;
     if (m->ctx) rt_sync(m->ctx);
     if (m->comm) hipStreamSynchronize(m->comm);
+    if (m->prep) hipStreamSynchronize(m->prep);
     m->pending_local.clear();
     for (auto& s : m->sides)
     {
@@ -408,7 +412,10 @@ int rt_mg_destroy(rt_mg* m)
     if (m->ev_packed) hipEventDestroy(m->ev_packed);
     if (m->ev_arrived) hipEventDestroy(m->ev_arrived);
     for (auto& e : m->ev_plan) if (e) hipEventDestroy(e);
+    if (m->ev_gbuf) hipEventDestroy(m->ev_gbuf);
+    if (m->ev_marked) hipEventDestroy(m->ev_marked);
     if (m->comm) hipStreamDestroy(m->comm);
+    if (m->prep) hipStreamDestroy(m->prep);
     delete m;
     return RT_OK;
 }
@@ -555,13 +562,12 @@ static void add_bitmap_parts(rt_mg* m, int slot, std::vector<Exchange>& xs)
     }
 }
 
+/* up to two row ranges, ONE launch per kernel (a small launch lasts as long as its slowest wavefront:
+ * two boundary bands back to back would pay that twice) */
 static int run_rows(rt_mg* m, int stage, int part, const int (*ranges)[2], int n, bool second_lane)
 {
-    for (int i = 0; i < n; ++i)
-    {
-        if (second_lane) MG_RT(m, rt_frame_stage_run_async(m->ctx, m->frame, stage, part, ranges[i][0], ranges[i][1]));
-        else MG_RT(m, rt_frame_stage_run_part(m->ctx, m->frame, stage, part, ranges[i][0], ranges[i][1]));
-    }
+    if (n <= 0) return RT_OK;
+    MG_RT(m, rt_frame_stage_run_ranges(m->ctx, m->frame, stage, part, n, &ranges[0][0], second_lane ? 1 : 0));
     return RT_OK;
 }
 
@@ -764,13 +770,16 @@ static int frame_step(rt_mg* m, int* more)
             }
             if (m->use_sparse)
             {
-                /* the plan of the NEXT frame, beside this frame's work (valid if the camera stays) */
-                if (m->two_lanes) { if (!lanes) MG_RT(m, rt_frame_stage_fork(m->ctx)); MG_RT(m, rt_lane(m->ctx, 1)); }
-                void* ws = nullptr;
-                rt_get_stream(m->ctx, &ws);
-                rc = mark_plan(m, m->frame + 1, nslot, (hipStream_t)ws);
-                if (m->two_lanes) rt_lane(m->ctx, 0);
+                /* The plan of the NEXT frame (valid if the camera stays): marked on a stream of its own behind
+                 * this frame's raycast, so that its bitmaps can ride on the FIRST halo message and its counts
+                 * reach the host while most of this frame is still to run. */
+                MG_HIP(m, hipEventRecord(m->ev_gbuf, ms));
+                MG_HIP(m, hipStreamWaitEvent(m->prep, m->ev_gbuf, 0));
+                MG_RT(m, rt_set_stream(m->ctx, m->prep));
+                rc = mark_plan(m, m->frame + 1, nslot, m->prep);
+                rt_set_stream(m->ctx, ms);
                 if (rc != RT_OK) return rc;
+                MG_HIP(m, hipEventRecord(m->ev_marked, m->prep));
             }
             if (exchanges)
             {
@@ -781,14 +790,14 @@ static int frame_step(rt_mg* m, int* more)
             else { rc = run_rows(m, 0, 2, all, 1, false); if (rc != RT_OK) return rc; }
             if (exchanges)
             {
-                /* joins the second lane first when the next frame's bitmaps ride on this message */
-                const bool carry = m->use_sparse && P == 1;
+                /* the next frame's bitmaps ride on this first message */
+                const bool carry = m->use_sparse;
                 int buf = 0;
                 MG_RT(m, rt_frame_stage_output(m->ctx, 0, &buf));
-                if (carry) { MG_RT(m, rt_frame_stage_end(m->ctx, 0)); }
+                if (carry) MG_HIP(m, hipStreamWaitEvent(ms, m->ev_marked, 0));
                 rc = post_halo(m, 0, RT_RES_PHYS + buf, carry);
                 if (rc != RT_OK) return rc;
-                if (!carry) MG_RT(m, rt_frame_stage_end(m->ctx, 0));
+                MG_RT(m, rt_frame_stage_end(m->ctx, 0));
             }
             else MG_RT(m, rt_frame_stage_end(m->ctx, 0));
             m->stage = 1;
@@ -812,10 +821,9 @@ static int frame_step(rt_mg* m, int* more)
             bool posted = false;
             if (exchanges && s < P)
             {
-                const bool carry = m->use_sparse && s == P - 1;
                 int buf = 0;
                 MG_RT(m, rt_frame_stage_output(m->ctx, s, &buf));
-                rc = post_halo(m, s, RT_RES_PHYS + buf, carry);
+                rc = post_halo(m, s, RT_RES_PHYS + buf, false);
                 if (rc != RT_OK) return rc;
                 posted = true;
             }

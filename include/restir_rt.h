@@ -168,6 +168,10 @@ int rt_frame_stage_run_part(rt_ctx* ctx, int frame, int stage, int part, int row
  * be disjoint and the lane must not read halo rows that are still being received. */
 int rt_frame_stage_fork(rt_ctx* ctx);
 int rt_frame_stage_run_async(rt_ctx* ctx, int frame, int stage, int part, int row0, int row1);
+/* the same over up to two disjoint row ranges in ONE launch per kernel (ranges: n x {row0,row1}, n <= 2;
+ * lane 1 = second stream): a launch that fits the GPU in one round lasts as long as its slowest
+ * wavefront, so a strip's two boundary bands are cheaper as one launch than as two */
+int rt_frame_stage_run_ranges(rt_ctx* ctx, int frame, int stage, int part, int n, const int* ranges, int lane);
 int rt_frame_stage_end(rt_ctx* ctx, int stage);
 int rt_frame_stage_output(rt_ctx* ctx, int stage, int* physical_buffer);
 

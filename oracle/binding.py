@@ -309,6 +309,36 @@ def have_ref():
     return os.path.exists(REF_BIN)
 
 
+REF_CAMERA_BIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "ref_camera")
+
+
+def camera_control(eye, lookat, button, dx, dy):
+    """The oracle's restatement of CameraControl::cursorPosCallback (common/misc.hpp:129-205): one drag
+    event with one button held. Returns (eye, lookat, updated)."""
+    e = np.array(eye, dtype=np.float32)
+    a = np.array(lookat, dtype=np.float32)
+    L = lib()
+    L.o_camera_control.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float]
+    upd = L.o_camera_control(_p(e), _p(a), int(button), C.c_float(np.float32(dx)), C.c_float(np.float32(dy)))
+    return e, a, bool(upd)
+
+
+def ref_camera_run(eye, lookat, W, H, fovy, events):
+    """The REFERENCE'S CameraControl + RayGenerator::lookat (oracle/_ref/ref_camera) over a sequence of
+    (button, dx, dy) drag events. Returns per event (eye, lookat, updated, raygen[9]) as uint32 bit patterns."""
+    txt = "%r %r %r %r %r %r %d %d %r\n" % (*[float(np.float32(v)) for v in eye], *[float(np.float32(v)) for v in lookat], W, H, float(np.float32(fovy)))
+    txt += "".join("%d %r %r\n" % (int(b), float(np.float32(dx)), float(np.float32(dy))) for b, dx, dy in events)
+    out = subprocess.check_output([REF_CAMERA_BIN], input=txt.encode()).decode().split("\n")
+    rows = []
+    for line in out:
+        t = line.split()
+        if len(t) != 16:
+            continue
+        v = [int(x, 16) for x in t[:6]] + [int(t[6])] + [int(x, 16) for x in t[7:]]
+        rows.append(v)
+    return np.array(rows, dtype=np.uint64)
+
+
 def _write_blobs(path, blobs):
     with open(path, "wb") as f:
         for name, arr in blobs.items():

@@ -255,6 +255,68 @@ ORACLE_API void o_raygen_shoot(const ORayGen* rg, float u, float v, float* ro, f
     rd[0] = d.x; rd[1] = d.y; rd[2] = d.z;
 }
 
+/* The examples' interactive camera: CameraControl::cursorPosCallback, common/misc.hpp:129-205, one drag
+ * event of (dx, dy) pixels with ONE button held (0 = left: orbit :147-181, 1 = right: dolly :183-190,
+ * 2 = middle: pan :192-205). Host code in the reference (glibc sinf/cosf whatever the math mode).
+ * eye / lookat are updated in place; returns m_updated (always 1 for a known button, as in the reference). */
+ORACLE_API int o_camera_control(float* eye3, float* lookat3, int button, float dx, float dy)
+{
+    v3 orig = V3(eye3[0], eye3[1], eye3[2]), lookat = V3(lookat3[0], lookat3[1], lookat3[2]);
+    v3 cameraLocal = sub(orig, lookat);
+    const float r = length3(cameraLocal);
+    int updated = 0;
+    if (button == 0)
+    {
+        const float sensitivity = 0.004f;
+        {
+            const float sinTheta = sinf(dx * sensitivity);
+            const float cosTheta = cosf(dx * sensitivity);
+            const float new_x = cosTheta * cameraLocal.x - sinTheta * cameraLocal.z;
+            const float new_z = sinTheta * cameraLocal.x + cosTheta * cameraLocal.z;
+            cameraLocal.x = new_x;
+            cameraLocal.z = new_z;
+        }
+        {
+            const float xz = sqrtf(cameraLocal.x * cameraLocal.x + cameraLocal.z * cameraLocal.z);
+            const float sinTheta = sinf(dy * sensitivity);
+            const float cosTheta = cosf(dy * sensitivity);
+            const float new_xz = cosTheta * xz - sinTheta * cameraLocal.y;
+            const float new_y = sinTheta * xz + cosTheta * cameraLocal.y;
+            if (-r + r * 0.01f < new_y && new_y < r - r * 0.01f)
+            {
+                cameraLocal.x = cameraLocal.x * (new_xz / xz);
+                cameraLocal.z = cameraLocal.z * (new_xz / xz);
+                cameraLocal.y = new_y;
+            }
+        }
+        orig = add(lookat, cameraLocal);
+        updated = 1;
+    }
+    if (button == 1)
+    {
+        const float sensitivity = 0.002f;
+        const float new_r = fmaxf(r - r * sensitivity * dy, 0.01f);
+        const float s = new_r / r;
+        orig = add(lookat, muls(cameraLocal, s));
+        updated = 1;
+    }
+    if (button == 2)
+    {
+        const float sensitivity = 0.001f;
+        const v3 forward = normalize(sub(lookat, orig));
+        const v3 right = normalize(cross(forward, V3(0.0f, 1.0f, 0.0f)));
+        const v3 up = cross(right, forward);
+        const float amount = fmaxf(r * sensitivity, 0.01f);
+        const v3 delta = add(muls(muls(neg(right), dx), amount), muls(muls(up, dy), amount));
+        orig = add(orig, delta);
+        lookat = add(lookat, delta);
+        updated = 1;
+    }
+    eye3[0] = orig.x; eye3[1] = orig.y; eye3[2] = orig.z;
+    lookat3[0] = lookat.x; lookat3[1] = lookat.y; lookat3[2] = lookat.z;
+    return updated;
+}
+
 /* ---------------------------------------------------------- triangle math */
 /* common/core.hpp:45-68 */
 static inline v3 a_tangent_of(const OTriangle* t) { return normalize(sub(t->v[1], t->v[0])); }

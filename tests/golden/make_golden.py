@@ -11,6 +11,13 @@ Outputs (data only — inputs and expected outputs, no reference source):
   ref_kernels.npz   inputs + outputs of the reference's kernels run on the host at 48x27:
                     04_ao kernelMain, generate_candidate (no visibility reuse: that needs HIPRT),
                     temporal_resampling, 3 x spatial_resampling, tone_mapping
+  ref_ao04_256.npz  BASELINE config #1 at its real size: 04_ao kernelMain, cornellbox1.obj, 256x256 (RGBA8)
+  ref_camera.npz    the reference's CameraControl (common/misc.hpp:108-224) + RayGenerator::lookat over
+                    sequences of random orbit / zoom / pan drags: eye, look-at, updated flag, raygen bits
+  ref_tinyobj.npz   triangle arrays the reference's vendored tinyobjloader + common/loader.hpp:25-64 loop
+                    produce for assets/cornellbox1.obj and assets/blocks_ao.obj
+  assets/           those two OBJ/MTL pairs themselves (MIT-licensed data files of the reference, (c) 2024
+                    Kenta Eto, see assets/ATTRIBUTION): the INPUTS of the OBJ-reader test on the GPU box
 The oracle (MATH_LIBM mode) must reproduce every output bit for bit: tests/test_oracle_golden.py.
 """
 import json
@@ -103,6 +110,54 @@ def main():
     k["tone_accum"] = acc
     k["tone_pixels"] = np.frombuffer(o["pixels"], dtype=np.uint8).reshape(H, W, 4).copy()
     np.savez_compressed(os.path.join(HERE, "ref_kernels.npz"), **k)
+
+    # BASELINE config #1 at its real size (256x256): the reference's 04_ao kernel on cornellbox1, default camera
+    W2, H2 = 256, 256
+    cam2 = np.array(list(scenes.DEFAULT_EYE) + list(scenes.DEFAULT_LOOKAT) + [0, 1, 0, fovy], dtype=np.float32)
+    o = ob.ref_run("camera", cam=cam2, W=W2, H=H2, uv=uv)
+    rg2 = np.frombuffer(o["raygen"], dtype=ob.RAYGEN).copy()
+    o = ob.ref_run("ao04", W=W2, H=H2, tris=c1, raygen=rg2)
+    np.savez_compressed(os.path.join(HERE, "ref_ao04_256.npz"), W=W2, H=H2, raygen=rg2,
+                        pixels=np.frombuffer(o["pixels"], dtype=np.uint8).reshape(H2, W2, 4).copy())
+
+    # interactive camera: random drag sequences from three start poses
+    cam = {}
+    poses = [(scenes.DEFAULT_EYE, scenes.DEFAULT_LOOKAT, 1920, 1080), (scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT, 1920, 1080),
+             ((0.5, 2.5, 6.0), (0.0, 1.5, -1.0), 96, 54)]
+    for i, (e0, a0, w, h) in enumerate(poses):
+        ev = np.zeros((120, 3), dtype=np.float32)
+        ev[:, 0] = rng.integers(0, 3, 120)
+        ev[:, 1:] = (rng.normal(size=(120, 2)) * 80.0).astype(np.float32)
+        ev[5] = (0, 0.0, 5000.0)   # orbit past the pole: the clamp of misc.hpp:172 keeps the old elevation
+        ev[6] = (1, 0.0, 1e6)      # zoom through the look-at point: the 0.01 floor of :186
+        out = ob.ref_camera_run(e0, a0, w, h, fovy, [(int(b), float(dx), float(dy)) for b, dx, dy in ev])
+        cam[f"pose{i}_start"] = np.array(list(e0) + list(a0) + [w, h], dtype=np.float32)
+        cam[f"pose{i}_events"] = ev
+        cam[f"pose{i}_out"] = out
+    cam["fovy"] = np.array([fovy], dtype=np.float32)
+    np.savez_compressed(os.path.join(HERE, "ref_camera.npz"), **cam)
+
+    # OBJ ingest: the reference's tinyobj path on two shipped scenes + the scene files themselves
+    import shutil
+    import subprocess
+    import tempfile
+
+    os.makedirs(os.path.join(HERE, "assets"), exist_ok=True)
+    tiny = {}
+    for name, count in (("cornellbox1", 36), ("blocks_ao", 3034)):
+        for ext in ("obj", "mtl"):
+            shutil.copyfile(os.path.join(REF, "assets", f"{name}.{ext}"), os.path.join(HERE, "assets", f"{name}.{ext}"))
+        with tempfile.TemporaryDirectory() as d:
+            outp = os.path.join(d, "t.tris")
+            subprocess.check_call([os.path.join(ROOT, "oracle", "_ref", "ref_tinyobj"), os.path.join(REF, "assets", name + ".obj"),
+                                   os.path.join(REF, "assets") + "/", outp], stdout=subprocess.DEVNULL)
+            t = np.fromfile(outp, dtype=ob.TRIANGLE)
+        assert len(t) == count
+        tiny[name] = t
+    np.savez_compressed(os.path.join(HERE, "ref_tinyobj.npz"), **tiny)
+    with open(os.path.join(HERE, "assets", "ATTRIBUTION"), "w") as f:
+        f.write("cornellbox1.obj/.mtl and blocks_ao.obj/.mtl are data files of yumcyaWiz/CEDEC-2024-RT (assets/), MIT License,\n"
+                "Copyright (c) 2024 Kenta Eto. They are test INPUTS here (OBJ reader parity on machines without the reference checkout).\n")
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 

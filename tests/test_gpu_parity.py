@@ -620,16 +620,10 @@ def test_interactive_camera_and_accumulation_reset(api, oracle, scenes):
     r.orbit(40.0, -25.0)
     e, a = r.camera_pose()
     assert np.allclose(a, at0) and abs(np.linalg.norm(e - a) - np.linalg.norm(eye0 - at0)) < 1e-4 and not np.allclose(e, eye0)
-    # expected pose by an independent float32 restatement of misc.hpp:147-181
-    l = (eye0 - at0).astype(np.float32)
-    rr = np.float32(np.sqrt(np.float32(l @ l)))
-    s, c = np.float32(np.sin(np.float32(40.0 * 0.004))), np.float32(np.cos(np.float32(40.0 * 0.004)))
-    l = np.float32([c * l[0] - s * l[2], l[1], s * l[0] + c * l[2]])
-    xz = np.float32(np.sqrt(l[0] * l[0] + l[2] * l[2]))
-    s, c = np.float32(np.sin(np.float32(-25.0 * 0.004))), np.float32(np.cos(np.float32(-25.0 * 0.004)))
-    nxz, ny = c * xz - s * l[1], s * xz + c * l[1]
-    l = np.float32([l[0] * (nxz / xz), ny, l[2] * (nxz / xz)])
-    assert np.allclose(e, at0 + l, atol=2e-6)
+    # the pose is the oracle's restatement of misc.hpp:147-181 (itself pinned to the reference's CameraControl,
+    # tests/test_oracle_golden.py::test_camera_control_vs_reference_fixture), bit for bit
+    oe, oa, upd = oracle.camera_control(eye0, at0, 0, 40.0, -25.0)
+    assert upd and e.tobytes() == oe.tobytes() and a.tobytes() == oa.tobytes()
     assert r.camera_updated() and not r.camera_updated()
     # the frame after a camera move starts a new accumulation
     r.frame(4, clear_first=True)
@@ -650,6 +644,76 @@ def test_interactive_camera_and_accumulation_reset(api, oracle, scenes):
     assert np.allclose(e3 - e2, a3 - a2, atol=1e-6) and np.linalg.norm(e3 - e2) > 0
     r.close()
     r2.close()
+
+
+def test_camera_api_equals_the_references_camera_control(api, scenes, golden_dir):
+    """rt_camera_orbit / _zoom / _pan + the RayGenerator they re-derive == the REFERENCE'S CameraControl
+    (common/misc.hpp:108-224) + RayGenerator::lookat over the committed drag sequences (3 x 120 events, produced by
+    the reference's own code: tests/golden/ref_camera.npz), bit for bit."""
+    g = np.load(os.path.join(golden_dir, "ref_camera.npz"))
+    fovy = g["fovy"][0]
+    tris = scenes.make_quad_room()
+    for i in range(3):
+        start, events, want = g[f"pose{i}_start"], g[f"pose{i}_events"], g[f"pose{i}_out"]
+        r = api.Renderer(int(start[6]), int(start[7]))
+        r.set_scene(tris)
+        r.lookat(start[:3], start[3:6], fovy=fovy)
+        for k, (b, dx, dy) in enumerate(events):
+            (r.orbit, r.zoom, r.pan)[int(b)](*((float(dx), float(dy)) if int(b) != 1 else (float(dy),)))
+            e, a = r.camera_pose()
+            got = [int(v) for v in e.view(np.uint32)] + [int(v) for v in a.view(np.uint32)] + [int(r.camera_updated())]
+            got += [int(v) for v in r.raygen().view(np.uint32).reshape(-1)]
+            assert got == [int(v) for v in want[k]], f"pose {i}, event {k} (button {int(b)}, dx {dx}, dy {dy})"
+        r.close()
+
+
+def test_frame_sequence_across_a_camera_move(api, oracle, scenes):
+    """The interactive loop of 10_restir_di.cpp:231-383 with a camera drag in the middle: frames 1-2, an orbit
+    (is_updated() -> `clear`, :257-267), frames 3-4 — which merge temporal history gathered at the OLD pose at
+    the same pixel (no reprojection, 10_restir_di.cu:178). Accumulation, pixels and the temporal reservoirs of
+    every frame == the oracle driven through the same sequence, bit for bit."""
+    from cedec_2024_rt_amd.types import bench_options
+
+    oracle.set_math_mode(oracle.MATH_PORTABLE)
+    tris = scenes.make_quad_room()
+    W, H = 96, 54
+    eye, at = np.float32([0.5, 2.5, 6.0]), np.float32([0.0, 1.5, -1.0])
+    fovy = np.float32(np.pi) / np.float32(4)
+    for optkw in (dict(accumulate=1), dict(accumulate=1, use_shadowed_target_function=1, spatial_resampling_passes=2)):
+        r = api.Renderer(W, H)
+        r.set_scene(tris)
+        r.lookat(eye, at)
+        r.set_options(bench_options(**optkw))
+        r.clear()
+        sc = oracle.Scene(tris, use_bvh=True)
+        oopt = oracle.bench_options(**optkw)
+        st = oracle.new_state(W, H)
+        oe, oa = eye.copy(), at.copy()
+        for frame in (1, 2, 3, 4, 5):
+            if frame == 3:
+                r.orbit(55.0, -20.0)
+                oe, oa, _ = oracle.camera_control(oe, oa, 0, 55.0, -20.0)
+            if frame == 5:
+                r.pan(-30.0, 12.0)
+                r.zoom(40.0)
+                oe, oa, _ = oracle.camera_control(oe, oa, 2, -30.0, 12.0)
+                oe, oa, _ = oracle.camera_control(oe, oa, 1, 0.0, 40.0)
+            moved = r.camera_updated()
+            assert moved == (frame in (3, 5))
+            rg = oracle.raygen_lookat(oe, oa, (0, 1, 0), fovy, W, H)
+            assert rg.tobytes() == r.raygen().tobytes()
+            if moved:
+                oracle.clear(st["accum"], W, H)
+            r.frame(frame, clear_first=moved)
+            sc.frame(W, H, frame, rg, oe, oopt, st)
+            acc = r.download(api.RT_BUF_ACCUMULATION)
+            assert _eq_bits(acc, st["accum"].reshape(acc.shape)), f"{optkw} frame {frame}: accumulation"
+            assert np.array_equal(r.download(api.RT_BUF_PIXELS).reshape(H, W, 4), st["pixels"])
+            hist = r.download(api.RT_BUF_RES_TEMPORAL)
+            vis = r.download(api.RT_BUF_VISIBILITY)
+            shaded = (vis["index"] >= 0) & ~np.isin(vis["index"], scenes.light_indices(tris))
+            assert not _res_fields_equal(hist, st["temporal"].reshape(hist.shape), mask=shaded), f"{optkw} frame {frame}: temporal history"
+        r.close()
 
 
 @pytest.mark.parametrize("W,H", [(1920, 1080), (3840, 2160)])  # BASELINE configs #4 and #5

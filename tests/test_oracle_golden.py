@@ -148,3 +148,63 @@ def test_restir_kernels_vs_reference_live(oracle, gscenes):
         o = oracle.ref_run("spatial_resampling", frame=6, res=rin, **{"pass": p}, **kw)
         assert _fields_equal(out, np.frombuffer(o["res"], dtype=oracle.RESERVOIR), mask=shaded) is None
         rin = out
+
+
+# ---------------------------------------------------------------- round 2: interactive camera, config #1 at 256x256
+def _camera_rows(oracle, start, events, fovy):
+    """the oracle's CameraControl + RayGenerator::lookat over a drag sequence, as uint32 bit patterns"""
+    e, a = start[:3].astype(np.float32), start[3:6].astype(np.float32)
+    W, H = int(start[6]), int(start[7])
+    rows = []
+    for b, dx, dy in events:
+        e, a, upd = oracle.camera_control(e, a, int(b), dx, dy)
+        rg = oracle.raygen_lookat(e, a, (0, 1, 0), fovy, W, H)
+        rows.append([int(v) for v in e.view(np.uint32)] + [int(v) for v in a.view(np.uint32)] + [int(upd)]
+                    + [int(v) for v in rg.view(np.uint32).reshape(-1)])
+    return np.array(rows, dtype=np.uint64)
+
+
+def test_camera_control_vs_reference_fixture(oracle, golden_dir):
+    """CameraControl::cursorPosCallback (common/misc.hpp:129-205) + RayGenerator::lookat (common/camera.hpp:11-25):
+    the oracle's restatement == the reference's own code over 3 x 120 random orbit / zoom / pan drags, incl. the
+    pole clamp and the zoom floor, bit for bit (eye, look-at, updated flag, raygen)."""
+    g = np.load(os.path.join(golden_dir, "ref_camera.npz"))
+    fovy = g["fovy"][0]
+    for i in range(3):
+        got = _camera_rows(oracle, g[f"pose{i}_start"], g[f"pose{i}_events"], fovy)
+        want = g[f"pose{i}_out"]
+        assert got.shape == want.shape and np.array_equal(got, want), f"pose {i}: first bad event {np.flatnonzero((got != want).any(axis=1))[:3]}"
+    # the two special events really exercised their branches
+    ev = g["pose0_events"]
+    assert ev[5][2] == 5000.0 and ev[6][2] == 1e6
+
+
+def test_camera_control_vs_reference_live(oracle):
+    if not os.path.exists(oracle.REF_CAMERA_BIN):
+        pytest.skip("oracle/_ref/ref_camera not built here")
+    rng = np.random.default_rng(5)
+    ev = np.zeros((300, 3), np.float32)
+    ev[:, 0] = rng.integers(0, 3, 300)
+    ev[:, 1:] = (rng.normal(size=(300, 2)) * 120).astype(np.float32)
+    start = np.array([3.0, 4.0, -5.0, 0.5, 0.25, 1.0, 640, 360], np.float32)
+    fovy = np.float32(np.pi) / np.float32(4)
+    want = oracle.ref_camera_run(start[:3], start[3:6], 640, 360, fovy, [(int(b), float(x), float(y)) for b, x, y in ev])
+    assert np.array_equal(_camera_rows(oracle, start, ev, fovy), want)
+
+
+def test_config1_04_ao_at_256x256(oracle, golden_dir, gscenes):
+    """BASELINE config #1 at its real size: 04_ao kernelMain (examples/04_ao/04_ao.cu:31-88) on cornellbox1.obj,
+    256x256, default camera — the oracle's host loop == the reference's own kernel run on the host, every byte."""
+    g = np.load(os.path.join(golden_dir, "ref_ao04_256.npz"))
+    W, H = int(g["W"]), int(g["H"])
+    assert (W, H) == (256, 256)
+    sc = oracle.Scene(gscenes["cornellbox1"], use_bvh=False)  # brute force, as 04_ao.cu:8-29
+    from cedec_2024_rt_amd import scenes
+
+    rg = oracle.raygen_lookat(scenes.DEFAULT_EYE, scenes.DEFAULT_LOOKAT, (0, 1, 0), np.float32(np.pi) / np.float32(4), W, H)
+    assert rg.tobytes() == g["raygen"].tobytes()
+    px = sc.ao_04(W, H, rg)
+    assert np.array_equal(np.asarray(px).reshape(H, W, 4), g["pixels"])
+    # and the oracle's BVH gives the same image as its brute force (the intersection definition)
+    sc2 = oracle.Scene(gscenes["cornellbox1"], use_bvh=True)
+    assert np.array_equal(np.asarray(sc2.ao_04(W, H, rg)).reshape(H, W, 4), g["pixels"])

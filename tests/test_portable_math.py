@@ -69,25 +69,33 @@ def test_special_values(oracle):
     assert not np.isfinite(g).any()
 
 
-def test_portable_vs_libm_frame_is_statistically_the_same(oracle):
-    """Swapping glibc for the portable functions flips a few discrete decisions but leaves the
-    image statistically unchanged (reported, not gated tightly: SURVEY.md §8c 'two oracle modes')."""
+def test_portable_vs_libm_frame_within_the_north_star_tolerance(oracle):
+    """The link between what the GPU computes (portable transcendental functions) and what the reference computes
+    (glibc: MATH_LIBM == oracle/_ref bit for bit): two full frames of the BENCHMARK workload (blocks_restir stand-in,
+    1920x1080, bench options) in both modes. The two may flip a handful of discrete reservoir decisions (a <= 1 ulp
+    difference in log/exp/sin/cos landing on the other side of a comparison); the radiance must agree within the
+    north star's 1e-4 relative L2 (BASELINE.json), at the benchmark's own size."""
     from cedec_2024_rt_amd import scenes
 
-    tris = scenes.make_quad_room()
-    W, H = 96, 54
-    eye, center = (0.5, 2.5, 6.0), (0.0, 1.5, -1.0)
+    tris = scenes.make_blocks_restir()
+    W, H = 1920, 1080
+    eye, center = scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT
     rg = oracle.raygen_lookat(eye, center, (0, 1, 0), np.float32(np.pi) / np.float32(4), W, H)
     acc = {}
     for mode in (oracle.MATH_LIBM, oracle.MATH_PORTABLE):
         oracle.set_math_mode(mode)
         sc = oracle.Scene(tris, use_bvh=True)
         st = oracle.new_state(W, H)
-        for fr in (1, 2, 3):
-            sc.frame(W, H, fr, rg, np.asarray(eye, np.float32), oracle.bench_options(), st)
-        acc[mode] = st["accum"].copy()
+        per_frame = []
+        for fr in (1, 2):
+            sc.frame(W, H, fr, rg, np.asarray(eye, np.float32), oracle.bench_options(), st, tone_map=False)
+            per_frame.append(st["accum"].copy())
+        acc[mode] = per_frame
     oracle.set_math_mode(oracle.MATH_PORTABLE)
-    a, b = acc[oracle.MATH_LIBM], acc[oracle.MATH_PORTABLE]
-    flipped = (a != b).any(axis=1).mean()
-    assert flipped < 0.05
-    assert abs(a[:, :3].mean() - b[:, :3].mean()) / a[:, :3].mean() < 0.02
+    for fr in (0, 1):
+        a, b = acc[oracle.MATH_LIBM][fr].astype(np.float64), acc[oracle.MATH_PORTABLE][fr].astype(np.float64)
+        flipped = int((acc[oracle.MATH_LIBM][fr] != acc[oracle.MATH_PORTABLE][fr]).any(axis=1).sum())
+        rel = float(np.sqrt(((a[:, :3] - b[:, :3]) ** 2).sum()) / np.sqrt((a[:, :3] ** 2).sum()))
+        print(f"frame {fr + 1}: {flipped} of {W * H} pixels differ between libm and portable math, rel-L2 {rel:.3e}")
+        assert rel <= 1e-4, (fr, flipped, rel)
+        assert flipped < 2000  # reported above; the gate is the radiance tolerance

@@ -47,6 +47,31 @@ def test_blocks_restir_stand_in_is_deterministic():
     assert area.min() > 1e-6
 
 
+def test_obj_readers_match_tinyobj_fixture(tmp_path):
+    """Runs everywhere (GPU box included): both OBJ readers on the committed copies of two scene files the reference
+    ships (tests/golden/assets, MIT) against the triangle arrays the reference's vendored tinyobjloader v1.0.6 +
+    the loop of common/loader.hpp:25-64 produced for them (tests/golden/ref_tinyobj.npz, made by make_golden.py)."""
+    import subprocess
+
+    from cedec_2024_rt_amd import scenes
+    from cedec_2024_rt_amd.types import TRIANGLE
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = np.load(os.path.join(root, "tests", "golden", "ref_tinyobj.npz"))
+    assets = os.path.join(root, "tests", "golden", "assets")
+    app = os.path.join(root, "app", "restir_app")
+    for name, count, lights in (("cornellbox1", 36, 2), ("blocks_ao", 3034, 0)):
+        ref = gold[name]
+        assert len(ref) == count
+        mine = scenes.load_obj(os.path.join(assets, name + ".obj"))
+        assert mine.tobytes() == ref.tobytes(), name
+        assert len(scenes.light_indices(mine)) == lights
+        if os.path.exists(app):
+            out2 = str(tmp_path / (name + "_app.tris"))
+            subprocess.check_call([app, "--obj", os.path.join(assets, name + ".obj"), "--dump-tris", out2], stdout=subprocess.DEVNULL)
+            assert np.fromfile(out2, dtype=TRIANGLE).tobytes() == ref.tobytes(), name + " (C++ app)"
+
+
 def test_obj_readers_match_the_references_tinyobj_loader(tmp_path):
     """Both OBJ readers (scenes.load_obj and app/restir_main.cpp) produce, byte for byte, the
     triangle array that the reference's vendored tinyobjloader v1.0.6 + the loop of
