@@ -27,7 +27,7 @@ EXPORTS = [
     "rt_spatial_resampling", "rt_resolve", "rt_tone_mapping", "rt_frame", "rt_frame_stage", "rt_frame_stage_input", "rt_frame_stage_begin", "rt_frame_stage_run", "rt_frame_stage_end", "rt_frame_stage_output", "rt_frame_stage_run_part", "rt_frame_stage_fork", "rt_frame_stage_run_async", "rt_frame_stage_run_ranges", "rt_halo_bitmap_words", "rt_halo_flags_bytes",
     "rt_halo_flags_pack", "rt_halo_flags_unpack", "rt_halo_mark", "rt_halo_scan", "rt_halo_pack_sparse", "rt_halo_unpack_sparse", "rt_path_trace", "rt_path_trace_rays", "rt_local_rows", "rt_download",
     "rt_upload", "rt_halo_bytes", "rt_halo_pack", "rt_halo_unpack", "rt_ray_count", "rt_timing_enable",
-    "rt_timing", "rt_spatial_bytes", "rt_trace_closest", "rt_trace_stats", "rt_bvh_config", "rt_bvh_info", "rt_trace_mode", "rt_trace_time", "rt_tuning", "rt_math_eval",
+    "rt_timing", "rt_spatial_bytes", "rt_trace_closest", "rt_trace_stats", "rt_bvh_config", "rt_bvh_info", "rt_build_ms", "rt_trace_mode", "rt_trace_time", "rt_tuning", "rt_math_eval",
     "rt_row_shaded", "rt_state_epoch", "rt_get_stream", "rt_geometry", "rt_res_region", "rt_lane",
     "rt_mg_partition", "rt_mg_bands", "rt_mg_unique_id", "rt_mg_load_error", "rt_mg_hub_create", "rt_mg_hub_destroy", "rt_mg_create",
     "rt_mg_destroy", "rt_mg_last_error", "rt_mg_frame", "rt_mg_frame_begin", "rt_mg_frame_step", "rt_mg_get_stats", "rt_mg_reset_stats",
@@ -129,6 +129,7 @@ def load_library():
     L.rt_trace_stats.argtypes = [vp, vp, C.c_uint32, vp]
     L.rt_bvh_config.argtypes = [vp, cf]
     L.rt_bvh_info.argtypes = [vp, vp, vp, vp]
+    L.rt_build_ms.argtypes = [vp, vp]
     L.rt_trace_mode.argtypes = [vp, ci]
     L.rt_trace_time.argtypes = [vp, vp]
     L.rt_tuning.argtypes = [vp, ci, ci]
@@ -584,6 +585,11 @@ class Renderer:
 
     def tuning(self, key, value):
         self._ck(self.L.rt_tuning(self.h, int(key), int(value)))
+
+    def build_ms(self):
+        ms = C.c_float()
+        self._ck(self.L.rt_build_ms(self.h, C.byref(ms)))
+        return ms.value
 
     def bvh_info(self):
         a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()

@@ -408,17 +408,12 @@ __global__ __launch_bounds__(BLOCK) void k_temporal(SceneView S, FrameParams P, 
 #ifndef RT_SHSPATIAL_WAVES
 #define RT_SHSPATIAL_WAVES 4 /* <= 128 VGPRs: 4 wavefronts per SIMD instead of 3 (shadowed frame 10.0 -> 9.2 ms; 5 and 6 spill: 14.5, 11.8 ms) */
 #endif
-template <bool SHADOWED>
-__global__ __launch_bounds__(SHADOWED ? TRACE_BLOCK : BLOCK, SHADOWED ? RT_SHSPATIAL_WAVES : 1) void k_spatial(SceneView S, FrameParams P, const float4* __restrict__ g0,
-                                                    const float4* __restrict__ g1,
-                                                    const float4* __restrict__ in_rec,
-                                                    const float4* __restrict__ in_rad,
-                                                    float4* __restrict__ out_rec, float4* __restrict__ out_rad)
+/* one pixel of the pass (x, row already resolved by the caller's tile mapping) */
+template <bool SHADOWED, int TB>
+RT_DEV void spatial_pixel(const SceneView& S, const FrameParams& P, uint32_t* s_stack, int x, int row, const float4* __restrict__ g0,
+                          const float4* __restrict__ g1, const float4* __restrict__ in_rec, const float4* __restrict__ in_rad,
+                          float4* __restrict__ out_rec, float4* __restrict__ out_rad)
 {
-    constexpr int TB = SHADOWED ? TRACE_BLOCK : BLOCK; /* the shadowed variant is a tracing kernel */
-    __shared__ __attribute__((aligned(16))) uint32_t s_stack[SHADOWED ? WIDE_LDS_STACK * TB : 4];
-    int x, row;
-    if (!tile_pixel<TB>(P, x, row)) return;
     const int yi = P.H - 1 - row;
     const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
     const float4 G0 = g0[li], G1 = g1[li];
@@ -553,6 +548,169 @@ __global__ __launch_bounds__(SHADOWED ? TRACE_BLOCK : BLOCK, SHADOWED ? RT_SHSPA
             }
         }
         const float p_hat = target_function<SHADOWED, TB>(S, s_stack, sp, sn, r.hit_p, r.hit_n, r.lum);
+        r.ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
+    }
+    const float4 rq = in_rad[rad_from];
+    r.rad = F3(rq.x, rq.y, rq.z);
+    res_store(out_rec, out_rad, li, r, true);
+}
+
+/* shadowed target function: a tracing kernel (one-wavefront workgroups, LDS traversal stack) */
+template <bool SHADOWED>
+__global__ __launch_bounds__(TRACE_BLOCK, RT_SHSPATIAL_WAVES) void k_spatial(SceneView S, FrameParams P, const float4* __restrict__ g0,
+                                                    const float4* __restrict__ g1, const float4* __restrict__ in_rec,
+                                                    const float4* __restrict__ in_rad, float4* __restrict__ out_rec,
+                                                    float4* __restrict__ out_rad)
+{
+    static_assert(SHADOWED, "the unshadowed pass is k_spatial_gather / k_spatial_lds");
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_STACK * TRACE_BLOCK];
+    int x, row;
+    if (!tile_pixel<TRACE_BLOCK>(P, x, row)) return;
+    spatial_pixel<true, TRACE_BLOCK>(S, P, s_stack, x, row, g0, g1, in_rec, in_rad, out_rec, out_rad);
+}
+
+/* Unshadowed target function = the roofline kernel: no rays, five dependent 64-B record gathers per pixel.
+ * Its neighbour window must stay in the XCD's 4 MiB L2, which bounds the workgroups in flight per CU: the
+ * register allocation is told to allow at most RT_SPATIAL_MAX_WAVES wavefronts per SIMD (round 1 did this
+ * with a dummy 32 KB LDS allocation; rt_tuning key 4 still adds LDS for A/B runs, default 0). */
+#ifndef RT_SPATIAL_MAX_WAVES
+#define RT_SPATIAL_MAX_WAVES 5
+#endif
+/* amdgpu_waves_per_eu(1, 5) alone leaves .vgpr_count at the 70 registers the kernel uses (7 wavefronts per SIMD at
+ * dispatch: measured 0.200 ms per pass against 0.188 with 5). Naming the last register of the 96-register
+ * allocation step as clobbered makes the descriptor ask for 96 VGPRs = floor(512 / 96) = 5 wavefronts per SIMD
+ * (MI355X_MICROARCH.md, register-file table) — an explicit register budget instead of round 1's dummy LDS. */
+template <int WAVES> RT_DEV void occupancy_bound()
+{
+    /* the last register of the allocation step that admits WAVES wavefronts per SIMD: 512 / {128, 96, 80} */
+    if (WAVES == 4) asm volatile("; occupancy: 128 VGPRs -> 4 wavefronts per SIMD" ::: "v127");
+    if (WAVES == 5) asm volatile("; occupancy: 96 VGPRs -> 5 wavefronts per SIMD" ::: "v95");
+    if (WAVES == 6) asm volatile("; occupancy: 80 VGPRs -> 6 wavefronts per SIMD" ::: "v79");
+}
+template <int WAVES>
+__global__ __launch_bounds__(BLOCK) void k_spatial_gather(
+    SceneView S, FrameParams P, const float4* __restrict__ g0, const float4* __restrict__ g1, const float4* __restrict__ in_rec,
+    const float4* __restrict__ in_rad, float4* __restrict__ out_rec, float4* __restrict__ out_rad)
+{
+    occupancy_bound<WAVES>();
+    int x, row;
+    if (!tile_pixel<BLOCK>(P, x, row)) return;
+    spatial_pixel<false, BLOCK>(S, P, nullptr, x, row, g0, g1, in_rec, in_rad, out_rec, out_rad);
+}
+
+/* LDS-staged variant of the same pass (north star: "LDS-staged neighbour reservoirs"; rt_tuning key 8 = 1).
+ * What can be staged: a 32x8 tile's +-87-pixel neighbour window holds (32+174) x (8+174) = 37 492 records = 2.4 MB
+ * against 160 KB of LDS, and each pixel consumes 5 of them, so the RECORDS cannot be staged. What serialises the
+ * gathers is the data dependence between them: neighbour k+1's address needs the random draw that is consumed only
+ * if neighbour k is shaded, i.e. it waits for gather k. The shaded flags of the window are 1 bit per pixel:
+ * 182 rows x 7 words = 5 KB. This kernel stages that bitmap (k_shaded_bitmap writes it once per frame), derives all
+ * neighbour addresses and random draws from LDS alone, and then runs the merge chain with the record of
+ * neighbour k+1 already in flight while neighbour k is merged. Same decisions, same arithmetic, same results. */
+constexpr int SPL_HALO = 87, SPL_ROWS = TILE_H + 2 * SPL_HALO, SPL_WORDS = 7;
+__global__ void k_shaded_bitmap(int W, int rows, const float4* __restrict__ g1, uint32_t* __restrict__ bits)
+{
+    /* one wavefront per 64 pixels of a row: two 32-bit words by ballot */
+    const int words = (W + 31) / 32;
+    const int row = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool sh = x < W && row < rows && (as_uint(g1[(size_t)row * W + x].w) & GB_SHADED) != 0u;
+    const unsigned long long m = __ballot(sh);
+    const int lane = threadIdx.x & 63, w0 = (x - lane) >> 5;
+    if (lane == 0 && w0 < words) bits[(size_t)row * words + w0] = (uint32_t)m;
+    if (lane == 32 && w0 + 1 < words) bits[(size_t)row * words + w0 + 1] = (uint32_t)(m >> 32);
+}
+template <int WAVES>
+__global__ __launch_bounds__(BLOCK) void k_spatial_lds(
+    FrameParams P, const uint32_t* __restrict__ bits, const float4* __restrict__ g0, const float4* __restrict__ g1,
+    const float4* __restrict__ in_rec, const float4* __restrict__ in_rad, float4* __restrict__ out_rec, float4* __restrict__ out_rad)
+{
+    occupancy_bound<WAVES>();
+    __shared__ uint32_t s_bits[SPL_ROWS * SPL_WORDS];
+    /* the tile of this workgroup (all its threads share it): window = rows [trow0 - 87, trow0 + 8 + 87), words [tw0, tw0 + 7) */
+    int x = 0, row = P.row0;
+    const bool ok = tile_pixel<BLOCK>(P, x, row);
+    /* every thread of a 32x8 tile derives the same tile origin from its own (x, row), in or out of the image */
+    const int tx0 = x & ~(TILE_W - 1), trow0 = P.row0 + ((row - P.row0) & ~(TILE_H - 1));
+    const int words = (P.W + 31) / 32, tw0 = (tx0 >> 5) - 3;
+    for (int i = threadIdx.x; i < SPL_ROWS * SPL_WORDS; i += BLOCK)
+    {
+        const int r = i / SPL_WORDS, w = i - r * SPL_WORDS;
+        const int grow = trow0 - SPL_HALO + r, gw = tw0 + w;
+        const int lr = grow - P.lrow0;
+        s_bits[i] = (lr >= 0 && lr < P.lrows && gw >= 0 && gw < words) ? bits[(size_t)lr * words + gw] : 0u;
+    }
+    __syncthreads();
+    if (!ok) return;
+    const int yi = P.H - 1 - row;
+    const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
+    const float4 G0 = g0[li], G1 = g1[li];
+    if (!(as_uint(G1.w) & GB_SHADED))
+    {
+        res_store(out_rec, out_rad, li, res_zero(), false);
+        return;
+    }
+    const f3 sp = F3(G0.x, G0.y, G0.z), sn = F3(G1.x, G1.y, G1.z);
+    PCG rng = pcg_init(hashPCG4((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame, (uint32_t)(2 + P.pass)), 0);
+    bool own_shaded;
+    Res r = res_load(in_rec, li, own_shaded);
+    size_t rad_from = li;
+    if (P.use_spatial)
+    {
+        /* 1. all neighbour choices from the RNG and the staged shaded bits (10_restir_di.cu:305-340) */
+        const float scale = P.spatial_radius / 1.96f;
+        long long pid[5];
+        float ud[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+        {
+            pid[k] = -1; ud[k] = 0.0f;
+            if (k < P.spatial_count)
+            {
+                const float rv0 = rng.uniformf();
+                const float rv1 = rng.uniformf();
+                const float radius = sqrtf(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
+                const float phi = 2.0f * kPI * rv1;
+                float sn_phi, cs_phi;
+                pm_sincosf(phi, &sn_phi, &cs_phi);
+                const int nx = f2i_sat((float)x + scale * (radius * cs_phi));
+                const int ny = f2i_sat((float)yi + scale * (radius * sn_phi));
+                const int nrow = P.H - 1 - ny, lr = nrow - P.lrow0;
+                const bool okn = !(nx < 0 || nx >= P.W || ny < 0 || ny >= P.H) && !(nx == x && ny == yi) && !(lr < 0 || lr >= P.lrows);
+                if (okn)
+                {
+                    /* |offset| <= 86.43 px for the default radius: inside the staged window */
+                    const int wr = nrow - (trow0 - SPL_HALO), ww = (nx >> 5) - tw0;
+                    const uint32_t word = s_bits[wr * SPL_WORDS + ww];
+                    if (word & (1u << (nx & 31)))
+                    {
+                        pid[k] = (long long)((size_t)nx + (size_t)lr * P.W);
+                        ud[k] = rng.uniformf();
+                    }
+                }
+            }
+        }
+        /* 2. the merge chain of :340-371; the loads of neighbour k+1 do not depend on the merge of neighbour k */
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+        {
+            if (pid[k] >= 0)
+            {
+                bool n_shaded;
+                Res nr = res_load(in_rec, (size_t)pid[k], n_shaded);
+                float p_hat_y = target_unshadowed(sp, sn, nr.hit_p, nr.hit_n, nr.lum);
+                if (P.vis_reuse) p_hat_y *= nr.vis ? 1.0f : 0.0f;
+                nr.M = scale_M(nr.M, rejection_heuristics(r.org_p, r.org_n, nr.org_p, nr.org_n, P.eye));
+                const float weight = p_hat_y * nr.ucw * (float)nr.M;
+                r.w_sum += weight;
+                r.M += nr.M;
+                if (ud[k] < weight / r.w_sum)
+                {
+                    res_take_sample(r, nr);
+                    rad_from = (size_t)pid[k];
+                }
+            }
+        }
+        const float p_hat = target_unshadowed(sp, sn, r.hit_p, r.hit_n, r.lum);
         r.ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
     }
     const float4 rq = in_rad[rad_from];
@@ -863,7 +1021,84 @@ RT_DEV bool path_bounce(const SceneView& S, uint32_t* s_stack, const FrameParams
         const float4 ke = S.light_ke[nth];
         st.radiance = st.radiance + st.throughput * brdf * G * V * F3(ke.x, ke.y, ke.z) / L2.z; /* :89-90 */
     }
-    if (EXAMPLE == 9)
+    if (EXAMPLE == 9 && SHADOWED)
+    {
+        /* RIS with the shadowed target function (09_ris.cu:61-99 with options.use_shadowed_target_function):
+         * one shadow ray per candidate. The rays do not depend on the reservoir chain, so the candidates are taken
+         * eight at a time: draw their random numbers (same order: rv0, rv1, rv2, u per candidate), walk the eight
+         * rays back to back in one traversal loop (occluded_batch: a lane starts its next ray when its current one
+         * is settled), then run the reservoir updates with the visibilities. A candidate whose unshadowed weight
+         * is 0 is not walked (V cannot matter); the final contribution's ray (:110-113) and its p-hat ray
+         * (:116-120) repeat the selected candidate's ray. Same results, same reference ray count. */
+        const float fL = (float)(size_t)P.n_lights;
+        Res r = res_zero();
+        float V_sel = 1.0f;
+        bool have_sel = false;
+        for (int i0 = 0; i0 < P.ris_sample_count; i0 += 8)
+        {
+            f3 tgt[8];
+            uint32_t nthv[8];
+            float uuv[8];
+            uint32_t need = 0u, live = 0u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+            {
+                tgt[j] = F3(0.0f, 0.0f, 0.0f); nthv[j] = 0u; uuv[j] = 0.0f;
+                if (i0 + j < P.ris_sample_count)
+                {
+                    const float rv0 = st.rng.uniformf();
+                    float bx = st.rng.uniformf();
+                    float by = st.rng.uniformf();
+                    uint32_t nth = (uint32_t)(rv0 * fL);
+                    if (nth == (uint32_t)P.n_lights) nth = (uint32_t)P.n_lights - 1u;
+                    const float4* L = S.lights + RT_LIGHT_STRIDE * (size_t)nth;
+                    const float4 L0 = L[0], L1 = L[1], L2 = L[2];
+                    const f3 a0 = F3(L0.x, L0.y, L0.z), a1 = F3(L0.w, L1.x, L1.y), a2 = F3(L1.z, L1.w, L2.x);
+                    warp_unit_triangle(bx, by);
+                    const f3 lp = (1.0f - bx - by) * a0 + bx * a1 + by * a2;
+                    uuv[j] = st.rng.uniformf();
+                    tgt[j] = lp; nthv[j] = nth;
+                    live |= 1u << j;
+                    ++nrays; /* the reference traces this ray (common/reservoir.hpp:52-57) */
+                    const f3 ln = tri_normal(a0, a1, a2);
+                    if (target_unshadowed(sp, sn, lp, ln, L2.y) != 0.0f) need |= 1u << j; /* weight 0 whatever V says otherwise */
+                }
+            }
+            const uint32_t occl = occluded_batch<8, STRIDE>(S.wide, s_stack, sp, sn, tgt, need);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+            {
+                if (live & (1u << j))
+                {
+                    const float4* L = S.lights + RT_LIGHT_STRIDE * (size_t)nthv[j];
+                    const float4 L0 = L[0], L1 = L[1], L2 = L[2];
+                    const f3 a0 = F3(L0.x, L0.y, L0.z), a1 = F3(L0.w, L1.x, L1.y), a2 = F3(L1.z, L1.w, L2.x);
+                    const f3 ln = tri_normal(a0, a1, a2);
+                    const float V = (occl >> j) & 1u ? 0.0f : 1.0f;
+                    const float p_hat = target_shadowed(sp, sn, tgt[j], ln, L2.y, V);
+                    const float weight = p_hat / L2.z;
+                    r.w_sum += weight;
+                    r.M += 1;
+                    if (uuv[j] < weight / r.w_sum)
+                    {
+                        r.hit_p = tgt[j]; r.hit_n = ln; r.lum = L2.y;
+                        const float4 ke = S.light_ke[nthv[j]];
+                        r.rad = F3(ke.x, ke.y, ke.z);
+                        V_sel = V; have_sel = true;
+                    }
+                }
+            }
+        }
+        const f3 brdf = (1.0f / kPI) * kd;
+        const float G = geometry_term(sp, sn, r.hit_p, r.hit_n);
+        /* no candidate selected (all weights 0): the reference still walks surface -> Reservoir{}'s zero position */
+        const float V = have_sel ? V_sel : (check_visibility_wide<STRIDE>(S.wide, s_stack, sp, sn, r.hit_p) ? 1.0f : 0.0f);
+        nrays += 2; /* :110-113 and :116-120 */
+        const float p_hat = target_shadowed(sp, sn, r.hit_p, r.hit_n, r.lum, V);
+        const float ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
+        st.radiance = st.radiance + st.throughput * brdf * G * V * r.rad * ucw;
+    }
+    if (EXAMPLE == 9 && !SHADOWED)
     {
         /* RIS over the lights (09_ris.cu:61-99), then the shaded contribution (:101-126) */
         const float fL = (float)(size_t)P.n_lights;
@@ -881,13 +1116,7 @@ RT_DEV bool path_bounce(const SceneView& S, uint32_t* s_stack, const FrameParams
             warp_unit_triangle(bx, by);
             const f3 lp = (1.0f - bx - by) * a0 + bx * a1 + by * a2;
             const f3 ln = tri_normal(a0, a1, a2);
-            float p_hat;
-            if (SHADOWED)
-            {
-                p_hat = target_function<true, STRIDE>(S, s_stack, sp, sn, lp, ln, L2.y);
-                ++nrays;
-            }
-            else { p_hat = target_unshadowed(sp, sn, lp, ln, L2.y); }
+            const float p_hat = target_unshadowed(sp, sn, lp, ln, L2.y);
             const float weight = p_hat / L2.z;
             const float uu = st.rng.uniformf();
             r.w_sum += weight;
@@ -903,10 +1132,7 @@ RT_DEV bool path_bounce(const SceneView& S, uint32_t* s_stack, const FrameParams
         const float G = geometry_term(sp, sn, r.hit_p, r.hit_n);
         const float V = check_visibility_wide<STRIDE>(S.wide, s_stack, sp, sn, r.hit_p) ? 1.0f : 0.0f;
         ++nrays;
-        /* the reference traces this ray again for the shadowed p-hat (09_ris.cu:110-118): same ray, same answer */
-        const float p_hat = SHADOWED ? target_shadowed(sp, sn, r.hit_p, r.hit_n, r.lum, V)
-                                     : target_unshadowed(sp, sn, r.hit_p, r.hit_n, r.lum);
-        if (SHADOWED) ++nrays;
+        const float p_hat = target_unshadowed(sp, sn, r.hit_p, r.hit_n, r.lum);
         const float ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
         st.radiance = st.radiance + st.throughput * brdf * G * V * r.rad * ucw;
     }

@@ -8,6 +8,7 @@
  *   rt_device.h        vector math, PCG, the reference's pure functions, HBM record layouts
  * Compile with -ffp-contract=off (parity contract, rt_device.h).
  */
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -35,6 +36,7 @@ static_assert(sizeof(BvhNode) == 64, "BVH node");
 
 #include "frame_kernels.h"
 #include "bvh_build_host.h"
+#include "bvh_build_device.h"
 
 /* ======================================================================= host */
 
@@ -55,13 +57,19 @@ struct rt_ctx
     /* rt_tuning: tile order per kernel {raycast, generate, spatial, resolve, other} and the spatial
      * pass's occupancy limiter (extra dynamic LDS). Defaults from the sweep in DESIGN.md §5. */
     int tune_tile_mode[5] = {1, 0, 1, 0, 0};
-    int tune_spatial_lds = 32768;
+    int tune_spatial_lds = 0;     /* rt_tuning key 4: extra dynamic LDS per unshadowed spatial workgroup (A/B of the old throttle) */
+    int tune_spatial_variant = 1; /* rt_tuning key 8: 0 = k_spatial_gather, 1 = k_spatial_lds (staged shaded-bit window; falls back to 0 where it does not apply) */
+    int tune_spatial_waves = 5;   /* rt_tuning key 9: register budget of the unshadowed spatial pass in wavefronts per SIMD: 4, 5, 6 or 0 = what the kernel needs (7) */
+    uint32_t* d_shaded_bits = nullptr;
+    bool shaded_bits_stale = true;
     float last_trace_ms = 0.0f;
     int last_frame = 0; /* frame number of the last rt_frame_stage / rt_spatial_resampling (ray counting) */
     int trace_mode = 0; /* rt_trace_closest / rt_trace_stats: 0 = wide (what the frame kernels use), 1 = binary stackless */
     float bvh_split_factor = 10.0f; /* fragment length in median triangle extents; 0 = no pre-split */
     int bvh_bfs_records = 2048; /* rt_tuning key 7: records emitted breadth-first (top of the tree contiguous) */
-    int bvh_builder = 1; /* 0 = device LBVH (Morton/Karras), 1 = host binned SAH (high quality) */
+    int bvh_builder = 1; /* 0 = device LBVH (Morton/Karras, host pre-split + collapse), 1 = host binned SAH (high quality), 2 = all-device: pre-split, PLOC, wide collapse */
+    float build_ms = 0.0f; /* wall time of the last rt_scene_set */
+    int ploc_radius = RT_PLOC_RADIUS; /* rt_tuning key 10 */
     float* d_tris = nullptr;
     float4* d_tv = nullptr;
     BvhNode* d_nodes = nullptr;
@@ -235,6 +243,7 @@ int rt_destroy(rt_ctx* c)
     free_scene(c);
     hipFree(c->d_vis); hipFree(c->d_g0); hipFree(c->d_g1); hipFree(c->d_accum); hipFree(c->d_pixels);
     for (int k = 0; k < 3; ++k) { hipFree(c->d_rec[k]); hipFree(c->d_rad[k]); }
+    hipFree(c->d_shaded_bits);
     hipFree(c->d_counter); hipFree(c->d_stage); hipFree(c->d_paths[0]); hipFree(c->d_paths[1]); hipFree(c->d_pt_counters);
     if (c->ev_created) for (auto& e : c->ev) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -292,9 +301,164 @@ static int build_wide(rt_ctx* c, const rt_triangle* tris, int n_refs)
     return RT_OK;
 }
 
+/* The whole build on the device (bvh_build_device.h): pre-split, Morton sort, PLOC hierarchy, wide collapse.
+ * The host only reads counters back. */
+static int build_bvh_device(rt_ctx* c, int n_tris)
+{
+    hipStream_t st = c->stream;
+    std::vector<void*> tmp; /* device scratch, freed on every exit */
+    auto cleanup = [&]() { for (void* p : tmp) hipFree(p); tmp.clear(); };
+    auto dalloc = [&](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr; tmp.push_back(p); return p; };
+#define BD_FAIL(code, ...) do { char _b[256]; snprintf(_b, sizeof(_b), __VA_ARGS__); c->err = _b; cleanup(); return (code); } while (0)
+#define BD_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) BD_FAIL(RT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(_e)); } while (0)
+#define BD_PTR(p) do { if (!(p)) BD_FAIL(RT_ERR_HIP, "out of device memory in the BVH build"); } while (0)
+    const int gt = (n_tris + 255) / 256;
+    /* 1. extents, scene bounds, median extent */
+    float* d_ext = (float*)dalloc((size_t)n_tris * 4); BD_PTR(d_ext);
+    float* d_ext2 = (float*)dalloc((size_t)n_tris * 4); BD_PTR(d_ext2);
+    unsigned int* d_bounds = (unsigned int*)dalloc(24); BD_PTR(d_bounds);
+    const unsigned int binit[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    BD_HIP(hipMemcpyAsync(d_bounds, binit, 24, hipMemcpyHostToDevice, st));
+    k_tri_extents<<<gt, 256, 0, st>>>(c->d_tris, n_tris, d_ext, d_bounds);
+    BD_HIP(hipGetLastError());
+    size_t tb = 0;
+    BD_HIP(rocprim::radix_sort_keys(nullptr, tb, d_ext, d_ext2, (size_t)n_tris, 0, 32, st));
+    void* d_t0 = dalloc(tb); BD_PTR(d_t0);
+    BD_HIP(rocprim::radix_sort_keys(d_t0, tb, d_ext, d_ext2, (size_t)n_tris, 0, 32, st));
+    float median = 0.0f;
+    unsigned int hb[6];
+    BD_HIP(hipMemcpyAsync(&median, d_ext2 + n_tris / 2, 4, hipMemcpyDeviceToHost, st));
+    BD_HIP(hipMemcpyAsync(hb, d_bounds, 24, hipMemcpyDeviceToHost, st));
+    BD_HIP(hipStreamSynchronize(st));
+    auto dec = [](unsigned int u) -> float { const unsigned int v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; float f; memcpy(&f, &v, 4); return f; };
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) { lo[a] = dec(hb[a]); hi[a] = dec(hb[3 + a]); }
+    float ext = 0.0f;
+    for (int a = 0; a < 3; ++a) ext = fmaxf(ext, fmaxf(fabsf(lo[a]), fabsf(hi[a])));
+    const float pad = 4e-5f * (ext > 1.0f ? ext : 1.0f); /* as the host path: hits lie within rounding distance of the triangle */
+    const float3 slo = make_float3(lo[0], lo[1], lo[2]);
+    const float3 sext = make_float3(fmaxf(hi[0] - lo[0], 1e-20f), fmaxf(hi[1] - lo[1], 1e-20f), fmaxf(hi[2] - lo[2], 1e-20f));
+    /* 2. early split clipping: count, scan, emit */
+    uint32_t* d_cnt = (uint32_t*)dalloc((size_t)n_tris * 4); BD_PTR(d_cnt);
+    uint32_t* d_off = (uint32_t*)dalloc((size_t)n_tris * 4); BD_PTR(d_off);
+    size_t sb = 0;
+    BD_HIP(rocprim::exclusive_scan(nullptr, sb, d_cnt, d_off, 0u, (size_t)n_tris, rocprim::plus<uint32_t>(), st));
+    void* d_t1 = dalloc(sb); BD_PTR(d_t1);
+    float L = c->bvh_split_factor > 0.0f ? c->bvh_split_factor * median : 0.0f;
+    const size_t budget = (size_t)n_tris * 4 + 1024;
+    int n = 0;
+    for (int it = 0; it < 16; ++it)
+    {
+        k_split_refs<false><<<gt, 256, 0, st>>>(c->d_tris, n_tris, L, pad, nullptr, d_cnt, nullptr, nullptr);
+        BD_HIP(hipGetLastError());
+        BD_HIP(rocprim::exclusive_scan(d_t1, sb, d_cnt, d_off, 0u, (size_t)n_tris, rocprim::plus<uint32_t>(), st));
+        uint32_t last[2];
+        BD_HIP(hipMemcpyAsync(&last[0], d_off + n_tris - 1, 4, hipMemcpyDeviceToHost, st));
+        BD_HIP(hipMemcpyAsync(&last[1], d_cnt + n_tris - 1, 4, hipMemcpyDeviceToHost, st));
+        BD_HIP(hipStreamSynchronize(st));
+        n = (int)(last[0] + last[1]);
+        if ((size_t)n <= budget || L <= 0.0f) break;
+        L *= 1.5f;
+    }
+    c->n_refs = n;
+    float* d_boxes = (float*)dalloc((size_t)n * 24); BD_PTR(d_boxes);
+    int* d_ref_tri = (int*)dalloc((size_t)n * 4); BD_PTR(d_ref_tri);
+    k_split_refs<true><<<gt, 256, 0, st>>>(c->d_tris, n_tris, L, pad, d_off, nullptr, d_boxes, d_ref_tri);
+    BD_HIP(hipGetLastError());
+    BD_HIP(hipMalloc(&c->d_tv, (size_t)n_tris * 48));
+    k_bvh_tv<<<gt, 256, 0, st>>>(c->d_tris, n_tris, c->d_tv);
+    BD_HIP(hipGetLastError());
+    if (n < 2) BD_FAIL(RT_ERR_STATE, "internal: the device build needs at least two references");
+    /* 3. Morton order */
+    const int grid = (n + 255) / 256;
+    uint64_t* d_keys = (uint64_t*)dalloc((size_t)n * 8); BD_PTR(d_keys);
+    uint64_t* d_keys2 = (uint64_t*)dalloc((size_t)n * 8); BD_PTR(d_keys2);
+    uint32_t* d_ids = (uint32_t*)dalloc((size_t)n * 4); BD_PTR(d_ids);
+    uint32_t* d_ids2 = (uint32_t*)dalloc((size_t)n * 4); BD_PTR(d_ids2);
+    k_bvh_keys<<<grid, 256, 0, st>>>(d_boxes, n, slo, sext, d_keys, d_ids);
+    BD_HIP(hipGetLastError());
+    size_t rb = 0;
+    BD_HIP(rocprim::radix_sort_pairs(nullptr, rb, d_keys, d_keys2, d_ids, d_ids2, (size_t)n, 0, 64, st));
+    void* d_t2 = dalloc(rb); BD_PTR(d_t2);
+    BD_HIP(rocprim::radix_sort_pairs(d_t2, rb, d_keys, d_keys2, d_ids, d_ids2, (size_t)n, 0, 64, st));
+    /* 4. PLOC hierarchy */
+    int2* d_children = (int2*)dalloc((size_t)n * 8); BD_PTR(d_children);
+    int* d_parent = (int*)dalloc((size_t)n * 4); BD_PTR(d_parent);
+    float* d_node_boxes = (float*)dalloc((size_t)n * 24); BD_PTR(d_node_boxes);
+    int* d_cid[2] = {(int*)dalloc((size_t)n * 4), (int*)dalloc((size_t)n * 4)}; BD_PTR(d_cid[0]); BD_PTR(d_cid[1]);
+    float* d_cbox[2] = {(float*)dalloc((size_t)n * 24), (float*)dalloc((size_t)n * 24)}; BD_PTR(d_cbox[0]); BD_PTR(d_cbox[1]);
+    int* d_nn = (int*)dalloc((size_t)n * 4); BD_PTR(d_nn);
+    unsigned int* d_keep = (unsigned int*)dalloc((size_t)n * 4); BD_PTR(d_keep);
+    unsigned int* d_pos = (unsigned int*)dalloc((size_t)n * 4); BD_PTR(d_pos);
+    PlocState* d_ps = (PlocState*)dalloc(sizeof(PlocState)); BD_PTR(d_ps);
+    size_t pb = 0;
+    BD_HIP(rocprim::exclusive_scan(nullptr, pb, d_keep, d_pos, 0u, (size_t)n, rocprim::plus<unsigned int>(), st));
+    void* d_t3 = dalloc(pb); BD_PTR(d_t3);
+    k_ploc_init<<<grid, 256, 0, st>>>(n, d_ids2, d_boxes, d_cid[0], d_cbox[0], d_ps, d_parent);
+    BD_HIP(hipGetLastError());
+    int cur = 0;
+    bool done = false;
+    for (int batch = 0; batch < 64 && !done; ++batch)
+    {
+        for (int it = 0; it < 12; ++it)
+        {
+            k_ploc_nn<<<grid, 256, 0, st>>>(d_ps, d_cbox[cur], d_nn, c->ploc_radius);
+            k_ploc_merge<<<grid, 256, 0, st>>>(d_ps, n, d_cid[cur], d_cbox[cur], d_nn, d_children, d_parent, d_node_boxes, d_keep);
+            BD_HIP(rocprim::exclusive_scan(d_t3, pb, d_keep, d_pos, 0u, (size_t)n, rocprim::plus<unsigned int>(), st));
+            k_ploc_compact<<<grid, 256, 0, st>>>(d_ps, n, d_keep, d_pos, d_cid[cur], d_cbox[cur], d_cid[cur ^ 1], d_cbox[cur ^ 1]);
+            cur ^= 1;
+        }
+        BD_HIP(hipGetLastError());
+        PlocState ps;
+        BD_HIP(hipMemcpyAsync(&ps, d_ps, sizeof(ps), hipMemcpyDeviceToHost, st));
+        BD_HIP(hipStreamSynchronize(st));
+        done = ps.m <= 1u;
+        if (done && ps.merges != (unsigned int)(n - 1)) BD_FAIL(RT_ERR_STATE, "internal: PLOC made %u nodes for %d references", ps.merges, n);
+    }
+    if (!done) BD_FAIL(RT_ERR_BVH_DEPTH, "PLOC did not converge");
+    int* d_height = (int*)dalloc(4); BD_PTR(d_height);
+    BD_HIP(hipMemsetAsync(d_height, 0, 4, st));
+    k_bvh_height<<<grid, 256, 0, st>>>(n, d_children, d_parent, d_height);
+    BD_HIP(hipMalloc(&c->d_nodes, (size_t)(n - 1) * sizeof(BvhNode)));
+    k_bvh_emit<<<grid, 256, 0, st>>>(n, d_ids2, d_ref_tri, d_boxes, d_children, d_parent, d_node_boxes, c->d_nodes);
+    BD_HIP(hipGetLastError());
+    /* 5. wide collapse, level by level */
+    const size_t rec_cap = (size_t)n * 2 + 8;
+    BD_HIP(hipMalloc(&c->d_wide, rec_cap * 48));
+    CollapseItem* d_q[2] = {(CollapseItem*)dalloc((size_t)n * sizeof(CollapseItem)), (CollapseItem*)dalloc((size_t)n * sizeof(CollapseItem))};
+    BD_PTR(d_q[0]); BD_PTR(d_q[1]);
+    CollapseState* d_cs = (CollapseState*)dalloc(sizeof(CollapseState)); BD_PTR(d_cs);
+    k_collapse_init<<<1, 1, 0, st>>>(d_cs, d_q[0]);
+    const int max_levels = (WIDE_LDS_STACK + WIDE_OVF_STACK - 1) / 3 + 1;
+    for (int level = 0; level <= max_levels; ++level)
+    {
+        k_collapse_level<<<grid, 256, 0, st>>>(c->d_nodes, c->d_tris, level, d_cs, d_q[level & 1], d_q[(level + 1) & 1], (uint32_t*)c->d_wide);
+        k_collapse_swap<<<1, 1, 0, st>>>(level, d_cs);
+    }
+    BD_HIP(hipGetLastError());
+    CollapseState cs;
+    int bh = 0;
+    BD_HIP(hipMemcpyAsync(&cs, d_cs, sizeof(cs), hipMemcpyDeviceToHost, st));
+    BD_HIP(hipMemcpyAsync(&bh, d_height, 4, hipMemcpyDeviceToHost, st));
+    BD_HIP(hipStreamSynchronize(st));
+    if (cs.count[0] != 0u || cs.count[1] != 0u || 3 * (int)cs.height + 1 > WIDE_LDS_STACK + WIDE_OVF_STACK)
+        BD_FAIL(RT_ERR_BVH_DEPTH, "wide BVH height %u exceeds the traversal stack (%d entries)", cs.height, WIDE_LDS_STACK + WIDE_OVF_STACK);
+    if (cs.n_rec > rec_cap) BD_FAIL(RT_ERR_STATE, "internal: %u wide records for %d references", cs.n_rec, n);
+    if (bh > 62) BD_FAIL(RT_ERR_BVH_DEPTH, "binary tree height %d exceeds the 63-level trail word", bh);
+    c->bvh_height = bh;
+    c->n_wide = (int)cs.n_rec;
+    c->wide_height = (int)cs.height;
+    cleanup();
+#undef BD_FAIL
+#undef BD_HIP
+#undef BD_PTR
+    return RT_OK;
+}
+
 /* LBVH build, see bvh.h */
 static int build_bvh(rt_ctx* c, const rt_triangle* tris, int n_tris)
 {
+    if (c->bvh_builder == 2 && n_tris >= 2) return build_bvh_device(c, n_tris);
     hipStream_t st = c->stream;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     std::vector<float> extents((size_t)n_tris);
@@ -461,6 +625,7 @@ int rt_scene_set(rt_ctx* c, const rt_triangle* triangles, uint32_t count)
     if (!triangles && count) RT_FAIL(c, RT_ERR_ARG, "null triangles");
     RT_HIP(c, hipSetDevice(c->device));
     RT_HIP(c, hipStreamSynchronize(c->stream));
+    const auto t_build0 = std::chrono::steady_clock::now();
     free_scene(c);
     ++c->epoch;
     const int n = (int)count;
@@ -492,6 +657,8 @@ int rt_scene_set(rt_ctx* c, const rt_triangle* triangles, uint32_t count)
     }
     const int rc = build_bvh(c, triangles, n);
     if (rc != RT_OK) return rc;
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    c->build_ms = (float)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_build0).count() * 1e-3f;
     c->has_scene = true;
     return RT_OK;
 }
@@ -502,6 +669,13 @@ int rt_scene_info(rt_ctx* c, uint32_t* n_triangles, uint32_t* n_lights, uint32_t
     if (n_triangles) *n_triangles = (uint32_t)c->n_tris;
     if (n_lights) *n_lights = (uint32_t)c->n_lights;
     if (bvh_height) *bvh_height = (uint32_t)c->bvh_height;
+    return RT_OK;
+}
+int rt_build_ms(rt_ctx* c, float* ms)
+{
+    RT_CHECK_CTX(c);
+    if (!ms) return RT_ERR_ARG;
+    *ms = c->build_ms;
     return RT_OK;
 }
 int rt_bvh_info(rt_ctx* c, uint32_t* n_refs, uint32_t* n_nodes, uint32_t* wide_height)
@@ -698,6 +872,7 @@ int rt_raycast(rt_ctx* c)
     k_raycast<<<trace_grid(c), TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_vis, c->d_g0, c->d_g1);
     RT_HIP(c, hipGetLastError());
     c->has_gbuffer = true;
+    c->shaded_bits_stale = true;
     /* halo rows of the G-buffer keep the neighbours' shaded flags: they stay valid until the camera,
      * the scene or the options change (halo_flags_epoch), which is when the neighbours' G-buffers change */
     return RT_OK;
@@ -782,10 +957,32 @@ static int launch_spatial(rt_ctx* c, int frame, int pass, int in_phys, int out_p
                 c->opt.spatial_resampling_radius, need);
     const SceneView S = make_scene(c);
     const FrameParams P = make_params(c, frame, pass, K_SPATIAL);
+    /* the LDS-staged variant covers the default reach (87 px), up to 5 neighbours, whole-frame contexts */
+    const bool lds_variant = c->tune_spatial_variant == 1 && !c->opt.use_shadowed_target_function && need <= SPL_HALO &&
+                             c->opt.spatial_resampling_sample_count <= 5 && c->row_begin == 0 && c->row_end == c->H &&
+                             (c->sub0 < 0 || (c->sub0 == 0 && c->sub1 == c->H && c->subb1 <= c->subb0));
     if (c->opt.use_shadowed_target_function)
         k_spatial<true><<<trace_grid(c), TRACE_BLOCK, (size_t)(RT_SHADOWED_SPATIAL_LDS), c->stream>>>(S, P, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys]);
+    else if (lds_variant)
+    {
+        const int words = (c->W + 31) / 32;
+        if (!c->d_shaded_bits) RT_HIP(c, hipMalloc(&c->d_shaded_bits, (size_t)c->lrows * words * 4));
+        if (c->shaded_bits_stale)
+        {
+            k_shaded_bitmap<<<dim3((c->W + 255) / 256, c->lrows), 256, 0, c->stream>>>(c->W, c->lrows, c->d_g1, c->d_shaded_bits);
+            RT_HIP(c, hipGetLastError());
+            c->shaded_bits_stale = false;
+        }
+#define RT_SPL(WV) k_spatial_lds<WV><<<launch_grid(c), BLOCK, (size_t)c->tune_spatial_lds, c->stream>>>(P, c->d_shaded_bits, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys])
+        switch (c->tune_spatial_waves) { case 4: RT_SPL(4); break; case 5: RT_SPL(5); break; case 6: RT_SPL(6); break; default: RT_SPL(0); break; }
+#undef RT_SPL
+    }
     else
-        k_spatial<false><<<launch_grid(c), BLOCK, (size_t)c->tune_spatial_lds, c->stream>>>(S, P, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys]);
+    {
+#define RT_SPG(WV) k_spatial_gather<WV><<<launch_grid(c), BLOCK, (size_t)c->tune_spatial_lds, c->stream>>>(S, P, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys])
+        switch (c->tune_spatial_waves) { case 4: RT_SPG(4); break; case 5: RT_SPG(5); break; case 6: RT_SPG(6); break; default: RT_SPG(0); break; }
+#undef RT_SPG
+    }
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }
@@ -1205,6 +1402,7 @@ int rt_upload(rt_ctx* c, int buf, const void* src, size_t bytes)
             k_gbuffer_from_vis<<<tile_grid(c->W, c->lrows), BLOCK, 0, c->stream>>>(make_scene(c), P, c->d_vis, c->d_g0, c->d_g1);
             RT_HIP(c, hipGetLastError());
             c->has_gbuffer = true;
+            c->shaded_bits_stale = true;
             ++c->epoch;
             break;
         }
@@ -1612,9 +1810,12 @@ int rt_tuning(rt_ctx* c, int key, int value)
     RT_CHECK_CTX(c);
     if (key >= 0 && key <= 3 && (value == 0 || value == 1)) c->tune_tile_mode[key] = value;
     else if (key == 4 && value >= 0 && value <= 160 * 1024) c->tune_spatial_lds = value;
-    else if (key == 5 && (value == 0 || value == 1)) c->bvh_builder = value; /* before rt_scene_set */
+    else if (key == 5 && value >= 0 && value <= 2) c->bvh_builder = value; /* before rt_scene_set */
     else if (key == 6 && value >= 0 && value <= 2) c->pt_wavefront = value;
     else if (key == 7 && value >= 0) c->bvh_bfs_records = value; /* before rt_scene_set */
+    else if (key == 8 && (value == 0 || value == 1)) c->tune_spatial_variant = value;
+    else if (key == 9 && (value == 0 || (value >= 4 && value <= 6))) c->tune_spatial_waves = value;
+    else if (key == 10 && value >= 1 && value <= 256) c->ploc_radius = value; /* before rt_scene_set */
     else RT_FAIL(c, RT_ERR_ARG, "bad tuning key/value %d/%d", key, value);
     return RT_OK;
 }

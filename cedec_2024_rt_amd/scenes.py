@@ -333,6 +333,83 @@ def make_blocks_restir(detail=1.0):
     return out
 
 
+# ---- blocks_pt stand-in (assets/blocks_pt.obj is a missing blob; its material file is present) ----
+# (name, Kd, Ke) exactly as assets/blocks_pt.mtl lists them: 8 materials, 2 emissive
+BLOCKS_PT_MATERIALS = [
+    ("Black", (0.018829, 0.018829, 0.018829), (0.0, 0.0, 0.0)),
+    ("Brown", (0.100000, 0.046767, 0.021787), (0.0, 0.0, 0.0)),
+    ("Emmisive", (0.800000, 0.800000, 0.800000), (120.000015, 116.813454, 99.692398)),
+    ("FloorMaterial", (0.538017, 0.523392, 0.489841), (0.0, 0.0, 0.0)),
+    ("Green", (0.057167, 0.136217, 0.024592), (0.0, 0.0, 0.0)),
+    ("WeakLight", (0.800000, 0.800000, 0.800000), (0.500000, 0.500000, 0.500000)),
+    ("Yellow", (0.617207, 0.419342, 0.179603), (0.0, 0.0, 0.0)),
+    ("white", (0.546776, 0.508329, 0.527966), (0.0, 0.0, 0.0)),
+]
+# camera "blocks_pt.obj" of examples/07_pt/07_pt.cpp:139-140 (also 08_nee)
+BLOCKS_PT_EYE = (5.983407, 13.970583, -28.553869)
+BLOCKS_PT_LOOKAT = (-5.354514, 4.815835, -2.047728)
+
+
+def make_blocks_pt(detail=1.0):
+    """Synthetic stand-in for assets/blocks_pt.obj (the scene of 07_pt / 08_nee and of BASELINE config #3's text):
+    the 8 materials of assets/blocks_pt.mtl, one small bright lamp (Emmisive, Ke 120) and a large weak ceiling
+    light (WeakLight, Ke 0.5), a studded-brick tree on a brick base over a tiled floor, seen from the camera of
+    07_pt.cpp:139-140. Integer LCG (seed 2025), no libm; triangle order = file order = primID = light order."""
+    b = _Builder()
+    rng = _LCG(2025)
+    M = {m[0]: i for i, m in enumerate(BLOCKS_PT_MATERIALS)}
+    # floor and a back wall behind the look-at point (the camera looks towards +z and slightly -x, down)
+    b.patch(lambda i, j: (-70.0 + 140.0 * i / 48.0, 0.0, -50.0 + 120.0 * j / 48.0), 48, 48, M["FloorMaterial"])
+    b.patch(lambda i, j: (-70.0 + 140.0 * i / 24.0, 50.0 * j / 12.0, 70.0), 24, 12, M["white"])
+    b.patch(lambda i, j: (-70.0, 50.0 * j / 12.0, -50.0 + 120.0 * i / 24.0), 24, 12, M["white"])
+    # weak area light under the ceiling, and the ceiling itself
+    b.patch(lambda i, j: (-30.0 + 60.0 * i / 8.0, 44.0, -20.0 + 60.0 * j / 8.0), 8, 8, M["WeakLight"])
+    # the lamp: a 2x2 emissive brick on a black post, to the left of the tree
+    for k in range(8):
+        b.brick(-18, 1.2 * k, 2, 1, 1, M["Black"])
+    b.brick(-19, 9.6, 1, 2, 2, M["Emmisive"])
+    # brick base under the tree
+    for i in range(-4, 3):
+        for j in range(-3, 3):
+            b.brick(4 * i - 5, 1.2 * ((i + j) % 2), 4 * j - 2, 4, 4, M["Black"] if (i + j) % 3 else M["Brown"])
+    # trunk and foliage pads around the look-at point (-5.35, 4.8, -2.05)
+    tx, tz = -6, -3
+    for k in range(7):
+        b.brick(tx, 2.4 + 1.2 * k, tz, 2, 2, M["Brown"])
+        tx += rng.below(3) - 1
+        tz += rng.below(3) - 1
+        tx = max(-9, min(-3, tx))
+        tz = max(-6, min(0, tz))
+    pads = [(-11, 4.8, -6, 7), (0, 6.0, 2, 7), (-7, 7.2, 5, 6), (-1, 8.4, -7, 6), (-12, 9.6, 0, 6),
+            (-5, 10.8, -2, 7), (2, 12.0, 4, 5), (-9, 13.2, -8, 5), (-3, 14.4, 2, 5), (-6, 15.6, -3, 4)]
+    keep = int(256 * min(1.0, max(0.0, detail)))
+    for (cx, cy, cz, rad) in pads:
+        for layer in range(3):
+            r = rad - layer
+            nx, nz = (4, 2) if layer % 2 == 0 else (2, 4)
+            for ix in range(-r, r, nx):
+                for iz in range(-r, r, nz):
+                    mx, mz = ix + nx * 0.5, iz + nz * 0.5
+                    u = rng.below(256)
+                    if mx * mx + mz * mz > r * r:
+                        continue
+                    if u >= keep or u >= 236:
+                        continue
+                    mat = M["Green"] if rng.below(12) else M["Yellow"]
+                    b.brick(cx + ix, cy + 1.2 * layer, cz + iz, nx, nz, mat)
+    n = len(b.tris)
+    out = np.zeros(n, dtype=TRIANGLE)
+    P = np.zeros((n, 3, 3), dtype=np.float64)
+    mat_ids = np.zeros(n, dtype=np.int64)
+    for k, (p0, p1, p2, m) in enumerate(b.tris):
+        P[k, 0], P[k, 1], P[k, 2] = p0, p1, p2
+        mat_ids[k] = m
+    out["v"] = P.astype(np.float32)
+    out["color"] = np.asarray([m[1] for m in BLOCKS_PT_MATERIALS], dtype=np.float32)[mat_ids]
+    out["emissive"] = np.asarray([m[2] for m in BLOCKS_PT_MATERIALS], dtype=np.float32)[mat_ids]
+    return out
+
+
 def make_quad_room(n_lights=8, seed=7):
     """Tiny deterministic test scene: a floor, a back wall, a box and a few small emissive
     quads. For unit tests where cornellbox fixtures are too large or too regular."""

@@ -292,6 +292,7 @@ int rt_trace_stats(rt_ctx* ctx, const float* rays, uint32_t n, uint32_t* stats);
 int rt_bvh_config(rt_ctx* ctx, float split_factor);
 /* wide_height: levels of the 4-wide tree the kernels walk; a walk holds at most 3 stack entries per level */
 int rt_bvh_info(rt_ctx* ctx, uint32_t* n_references, uint32_t* n_wide_records, uint32_t* wide_height);
+int rt_build_ms(rt_ctx* ctx, float* ms); /* wall time of the last rt_scene_set (upload + tables + BVH build), synchronised */
 /* which traversal rt_trace_closest / rt_trace_stats exercise: 0 = 4-wide quantised BVH + LDS stack
  * (what every frame kernel uses, default), 1 = binary LBVH + stackless trail (A/B measurements),
  * 2/3 = persistent lane-refill queue (closest / any hit), 4 = mode 0 with any-hit (shadow-ray)
@@ -300,16 +301,23 @@ int rt_trace_mode(rt_ctx* ctx, int mode);
 int rt_trace_time(rt_ctx* ctx, float* ms);
 /* performance knobs; results never depend on them. keys 0..3: workgroup->tile order inside an XCD
  * band for raycast / generate_candidate / spatial_resampling / resolve (0 row-major, 1 column-major);
- * key 4: extra LDS bytes per spatial_resampling workgroup (limits the workgroups resident per CU,
- * i.e. the neighbour window that must stay in L2). Defaults: {1,0,1,0}, 32768.
- * key 5 (before rt_scene_set): binary-tree builder, 0 = device LBVH (Morton codes + Karras, fast),
- * 1 = host binned SAH (default; the reference requests HIPRT's high-quality build,
- * common/loader.hpp:98-99). Both feed the same wide-BVH collapse and both traversals.
+ * key 4: extra LDS bytes per unshadowed spatial_resampling workgroup (round 1's occupancy throttle, kept for
+ * A/B runs; the kernel now carries an explicit bound of 5 wavefronts per SIMD). Defaults: {1,0,1,0}, 0.
+ * key 5 (before rt_scene_set): builder. 0 = device LBVH (Morton codes + Karras) with host pre-split and host
+ * collapse (round 1), 1 = host binned SAH (the reference requests HIPRT's high-quality build,
+ * common/loader.hpp:98-99), 2 = all on the device: pre-split, Morton sort, PLOC hierarchy, wide collapse
+ * (no tree data crosses the host). All feed the same traversals; results never depend on the builder.
  * key 6: rt_path_trace as 0 = one launch per frame (the reference's shape), 1 = wavefront (one launch
  * per bounce over the list of live paths, compacted with wave ballots), 2 = auto (default: wavefront
  * for 09_ris, whose per-bounce RIS makes compaction pay; one launch for 07_pt). Same results.
  * key 7 (before rt_scene_set): number of wide-BVH records emitted breadth-first before the
- * collapse switches to depth-first order (record order only; no measurable effect, default 2048). */
+ * collapse switches to depth-first order (record order only; no measurable effect, default 2048).
+ * key 10 (before rt_scene_set): PLOC search radius of builder 2 (places in Morton order, default 16).
+ * key 9: register budget of the unshadowed spatial pass, in wavefronts per SIMD (4, 5, 6; 0 = unbounded = 7): fewer
+ * workgroups in flight keep the neighbour window inside the XCD's 4 MiB L2. Default 5.
+ * key 8: unshadowed spatial_resampling as 0 = dependent record gathers, 1 (default) = LDS-staged variant: the
+ * tile's +-87-pixel window of shaded bits staged in LDS, neighbour addresses derived from LDS alone, the
+ * record of neighbour k+1 in flight while neighbour k is merged (whole-frame contexts, radius <= 30). */
 int rt_tuning(rt_ctx* ctx, int key, int value);
 /* elementwise device evaluation of the portable math / IEEE div & sqrt (parity tests);
  * fn ids as in tests/test_portable_math.py */

@@ -123,7 +123,7 @@ def test_lbvh_equals_brute_force(api, oracle, scenes, golden_scenes):
         rays = _random_rays(rng, 60000 if len(tris) < 1000 else 20000, lo - 0.5, hi + 0.5)
         sc = oracle.Scene(tris, use_bvh=False)
         ref = sc.trace_closest(rays, force_brute=True)
-        for builder in (0, 1):  # 0: device LBVH (Morton + Karras), 1: host binned SAH
+        for builder in (0, 1, 2):  # 0: device LBVH (Morton + Karras), 1: host binned SAH, 2: all-device (pre-split, PLOC, collapse)
             r = api.Renderer(8, 8)
             r.tuning(5, builder)
             r.set_scene(tris)
@@ -168,7 +168,7 @@ def test_deep_traversal_stack_spills_past_lds(api, oracle):
     sc = oracle.Scene(tris, use_bvh=False)
     ref = sc.trace_closest(rays, force_brute=True)
     assert (ref[:, 3].view(np.int32) >= 0).mean() > 0.5
-    for builder in (0, 1):
+    for builder in (0, 1, 2):
         r = api.Renderer(8, 8)
         r.tuning(5, builder)
         r.set_scene(tris)
@@ -192,11 +192,12 @@ def test_lbvh_blocks_scene_vs_oracle_bvh(api, oracle, scenes):
     rays = _random_rays(rng, 200000, np.float32([-20, 0, -10]), np.float32([40, 40, 60]))
     sc = oracle.Scene(tris, use_bvh=True)
     ref = sc.trace_closest(rays)
-    for builder in (0, 1):
+    for builder in (0, 1, 2):
         r = api.Renderer(8, 8)
         r.tuning(5, builder)
         r.set_scene(tris)
         info = r.scene_info()
+        print(f"builder {builder}: rt_scene_set {r.build_ms():.1f} ms, {r.bvh_info()}, binary height {info['bvh_height']}")
         assert info["triangles"] == len(tris) and info["lights"] == len(scenes.light_indices(tris))
         for mode in (0, 1, 2):
             r.trace_mode(mode)
@@ -448,7 +449,11 @@ def test_random_strip_partitions_match_single_context(api, scenes, seed):
     (9, "quad_room", 96, 54, 2, dict(accumulate=1)),
     (9, "quad_room", 64, 36, 1, dict(use_shadowed_target_function=1, ris_sample_count=8)),
     (9, "blocks", 320, 180, 1, dict()),                                        # config #3 at quarter res
-    (9, "blocks", 1280, 720, 1, dict()),                                       # BASELINE config #3 at full size
+    (9, "blocks", 1280, 720, 1, dict()),                                       # BASELINE config #3 at full size (scene as 09_ris.cpp:149 loads it)
+    (9, "blocks_pt", 1280, 720, 1, dict()),                                    # BASELINE config #3 as its text names it: blocks_pt + the 07_pt camera
+    (7, "blocks_pt", 480, 270, 2, dict(accumulate=1)),
+    (8, "blocks_pt", 480, 270, 1, dict()),
+    (9, "blocks_pt", 320, 180, 1, dict(use_shadowed_target_function=1, ris_sample_count=8, max_depth=3)),
     (8, "quad_room", 96, 54, 2, dict(accumulate=1)),                           # 08_nee
     (8, "cornellbox2", 256, 256, 2, dict(accumulate=1, max_depth=3)),
     (8, "blocks", 320, 180, 1, dict()),
@@ -462,6 +467,8 @@ def test_path_tracers_07_and_09(api, oracle, scenes, golden_scenes, example, sce
         tris, eye, center = golden_scenes["cornellbox2"], scenes.CORNELLBOX_EYE, scenes.CORNELLBOX_LOOKAT
     elif scene_name == "blocks":
         tris, eye, center = scenes.make_blocks_restir(), scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT
+    elif scene_name == "blocks_pt":
+        tris, eye, center = scenes.make_blocks_pt(), scenes.BLOCKS_PT_EYE, scenes.BLOCKS_PT_LOOKAT
     else:
         tris, eye, center = scenes.make_quad_room(), (0.5, 2.5, 6.0), (0.0, 1.5, -1.0)
     oracle.set_math_mode(oracle.MATH_PORTABLE)
@@ -644,6 +651,32 @@ def test_interactive_camera_and_accumulation_reset(api, oracle, scenes):
     assert np.allclose(e3 - e2, a3 - a2, atol=1e-6) and np.linalg.norm(e3 - e2) > 0
     r.close()
     r2.close()
+
+
+@pytest.mark.parametrize("W,H,optkw", [(480, 270, dict()), (333, 190, dict(spatial_resampling_sample_count=3, use_visibility_reuse=0)),
+                                       (1920, 1080, dict())])
+def test_lds_staged_spatial_variant_is_bit_identical(api, scenes, W, H, optkw):
+    """rt_tuning key 8 = 1: the unshadowed spatial pass with the tile's shaded-bit window staged in LDS makes the same
+    decisions as the gather kernel: accumulation, pixels and all three reservoir buffers identical over 3 frames."""
+    from cedec_2024_rt_amd.types import bench_options
+
+    tris = scenes.make_blocks_restir() if W == 1920 else scenes.make_quad_room()
+    eye, at = (scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT) if W == 1920 else ((0.5, 2.5, 6.0), (0.0, 1.5, -1.0))
+    rs = []
+    for variant in (0, 1):
+        r = api.Renderer(W, H)
+        r.set_scene(tris)
+        r.lookat(eye, at)
+        r.set_options(bench_options(**optkw))
+        r.tuning(8, variant)
+        rs.append(r)
+    for frame in (1, 2, 3):
+        for r in rs:
+            r.frame(frame)
+        for buf in (api.RT_BUF_ACCUMULATION, api.RT_BUF_PIXELS, api.RT_BUF_RES_0, api.RT_BUF_RES_1, api.RT_BUF_RES_TEMPORAL):
+            assert _eq_bits(rs[0].download(buf), rs[1].download(buf)), (frame, buf)
+    for r in rs:
+        r.close()
 
 
 def test_camera_api_equals_the_references_camera_control(api, scenes, golden_dir):

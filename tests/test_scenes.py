@@ -47,6 +47,25 @@ def test_blocks_restir_stand_in_is_deterministic():
     assert area.min() > 1e-6
 
 
+def test_blocks_pt_stand_in():
+    """The stand-in for the missing assets/blocks_pt.obj (07_pt / 08_nee scene, BASELINE config #3's text): fixed
+    triangle count and hash, the 8 materials of assets/blocks_pt.mtl with its 2 emissive ones, no degenerate triangle."""
+    from cedec_2024_rt_amd import scenes
+
+    t = scenes.make_blocks_pt()
+    assert len(t) == 151816 and len(scenes.light_indices(t)) == 324
+    assert scenes.scene_sha256(t).startswith("886d2264a483a8c9")
+    e = np.unique(t["emissive"][scenes.light_indices(t)], axis=0)
+    assert len(e) == 2 and e.max() == np.float32(120.000015) and e.min() == np.float32(0.5)
+    v = t["v"].astype(np.float64)
+    assert (0.5 * np.linalg.norm(np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]), axis=1)).min() > 1e-6
+    mtl = "/root/reference/assets/blocks_pt.mtl"
+    if os.path.exists(mtl):  # build container: the table in scenes.py is the file
+        m = scenes.load_mtl(mtl)
+        assert sorted(m) == sorted(n for n, _, _ in scenes.BLOCKS_PT_MATERIALS)
+    assert scenes.BLOCKS_PT_EYE == (5.983407, 13.970583, -28.553869)  # 07_pt.cpp:139
+
+
 def test_obj_readers_match_tinyobj_fixture(tmp_path):
     """Runs everywhere (GPU box included): both OBJ readers on the committed copies of two scene files the reference
     ships (tests/golden/assets, MIT) against the triangle arrays the reference's vendored tinyobjloader v1.0.6 +

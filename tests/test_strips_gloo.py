@@ -113,7 +113,7 @@ class OracleBackend:
         self.res[res][row0 * self.W:(row0 + n) * self.W] = np.frombuffer(t.numpy().tobytes(), dtype=self.ob.RESERVOIR)
 
 
-def _worker(rank, world, port, W, H, frames, q):
+def _worker(rank, world, port, W, H, frames, q, native=False):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -133,8 +133,19 @@ def _worker(rank, world, port, W, H, frames, q):
         eye, center = (0.5, 2.5, 6.0), (0.0, 1.5, -1.0)
         opt = ob.bench_options()
         bounds = strips.partition_rows(H, world)
+        if native:
+            # the partition and the row bands of the NATIVE strip driver (rt_mg_partition with a row cost ->
+            # irregular strip heights, rt_mg_bands), driving the same exchange logic
+            from cedec_2024_rt_amd import api
+
+            cost = np.full(H, 40, np.uint32)
+            cost[: H // 3] = 3  # a cheap band (sky-like rows): the first strip grows
+            bounds = api.mg_partition(H, world, strips.HALO_ROWS, cost)
+            assert bounds != strips.partition_rows(H, world) and all(e - a >= strips.HALO_ROWS for a, e in bounds)
         be = OracleBackend(ob, tris, W, H, bounds[rank], strips.HALO_ROWS, eye, center, opt)
         sf = strips.StripFrame(be, bounds, rank, strips.DistTransport(dist))
+        if native:
+            assert (sf.boundary, sf.interior) == api.mg_bands(bounds, rank)
         # single-rank truth
         sc = ob.Scene(tris, use_bvh=True)
         rg = ob.raygen_lookat(eye, center, (0, 1, 0), np.float32(np.pi) / np.float32(4), W, H)
@@ -161,8 +172,8 @@ def _worker(rank, world, port, W, H, frames, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,H", [(2, 200), (3, 270)])
-def test_strips_bit_identical_over_gloo(world, H):
+@pytest.mark.parametrize("world,H,native", [(2, 200, False), (3, 270, False), (3, 330, True)])
+def test_strips_bit_identical_over_gloo(world, H, native):
     import torch.multiprocessing as mp
 
     s = socket.socket()
@@ -171,7 +182,7 @@ def test_strips_bit_identical_over_gloo(world, H):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, 40, H, 2, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 40, H, 2, q, native)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

@@ -35,26 +35,32 @@ def pt7():
 ms = timed(pt7, 8); rays = r.path_trace_rays()
 out["config2_07_pt"] = dict(ms_per_spp=ms, ms_4spp=4 * ms, rays_per_spp=rays, mray_s=rays / ms / 1e3)
 r.close()
-# config #3: 09_ris 1280x720 on the blocks stand-in
+# config #3: 09_ris 1280x720 — on the scene its text names (blocks_pt stand-in, camera of 07_pt.cpp:139-140) and on
+# the scene 09_ris.cpp:149 actually loads (blocks_restir stand-in)
 tris = scenes.make_blocks_restir()
-r = api.Renderer(1280, 720); r.set_scene(tris); r.lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)
-r.set_options(default_options())
-fr = [0]
-def pt9():
-    fr[0] += 1; r.path_trace(9, fr[0])
-ms = timed(pt9, 8); rays = r.path_trace_rays()
-out["config3_09_ris"] = dict(ms_per_frame=ms, rays=rays, mray_s=rays / ms / 1e3)
-r.close()
-# 08_nee and 07_pt at 1080p on the blocks stand-in (the reference's img/8.png, img/7.png settings)
-r = api.Renderer(1920, 1080); r.set_scene(tris); r.lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)
-r.set_options(default_options())
-for ex in (8, 7, 9):
+tris_pt = scenes.make_blocks_pt()
+for key, tt, eye, at in (("config3_09_ris_blocks_pt", tris_pt, scenes.BLOCKS_PT_EYE, scenes.BLOCKS_PT_LOOKAT),
+                         ("config3_09_ris_blocks_restir", tris, scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)):
+    r = api.Renderer(1280, 720); r.set_scene(tt); r.lookat(eye, at)
+    r.set_options(default_options())
     fr = [0]
-    def pt():
-        fr[0] += 1; r.path_trace(ex, fr[0])
-    ms = timed(pt, 8); rays = r.path_trace_rays()
-    out["example_%02d_1080p" % ex] = dict(ms_per_frame=ms, rays=rays, mray_s=rays / ms / 1e3)
-r.close()
+    def pt9():
+        fr[0] += 1; r.path_trace(9, fr[0])
+    ms = timed(pt9, 8); rays = r.path_trace_rays()
+    out[key] = dict(ms_per_frame=ms, rays=rays, mray_s=rays / ms / 1e3)
+    r.close()
+# 07_pt / 08_nee / 09_ris at 1080p (the reference's img/7-9.png settings): blocks_pt stand-in
+# with the 07_pt camera, and the blocks_restir stand-in for comparison with round 1
+for key, tt, eye, at in (("blocks_pt", tris_pt, scenes.BLOCKS_PT_EYE, scenes.BLOCKS_PT_LOOKAT), ("blocks_restir", tris, scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)):
+    r = api.Renderer(1920, 1080); r.set_scene(tt); r.lookat(eye, at)
+    r.set_options(default_options())
+    for ex in (7, 8, 9):
+        fr = [0]
+        def pt():
+            fr[0] += 1; r.path_trace(ex, fr[0])
+        ms = timed(pt, 8); rays = r.path_trace_rays()
+        out["example_%02d_1080p_%s" % (ex, key)] = dict(ms_per_frame=ms, rays=rays, mray_s=rays / ms / 1e3)
+    r.close()
 # config #4 at 3840x2160 on ONE GPU (the 8-GPU config #5 is the driver's to run)
 r = api.Renderer(3840, 2160); r.set_scene(tris); r.lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)
 r.set_options(bench_options())

@@ -85,7 +85,7 @@ json.dump(out, open(os.path.join(dst, f"{tag}_pmc_valu.json"), "w"), indent=1)
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
 
 # spatial kernel HBM traffic, corrected as calibrated in profiles/r01_fetch_calibration.json
-sp = [k for k in fw["FETCH_SIZE"] if k.startswith("k_spatial<")]
+sp = [k for k in fw["FETCH_SIZE"] if k.startswith(("k_spatial_gather", "k_spatial_lds", "k_spatial<false"))]
 if sp:
     k = sp[0]
     W, H = 1920, 1080
@@ -98,7 +98,7 @@ if sp:
     if os.path.exists(shaf):
         sha = open(shaf).read().split()[0]
     vfrac = {kk: round(e["valu_issue_fraction"], 3) for kk, e in out.items()
-             if "valu_issue_fraction" in e and kk.split("<")[0] in ("k_raycast", "k_generate_candidate", "k_resolve", "k_spatial")}
+             if "valu_issue_fraction" in e and kk.split("<")[0] in ("k_raycast", "k_generate_candidate", "k_resolve", "k_spatial", "k_spatial_gather", "k_spatial_lds")}
     json.dump({
         "kernel": k, "round": tag, "lib_sha256": sha, "valu_issue_frac": vfrac,
         "workload": "blocks_restir stand-in 1920x1080, bench options",
