@@ -59,7 +59,9 @@ struct rt_ctx
     int tune_tile_mode[5] = {1, 0, 1, 0, 0};
     int tune_spatial_lds = 0;     /* rt_tuning key 4: extra dynamic LDS per unshadowed spatial workgroup (A/B of the old throttle) */
     int tune_spatial_variant = 1; /* rt_tuning key 8: 0 = k_spatial_gather, 1 = k_spatial_lds (staged shaded-bit window; falls back to 0 where it does not apply) */
-    int tune_spatial_waves = 5;   /* rt_tuning key 9: register budget of the unshadowed spatial pass in wavefronts per SIMD: 4, 5, 6 or 0 = what the kernel needs (7) */
+    int tune_spatial_waves = -1;  /* rt_tuning key 9: register budget of the unshadowed spatial pass in wavefronts per SIMD: 4, 5, 6, 0 = what the
+                                     kernel needs (7), -1 = auto: 4 for the gather kernel (its neighbour window must stay in L2: 0.184 vs 0.202 ms
+                                     per pass), none for the LDS-staged kernel (0.181 ms unbounded, 0.188 at 4) — profiles/r02_spatial_variants.json */
     uint32_t* d_shaded_bits = nullptr;
     bool shaded_bits_stale = true;
     float last_trace_ms = 0.0f;
@@ -980,7 +982,7 @@ static int launch_spatial(rt_ctx* c, int frame, int pass, int in_phys, int out_p
     else
     {
 #define RT_SPG(WV) k_spatial_gather<WV><<<launch_grid(c), BLOCK, (size_t)c->tune_spatial_lds, c->stream>>>(S, P, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys])
-        switch (c->tune_spatial_waves) { case 4: RT_SPG(4); break; case 5: RT_SPG(5); break; case 6: RT_SPG(6); break; default: RT_SPG(0); break; }
+        switch (c->tune_spatial_waves < 0 ? 4 : c->tune_spatial_waves) { case 4: RT_SPG(4); break; case 5: RT_SPG(5); break; case 6: RT_SPG(6); break; default: RT_SPG(0); break; }
 #undef RT_SPG
     }
     RT_HIP(c, hipGetLastError());
@@ -1814,7 +1816,7 @@ int rt_tuning(rt_ctx* c, int key, int value)
     else if (key == 6 && value >= 0 && value <= 2) c->pt_wavefront = value;
     else if (key == 7 && value >= 0) c->bvh_bfs_records = value; /* before rt_scene_set */
     else if (key == 8 && (value == 0 || value == 1)) c->tune_spatial_variant = value;
-    else if (key == 9 && (value == 0 || (value >= 4 && value <= 6))) c->tune_spatial_waves = value;
+    else if (key == 9 && (value == 0 || value == -1 || (value >= 4 && value <= 6))) c->tune_spatial_waves = value;
     else if (key == 10 && value >= 1 && value <= 256) c->ploc_radius = value; /* before rt_scene_set */
     else RT_FAIL(c, RT_ERR_ARG, "bad tuning key/value %d/%d", key, value);
     return RT_OK;

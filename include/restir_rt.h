@@ -313,8 +313,9 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
  * key 7 (before rt_scene_set): number of wide-BVH records emitted breadth-first before the
  * collapse switches to depth-first order (record order only; no measurable effect, default 2048).
  * key 10 (before rt_scene_set): PLOC search radius of builder 2 (places in Morton order, default 16).
- * key 9: register budget of the unshadowed spatial pass, in wavefronts per SIMD (4, 5, 6; 0 = unbounded = 7): fewer
- * workgroups in flight keep the neighbour window inside the XCD's 4 MiB L2. Default 5.
+ * key 9: register budget of the unshadowed spatial pass, in wavefronts per SIMD (4, 5, 6; 0 = unbounded = 7; -1 = auto,
+ * default: 4 for the gather kernel — fewer workgroups in flight keep its neighbour window inside the XCD's 4 MiB L2 —
+ * and none for the LDS-staged kernel).
  * key 8: unshadowed spatial_resampling as 0 = dependent record gathers, 1 (default) = LDS-staged variant: the
  * tile's +-87-pixel window of shaded bits staged in LDS, neighbour addresses derived from LDS alone, the
  * record of neighbour k+1 in flight while neighbour k is merged (whole-frame contexts, radius <= 30). */

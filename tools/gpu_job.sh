@@ -2,7 +2,8 @@
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/r02_f; mkdir -p $O
-timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; grep -n "passed\|failed\|Error" $O/pytest.log | head -20
-timeout 300 python tools/bvh_builders.py > $O/bvh_builders.json 2> $O/bvh_builders.err; cat $O/bvh_builders.json; tail -3 $O/bvh_builders.err
-timeout 300 python tools/spatial_variants.py > $O/spatial_variants.json 2> $O/spatial_variants.err; cat $O/spatial_variants.json
+bash tools/profile_round.sh r02_g > /tmp/prof.log 2>&1; tail -3 /tmp/prof.log | cut -c1-300
+O=gpurun_out/r02_g
+timeout 600 python tools/config_table.py > $O/config_table.json 2> $O/config_table.err
+timeout 300 python tools/experiments/shadowed_mode.py > $O/shadowed_mode.txt 2>&1; tail -4 $O/shadowed_mode.txt
+du -sh gpurun_out
