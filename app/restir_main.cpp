@@ -7,14 +7,15 @@
  *              [--eye x y z] [--lookat x y z] [--temporal 0|1] [--spatial 0|1]
  *              [--shadowed 0|1] [--visreuse 0|1] [--accumulate 0|1] [--by-kernel]
  *              [--example 10|7|8|9] [--ppm out.ppm] [--png out.png] [--pfm out.pfm] [--dump-tris out.tris]
- *              [--ranks N [--mirror] [--equal-strips]]
+ *              [--ranks N [--mirror | --shm] [--equal-strips]]
  *
  * --ranks N: the multi-GPU frame loop: N processes, forked before anything touches a GPU,
  * rank r on device r, each rendering one row strip through the native strip driver (rt_mg_*: sparse
  * reservoir halos over RCCL send/recv with rank +-1). Strip heights are cost-weighted from the shaded
  * pixels per row unless --equal-strips. --pfm then receives every rank's rows (one file, written in
  * place). --mirror: all ranks on device 0 with the MIRROR transport (1-GPU boxes; timing/launch smoke
- * run, the image is not a frame).
+ * run, the image is not a frame). --shm: all ranks on device 0 with the host-staged shared-memory transport
+ * (exact image, slow).
  * --example 7|8|9 runs the `path_trace` kernel of examples/07_pt, 08_nee or 09_ris instead of the
  * ReSTIR DI frame (one sample per pixel and frame; use --accumulate 1 to average frames).
  * Keys 1,2,3,4,A of the example (10_restir_di.cpp:143-174) are the --temporal/--spatial/
@@ -205,12 +206,13 @@ static void shared_barrier(Shared* sh, int which, int ranks)
         usleep(200);
     }
 }
-static int rank_main(int rank, int ranks, bool mirror, bool equal_strips, Shared* sh, const std::vector<rt_triangle>& triangles, int W,
+static int rank_main(int rank, int ranks, bool mirror, bool shm, bool equal_strips, Shared* sh, const std::vector<rt_triangle>& triangles, int W,
                      int H, int frames, const float* eye, const float* lookat, const rt_options& opt, const std::string& pfm)
 {
     const float up[3] = {0, 1, 0};
-    const int halo = 87, device = mirror ? 0 : rank;
-    if (rank == 0 && !mirror)
+    const int halo = 87, device = (mirror || shm) ? 0 : rank;
+    if (rank == 0 && shm) snprintf(sh->uid, sizeof(sh->uid), "rtmg_app_%d", (int)getppid());
+    if (rank == 0 && !mirror && !shm)
     {
         if (rt_mg_unique_id(sh->uid) != RT_OK) { fprintf(stderr, "rank 0: %s\n", rt_mg_load_error()); return 1; }
     }
@@ -247,7 +249,8 @@ static int rank_main(int rank, int ranks, bool mirror, bool equal_strips, Shared
         }
     }
     rt_mg* mg = nullptr;
-    rc = rt_mg_create(ctx, rank, ranks, bounds.data(), mirror ? RT_MG_TRANSPORT_MIRROR : RT_MG_TRANSPORT_RCCL, mirror ? nullptr : sh->uid, 0, &mg);
+    rc = rt_mg_create(ctx, rank, ranks, bounds.data(), shm ? RT_MG_TRANSPORT_SHM : (mirror ? RT_MG_TRANSPORT_MIRROR : RT_MG_TRANSPORT_RCCL),
+                      mirror ? nullptr : sh->uid, 0, &mg);
     if (rc != RT_OK) { fprintf(stderr, "rank %d: rt_mg_create failed (%d): %s\n", rank, rc, mg ? rt_mg_last_error(mg) : ""); return 1; }
     CK(rt_clear(ctx));
     const int warm = frames > 4 ? 2 : 0;
@@ -309,7 +312,7 @@ int main(int argc, char** argv)
     float eye[3] = {-0.579885f, 22.194597f, -6.567105f}, lookat[3] = {5.224952f, 20.847435f, 1.431192f};
     const float up[3] = {0, 1, 0};
     std::string obj, tris_path, ppm, png, pfm, dump;
-    bool by_kernel = false, mirror = false, equal_strips = false;
+    bool by_kernel = false, mirror = false, shm = false, equal_strips = false;
     int example = 10, ranks = 1;
     rt_options opt;
     memset(&opt, 0, sizeof(opt));
@@ -336,6 +339,7 @@ int main(int argc, char** argv)
         else if (a == "--example") example = atoi(argv[++i]);
         else if (a == "--ranks") ranks = atoi(argv[++i]);
         else if (a == "--mirror") mirror = true;
+        else if (a == "--shm") shm = true;
         else if (a == "--equal-strips") equal_strips = true;
         else if (a == "--dump-tris") dump = argv[++i]; /* write the loaded triangle array and exit (no GPU needed) */
         else if (a == "--ppm") ppm = argv[++i];
@@ -374,7 +378,13 @@ int main(int argc, char** argv)
         for (int r = 0; r < ranks; ++r)
         {
             const pid_t pid = fork();
-            if (pid == 0) _exit(rank_main(r, ranks, mirror, equal_strips, sh, triangles, W, H, frames, eye, lookat, opt, pfm));
+            if (pid == 0)
+            {
+                const int code = rank_main(r, ranks, mirror, shm, equal_strips, sh, triangles, W, H, frames, eye, lookat, opt, pfm);
+                fflush(stdout);
+                fflush(stderr);
+                _exit(code); /* no atexit handlers of the parent's image in a forked child */
+            }
             kids.push_back(pid);
         }
         int worst = 0;

@@ -137,6 +137,11 @@ def main():
     # GPU 0 with the MIRROR transport (every rank receives what it sent) and a gloo control plane. It exercises this
     # script's N > 1 branch and the native driver's launch sequence; its images and timings are NOT a multi-GPU result.
     dev_mirror = bool(os.environ.get("BENCH_DEV_MIRROR")) and world > 1
+    # BENCH_DEV_SHM=1: the same N processes on GPU 0, but with the SHM transport (host-staged through shared memory):
+    # exact images, so BENCH_VERIFY=1 can compare the assembled N-rank frame with a single context. Slow by design.
+    dev_shm = bool(os.environ.get("BENCH_DEV_SHM")) and world > 1
+    if dev_shm:
+        dev_mirror = True  # same control plane (gloo) and device placement
     if dev_mirror:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -196,6 +201,8 @@ def main():
         renders the G-buffer once, every rank reports the shaded pixels of its rows, and the strips are cut so
         that the most expensive one is as cheap as possible (>= 87 rows each)."""
         uid = [api.mg_unique_id() if rank == 0 and not dev_mirror else None]
+        if dev_shm:
+            uid = [f"rtmg_{os.getpid()}_{w}x{h}" if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         bounds = api.mg_partition(h, world, HALO)
         r, build_ms = make_renderer(w, h, bounds[rank])
@@ -212,7 +219,10 @@ def main():
                 bounds = nb
                 r, build_ms = make_renderer(w, h, bounds[rank])
             part = "cost-weighted rows"
-        mg = api.MultiGpu(r, rank, bounds, transport=api.RT_MG_TRANSPORT_MIRROR if dev_mirror else api.RT_MG_TRANSPORT_RCCL, unique_id=uid[0])
+        if dev_shm:
+            mg = api.MultiGpu(r, rank, bounds, transport=api.RT_MG_TRANSPORT_SHM, shm_name=uid[0])
+        else:
+            mg = api.MultiGpu(r, rank, bounds, transport=api.RT_MG_TRANSPORT_MIRROR if dev_mirror else api.RT_MG_TRANSPORT_RCCL, unique_id=uid[0])
         return r, mg, bounds, build_ms, part
 
     def run(w, h, steps, warm):
@@ -338,7 +348,9 @@ def main():
             # (DESIGN.md section 2); everything else is bit-exact against the reference's own sources
             "parity_unpinned": ["raytrace()/HIPRT: intersection pinned by definition (brute force of common/core.hpp:91-136)"],
         }
-        if dev_mirror:
+        if dev_shm:
+            out["dev_shm"] = "N ranks on ONE GPU with the host-staged SHM transport: exact images, not a multi-GPU measurement"
+        elif dev_mirror:
             out["dev_mirror"] = "N ranks on ONE GPU with the MIRROR transport: script/driver smoke run, not a multi-GPU measurement"
         if world > 1:
             out["config"]["strips"] = [list(b) for b in R["bounds"]]

@@ -28,13 +28,13 @@ EXPORTS = [
     "rt_halo_flags_pack", "rt_halo_flags_unpack", "rt_halo_mark", "rt_halo_scan", "rt_halo_pack_sparse", "rt_halo_unpack_sparse", "rt_path_trace", "rt_path_trace_rays", "rt_local_rows", "rt_download",
     "rt_upload", "rt_halo_bytes", "rt_halo_pack", "rt_halo_unpack", "rt_ray_count", "rt_timing_enable",
     "rt_timing", "rt_spatial_bytes", "rt_trace_closest", "rt_trace_stats", "rt_bvh_config", "rt_bvh_info", "rt_build_ms", "rt_trace_mode", "rt_trace_time", "rt_tuning", "rt_math_eval",
-    "rt_row_shaded", "rt_state_epoch", "rt_get_stream", "rt_geometry", "rt_res_region", "rt_lane",
+    "rt_row_shaded", "rt_visibility_rays_walked", "rt_state_epoch", "rt_get_stream", "rt_geometry", "rt_res_region", "rt_lane",
     "rt_mg_partition", "rt_mg_bands", "rt_mg_unique_id", "rt_mg_load_error", "rt_mg_hub_create", "rt_mg_hub_destroy", "rt_mg_create",
     "rt_mg_destroy", "rt_mg_last_error", "rt_mg_frame", "rt_mg_frame_begin", "rt_mg_frame_step", "rt_mg_get_stats", "rt_mg_reset_stats",
     "rt_mg_selftest_rccl",
 ]
 
-RT_MG_TRANSPORT_RCCL, RT_MG_TRANSPORT_LOCAL, RT_MG_TRANSPORT_MIRROR = 0, 1, 2
+RT_MG_TRANSPORT_RCCL, RT_MG_TRANSPORT_LOCAL, RT_MG_TRANSPORT_MIRROR, RT_MG_TRANSPORT_SHM = 0, 1, 2, 3
 RT_MG_DENSE, RT_MG_ONE_LANE = 1, 2
 
 
@@ -134,6 +134,7 @@ def load_library():
     L.rt_trace_time.argtypes = [vp, vp]
     L.rt_tuning.argtypes = [vp, ci, ci]
     L.rt_row_shaded.argtypes = [vp, vp]
+    L.rt_visibility_rays_walked.argtypes = [vp, vp]
     L.rt_state_epoch.argtypes = [vp, vp]
     L.rt_get_stream.argtypes = [vp, vp]
     L.rt_geometry.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -221,7 +222,7 @@ class _MgStats(C.Structure):
 class MultiGpu:
     """One rank of the native strip driver: rt_mg_* over this rank's strip Renderer."""
 
-    def __init__(self, renderer, rank, bounds, transport=RT_MG_TRANSPORT_RCCL, unique_id=None, hub=None, flags=0):
+    def __init__(self, renderer, rank, bounds, transport=RT_MG_TRANSPORT_RCCL, unique_id=None, hub=None, flags=0, shm_name=None):
         self.L, self.r, self.rank, self.bounds = renderer.L, renderer, int(rank), list(bounds)
         world = len(bounds)
         flat = np.array([bounds[0][0]] + [e for _, e in bounds], dtype=np.int32)
@@ -232,6 +233,9 @@ class MultiGpu:
                 arg = C.cast(self._id, C.c_void_p)
             elif transport == RT_MG_TRANSPORT_LOCAL:
                 arg = hub.h
+            elif transport == RT_MG_TRANSPORT_SHM:
+                self._name = C.create_string_buffer(str(shm_name).encode())
+                arg = C.cast(self._name, C.c_void_p)
         h = C.c_void_p()
         rc = self.L.rt_mg_create(renderer.h, self.rank, world, _p(flat), int(transport), arg, int(flags), C.byref(h))
         self.h = h
@@ -537,6 +541,11 @@ class Renderer:
         a, b = C.c_uint64(), C.c_uint64()
         self._ck(self.L.rt_ray_count(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def visibility_rays_walked(self):
+        a = C.c_uint64()
+        self._ck(self.L.rt_visibility_rays_walked(self.h, C.byref(a)))
+        return a.value
 
     def row_shaded(self):
         """shaded pixels per owned storage row (uint32)"""

@@ -242,8 +242,9 @@ RT_DEV void temporal_rays(const SceneView& S, uint32_t* s_stack, const FramePara
 }
 
 template <bool SHADOWED>
-RT_DEV void temporal_merge(const FrameParams& P, int x, int yi, f3 sp, f3 sn, Res& r, Res pr, float V_cur, float V_prev)
+RT_DEV bool temporal_merge(const FrameParams& P, int x, int yi, f3 sp, f3 sn, Res& r, Res pr, float V_cur, float V_prev)
 {
+    bool took_prev = false;
     PCG rng = pcg_init(hashPCG4((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame, 1u), 0);
     const int cap = 20 * P.ris_sample_count;
     pr.M = pr.M < cap ? pr.M : cap;
@@ -260,41 +261,104 @@ RT_DEV void temporal_merge(const FrameParams& P, int x, int yi, f3 sp, f3 sn, Re
     {
         res_take_sample(r, pr);
         V = V_prev;
+        took_prev = true;
     }
     const float p_hat = SHADOWED ? target_shadowed(sp, sn, r.hit_p, r.hit_n, r.lum, V)
                                  : target_unshadowed(sp, sn, r.hit_p, r.hit_n, r.lum);
     r.ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
+    return took_prev;
 }
 
+#ifndef RT_RESOLVE_WAVES_FWD
+#define RT_RESOLVE_WAVES_FWD 6 /* k_candidate_visibility: the register budget of k_resolve (one shadow ray per lane) */
+#endif
 /* --------------------------------------------------------- generate_candidate */
 /* examples/10_restir_di/10_restir_di.cu:36-135; with FUSE_TEMPORAL also :137-237 on the
  * value still in registers (the reference round-trips it through reservoir_buffer0). */
-template <bool FUSE_TEMPORAL, bool SHADOWED>
+/* DEFER (fused, unshadowed only): the visibility-reuse ray of :127-131 is NOT walked here. Its answer is observable
+ * only if the candidate's sample survives the temporal merge — if the previous frame's sample is taken, the stored
+ * visibility is that sample's (reservoir.hpp:36) and the ray was dead work. In a steady sequence the history carries
+ * M = 640 against the candidates' 32, so ~95 % of these rays are dead. Survivors are appended to a queue (wave
+ * ballot + one atomic) and k_candidate_visibility walks them with full wavefronts and sets the bit. */
+template <bool FUSE_TEMPORAL, bool SHADOWED, bool DEFER = false, bool PIPE = false>
 __global__ __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_generate_candidate(
     SceneView S, FrameParams P, const float4* __restrict__ g0, const float4* __restrict__ g1,
     const float4* __restrict__ prev_rec, const float4* __restrict__ prev_rad, float4* __restrict__ out_rec,
-    float4* __restrict__ out_rad)
+    float4* __restrict__ out_rad, uint32_t* __restrict__ vis_queue = nullptr, unsigned int* __restrict__ vis_count = nullptr)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_STACK * TRACE_BLOCK];
-    int x, row;
-    if (!tile_pixel<TRACE_BLOCK>(P, x, row)) return;
+    static_assert(!DEFER || (FUSE_TEMPORAL && !SHADOWED), "deferred visibility: fused unshadowed kernel only");
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[DEFER ? 4 : WIDE_LDS_STACK * TRACE_BLOCK];
+    int x = 0, row = P.row0;
+    const bool in_image = tile_pixel<TRACE_BLOCK>(P, x, row);
+    if (!DEFER && !in_image) return;
     const int yi = P.H - 1 - row;
     const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
-
-    const float4 G0 = g0[li], G1 = g1[li];
-    const uint32_t flags = as_uint(G1.w);
+    bool need_ray = false; /* DEFER: this lane's candidate survived and needs its visibility walked */
     Res r = res_zero();
-    if (!(flags & GB_SHADED))
+    float4 G0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), G1 = G0;
+    if (in_image) { G0 = g0[li]; G1 = g1[li]; }
+    const uint32_t flags = as_uint(G1.w);
+    if (in_image && !(flags & GB_SHADED))
     {
         res_store(out_rec, out_rad, li, r, false); /* Reservoir{} (:56-70) */
-        return;
+        if (!DEFER) return;
     }
+    /* DEFER keeps every lane to the end (the queue append is a wave-level operation) */
+    if (in_image && (flags & GB_SHADED))
+    {
     const f3 sp = F3(G0.x, G0.y, G0.z), sn = F3(G1.x, G1.y, G1.z);
 
     PCG rng = pcg_init(hashPCG4((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame, 0u), 0);
     const float fL = (float)(size_t)P.n_lights;
     int sel = -1;
     float sel_bx = 0.0f, sel_by = 0.0f; /* warped barycentrics of the selected candidate */
+    if (PIPE)
+    {
+        /* Software-pipelined form of the loop below (same draws in the same order, same arithmetic): the light record
+         * of candidate i+1 is requested before the arithmetic of candidate i, so the L2 gather (four 16-B loads of a
+         * random 64-B record) travels behind ~190 vector instructions instead of in front of them. */
+        const int n = P.ris_sample_count;
+        uint32_t nth = 0u;
+        float4 C0 = make_float4(0, 0, 0, 0), C1 = C0, C2 = C0, C3 = C0;
+        if (n > 0)
+        {
+            const float rv0 = rng.uniformf();
+            nth = (uint32_t)(rv0 * fL);
+            if (nth == (uint32_t)P.n_lights) nth = (uint32_t)P.n_lights - 1u;
+            const float4* L = S.lights + RT_LIGHT_STRIDE * (size_t)nth;
+            C0 = L[0]; C1 = L[1]; C2 = L[2]; C3 = L[3];
+        }
+        for (int i = 0; i < n; ++i)
+        {
+            float bx = rng.uniformf();
+            float by = rng.uniformf();
+            const float u = rng.uniformf();
+            uint32_t nth_n = 0u;
+            float4 N0 = C0, N1 = C1, N2 = C2, N3 = C3;
+            if (i + 1 < n)
+            {
+                const float rv0n = rng.uniformf();
+                nth_n = (uint32_t)(rv0n * fL);
+                if (nth_n == (uint32_t)P.n_lights) nth_n = (uint32_t)P.n_lights - 1u;
+                const float4* Ln = S.lights + RT_LIGHT_STRIDE * (size_t)nth_n;
+                N0 = Ln[0]; N1 = Ln[1]; N2 = Ln[2]; N3 = Ln[3];
+            }
+            const f3 v0 = F3(C0.x, C0.y, C0.z), v1 = F3(C0.w, C1.x, C1.y), v2 = F3(C1.z, C1.w, C2.x);
+            warp_unit_triangle(bx, by);
+            const f3 lp = (1.0f - bx - by) * v0 + bx * v1 + by * v2;
+            const f3 ln = F3(C3.x, C3.y, C3.z);
+            const float p_hat = target_unshadowed(sp, sn, lp, ln, C2.y);
+            const float weight = p_hat / C2.z;
+            r.w_sum += weight;
+            r.M += 1;
+            if (u < weight / r.w_sum)
+            {
+                sel = (int)nth; sel_bx = bx; sel_by = by;
+            }
+            nth = nth_n; C0 = N0; C1 = N1; C2 = N2; C3 = N3;
+        }
+    }
+    else
     for (int i = 0; i < P.ris_sample_count; ++i)
     {
         /* draw order rv0, rv1, rv2, u: left-to-right argument evaluation (hipcc) */
@@ -352,20 +416,65 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_generate_candid
     if (FUSE_TEMPORAL && SHADOWED) load_prev(); /* its sample is a ray target */
     float V_cur = 1.0f, V_prev = 1.0f;
     if (SHADOWED) temporal_rays<TRACE_BLOCK>(S, s_stack, P, sp, sn, r, pr, FUSE_TEMPORAL, V_cur, V_prev);
-    else if (P.vis_reuse) V_cur = check_visibility_wide<TRACE_BLOCK>(S.wide, s_stack, sp, sn, r.hit_p) ? 1.0f : 0.0f;
+    else if (P.vis_reuse && !DEFER) V_cur = check_visibility_wide<TRACE_BLOCK>(S.wide, s_stack, sp, sn, r.hit_p) ? 1.0f : 0.0f;
     {
         const float p_hat = SHADOWED ? target_shadowed(sp, sn, r.hit_p, r.hit_n, r.lum, V_cur)
                                      : target_unshadowed(sp, sn, r.hit_p, r.hit_n, r.lum);
         r.ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
     }
-    if (P.vis_reuse) r.vis = V_cur != 0.0f; /* :127-131 */
+    if (P.vis_reuse && !DEFER) r.vis = V_cur != 0.0f; /* :127-131 */
 
     if (FUSE_TEMPORAL)
     {
         if (!SHADOWED) load_prev(); /* after the walk: not live across it */
-        temporal_merge<SHADOWED>(P, x, yi, sp, sn, r, pr, V_cur, V_prev);
+        const bool took_prev = temporal_merge<SHADOWED>(P, x, yi, sp, sn, r, pr, V_cur, V_prev);
+        /* unshadowed: neither the merge decision nor ucw depends on the candidate's visibility; the bit is stored
+         * clear here and set by k_candidate_visibility if the ray finds the light unoccluded */
+        if (DEFER) need_ray = P.vis_reuse && !took_prev;
     }
     res_store(out_rec, out_rad, li, r, true);
+    }
+    if (DEFER)
+    {
+        const unsigned long long m = __ballot(need_ray);
+        if (m)
+        {
+            const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+            unsigned int base = 0;
+            if (lane == leader) base = atomicAdd(vis_count, (unsigned int)__popcll(m));
+            base = __shfl(base, leader);
+            if (need_ray) vis_queue[base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)li;
+        }
+    }
+}
+
+/* the deferred visibility-reuse rays of k_generate_candidate<.., DEFER>: a compact list of pixels, walked by full
+ * wavefronts. Persistent-style grid: a lane takes queue entries blockIdx*64+lane, +gridDim*64, ... (the host sizes
+ * the grid from the previous frame's count, so that is normally one entry per lane). Sets the visibility bit of the
+ * pixel's record when the light sample is unoccluded (check_visibility, common/raytrace.hpp:45-52). */
+__global__ __launch_bounds__(TRACE_BLOCK, RT_RESOLVE_WAVES_FWD) void k_candidate_visibility(
+    SceneView S, const float4* __restrict__ g0, const float4* __restrict__ g1, float4* __restrict__ rec,
+    const uint32_t* __restrict__ vis_queue, const unsigned int* __restrict__ vis_count)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_STACK * TRACE_BLOCK];
+    const unsigned int n = *vis_count;
+    for (unsigned int i = blockIdx.x * TRACE_BLOCK + threadIdx.x; ; i += gridDim.x * TRACE_BLOCK)
+    {
+        const bool have = i < n;
+        if (__ballot(have) == 0ull) break;
+        if (have)
+        {
+            const size_t li = vis_queue[i];
+            const float4 G0 = g0[li], G1 = g1[li];
+            const float4 q0 = rec[4 * li + 0];
+            const bool visible = check_visibility_wide<TRACE_BLOCK>(S.wide, s_stack, F3(G0.x, G0.y, G0.z), F3(G1.x, G1.y, G1.z), F3(q0.x, q0.y, q0.z));
+            if (visible)
+            {
+                uint32_t* w = reinterpret_cast<uint32_t*>(rec) + 16 * li + 7; /* q1.w = M | vis << 31 | shaded << 30 */
+                *w = *w | RES_VIS_BIT;
+            }
+        }
+    }
 }
 
 /* -------------------------------------------------------- temporal_resampling */

@@ -64,6 +64,14 @@ struct rt_ctx
                                      per pass), none for the LDS-staged kernel (0.181 ms unbounded, 0.188 at 4) — profiles/r02_spatial_variants.json */
     uint32_t* d_shaded_bits = nullptr;
     bool shaded_bits_stale = true;
+    /* deferred visibility-reuse rays of the fused candidate kernel (frame_kernels.h, DEFER): one queue per lane
+     * (main / second stream), its counter, and the last count that reached the host (sizes the next launch) */
+    int tune_defer_vis = 0; /* rt_tuning key 11 */
+    int tune_ris_pipe = 0;  /* rt_tuning key 12: software-pipelined RIS loop in the fused unshadowed candidate kernel */
+    uint32_t* d_visq[2] = {nullptr, nullptr};
+    unsigned int* d_visq_count = nullptr; /* [2] */
+    unsigned int* h_visq_count = nullptr; /* pinned [2]; 0xffffffff = unknown */
+    uint64_t visq_epoch = 0;
     float last_trace_ms = 0.0f;
     int last_frame = 0; /* frame number of the last rt_frame_stage / rt_spatial_resampling (ray counting) */
     int trace_mode = 0; /* rt_trace_closest / rt_trace_stats: 0 = wide (what the frame kernels use), 1 = binary stackless */
@@ -246,6 +254,8 @@ int rt_destroy(rt_ctx* c)
     hipFree(c->d_vis); hipFree(c->d_g0); hipFree(c->d_g1); hipFree(c->d_accum); hipFree(c->d_pixels);
     for (int k = 0; k < 3; ++k) { hipFree(c->d_rec[k]); hipFree(c->d_rad[k]); }
     hipFree(c->d_shaded_bits);
+    hipFree(c->d_visq[0]); hipFree(c->d_visq[1]); hipFree(c->d_visq_count);
+    if (c->h_visq_count) hipHostFree(c->h_visq_count);
     hipFree(c->d_counter); hipFree(c->d_stage); hipFree(c->d_paths[0]); hipFree(c->d_paths[1]); hipFree(c->d_pt_counters);
     if (c->ev_created) for (auto& e : c->ev) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -890,7 +900,42 @@ static int launch_generate(rt_ctx* c, int frame, int dst_phys, int prev_phys, bo
     float4 *orec = c->d_rec[dst_phys], *orad = c->d_rad[dst_phys];
     const float4 *prec = fuse ? c->d_rec[prev_phys] : nullptr, *prad = fuse ? c->d_rad[prev_phys] : nullptr;
     const int g = trace_grid(c);
+    if (fuse && !sh && c->tune_defer_vis)
+    {
+        /* fused + unshadowed: the visibility-reuse rays that survive the temporal merge go through a queue */
+        const int lane = (c->stream == c->aux_stream) ? 1 : 0;
+        const size_t npx = local_pixels(c);
+        if (!c->d_visq[0])
+        {
+            RT_HIP(c, hipMalloc(&c->d_visq[0], npx * 4));
+            RT_HIP(c, hipMalloc(&c->d_visq[1], npx * 4));
+            RT_HIP(c, hipMalloc(&c->d_visq_count, 8));
+            RT_HIP(c, hipMemsetAsync(c->d_visq_count, 0, 8, c->stream));
+            RT_HIP(c, hipHostMalloc(&c->h_visq_count, 8, hipHostMallocDefault));
+            c->h_visq_count[0] = c->h_visq_count[1] = 0xffffffffu;
+        }
+        if (c->visq_epoch != c->epoch) { c->h_visq_count[0] = c->h_visq_count[1] = 0xffffffffu; c->visq_epoch = c->epoch; }
+        RT_HIP(c, hipMemsetAsync(c->d_visq_count + lane, 0, 4, c->stream));
+        if (c->tune_ris_pipe) k_generate_candidate<true, false, true, true><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad, c->d_visq[lane], c->d_visq_count + lane);
+        else k_generate_candidate<true, false, true><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad, c->d_visq[lane], c->d_visq_count + lane);
+        RT_HIP(c, hipGetLastError());
+        /* grid of the walk: one queue entry per lane if the count is like the last one that reached the host (+50 %),
+         * every pixel of the launch if that is unknown (first frame, camera / option change); the kernel's stride loop
+         * covers any count */
+        const unsigned int last = c->h_visq_count[lane];
+        int gv = g;
+        if (last != 0xffffffffu)
+        {
+            const unsigned long long want = ((unsigned long long)last * 3ull / 2ull + TRACE_BLOCK - 1) / TRACE_BLOCK + 64ull;
+            gv = want < (unsigned long long)g ? (int)want : g;
+        }
+        k_candidate_visibility<<<gv, TRACE_BLOCK, 0, c->stream>>>(S, c->d_g0, c->d_g1, orec, c->d_visq[lane], c->d_visq_count + lane);
+        RT_HIP(c, hipGetLastError());
+        RT_HIP(c, hipMemcpyAsync(c->h_visq_count + lane, c->d_visq_count + lane, 4, hipMemcpyDeviceToHost, c->stream));
+        return RT_OK;
+    }
     if (fuse && sh) k_generate_candidate<true, true><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
+    else if (fuse && c->tune_ris_pipe) k_generate_candidate<true, false, false, true><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
     else if (fuse) k_generate_candidate<true, false><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
     else if (sh) k_generate_candidate<false, true><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
     else k_generate_candidate<false, false><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
@@ -1715,6 +1760,21 @@ int rt_row_shaded(rt_ctx* c, uint32_t* counts)
     return RT_OK;
 }
 
+/* visibility-reuse rays the last fused frame actually walked (rt_tuning key 11): the candidates that survived the
+ * temporal merge. Synchronises the stream. With key 11 = 0 or outside rt_frame every shaded pixel walks one. */
+int rt_visibility_rays_walked(rt_ctx* c, uint64_t* walked)
+{
+    RT_CHECK_CTX(c);
+    if (!walked) return RT_ERR_ARG;
+    if (!c->d_visq_count) RT_FAIL(c, RT_ERR_STATE, "no fused frame with deferred visibility rays has run");
+    unsigned int h[2] = {0u, 0u};
+    RT_HIP(c, hipMemcpyAsync(h, c->d_visq_count, 8, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->aux_stream) RT_HIP(c, hipStreamSynchronize(c->aux_stream));
+    *walked = (uint64_t)h[0] + (uint64_t)h[1];
+    return RT_OK;
+}
+
 int rt_spatial_bytes(rt_ctx* c, int frame, int pass, int in, uint64_t* bytes, uint64_t* accepted)
 {
     RT_CHECK_CTX(c);
@@ -1818,6 +1878,8 @@ int rt_tuning(rt_ctx* c, int key, int value)
     else if (key == 8 && (value == 0 || value == 1)) c->tune_spatial_variant = value;
     else if (key == 9 && (value == 0 || value == -1 || (value >= 4 && value <= 6))) c->tune_spatial_waves = value;
     else if (key == 10 && value >= 1 && value <= 256) c->ploc_radius = value; /* before rt_scene_set */
+    else if (key == 11 && (value == 0 || value == 1)) c->tune_defer_vis = value;
+    else if (key == 12 && (value == 0 || value == 1)) c->tune_ris_pipe = value;
     else RT_FAIL(c, RT_ERR_ARG, "bad tuning key/value %d/%d", key, value);
     return RT_OK;
 }

@@ -22,6 +22,7 @@
  * lock-step by rt_mg_frame_step; device-to-device copies ordered by events) — the latter exists
  * because the development boxes have one GPU and RCCL refuses two ranks on one device.
  */
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -31,7 +32,12 @@
 #include <string>
 #include <vector>
 
+#include <atomic>
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 
 #include "../../include/restir_rt.h"
@@ -98,6 +104,31 @@ struct LocalMsg
         if (consumed) hipEventDestroy(consumed);
     }
 };
+/* SHM transport: N processes of one node (e.g. N ranks sharing ONE GPU on a development box), host-staged through a
+ * POSIX shared-memory segment. One mailbox per directed neighbour pair: the sender copies its parts device -> mailbox
+ * and bumps `posted`, the receiver waits for it, copies mailbox -> device and bumps `consumed`. Blocking and slow by
+ * design: it exists to run the real multi-process code paths (bench.py --gpus N, restir_app --ranks N) with exact
+ * images where RCCL cannot (two ranks on one device). */
+struct ShmMailbox
+{
+    std::atomic<unsigned long long> posted, consumed;
+    unsigned long long bytes[8];
+    unsigned int n_parts, pad;
+};
+struct ShmSegment
+{
+    void* base = nullptr;
+    size_t bytes = 0, slot = 0;
+    int world = 0;
+    std::string name;
+    /* mailbox of messages src -> dst (|src - dst| == 1): index 2*min + (src > dst) */
+    ShmMailbox* box(int src, int dst) const
+    {
+        const int lo = src < dst ? src : dst;
+        return reinterpret_cast<ShmMailbox*>((char*)base + (size_t)(2 * lo + (src > dst ? 1 : 0)) * slot);
+    }
+    char* data(int src, int dst) const { return (char*)box(src, dst) + 256; }
+};
 struct LocalHub
 {
     int world = 0;
@@ -136,6 +167,7 @@ struct rt_mg
     hipEvent_t ev_packed = nullptr, ev_arrived = nullptr, ev_plan[2] = {nullptr, nullptr}, ev_gbuf = nullptr, ev_marked = nullptr;
     ncclComm_t nccl = nullptr;
     LocalHub* hub = nullptr;
+    ShmSegment shm;
 
     /* cached halo plans, slot = frame & 1 */
     int plan_passes = 0, max_passes = 0;
@@ -386,6 +418,24 @@ int rt_mg_create(rt_ctx* ctx, int rank, int world, const int* bounds, int transp
         m->hub = (LocalHub*)arg;
         if (m->hub->world != world) MG_FAIL(m, RT_ERR_ARG, "hub was created for %d ranks", m->hub->world);
     }
+    else if (world > 1 && transport == RT_MG_TRANSPORT_SHM)
+    {
+        if (!arg) MG_FAIL(m, RT_ERR_ARG, "SHM transport needs a segment name shared by all ranks");
+        /* capacity of a mailbox: the largest message = a dense halo band + the bitmaps of a plan */
+        size_t cap = rt_halo_bytes(ctx, m->halo) + 256;
+        for (auto& sd : m->sides) cap = std::max(cap, rt_halo_bytes(ctx, sd.n_rows) + sd.bm_words * 4 * (size_t)m->max_passes + 4096);
+        m->shm.slot = ((cap + 256 + 4095) / 4096) * 4096;
+        m->shm.world = world;
+        m->shm.bytes = m->shm.slot * 2 * (size_t)(world - 1);
+        m->shm.name = std::string("/") + (const char*)arg;
+        const int fd = shm_open(m->shm.name.c_str(), O_CREAT | O_RDWR, 0600);
+        if (fd < 0) MG_FAIL(m, RT_ERR_COMM, "shm_open(%s) failed", m->shm.name.c_str());
+        if (ftruncate(fd, (off_t)m->shm.bytes) != 0) { close(fd); MG_FAIL(m, RT_ERR_COMM, "ftruncate of the shared segment failed"); }
+        m->shm.base = mmap(nullptr, m->shm.bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (m->shm.base == MAP_FAILED) { m->shm.base = nullptr; MG_FAIL(m, RT_ERR_COMM, "mmap of the shared segment failed"); }
+        /* a fresh segment is zero-filled: every mailbox starts at posted = consumed = 0 */
+    }
     else if (world > 1 && transport != RT_MG_TRANSPORT_MIRROR) MG_FAIL(m, RT_ERR_ARG, "unknown transport %d", transport);
     return RT_OK;
 }
@@ -407,6 +457,11 @@ int rt_mg_destroy(rt_mg* m)
         }
         s.last_flags.reset();
         hipFree(s.recv_buf); hipFree(s.flags_send); hipFree(s.flags_recv);
+    }
+    if (m->shm.base)
+    {
+        munmap(m->shm.base, m->shm.bytes);
+        if (m->rank == 0) shm_unlink(m->shm.name.c_str());
     }
     if (m->nccl) g_rccl.CommDestroy(m->nccl);
     if (m->ev_packed) hipEventDestroy(m->ev_packed);
@@ -453,6 +508,31 @@ static int post(rt_mg* m, std::vector<Exchange>&& xs)
     for (auto& x : m->pending_x)
         for (auto& p : x.parts) { m->stats.bytes_sent += p.send_bytes; m->stats.messages += 1; }
     if (m->transport == RT_MG_TRANSPORT_MIRROR) return RT_OK;
+    if (m->transport == RT_MG_TRANSPORT_SHM)
+    {
+        MG_HIP(m, hipStreamSynchronize(ms)); /* what the parts hold must be final before the host copies it */
+        for (auto& x : m->pending_x)
+        {
+            ShmMailbox* b = m->shm.box(m->rank, x.peer);
+            for (long spins = 0; b->consumed.load(std::memory_order_acquire) != b->posted.load(std::memory_order_relaxed); ++spins)
+            {
+                if (spins > 600000000L) MG_FAIL(m, RT_ERR_COMM, "SHM transport: rank %d never consumed the previous message of rank %d", x.peer, m->rank);
+                if ((spins & 1023) == 1023) usleep(50);
+            }
+            if (x.parts.size() > 8) MG_FAIL(m, RT_ERR_STATE, "SHM transport: more than 8 parts in a message");
+            size_t off = 0;
+            for (size_t i = 0; i < x.parts.size(); ++i)
+            {
+                if (off + x.parts[i].send_bytes + 256 > m->shm.slot) MG_FAIL(m, RT_ERR_STATE, "SHM transport: message larger than the mailbox");
+                MG_HIP(m, hipMemcpy(m->shm.data(m->rank, x.peer) + off, x.parts[i].send, x.parts[i].send_bytes, hipMemcpyDeviceToHost));
+                b->bytes[i] = x.parts[i].send_bytes;
+                off += (x.parts[i].send_bytes + 255) & ~(size_t)255;
+            }
+            b->n_parts = (unsigned int)x.parts.size();
+            b->posted.fetch_add(1, std::memory_order_release);
+        }
+        return RT_OK;
+    }
     if (m->transport == RT_MG_TRANSPORT_RCCL)
     {
         MG_HIP(m, hipEventRecord(m->ev_packed, ms));
@@ -491,6 +571,30 @@ static int complete(rt_mg* m)
     if (m->transport == RT_MG_TRANSPORT_RCCL)
     {
         MG_HIP(m, hipStreamWaitEvent(ms, m->ev_arrived, 0));
+        return RT_OK;
+    }
+    if (m->transport == RT_MG_TRANSPORT_SHM)
+    {
+        MG_HIP(m, hipStreamSynchronize(ms)); /* whatever still reads the receive buffers is done */
+        for (auto& x : m->pending_x)
+        {
+            ShmMailbox* b = m->shm.box(x.peer, m->rank);
+            for (long spins = 0; b->posted.load(std::memory_order_acquire) == b->consumed.load(std::memory_order_relaxed); ++spins)
+            {
+                if (spins > 600000000L) MG_FAIL(m, RT_ERR_COMM, "SHM transport: rank %d never posted to rank %d", x.peer, m->rank);
+                if ((spins & 1023) == 1023) usleep(50);
+            }
+            if (b->n_parts != x.parts.size()) MG_FAIL(m, RT_ERR_STATE, "SHM transport: message shape mismatch between ranks %d and %d", x.peer, m->rank);
+            size_t off = 0;
+            for (size_t i = 0; i < x.parts.size(); ++i)
+            {
+                if (b->bytes[i] != x.parts[i].recv_bytes)
+                    MG_FAIL(m, RT_ERR_STATE, "SHM transport: rank %d sends %llu bytes, rank %d expects %zu", x.peer, b->bytes[i], m->rank, x.parts[i].recv_bytes);
+                MG_HIP(m, hipMemcpy(x.parts[i].recv, m->shm.data(x.peer, m->rank) + off, x.parts[i].recv_bytes, hipMemcpyHostToDevice));
+                off += (x.parts[i].recv_bytes + 255) & ~(size_t)255;
+            }
+            b->consumed.fetch_add(1, std::memory_order_release);
+        }
         return RT_OK;
     }
     if (m->transport == RT_MG_TRANSPORT_MIRROR)

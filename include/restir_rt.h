@@ -227,7 +227,9 @@ int rt_lane(rt_ctx* ctx, int second);
  * 87-row band); which ones is known one frame ahead while the camera is static, so a steady frame
  * needs no host synchronisation; a frame after a camera / option change synchronises once. ---- */
 typedef struct rt_mg rt_mg;
-enum { RT_MG_TRANSPORT_RCCL = 0, RT_MG_TRANSPORT_LOCAL = 1, RT_MG_TRANSPORT_MIRROR = 2 /* a rank receives what it sent: one rank alone, for overhead measurements (results are not a frame) */ };
+enum { RT_MG_TRANSPORT_RCCL = 0, RT_MG_TRANSPORT_LOCAL = 1, RT_MG_TRANSPORT_MIRROR = 2 /* a rank receives what it sent: one rank alone, for overhead measurements (results are not a frame) */,
+       RT_MG_TRANSPORT_SHM = 3 /* N processes of one node through a POSIX shared-memory segment (arg = its name, the same string on every
+                                  rank): host-staged and blocking, for exact multi-process runs where RCCL cannot go (N ranks on ONE GPU) */ };
 enum { RT_MG_DENSE = 1 /* whole 87-row bands, sent from the buffers in place */, RT_MG_ONE_LANE = 2 /* no second stream */ };
 typedef struct
 {
@@ -266,6 +268,9 @@ int rt_mg_selftest_rccl(size_t bytes);
  * the passes' RNG). The build walks fewer BVH rays than that where the reference repeats a ray or
  * the answer cannot matter. shaded = hit & not emissive. */
 int rt_ray_count(rt_ctx* ctx, uint64_t* rays, uint64_t* shaded_pixels);
+/* visibility-reuse rays the last rt_frame actually walked (rt_tuning key 11; the reference count of rt_ray_count does
+ * not change): candidates that survived the temporal merge */
+int rt_visibility_rays_walked(rt_ctx* ctx, uint64_t* walked);
 /* shaded pixels of each owned storage row (row_end - row_begin counters): the row cost of rt_mg_partition */
 int rt_row_shaded(rt_ctx* ctx, uint32_t* counts);
 /* time spent by the last `rt_frame` per kernel, HIP events on the context's stream.
@@ -312,6 +317,9 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
  * for 09_ris, whose per-bounce RIS makes compaction pay; one launch for 07_pt). Same results.
  * key 7 (before rt_scene_set): number of wide-BVH records emitted breadth-first before the
  * collapse switches to depth-first order (record order only; no measurable effect, default 2048).
+ * key 11: rt_frame's fused generate_candidate + temporal_resampling (unshadowed target) walks the visibility-reuse ray
+ * of 10_restir_di.cu:127-131 1 (default) = only for candidates that survive the temporal merge — the ray's answer is
+ * unobservable otherwise — through a compacted queue, 0 = for every candidate as the reference does. Same results.
  * key 10 (before rt_scene_set): PLOC search radius of builder 2 (places in Morton order, default 16).
  * key 9: register budget of the unshadowed spatial pass, in wavefronts per SIMD (4, 5, 6; 0 = unbounded = 7; -1 = auto,
  * default: 4 for the gather kernel — fewer workgroups in flight keep its neighbour window inside the XCD's 4 MiB L2 —

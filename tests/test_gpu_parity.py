@@ -679,6 +679,38 @@ def test_lds_staged_spatial_variant_is_bit_identical(api, scenes, W, H, optkw):
         r.close()
 
 
+def test_candidate_kernel_variants_are_bit_identical(api, scenes):
+    """rt_tuning key 11 (visibility-reuse rays only for candidates that survive the temporal merge, through a compacted
+    queue) and key 12 (software-pipelined RIS loop): same accumulation, pixels and reservoirs as the default kernel over
+    4 frames incl. the first (no history: every ray is walked) — and the queue really drops rays once history exists."""
+    from cedec_2024_rt_amd.types import bench_options
+
+    tris = scenes.make_quad_room()
+    W, H = 320, 180
+    rs = []
+    for k11, k12 in ((0, 0), (1, 0), (0, 1), (1, 1)):
+        r = api.Renderer(W, H)
+        r.set_scene(tris)
+        r.lookat((0.5, 2.5, 6.0), (0.0, 1.5, -1.0))
+        r.set_options(bench_options())
+        r.tuning(11, k11)
+        r.tuning(12, k12)
+        rs.append(r)
+    shaded = None
+    for frame in (1, 2, 3, 4):
+        for r in rs:
+            r.frame(frame)
+        for buf in (api.RT_BUF_ACCUMULATION, api.RT_BUF_PIXELS, api.RT_BUF_RES_0, api.RT_BUF_RES_1, api.RT_BUF_RES_TEMPORAL):
+            ref = rs[0].download(buf)
+            for r in rs[1:]:
+                assert _eq_bits(ref, r.download(buf)), (frame, buf)
+        walked = rs[1].visibility_rays_walked()
+        shaded = rs[0].ray_count()[1]
+        assert walked == shaded if frame == 1 else 0 < walked < shaded, (frame, walked, shaded)
+    for r in rs:
+        r.close()
+
+
 def test_camera_api_equals_the_references_camera_control(api, scenes, golden_dir):
     """rt_camera_orbit / _zoom / _pan + the RayGenerator they re-derive == the REFERENCE'S CameraControl
     (common/misc.hpp:108-224) + RayGenerator::lookat over the committed drag sequences (3 x 120 events, produced by

@@ -266,3 +266,29 @@ def test_native_single_rank_driver_equals_rt_frame():
     mg.close()
     a.close()
     b.close()
+
+
+@pytest.mark.gpu
+def test_multi_process_host_app_shm_equals_single_process(tmp_path):
+    """`restir_app --ranks 3 --shm`: three PROCESSES (forked before any HIP call) sharing this box's one GPU, strips
+    exchanged through the host-staged shared-memory transport, cost-weighted strip heights, every rank writing its rows
+    into one PFM — byte-identical to the single-process image of the same frames. (The RCCL transport needs one GPU per
+    rank; this runs the same process-level code with a transport that works on one.)"""
+    import subprocess
+
+    from cedec_2024_rt_amd import scenes
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    app = os.path.join(root, "app", "restir_app")
+    if not os.path.exists(app):
+        pytest.skip("app/restir_app not built")
+    tris = scenes.make_quad_room()
+    tpath = str(tmp_path / "scene.tris")
+    tris.tofile(tpath)
+    common = ["--tris", tpath, "--size", "160", "330", "--frames", "5", "--eye", "0.5", "2.5", "6.0", "--lookat", "0.0", "1.5", "-1.0"]
+    one, many = str(tmp_path / "one.pfm"), str(tmp_path / "many.pfm")
+    subprocess.check_call([app] + common + ["--pfm", one], stdout=subprocess.DEVNULL, timeout=120)
+    out = subprocess.check_output([app] + common + ["--pfm", many, "--ranks", "3", "--shm"], timeout=300).decode()
+    assert "3 ranks:" in out and out.count("cold frame") == 3, out
+    a, b = open(one, "rb").read(), open(many, "rb").read()
+    assert len(a) == len(b) and a == b
