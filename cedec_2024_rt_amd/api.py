@@ -50,8 +50,9 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RtError(f"{LIB_PATH} not built: run __graft_entry__.build() (make -C cedec_2024_rt_amd/csrc)")
+    path = os.environ.get("RT_LIB_PATH", LIB_PATH)  # A/B builds of the same HIP library (tools/experiments)
+    if not os.path.exists(path):
+        raise RtError(f"{path} not built: run __graft_entry__.build() (make -C cedec_2024_rt_amd/csrc)")
     # One HIP runtime per process: the torch wheel bundles its own libamdhip64 (same SONAME as
     # /opt/rocm's). If librestir_rt.so pulled in the system copy first and torch loaded its own
     # afterwards (torch.distributed / RCCL for the strips), the second runtime finds no GPU.
@@ -61,7 +62,7 @@ def load_library():
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, ci, cf = C.c_void_p, C.c_int, C.c_float
     L.rt_create.argtypes = [ci, ci, ci, ci, ci, ci, C.POINTER(vp)]
     L.rt_destroy.argtypes = [vp]
@@ -216,7 +217,7 @@ class MgHub:
 
 
 class _MgStats(C.Structure):
-    _fields_ = [(n, C.c_ulonglong) for n in ("frames", "cold_frames", "host_ns", "plan_wait_ns", "bytes_sent", "messages", "records_sent")]
+    _fields_ = [(n, C.c_ulonglong) for n in ("frames", "cold_frames", "host_ns", "plan_wait_ns", "bytes_sent", "messages", "records_sent", "gpu_ns_per_frame")]
 
 
 class MultiGpu:

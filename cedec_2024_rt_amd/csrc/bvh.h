@@ -202,7 +202,10 @@ constexpr uint32_t WIDE_LEAF_BIT = 0x80000000u;
 #define WIDE_ANY_SORTED 0 /* any-hit rays: visit children nearest-first (1) or in slot order (0) */
 #endif
 
-#define WIDE_LDS_WORDS (WIDE_LDS_STACK * BLOCK_THREADS)
+/* rows of the LDS array a kernel declares per thread: the stack + two rows of per-lane words used by the
+ * work-sharing shadow-ray walk (occluded_ws: hit flags, thief/victim matching) */
+constexpr int WIDE_LDS_ROWS = WIDE_LDS_STACK + 2;
+#define WIDE_LDS_WORDS (WIDE_LDS_ROWS * BLOCK_THREADS)
 
 RT_DEV float wide_byte(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }
 
@@ -392,11 +395,196 @@ RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3
     return true;
 }
 
+/* ---- Work-sharing any-hit walk (r02). A shadow ray's answer is the OR over the subtrees on its stack, so a
+ * lane that has run out of work can take the bottom half of a busy lane's stack — the big, far subtrees — and walk
+ * them for it: the busy lane's remaining work is split, not waited for. Idle lanes stay in the loop; every
+ * RT_WS_PERIOD passes, when at least RT_WS_MIN lanes are idle, the j-th idle lane takes from the j-th lane whose
+ * stack holds two or more entries (ray by shuffles, entries by reading the victim's LDS slots); whoever finds a hit
+ * raises the owner's flag in LDS and the owner's other helpers drop out at the next check. Per-wavefront passes are
+ * then set by the wavefront's TOTAL work / 64, not by its longest ray (a wavefront of the benchmark's shadow rays
+ * runs 49 passes for rays of 20 steps on average, 397 for the slowest: profiles/r02_wave_tail.txt). The boolean is
+ * exactly the single-lane walk's: the same subtrees are visited unless a hit ends the ray, and every hit is a hit.
+ * LDS rows WIDE_LDS_STACK (flags) and WIDE_LDS_STACK + 1 (matching) of the caller's array are used. ---- */
+#ifndef RT_WS_PERIOD
+#define RT_WS_PERIOD 2 /* check for idle lanes every 2^RT_WS_PERIOD... passes: mask = (1 << RT_WS_PERIOD) - 1 */
+#endif
+#ifndef RT_WS_MIN
+#define RT_WS_MIN 4
+#endif
 template <int STRIDE = BLOCK_THREADS>
+RT_DEV bool occluded_ws(const WideView& bvh, uint32_t* __restrict__ lds_generic, f3 ro, f3 rd, float tmin, float tmax,
+                        uint32_t* stats = nullptr /* [0] passes of the wavefront, [1] steals by this lane | own steps << 16 */)
+{
+    if (bvh.n_tris <= 0) return false;
+    /* an LDS-typed pointer: generic-pointer accesses in this loop (entries of another lane's slots) make the gfx950
+     * backend emit an aperture test it then rejects ("V_CMP_NE_U32 0, $src_shared_base: incorrect register class") */
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    lds_u32* lds_stack = (lds_u32*)lds_generic;
+    constexpr uint32_t NONE = 0x7fffffffu;
+    const int slot = threadIdx.x, lane = threadIdx.x & 63, wave0 = threadIdx.x & ~63;
+    lds_u32* s_hit = lds_stack + WIDE_LDS_STACK * STRIDE;         /* [slot]: ray owned by that lane is occluded */
+    lds_u32* s_match = lds_stack + (WIDE_LDS_STACK + 1) * STRIDE; /* [wave0 + rank]: lane of the rank-th rich lane */
+    s_hit[slot] = 0u;
+    f3 inv = F3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    inv.x = fminf(fmaxf(inv.x, -1e30f), 1e30f);
+    inv.y = fminf(fmaxf(inv.y, -1e30f), 1e30f);
+    inv.z = fminf(fmaxf(inv.z, -1e30f), 1e30f);
+    bool px = inv.x >= 0.0f, py = inv.y >= 0.0f, pz = inv.z >= 0.0f;
+    int owner = slot; /* LDS slot of the lane whose ray this lane is walking */
+    uint32_t ovf[WIDE_OVF_STACK];
+    int sp = 0, base = 0; /* live stack entries: [base, sp) */
+    auto push = [&](uint32_t e) {
+        if (sp < WIDE_LDS_STACK) lds_stack[sp * STRIDE + slot] = e;
+        else ovf[sp - WIDE_LDS_STACK] = e;
+        ++sp;
+    };
+    auto pop = [&]() -> uint32_t {
+        --sp;
+        uint32_t e;
+        if (sp < WIDE_LDS_STACK) e = lds_stack[sp * STRIDE + slot];
+        else e = ovf[sp - WIDE_LDS_STACK];
+        if (sp == base) { sp = 0; base = 0; }
+        return e;
+    };
+    const unsigned long long ba = __ballot(true); /* lanes that walk a ray of their own here */
+    uint32_t cur = 0u, pend = NONE, pend2 = NONE;
+    uint32_t pass = 0u;
+    for (;;)
+    {
+        if ((int)cur < 0 && pend2 == NONE)
+        {
+            if (pend == NONE) pend = cur; else pend2 = cur;
+            cur = sp > base ? pop() : NONE;
+        }
+        bool has_inner = cur < NONE;
+        bool has_pend = pend != NONE;
+        const unsigned long long bl = __ballot(has_inner || has_pend);
+        if (bl == 0ull) break; /* the whole wavefront is done */
+        ++pass;
+        if ((pass & ((1u << RT_WS_PERIOD) - 1u)) == 0u)
+        {
+            /* helpers of a ray that has been settled meanwhile drop their work */
+            if ((has_inner || has_pend) && s_hit[owner] != 0u)
+            {
+                cur = NONE; pend = NONE; pend2 = NONE; sp = 0; base = 0;
+                has_inner = false; has_pend = false;
+            }
+            const bool idle = !has_inner && !has_pend;
+            const bool rich = !idle && (sp - base) >= 2 && sp <= WIDE_LDS_STACK;
+            const unsigned long long bi = __ballot(idle), br = __ballot(rich);
+            const int nidle = __popcll(bi), nrich = __popcll(br);
+            if (nidle >= RT_WS_MIN && nrich > 0)
+            {
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                const int rank_i = __popcll(bi & lt), rank_r = __popcll(br & lt);
+                if (rich) s_match[wave0 + rank_r] = (uint32_t)lane;
+                const bool thief = idle && rank_i < nrich;
+                const bool robbed = rich && rank_r < nidle;
+                const int victim = thief ? (int)s_match[wave0 + rank_i] : lane;
+                /* the victim's ray and stack window, read by its thief */
+                const float vox = __shfl(ro.x, victim), voy = __shfl(ro.y, victim), voz = __shfl(ro.z, victim);
+                const float vdx = __shfl(rd.x, victim), vdy = __shfl(rd.y, victim), vdz = __shfl(rd.z, victim);
+                const float vix = __shfl(inv.x, victim), viy = __shfl(inv.y, victim), viz = __shfl(inv.z, victim);
+                const int vbase = __shfl(base, victim), vsp = __shfl(sp, victim), vowner = __shfl(owner, victim);
+                if (thief)
+                {
+                    const int k = (vsp - vbase + 1) >> 1; /* the bottom half: the largest pending subtrees */
+                    ro = F3(vox, voy, voz); rd = F3(vdx, vdy, vdz); inv = F3(vix, viy, viz);
+                    px = inv.x >= 0.0f; py = inv.y >= 0.0f; pz = inv.z >= 0.0f;
+                    owner = vowner;
+                    const int vslot = wave0 + victim;
+                    for (int e = 0; e < k; ++e) lds_stack[e * STRIDE + slot] = lds_stack[(vbase + e) * STRIDE + vslot];
+                    base = 0; sp = k;
+                    cur = pop();
+                    if (stats) stats[1] += 1u;
+                }
+                if (robbed) base += (sp - base + 1) >> 1;
+                has_inner = cur < NONE;
+            }
+        }
+        const unsigned long long bi2 = __ballot(has_inner), bp = __ballot(has_pend);
+        const int parked = __popcll(bp) + __popcll(__ballot(pend2 != NONE));
+        if (bp != 0ull && (bi2 == 0ull || RT_LEAF_DEN * parked >= RT_LEAF_NUM * __popcll(__ballot(has_inner || has_pend))))
+        {
+            if (has_pend)
+            {
+                const float4* g = bvh.rec + 3 * (size_t)(pend & ~WIDE_LEAF_BIT);
+                const float4 t0 = g[0], t1 = g[1], t2 = g[2];
+                pend = pend2; pend2 = NONE;
+                const f3 v0 = F3(t0.x, t0.y, t0.z), v1 = F3(t0.w, t1.x, t1.y), v2 = F3(t1.z, t1.w, t2.x);
+                float t, u, v;
+                if (intersect_ray_triangle(t, u, v, ro, rd, tmin, tmax, v0, v1, v2))
+                {
+                    s_hit[owner] = 1u; /* any hit settles a shadow ray */
+                    cur = NONE; pend = NONE; pend2 = NONE; sp = 0; base = 0;
+                }
+            }
+            continue;
+        }
+        if (has_inner)
+        {
+            if (stats) stats[1] += 0x10000u;
+            const float4* g = bvh.rec + 3 * (size_t)cur;
+            const float4 q0 = g[0], q1f = g[1], q2f = g[2];
+            const uint32_t e = as_uint(q0.w);
+            const uint32_t cbase = as_uint(q1f.x), meta = as_uint(q1f.y);
+            const uint32_t lx = as_uint(q1f.z), ly = as_uint(q1f.w), lz = as_uint(q2f.x);
+            const uint32_t hx = as_uint(q2f.y), hy = as_uint(q2f.z), hz = as_uint(q2f.w);
+            const uint32_t nx = px ? lx : hx, ny = py ? ly : hy, nz = pz ? lz : hz;
+            const uint32_t fx = px ? hx : lx, fy = py ? hy : ly, fz = pz ? hz : lz;
+            const float sx = as_float((e & 0xffu) << 23), sy = as_float(((e >> 8) & 0xffu) << 23),
+                        sz = as_float(((e >> 16) & 0xffu) << 23);
+            const float Ax = (q0.x - ro.x) * inv.x, Ay = (q0.y - ro.y) * inv.y, Az = (q0.z - ro.z) * inv.z;
+            const float Bx = sx * inv.x, By = sy * inv.y, Bz = sz * inv.z;
+            bool h[4];
+            uint32_t ce[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+            {
+                const uint32_t m = (meta >> (8 * k)) & 0xffu;
+                float tn = fmaxf(fmaxf(__builtin_fmaf(wide_byte(nx, k), Bx, Ax), __builtin_fmaf(wide_byte(ny, k), By, Ay)),
+                                 __builtin_fmaf(wide_byte(nz, k), Bz, Az));
+                float tf = fminf(fminf(__builtin_fmaf(wide_byte(fx, k), Bx, Ax), __builtin_fmaf(wide_byte(fy, k), By, Ay)),
+                                 __builtin_fmaf(wide_byte(fz, k), Bz, Az));
+                tn = fmaxf(tn * (1.0f - 4e-7f), tmin);
+                tf = fminf(tf * (1.0f + 4e-7f), tmax);
+                h[k] = (m != 0u) && (tn <= tf);
+                ce[k] = (cbase + (uint32_t)k) | (m == 2u ? WIDE_LEAF_BIT : 0u);
+            }
+            if (h[0] || h[1] || h[2] || h[3])
+            {
+                const bool deep = __ballot(sp + 3 > WIDE_LDS_STACK) != 0ull;
+                cur = h[0] ? ce[0] : (h[1] ? ce[1] : (h[2] ? ce[2] : ce[3]));
+                if (__builtin_expect(deep, 0))
+                {
+                    if (h[1] && h[0]) push(ce[1]);
+                    if (h[2] && (h[0] || h[1])) push(ce[2]);
+                    if (h[3] && (h[0] || h[1] || h[2])) push(ce[3]);
+                }
+                else
+                {
+                    if (h[3] && (h[0] || h[1] || h[2])) { lds_stack[sp * STRIDE + slot] = ce[3]; ++sp; }
+                    if (h[2] && (h[0] || h[1])) { lds_stack[sp * STRIDE + slot] = ce[2]; ++sp; }
+                    if (h[1] && h[0]) { lds_stack[sp * STRIDE + slot] = ce[1]; ++sp; }
+                }
+            }
+            else cur = sp > base ? pop() : NONE;
+        }
+    }
+    (void)ba;
+    if (stats) stats[0] = pass;
+    return s_hit[slot] != 0u;
+}
+
+/* WS: walk with occluded_ws (idle lanes of the wavefront take over part of a busy lane's stack). The answer is the
+ * same bit either way (any-hit of the same ray against the same triangles); it pays where a launch is a single round
+ * of wavefronts, i.e. the strips of the multi-GPU frame, and costs ~1-3 % on the full frame (rt_tuning key 13). */
+template <int STRIDE = BLOCK_THREADS, bool WS = false>
 RT_DEV bool check_visibility_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3 p0, f3 n0, f3 p1)
 {
     const f3 org = p0 + 0.001f * n0;
     const f3 dir = p1 - p0;
+    if (WS) return !occluded_ws<STRIDE>(bvh, lds_stack, org, dir, 0.0f, 0.99f);
     Hit h;
     return !trace_wide<true, false, STRIDE>(bvh, lds_stack, org, dir, 0.0f, 0.99f, h);
 }

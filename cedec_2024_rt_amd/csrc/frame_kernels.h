@@ -280,14 +280,14 @@ RT_DEV bool temporal_merge(const FrameParams& P, int x, int yi, f3 sp, f3 sn, Re
  * visibility is that sample's (reservoir.hpp:36) and the ray was dead work. In a steady sequence the history carries
  * M = 640 against the candidates' 32, so ~95 % of these rays are dead. Survivors are appended to a queue (wave
  * ballot + one atomic) and k_candidate_visibility walks them with full wavefronts and sets the bit. */
-template <bool FUSE_TEMPORAL, bool SHADOWED, bool DEFER = false, bool PIPE = false>
+template <bool FUSE_TEMPORAL, bool SHADOWED, bool DEFER = false, bool PIPE = false, bool WS = false>
 __global__ __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_generate_candidate(
     SceneView S, FrameParams P, const float4* __restrict__ g0, const float4* __restrict__ g1,
     const float4* __restrict__ prev_rec, const float4* __restrict__ prev_rad, float4* __restrict__ out_rec,
     float4* __restrict__ out_rad, uint32_t* __restrict__ vis_queue = nullptr, unsigned int* __restrict__ vis_count = nullptr)
 {
     static_assert(!DEFER || (FUSE_TEMPORAL && !SHADOWED), "deferred visibility: fused unshadowed kernel only");
-    __shared__ __attribute__((aligned(16))) uint32_t s_stack[DEFER ? 4 : WIDE_LDS_STACK * TRACE_BLOCK];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[DEFER ? 4 : (WS ? WIDE_LDS_ROWS : WIDE_LDS_STACK) * TRACE_BLOCK];
     int x = 0, row = P.row0;
     const bool in_image = tile_pixel<TRACE_BLOCK>(P, x, row);
     if (!DEFER && !in_image) return;
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_generate_candid
     if (FUSE_TEMPORAL && SHADOWED) load_prev(); /* its sample is a ray target */
     float V_cur = 1.0f, V_prev = 1.0f;
     if (SHADOWED) temporal_rays<TRACE_BLOCK>(S, s_stack, P, sp, sn, r, pr, FUSE_TEMPORAL, V_cur, V_prev);
-    else if (P.vis_reuse && !DEFER) V_cur = check_visibility_wide<TRACE_BLOCK>(S.wide, s_stack, sp, sn, r.hit_p) ? 1.0f : 0.0f;
+    else if (P.vis_reuse && !DEFER) V_cur = check_visibility_wide<TRACE_BLOCK, WS>(S.wide, s_stack, sp, sn, r.hit_p) ? 1.0f : 0.0f;
     {
         const float p_hat = SHADOWED ? target_shadowed(sp, sn, r.hit_p, r.hit_n, r.lum, V_cur)
                                      : target_unshadowed(sp, sn, r.hit_p, r.hit_n, r.lum);
@@ -1011,12 +1011,13 @@ __global__ void k_halo_flags(float4* __restrict__ g1, size_t off, int n_pix, uin
 #ifndef RT_RESOLVE_WAVES
 #define RT_RESOLVE_WAVES 6
 #endif
+template <bool WS>
 __global__ __launch_bounds__(TRACE_BLOCK, RT_RESOLVE_WAVES) void k_resolve(SceneView S, FrameParams P, const float4* __restrict__ g0,
                                                     const float4* __restrict__ g1,
                                                     const float4* __restrict__ rec,
                                                     const float4* __restrict__ radb, float4* __restrict__ accum)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_STACK * TRACE_BLOCK];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[(WS ? WIDE_LDS_ROWS : WIDE_LDS_STACK) * TRACE_BLOCK];
     int x, row;
     if (!tile_pixel<TRACE_BLOCK>(P, x, row)) return;
     const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
@@ -1037,7 +1038,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_RESOLVE_WAVES) void k_resolve(Scene
     const f3 hp = F3(q0.x, q0.y, q0.z), hn = F3(q1.x, q1.y, q1.z);
     const f3 brdf = (1.0f / kPI) * F3(kd.x, kd.y, kd.z);
     const float G = geometry_term(sp, sn, hp, hn);
-    const float V = check_visibility_wide<TRACE_BLOCK>(S.wide, s_stack, sp, sn, hp) ? 1.0f : 0.0f;
+    const float V = check_visibility_wide<TRACE_BLOCK, WS>(S.wide, s_stack, sp, sn, hp) ? 1.0f : 0.0f;
     const f3 radiance = brdf * G * V * F3(rq.x, rq.y, rq.z) * q0.w;
     if (P.accumulate)
     {
@@ -1049,6 +1050,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_RESOLVE_WAVES) void k_resolve(Scene
 
 
 /* ------------------------------------------------------- configs #2 / #3: path tracers */
+/* shadow rays of 08_nee / 09_ris through the work-sharing walk (bvh.h occluded_ws) */
+#ifndef RT_PT_WS
+#define RT_PT_WS 1
+#endif
 /* common/core.hpp:76-89 with portable cos/sin [parity] */
 RT_DEV f3 sample_hemisphere(float r0, float r1, float r2)
 {
@@ -1123,7 +1128,7 @@ RT_DEV bool path_bounce(const SceneView& S, uint32_t* s_stack, const FrameParams
         warp_unit_triangle(bx, by);
         const f3 lp = (1.0f - bx - by) * a0 + bx * a1 + by * a2;
         const f3 ln = tri_normal(a0, a1, a2);
-        const float V = check_visibility_wide<STRIDE>(S.wide, s_stack, sp, sn, lp) ? 1.0f : 0.0f;
+        const float V = check_visibility_wide<STRIDE, RT_PT_WS>(S.wide, s_stack, sp, sn, lp) ? 1.0f : 0.0f;
         ++nrays;
         const f3 brdf = (1.0f / kPI) * kd;
         const float G = geometry_term(sp, sn, lp, ln);
@@ -1201,7 +1206,7 @@ RT_DEV bool path_bounce(const SceneView& S, uint32_t* s_stack, const FrameParams
         const f3 brdf = (1.0f / kPI) * kd;
         const float G = geometry_term(sp, sn, r.hit_p, r.hit_n);
         /* no candidate selected (all weights 0): the reference still walks surface -> Reservoir{}'s zero position */
-        const float V = have_sel ? V_sel : (check_visibility_wide<STRIDE>(S.wide, s_stack, sp, sn, r.hit_p) ? 1.0f : 0.0f);
+        const float V = have_sel ? V_sel : (check_visibility_wide<STRIDE, RT_PT_WS>(S.wide, s_stack, sp, sn, r.hit_p) ? 1.0f : 0.0f);
         nrays += 2; /* :110-113 and :116-120 */
         const float p_hat = target_shadowed(sp, sn, r.hit_p, r.hit_n, r.lum, V);
         const float ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
@@ -1239,7 +1244,7 @@ RT_DEV bool path_bounce(const SceneView& S, uint32_t* s_stack, const FrameParams
         }
         const f3 brdf = (1.0f / kPI) * kd;
         const float G = geometry_term(sp, sn, r.hit_p, r.hit_n);
-        const float V = check_visibility_wide<STRIDE>(S.wide, s_stack, sp, sn, r.hit_p) ? 1.0f : 0.0f;
+        const float V = check_visibility_wide<STRIDE, RT_PT_WS>(S.wide, s_stack, sp, sn, r.hit_p) ? 1.0f : 0.0f;
         ++nrays;
         const float p_hat = target_unshadowed(sp, sn, r.hit_p, r.hit_n, r.lum);
         const float ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
@@ -1282,7 +1287,7 @@ __global__ __launch_bounds__(EXAMPLE == 7 ? BLOCK : TRACE_BLOCK, EXAMPLE == 7 ? 
 {
     /* 07_pt (one ray per bounce, no light sampling) is 3-8 % faster on 256-thread groups, 08/09 on one-wavefront groups */
     constexpr int TB = EXAMPLE == 7 ? BLOCK : TRACE_BLOCK;
-    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_STACK * TB];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[(RT_PT_WS ? WIDE_LDS_ROWS : WIDE_LDS_STACK) * TB];
     int x, row;
     const bool ok = tile_pixel<TB>(P, x, row);
     unsigned long long nrays = 0;
@@ -1341,7 +1346,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, EXAMPLE == 7 ? 1 : (EXAMPLE == 8 ? 6 :
                                                       const float4* __restrict__ in, float4* __restrict__ out,
                                                       float4* __restrict__ accum, unsigned long long* __restrict__ counters)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_STACK * TRACE_BLOCK];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[(RT_PT_WS ? WIDE_LDS_ROWS : WIDE_LDS_STACK) * TRACE_BLOCK];
     const size_t i = (size_t)blockIdx.x * TRACE_BLOCK + threadIdx.x;
     const bool have = i < counters[2 + depth];
     unsigned long long nrays = 0;
@@ -1507,6 +1512,19 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest(SceneView S, const floa
     else trace<ANY>(S.bvh, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7], h);
     float* o = hits + 4 * (size_t)i;
     o[0] = h.t; o[1] = h.u; o[2] = h.v; o[3] = as_float(h.prim);
+}
+/* statistics of the work-sharing shadow-ray walk: one-wavefront workgroups as in the frame kernels;
+ * stats[2i] = passes the ray's wavefront ran, stats[2i+1] = steals by this lane | inner records it visited << 16 */
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_stats_ws(SceneView S, const float* __restrict__ rays, int n, uint32_t* __restrict__ stats)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_ROWS * TRACE_BLOCK];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rays + 8 * (size_t)i;
+    uint32_t st[2] = {0u, 0u};
+    if (r[7] >= 0.0f) occluded_ws<TRACE_BLOCK>(S.wide, s_stack, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7], st);
+    stats[2 * (size_t)i] = st[0];
+    stats[2 * (size_t)i + 1] = st[1];
 }
 template <int MODE, bool ANY = false>
 __global__ __launch_bounds__(BLOCK) void k_trace_stats(SceneView S, const float* __restrict__ rays, int n, uint32_t* __restrict__ stats)

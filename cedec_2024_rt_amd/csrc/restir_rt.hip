@@ -68,6 +68,8 @@ struct rt_ctx
      * (main / second stream), its counter, and the last count that reached the host (sizes the next launch) */
     int tune_defer_vis = 0; /* rt_tuning key 11 */
     int tune_ris_pipe = 0;  /* rt_tuning key 12: software-pipelined RIS loop in the fused unshadowed candidate kernel */
+    int tune_ws = 1;        /* rt_tuning key 13: work-sharing shadow-ray walk in generate / resolve: -1 auto (launches of
+                               at most RT_WS_AUTO_WAVES wavefronts), 0 never, 1 always */
     uint32_t* d_visq[2] = {nullptr, nullptr};
     unsigned int* d_visq_count = nullptr; /* [2] */
     unsigned int* h_visq_count = nullptr; /* pinned [2]; 0xffffffff = unknown */
@@ -862,6 +864,14 @@ static int launch_grid(const rt_ctx* c)
 {
     return c->sub0 >= 0 ? tile_grid(c->W, c->sub1 - c->sub0, TILE_W, TILE_H, c->subb1 - c->subb0) : tile_grid(c->W, c->row_end - c->row_begin);
 }
+/* The work-sharing walk evens out the per-wavefront tail (longest lane 8x the mean: profiles/r02_wave_tail.txt). A launch
+ * of many rounds of wavefronts hides that tail behind the next wavefronts and only pays the bookkeeping; a launch of
+ * about one round (a strip of the multi-GPU frame: 135 rows x 1920 = 4050 wavefronts on 1024 SIMDs x 4-5) ends with
+ * its slowest wavefront and runs ~2x faster with it. */
+#ifndef RT_WS_AUTO_WAVES
+#define RT_WS_AUTO_WAVES 12288
+#endif
+static bool use_ws(const rt_ctx* c, int grid) { return c->tune_ws < 0 ? grid <= RT_WS_AUTO_WAVES : c->tune_ws != 0; }
 /* grid of the tracing kernels: TRACE_BLOCK threads on TileShape<TRACE_BLOCK> tiles */
 static int trace_grid(const rt_ctx* c)
 {
@@ -936,6 +946,7 @@ static int launch_generate(rt_ctx* c, int frame, int dst_phys, int prev_phys, bo
     }
     if (fuse && sh) k_generate_candidate<true, true><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
     else if (fuse && c->tune_ris_pipe) k_generate_candidate<true, false, false, true><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
+    else if (fuse && use_ws(c, g)) k_generate_candidate<true, false, false, false, true><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
     else if (fuse) k_generate_candidate<true, false><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
     else if (sh) k_generate_candidate<false, true><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
     else k_generate_candidate<false, false><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
@@ -1047,8 +1058,9 @@ int rt_spatial_resampling(rt_ctx* c, int frame, int pass, int in, int out)
 
 static int launch_resolve(rt_ctx* c, int phys)
 {
-    k_resolve<<<trace_grid(c), TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RESOLVE), c->d_g0, c->d_g1,
-                                                        c->d_rec[phys], c->d_rad[phys], c->d_accum);
+    const int g = trace_grid(c);
+    if (use_ws(c, g)) k_resolve<true><<<g, TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RESOLVE), c->d_g0, c->d_g1, c->d_rec[phys], c->d_rad[phys], c->d_accum);
+    else k_resolve<false><<<g, TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RESOLVE), c->d_g0, c->d_g1, c->d_rec[phys], c->d_rad[phys], c->d_accum);
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }
@@ -1846,7 +1858,8 @@ int rt_trace_stats(rt_ctx* c, const float* rays, uint32_t n, uint32_t* stats)
     RT_HIP(c, hipMalloc(&d_r, (size_t)n * 32));
     RT_HIP(c, hipMalloc(&d_s, (size_t)n * 8));
     RT_HIP(c, hipMemcpyAsync(d_r, rays, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
-    if (c->trace_mode == 0) k_trace_stats<0><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_s);
+    if (c->trace_mode == 5) k_trace_stats_ws<<<(n + TRACE_BLOCK - 1) / TRACE_BLOCK, TRACE_BLOCK, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_s);
+    else if (c->trace_mode == 0) k_trace_stats<0><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_s);
     else if (c->trace_mode == 4) k_trace_stats<0, true><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_s);
     else k_trace_stats<1><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_s);
     RT_HIP(c, hipGetLastError());
@@ -1880,6 +1893,7 @@ int rt_tuning(rt_ctx* c, int key, int value)
     else if (key == 10 && value >= 1 && value <= 256) c->ploc_radius = value; /* before rt_scene_set */
     else if (key == 11 && (value == 0 || value == 1)) c->tune_defer_vis = value;
     else if (key == 12 && (value == 0 || value == 1)) c->tune_ris_pipe = value;
+    else if (key == 13 && value >= -1 && value <= 1) c->tune_ws = value;
     else RT_FAIL(c, RT_ERR_ARG, "bad tuning key/value %d/%d", key, value);
     return RT_OK;
 }
@@ -1888,7 +1902,7 @@ int rt_tuning(rt_ctx* c, int key, int value)
 int rt_trace_mode(rt_ctx* c, int mode)
 {
     RT_CHECK_CTX(c);
-    if (mode < 0 || mode > 4) RT_FAIL(c, RT_ERR_ARG, "mode must be 0..4");
+    if (mode < 0 || mode > 5) RT_FAIL(c, RT_ERR_ARG, "mode must be 0..5");
     c->trace_mode = mode;
     return RT_OK;
 }

@@ -165,6 +165,8 @@ struct rt_mg
 
     hipStream_t comm = nullptr, prep = nullptr; /* prep: the next frame's halo marks, beside this frame's passes */
     hipEvent_t ev_packed = nullptr, ev_arrived = nullptr, ev_plan[2] = {nullptr, nullptr}, ev_gbuf = nullptr, ev_marked = nullptr;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr; /* GPU-side clock of the frame loop: start of the first / latest frame since rt_mg_reset_stats */
+    unsigned long long frames_timed = 0;
     ncclComm_t nccl = nullptr;
     LocalHub* hub = nullptr;
     ShmSegment shm;
@@ -402,6 +404,8 @@ int rt_mg_create(rt_ctx* ctx, int rank, int world, const int* bounds, int transp
     MG_HIP(m, hipEventCreateWithFlags(&m->ev_packed, hipEventDisableTiming));
     MG_HIP(m, hipEventCreateWithFlags(&m->ev_arrived, hipEventDisableTiming));
     for (auto& e : m->ev_plan) MG_HIP(m, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    MG_HIP(m, hipEventCreate(&m->ev_t0));
+    MG_HIP(m, hipEventCreate(&m->ev_t1));
     int rc = alloc_sides(m);
     if (rc != RT_OK) return rc;
     if (world > 1 && transport == RT_MG_TRANSPORT_RCCL)
@@ -478,6 +482,14 @@ int rt_mg_destroy(rt_mg* m)
 int rt_mg_get_stats(rt_mg* m, rt_mg_stats* out)
 {
     if (!m || !out) return RT_ERR_ARG;
+    m->stats.gpu_ns_per_frame = 0;
+    if (m->frames_timed >= 2)
+    {
+        /* GPU clock between the starts of the first and the latest frame since the reset */
+        float ms = 0.0f;
+        if (hipEventSynchronize(m->ev_t1) == hipSuccess && hipEventElapsedTime(&ms, m->ev_t0, m->ev_t1) == hipSuccess)
+            m->stats.gpu_ns_per_frame = (unsigned long long)((double)ms * 1e6 / (double)(m->frames_timed - 1));
+    }
     *out = m->stats;
     return RT_OK;
 }
@@ -485,6 +497,7 @@ int rt_mg_reset_stats(rt_mg* m)
 {
     if (!m) return RT_ERR_ARG;
     memset(&m->stats, 0, sizeof(m->stats));
+    m->frames_timed = 0;
     return RT_OK;
 }
 
@@ -772,6 +785,8 @@ int rt_mg_frame_begin(rt_mg* m, int frame, int clear_first)
         }
     }
     m->seg = rt_mg::SEG_RAYCAST;
+    MG_HIP(m, hipEventRecord(m->frames_timed == 0 ? m->ev_t0 : m->ev_t1, main_stream(m)));
+    m->frames_timed += 1;
     m->stats.frames += 1;
     if (m->use_sparse && !m->warm) m->stats.cold_frames += 1;
     return RT_OK;

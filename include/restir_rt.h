@@ -237,6 +237,7 @@ typedef struct
     unsigned long long host_ns;             /* host time spent inside rt_mg_frame_step (enqueueing) */
     unsigned long long plan_wait_ns;        /* host time waiting for the next frame's plan counts (0 in a steady loop) */
     unsigned long long bytes_sent, messages, records_sent;
+    unsigned long long gpu_ns_per_frame;    /* HIP-event time between the starts of the first and the latest frame / (frames - 1) */
 } rt_mg_stats;
 /* strips of >= halo rows; row_cost NULL: near-equal heights; else minimise the most expensive strip
  * (row_cost[r] = e.g. shaded pixels of storage row r). bounds: world + 1 entries. */
@@ -318,8 +319,13 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
  * key 7 (before rt_scene_set): number of wide-BVH records emitted breadth-first before the
  * collapse switches to depth-first order (record order only; no measurable effect, default 2048).
  * key 11: rt_frame's fused generate_candidate + temporal_resampling (unshadowed target) walks the visibility-reuse ray
- * of 10_restir_di.cu:127-131 1 (default) = only for candidates that survive the temporal merge — the ray's answer is
- * unobservable otherwise — through a compacted queue, 0 = for every candidate as the reference does. Same results.
+ * of 10_restir_di.cu:127-131 1 = only for candidates that survive the temporal merge — the ray's answer is
+ * unobservable otherwise — through a compacted queue, 0 (default: 75 % survive in the bench scene, no gain) = for
+ * every candidate as the reference does. Same results.
+ * key 12: 1 = software-pipelined RIS loop in the fused candidate kernel (A/B only, default 0).
+ * key 13: shadow rays of generate_candidate / resolve walked with the work-sharing any-hit traversal (idle lanes of a
+ * wavefront take over half of a busy lane's LDS stack): -1 (default) = for launches of at most ~one round of
+ * wavefronts (strips of the multi-GPU frame), 0 = never, 1 = always. Same results.
  * key 10 (before rt_scene_set): PLOC search radius of builder 2 (places in Morton order, default 16).
  * key 9: register budget of the unshadowed spatial pass, in wavefronts per SIMD (4, 5, 6; 0 = unbounded = 7; -1 = auto,
  * default: 4 for the gather kernel — fewer workgroups in flight keep its neighbour window inside the XCD's 4 MiB L2 —

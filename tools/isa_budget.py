@@ -160,8 +160,8 @@ def summarise(ops):
     return cls, cyc, buckets
 
 
-KERNELS = [("k_raycast", "k_raycast("), ("k_generate_candidate<true,false>", "k_generate_candidate<true, false>("),
-           ("k_spatial_gather", "k_spatial_gather("), ("k_spatial_lds", "k_spatial_lds("), ("k_resolve", "k_resolve("), ("k_spatial<true>", "k_spatial<true>("),
+KERNELS = [("k_raycast", "k_raycast("), ("k_generate_candidate<true,false>", "k_generate_candidate<true, false, false, false, false>("),
+           ("k_spatial_gather", "k_spatial_gather("), ("k_spatial_lds", "k_spatial_lds("), ("k_resolve", "k_resolve<false>("), ("k_spatial<true>", "k_spatial<true>("),
            ("k_temporal<false>", "k_temporal<false>("), ("k_tone_mapping", "k_tone_mapping("),
            ("k_path_trace<9,false>", "k_path_trace<9, false>(")]
 LOOP_KERNELS = {"k_raycast", "k_generate_candidate<true,false>", "k_spatial_gather", "k_resolve"}

@@ -46,7 +46,7 @@ def measure(W, H, N, flags, tris, frames=40, warm=6, rank=None):
     r.sync()
     wall = time.perf_counter() - t0
     st = mg.stats()
-    out = dict(rows=b - a, ms_per_frame=round(wall / frames * 1e3, 4), host_us=round(st["host_ns"] / frames / 1e3, 1),
+    out = dict(rows=b - a, ms_per_frame=round(wall / frames * 1e3, 4), gpu_event_ms_per_frame=round(st["gpu_ns_per_frame"] / 1e6, 4), host_us=round(st["host_ns"] / frames / 1e3, 1),
                host_loop_us=round(t_host / frames * 1e6, 1), plan_wait_us=round(st["plan_wait_ns"] / frames / 1e3, 1),
                cold_frames=st["cold_frames"], MB_sent_per_frame=round(st["bytes_sent"] / frames / 1e6, 3),
                messages_per_frame=st["messages"] / frames)

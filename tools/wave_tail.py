@@ -63,3 +63,17 @@ def report(name, mode, rays, live):
 
 report("shadow rays (any hit)", 4, shadow, sh)
 report("primary rays (closest)", 0, prim, np.ones(len(prim), bool))
+
+# the work-sharing walk (occluded_ws): passes per wavefront and steals
+r.trace_mode(5)
+st = r.trace_stats(shadow)  # masked to 16 bits by the binding: use the raw call
+import ctypes as C
+raw = np.zeros((len(shadow), 2), dtype=np.uint32)
+rr = np.ascontiguousarray(shadow, dtype=np.float32)
+r._ck(r.L.rt_trace_stats(r.h, rr.ctypes.data_as(C.c_void_p), len(rr), raw.ctypes.data_as(C.c_void_p)))
+wave = raw[:, 0].reshape(-1, 64).max(1).astype(np.int64)
+wave = wave[wave > 0]
+steals = (raw[:, 1] & 0xffff).astype(np.int64)
+steps = (raw[:, 1] >> 16).astype(np.int64)
+print("work-sharing shadow rays: per-wave passes mean %.1f p50 %d p90 %d p99 %d max %d; steals per wavefront %.1f; inner records per lane mean %.1f (sum over a wave / 64 = %.1f)" % (
+    wave.mean(), *np.percentile(wave, [50, 90, 99]).astype(int), wave.max(), steals.reshape(-1, 64).sum(1).mean(), steps[sh].mean(), steps.reshape(-1, 64).sum(1).mean() / 64), flush=True)
