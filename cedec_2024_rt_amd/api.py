@@ -25,7 +25,7 @@ EXPORTS = [
     "rt_camera_updated", "rt_camera_pose", "rt_options_set", "rt_options_get", "rt_clear",
     "rt_raycast", "rt_generate_candidate", "rt_temporal_resampling", "rt_save_temporal_reservoir",
     "rt_spatial_resampling", "rt_resolve", "rt_tone_mapping", "rt_frame", "rt_frame_stage", "rt_frame_stage_input", "rt_frame_stage_begin", "rt_frame_stage_run", "rt_frame_stage_end", "rt_frame_stage_output", "rt_frame_stage_run_part", "rt_frame_stage_fork", "rt_frame_stage_run_async", "rt_frame_stage_run_ranges", "rt_halo_bitmap_words", "rt_halo_flags_bytes",
-    "rt_halo_flags_pack", "rt_halo_flags_unpack", "rt_halo_mark", "rt_halo_scan", "rt_halo_pack_sparse", "rt_halo_unpack_sparse", "rt_path_trace", "rt_path_trace_rays", "rt_local_rows", "rt_download",
+    "rt_halo_flags_pack", "rt_halo_flags_unpack", "rt_halo_mark", "rt_halo_scan", "rt_halo_pack_sparse", "rt_halo_unpack_sparse", "rt_halo_mark_sides", "rt_halo_pack_sparse_ranges", "rt_halo_unpack_sparse_ranges", "rt_path_trace", "rt_path_trace_rays", "rt_local_rows", "rt_download",
     "rt_upload", "rt_halo_bytes", "rt_halo_pack", "rt_halo_unpack", "rt_ray_count", "rt_timing_enable",
     "rt_timing", "rt_spatial_bytes", "rt_trace_closest", "rt_trace_stats", "rt_bvh_config", "rt_bvh_info", "rt_build_ms", "rt_trace_mode", "rt_trace_time", "rt_tuning", "rt_math_eval",
     "rt_row_shaded", "rt_visibility_rays_walked", "rt_state_epoch", "rt_get_stream", "rt_geometry", "rt_res_region", "rt_lane",
@@ -113,6 +113,9 @@ def load_library():
     L.rt_halo_scan.argtypes = [vp, ci, ci, vp]
     L.rt_halo_pack_sparse.argtypes = [vp, ci, ci, ci, vp, vp]
     L.rt_halo_unpack_sparse.argtypes = [vp, ci, ci, ci, vp, vp]
+    L.rt_halo_mark_sides.argtypes = [vp, ci, ci, ci, vp, vp]
+    L.rt_halo_pack_sparse_ranges.argtypes = [vp, ci, ci, vp, vp, vp, vp]
+    L.rt_halo_unpack_sparse_ranges.argtypes = [vp, ci, ci, vp, vp, vp, vp]
     L.rt_frame_stage_output.argtypes = [vp, ci, vp]
     L.rt_local_rows.argtypes = [vp, vp, vp]
     L.rt_download.argtypes = [vp, ci, vp, C.c_size_t]
@@ -581,6 +584,18 @@ class Renderer:
         self._ck(self.L.rt_trace_stats(self.h, _p(r), len(r), _p(st)))
         self.last_wave_passes = st >> 16  # wide traversal: inner / leaf passes of the ray's wavefront
         return st & 0xFFFF
+
+    def trace_occluded_ws(self, rays):
+        """any-hit answers of the work-sharing walk (trace mode 5; rays with tmax < 0 are lanes without a ray), plus the
+        passes each ray's wavefront ran and the steals of each lane"""
+        rr = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        raw = np.zeros((len(rr), 2), dtype=np.uint32)
+        self._ck(self.L.rt_trace_mode(self.h, 5))
+        try:
+            self._ck(self.L.rt_trace_stats(self.h, _p(rr), len(rr), _p(raw)))
+        finally:
+            self._ck(self.L.rt_trace_mode(self.h, 0))
+        return (raw[:, 0] >> 31).astype(bool), raw[:, 0] & 0x7fffffff, raw[:, 1] & 0xffff
 
     def bvh_config(self, split_factor):
         self._ck(self.L.rt_bvh_config(self.h, C.c_float(split_factor)))

@@ -411,6 +411,9 @@ RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3
 #ifndef RT_WS_MIN
 #define RT_WS_MIN 4
 #endif
+#ifndef RT_WS_RICH
+#define RT_WS_RICH 1 /* a lane can be robbed when its stack holds at least this many entries */
+#endif
 template <int STRIDE = BLOCK_THREADS>
 RT_DEV bool occluded_ws(const WideView& bvh, uint32_t* __restrict__ lds_generic, f3 ro, f3 rd, float tmin, float tmax,
                         uint32_t* stats = nullptr /* [0] passes of the wavefront, [1] steals by this lane | own steps << 16 */)
@@ -470,7 +473,7 @@ RT_DEV bool occluded_ws(const WideView& bvh, uint32_t* __restrict__ lds_generic,
                 has_inner = false; has_pend = false;
             }
             const bool idle = !has_inner && !has_pend;
-            const bool rich = !idle && (sp - base) >= 2 && sp <= WIDE_LDS_STACK;
+            const bool rich = !idle && (sp - base) >= RT_WS_RICH && sp <= WIDE_LDS_STACK;
             const unsigned long long bi = __ballot(idle), br = __ballot(rich);
             const int nidle = __popcll(bi), nrich = __popcll(br);
             if (nidle >= RT_WS_MIN && nrich > 0)
@@ -485,9 +488,11 @@ RT_DEV bool occluded_ws(const WideView& bvh, uint32_t* __restrict__ lds_generic,
                 const float vox = __shfl(ro.x, victim), voy = __shfl(ro.y, victim), voz = __shfl(ro.z, victim);
                 const float vdx = __shfl(rd.x, victim), vdy = __shfl(rd.y, victim), vdz = __shfl(rd.z, victim);
                 const float vix = __shfl(inv.x, victim), viy = __shfl(inv.y, victim), viz = __shfl(inv.z, victim);
+                const float vtmin = __shfl(tmin, victim), vtmax = __shfl(tmax, victim);
                 const int vbase = __shfl(base, victim), vsp = __shfl(sp, victim), vowner = __shfl(owner, victim);
                 if (thief)
                 {
+                    tmin = vtmin; tmax = vtmax;
                     const int k = (vsp - vbase + 1) >> 1; /* the bottom half: the largest pending subtrees */
                     ro = F3(vox, voy, voz); rd = F3(vdx, vdy, vdz); inv = F3(vix, viy, viz);
                     px = inv.x >= 0.0f; py = inv.y >= 0.0f; pz = inv.z >= 0.0f;
@@ -498,7 +503,7 @@ RT_DEV bool occluded_ws(const WideView& bvh, uint32_t* __restrict__ lds_generic,
                     cur = pop();
                     if (stats) stats[1] += 1u;
                 }
-                if (robbed) base += (sp - base + 1) >> 1;
+                if (robbed) { base += (sp - base + 1) >> 1; if (base == sp) { base = 0; sp = 0; } }
                 has_inner = cur < NONE;
             }
         }

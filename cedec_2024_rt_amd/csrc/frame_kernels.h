@@ -903,9 +903,15 @@ __global__ __launch_bounds__(BLOCK) void k_spatial_bytes(FrameParams P, const fl
  * marked records only, in bitmap order (k_halo_sparse). Bitmap buffer (uint32 words):
  *   [0] = number of marked records, [1 .. nw] = bits (bit i of word w = pixel 32*w + i of the
  *   region, row-major from region row 0), [1+nw .. 1+2nw) = exclusive prefix counts per word. */
-__global__ __launch_bounds__(BLOCK) void k_halo_mark(FrameParams P, const float4* __restrict__ g1, int reg_row0,
-                                                      int reg_rows, int pass0, int n_pass, size_t words_per_pass,
-                                                      uint32_t* __restrict__ bitmaps)
+/* the neighbours' regions (side 0 below, side 1 above) marked by ONE launch over the own rows that can reach either;
+ * rows[s] == 0: no neighbour on that side */
+struct HaloRegions
+{
+    int row0[2], rows[2];
+    size_t words[2]; /* rt_halo_bitmap_words of the region = distance between the bitmaps of consecutive passes */
+    uint32_t* bitmaps[2];
+};
+__global__ __launch_bounds__(BLOCK) void k_halo_mark(FrameParams P, const float4* __restrict__ g1, HaloRegions R, int pass0, int n_pass)
 {
     int x, row;
     if (!tile_pixel(P, x, row)) return;
@@ -915,7 +921,6 @@ __global__ __launch_bounds__(BLOCK) void k_halo_mark(FrameParams P, const float4
     const float scale = P.spatial_radius / 1.96f;
     for (int pi = 0; pi < n_pass; ++pi) /* one bitmap per spatial pass, same launch */
     {
-        uint32_t* bitmap = bitmaps + (size_t)pi * words_per_pass;
         PCG rng = pcg_init(hashPCG4((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame, (uint32_t)(2 + pass0 + pi)), 0);
         for (int k = 0; k < P.spatial_count; ++k)
         {
@@ -932,21 +937,20 @@ __global__ __launch_bounds__(BLOCK) void k_halo_mark(FrameParams P, const float4
             const int nrow = P.H - 1 - ny;
             const int lr = nrow - P.lrow0;
             if (lr < 0 || lr >= P.lrows) continue;
-            if (nrow >= reg_row0 && nrow < reg_row0 + reg_rows)
-            {
-                const uint32_t bit = (uint32_t)(nrow - reg_row0) * (uint32_t)P.W + (uint32_t)nx;
-                atomicOr(&bitmap[1 + (bit >> 5)], 1u << (bit & 31u));
-            }
+#pragma unroll
+            for (int sd = 0; sd < 2; ++sd)
+                if (nrow >= R.row0[sd] && nrow < R.row0[sd] + R.rows[sd])
+                {
+                    const uint32_t bit = (uint32_t)(nrow - R.row0[sd]) * (uint32_t)P.W + (uint32_t)nx;
+                    atomicOr(&R.bitmaps[sd][(size_t)pi * R.words[sd] + 1 + (bit >> 5)], 1u << (bit & 31u));
+                }
             if (!(as_uint(g1[(size_t)nx + (size_t)lr * P.W].w) & GB_SHADED)) continue;
             rng.uniformf();
         }
     }
 }
-/* one workgroup per bitmap: exclusive prefix of the per-word popcounts, total into word 0 */
-__global__ void k_halo_scan(uint32_t* __restrict__ bitmaps, int nw, size_t words_per_bitmap)
+RT_DEV void halo_scan_one(uint32_t* __restrict__ bitmap, int nw, uint32_t* s_sum)
 {
-    __shared__ uint32_t s_sum[1024];
-    uint32_t* bitmap = bitmaps + (size_t)blockIdx.x * words_per_bitmap; /* one workgroup per bitmap */
     const int t = threadIdx.x, T = blockDim.x;
     const int per = (nw + T - 1) / T;
     const int w0 = t * per, w1 = min(nw, w0 + per);
@@ -969,19 +973,43 @@ __global__ void k_halo_scan(uint32_t* __restrict__ bitmaps, int nw, size_t words
     }
     if (t == T - 1) bitmap[0] = s_sum[t];
 }
+/* one workgroup per bitmap: exclusive prefix of the per-word popcounts, total into word 0 */
+__global__ void k_halo_scan(uint32_t* __restrict__ bitmaps, int nw, size_t words_per_bitmap)
+{
+    __shared__ uint32_t s_sum[1024];
+    uint32_t* bitmap = bitmaps + (size_t)blockIdx.x * words_per_bitmap; /* one workgroup per bitmap */
+    halo_scan_one(bitmap, nw, s_sum);
+}
+/* the bitmaps of both sides in one launch: blockIdx.y = side, blockIdx.x = pass */
+__global__ void k_halo_scan_sides(HaloRegions R)
+{
+    __shared__ uint32_t s_sum[1024];
+    const int sd = blockIdx.y;
+    if (R.rows[sd] <= 0) return;
+    halo_scan_one(R.bitmaps[sd] + (size_t)blockIdx.x * R.words[sd], (int)((R.words[sd] - 1) / 2), s_sum);
+}
+
 /* PACK: marked records of rows [row0, row0+rows) -> dense list (64 B record + 16 B radiance each);
  * UNPACK: the reverse. */
-template <bool PACK>
-__global__ void k_halo_sparse(const uint32_t* __restrict__ bitmap, int nw, int W, size_t region_off, int n_pix,
-                              float4* __restrict__ rec, float4* __restrict__ radb, float4* __restrict__ list)
+struct HaloLists /* up to two (bitmap, rows, list) sets served by one launch: blockIdx.y picks the set */
 {
+    const uint32_t* bitmap[2];
+    int nw[2], n_pix[2];
+    size_t region_off[2];
+    float4* list[2];
+};
+template <bool PACK>
+__global__ void k_halo_sparse(HaloLists H, float4* __restrict__ rec, float4* __restrict__ radb)
+{
+    const int sd = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pix) return;
+    if (i >= H.n_pix[sd]) return;
+    const uint32_t* __restrict__ bitmap = H.bitmap[sd];
     const uint32_t word = bitmap[1 + (i >> 5)];
     if (!(word & (1u << (i & 31)))) return;
-    const uint32_t idx = bitmap[1 + nw + (i >> 5)] + (uint32_t)__popc(word & ((1u << (i & 31)) - 1u));
-    float4* L = list + 5 * (size_t)idx;
-    const size_t p = region_off + (size_t)i;
+    const uint32_t idx = bitmap[1 + H.nw[sd] + (i >> 5)] + (uint32_t)__popc(word & ((1u << (i & 31)) - 1u));
+    float4* L = H.list[sd] + 5 * (size_t)idx;
+    const size_t p = H.region_off[sd] + (size_t)i;
     if (PACK)
     {
         L[0] = rec[4 * p + 0]; L[1] = rec[4 * p + 1]; L[2] = rec[4 * p + 2]; L[3] = rec[4 * p + 3];
@@ -992,7 +1020,6 @@ __global__ void k_halo_sparse(const uint32_t* __restrict__ bitmap, int nw, int W
         rec[4 * p + 0] = L[0]; rec[4 * p + 1] = L[1]; rec[4 * p + 2] = L[2]; rec[4 * p + 3] = L[3];
         radb[p] = L[4];
     }
-    (void)W;
 }
 /* shaded flags of rows as bytes (halo rows of the G-buffer only ever hold these flags) */
 template <bool PACK>
@@ -1514,7 +1541,8 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest(SceneView S, const floa
     o[0] = h.t; o[1] = h.u; o[2] = h.v; o[3] = as_float(h.prim);
 }
 /* statistics of the work-sharing shadow-ray walk: one-wavefront workgroups as in the frame kernels;
- * stats[2i] = passes the ray's wavefront ran, stats[2i+1] = steals by this lane | inner records it visited << 16 */
+ * stats[2i] = passes the ray's wavefront ran | occluded << 31, stats[2i+1] = steals by this lane | inner records it
+ * visited << 16 */
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_stats_ws(SceneView S, const float* __restrict__ rays, int n, uint32_t* __restrict__ stats)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_ROWS * TRACE_BLOCK];
@@ -1522,8 +1550,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_stats_ws(SceneView S, con
     if (i >= n) return;
     const float* r = rays + 8 * (size_t)i;
     uint32_t st[2] = {0u, 0u};
-    if (r[7] >= 0.0f) occluded_ws<TRACE_BLOCK>(S.wide, s_stack, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7], st);
-    stats[2 * (size_t)i] = st[0];
+    bool occ = false;
+    if (r[7] >= 0.0f) occ = occluded_ws<TRACE_BLOCK>(S.wide, s_stack, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7], st);
+    stats[2 * (size_t)i] = st[0] | (occ ? 0x80000000u : 0u);
     stats[2 * (size_t)i + 1] = st[1];
 }
 template <int MODE, bool ANY = false>

@@ -49,6 +49,18 @@ struct rt_ctx
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_stage = nullptr, ev_aux = nullptr;
     bool aux_used = false;
+    /* The raycast of frame f+1 does not depend on frame f (it needs the camera only), so rt_frame_stage launches it on a
+     * stream of its own behind stage 0 of frame f, into the second G-buffer set: it runs beside the spatial passes
+     * (HBM-bound) and the halo exchanges of frame f and frame f+1 starts at generate_candidate. The result is used only
+     * if nothing it depends on changed meanwhile (epoch: camera, scene, options); otherwise frame f+1 traces its
+     * primary rays as usual. rt_tuning key 14. */
+    hipStream_t spec_stream = nullptr;
+    hipEvent_t ev_spec_go = nullptr, ev_spec_done = nullptr, ev_spec_t[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    float4* d_gset[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}}; /* [set]{vis, g0, g1}; d_vis/d_g0/d_g1 = set gcur */
+    int gcur = 0, timed_spec_set = -1;
+    bool spec_valid = false, spec_timed[2] = {false, false};
+    uint64_t spec_epoch = 0;
+    int tune_spec = 1; /* rt_tuning key 14 */
     bool lane_saved = false, lane_timing = false; /* rt_lane */
     hipStream_t lane_main = nullptr;
     std::string err;
@@ -230,6 +242,7 @@ int rt_create(int device, int width, int height, int row_begin, int row_end, int
     RT_HIP(c, hipMemsetAsync(c->d_g1, 0, n * 16, c->stream));
     RT_HIP(c, hipMemsetAsync(c->d_accum, 0, n * 16, c->stream));
     RT_HIP(c, hipMemsetAsync(c->d_pixels, 0, n * 4, c->stream));
+    c->d_gset[0][0] = c->d_vis; c->d_gset[0][1] = c->d_g0; c->d_gset[0][2] = c->d_g1;
     RT_HIP(c, hipMalloc(&c->d_counter, 8));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     return RT_OK;
@@ -253,7 +266,12 @@ int rt_destroy(rt_ctx* c)
     if (c->ev_stage) hipEventDestroy(c->ev_stage);
     if (c->ev_aux) hipEventDestroy(c->ev_aux);
     free_scene(c);
-    hipFree(c->d_vis); hipFree(c->d_g0); hipFree(c->d_g1); hipFree(c->d_accum); hipFree(c->d_pixels);
+    if (c->spec_stream) { hipStreamSynchronize(c->spec_stream); hipStreamDestroy(c->spec_stream); }
+    if (c->ev_spec_go) hipEventDestroy(c->ev_spec_go);
+    if (c->ev_spec_done) hipEventDestroy(c->ev_spec_done);
+    for (auto& es : c->ev_spec_t) for (auto& e : es) if (e) hipEventDestroy(e);
+    for (auto& gs : c->d_gset) for (auto& p : gs) hipFree(p);
+    hipFree(c->d_accum); hipFree(c->d_pixels);
     for (int k = 0; k < 3; ++k) { hipFree(c->d_rec[k]); hipFree(c->d_rad[k]); }
     hipFree(c->d_shaded_bits);
     hipFree(c->d_visq[0]); hipFree(c->d_visq[1]); hipFree(c->d_visq_count);
@@ -285,6 +303,7 @@ int rt_sync(rt_ctx* c)
 {
     RT_CHECK_CTX(c);
     RT_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->spec_stream) RT_HIP(c, hipStreamSynchronize(c->spec_stream)); /* the next frame's raycast is work of this call too */
     return RT_OK;
 }
 
@@ -900,6 +919,57 @@ int rt_raycast(rt_ctx* c)
     return RT_OK;
 }
 
+/* the next frame's primary rays, behind everything enqueued on the main stream so far, on the stream of their own */
+static int launch_next_raycast(rt_ctx* c)
+{
+    if (!c->tune_spec) { c->spec_valid = false; return RT_OK; }
+    const size_t n = local_pixels(c);
+    if (!c->spec_stream)
+    {
+        RT_HIP(c, hipStreamCreateWithFlags(&c->spec_stream, hipStreamNonBlocking));
+        RT_HIP(c, hipEventCreateWithFlags(&c->ev_spec_go, hipEventDisableTiming));
+        RT_HIP(c, hipEventCreateWithFlags(&c->ev_spec_done, hipEventDisableTiming));
+        for (auto& es : c->ev_spec_t) for (auto& e : es) RT_HIP(c, hipEventCreate(&e));
+        const int o = c->gcur ^ 1;
+        for (int k = 0; k < 3; ++k) RT_HIP(c, hipMalloc(&c->d_gset[o][k], n * 16));
+        /* halo rows of g1 hold the neighbours' shaded flags (rt_halo_flags_unpack keeps both sets current from here on) */
+        for (int k = 0; k < 3; ++k) RT_HIP(c, hipMemcpyAsync(c->d_gset[o][k], c->d_gset[c->gcur][k], n * 16, hipMemcpyDeviceToDevice, c->stream));
+    }
+    const int o = c->gcur ^ 1;
+    RT_HIP(c, hipEventRecord(c->ev_spec_go, c->stream));
+    RT_HIP(c, hipStreamWaitEvent(c->spec_stream, c->ev_spec_go, 0));
+    const int s0 = c->sub0, s1 = c->sub1, b0 = c->subb0, b1 = c->subb1;
+    c->sub0 = c->sub1 = -1; c->subb0 = c->subb1 = 0; /* all owned rows */
+    if (c->timing) hipEventRecord(c->ev_spec_t[o][0], c->spec_stream);
+    k_raycast<<<trace_grid(c), TRACE_BLOCK, 0, c->spec_stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_gset[o][0], c->d_gset[o][1], c->d_gset[o][2]);
+    c->sub0 = s0; c->sub1 = s1; c->subb0 = b0; c->subb1 = b1;
+    RT_HIP(c, hipGetLastError());
+    if (c->timing) hipEventRecord(c->ev_spec_t[o][1], c->spec_stream);
+    c->spec_timed[o] = c->timing;
+    RT_HIP(c, hipEventRecord(c->ev_spec_done, c->spec_stream));
+    c->spec_valid = true;
+    c->spec_epoch = c->epoch;
+    return RT_OK;
+}
+/* stage 0's raycast over all owned rows: the G-buffer traced beside the previous frame if it is still the right one */
+static int raycast_or_take(rt_ctx* c, bool whole)
+{
+    c->timed_spec_set = -1;
+    if (whole && c->tune_spec && c->spec_valid && c->spec_epoch == c->epoch)
+    {
+        c->gcur ^= 1;
+        c->d_vis = c->d_gset[c->gcur][0]; c->d_g0 = c->d_gset[c->gcur][1]; c->d_g1 = c->d_gset[c->gcur][2];
+        RT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_spec_done, 0));
+        c->spec_valid = false;
+        c->has_gbuffer = true;
+        c->shaded_bits_stale = true;
+        if (c->spec_timed[c->gcur]) c->timed_spec_set = c->gcur;
+        return RT_OK;
+    }
+    c->spec_valid = false;
+    return rt_raycast(c);
+}
+
 static int launch_generate(rt_ctx* c, int frame, int dst_phys, int prev_phys, bool fuse)
 {
     if (c->n_lights == 0 && c->opt.ris_sample_count > 0)
@@ -1241,7 +1311,7 @@ static int stage_run_ranges(rt_ctx* c, int frame, int stage, int part, int row0,
         mark(0);
         if (part != 2 && c->f_clear) rc = rt_clear(c);
         mark(1);
-        if (part != 2 && rc == RT_OK) rc = rt_raycast(c);
+        if (part != 2 && rc == RT_OK) rc = raycast_or_take(c, row0 == c->row_begin && row1 == c->row_end && rowb0 >= rowb1);
         mark(2);
         if (part != 1 && rc == RT_OK) rc = launch_generate(c, frame, c->fY, c->fX, c->opt.use_temporal_resampling != 0);
         mark(3);
@@ -1317,6 +1387,7 @@ int rt_frame_stage_end(rt_ctx* c, int stage)
         c->aux_used = false;
     }
     const int passes = c->opt.spatial_resampling_passes;
+    if (stage == 0) { const int rc = launch_next_raycast(c); if (rc != RT_OK) return rc; }
     if (stage <= passes) { c->f_stage = stage + 1; return RT_OK; }
     const int X = c->fX, Y = c->fY, Z = c->fZ;
     if (passes < 2)
@@ -1395,6 +1466,13 @@ int rt_timing(rt_ctx* c, float ms[9])
     RT_HIP(c, hipEventSynchronize(c->ev[8]));
     for (int k = 0; k < 8; ++k) RT_HIP(c, hipEventElapsedTime(&ms[k], c->ev[k], c->ev[k + 1]));
     RT_HIP(c, hipEventElapsedTime(&ms[8], c->ev[0], c->ev[8]));
+    /* the frame's primary rays were traced beside the previous frame (rt_tuning key 14): the duration of that launch,
+     * which ran concurrently with other kernels and is not part of ms[8] */
+    if (c->timed_spec_set >= 0)
+    {
+        RT_HIP(c, hipEventSynchronize(c->ev_spec_t[c->timed_spec_set][1]));
+        RT_HIP(c, hipEventElapsedTime(&ms[1], c->ev_spec_t[c->timed_spec_set][0], c->ev_spec_t[c->timed_spec_set][1]));
+    }
     return RT_OK;
 }
 
@@ -1570,7 +1648,9 @@ int rt_halo_flags_unpack(rt_ctx* c, int row0, int n_rows, const void* device_src
     if (rc != RT_OK) return rc;
     if (row0 < c->row_end && row0 + n_rows > c->row_begin) RT_FAIL(c, RT_ERR_ARG, "flags may only be unpacked into halo rows");
     const int n = n_rows * c->W;
-    k_halo_flags<false><<<(n + 255) / 256, 256, 0, c->stream>>>(c->d_g1, (size_t)(row0 - c->lrow0) * c->W, n, (uint8_t*)const_cast<void*>(device_src));
+    for (int set = 0; set < 2; ++set)
+        if (c->d_gset[set][2])
+            k_halo_flags<false><<<(n + 255) / 256, 256, 0, c->stream>>>(c->d_gset[set][2], (size_t)(row0 - c->lrow0) * c->W, n, (uint8_t*)const_cast<void*>(device_src));
     RT_HIP(c, hipGetLastError());
     if (row0 == c->lrow0 && row0 + n_rows == c->row_begin) c->halo_flags_epoch[0] = c->epoch;
     if (row0 == c->row_end && row0 + n_rows == c->lrow0 + c->lrows) c->halo_flags_epoch[1] = c->epoch;
@@ -1578,31 +1658,56 @@ int rt_halo_flags_unpack(rt_ctx* c, int row0, int n_rows, const void* device_src
 }
 /* records of the neighbour on `side` that spatial passes [pass, pass + n_pass) of `frame` will
  * gather: n_pass consecutive bitmaps of rt_halo_bitmap_words() words each, one launch */
-int rt_halo_mark(rt_ctx* c, int frame, int pass, int n_pass, int side, void* device_bitmaps)
+int rt_halo_mark_sides(rt_ctx* c, int frame, int pass, int n_pass, void* bitmaps_side0, void* bitmaps_side1)
 {
     RT_CHECK_CTX(c);
     if (!c->has_gbuffer) RT_FAIL(c, RT_ERR_STATE, "no G-buffer yet");
-    if (n_pass <= 0) return RT_OK;
-    int r0, n;
-    int rc = halo_side_region(c, side, &r0, &n);
-    if (rc != RT_OK) return rc;
-    if (c->halo_flags_epoch[side] != c->epoch)
-        RT_FAIL(c, RT_ERR_STATE, "rt_halo_mark: the neighbour's shaded flags (rt_halo_flags_unpack of all %d halo rows on side %d) "
-                                 "must be refreshed after a camera, scene or option change", n, side);
-    const size_t words = rt_halo_bitmap_words(c, n);
-    const int nw = (int)((words - 1) / 2);
-    RT_HIP(c, hipMemsetAsync(device_bitmaps, 0, words * 4 * (size_t)n_pass, c->stream));
-    /* only own rows within `halo` rows of that side can reach across */
-    c->sub0 = side == 0 ? c->row_begin : (c->row_end - c->halo > c->row_begin ? c->row_end - c->halo : c->row_begin);
-    c->sub1 = side == 0 ? (c->row_begin + c->halo < c->row_end ? c->row_begin + c->halo : c->row_end) : c->row_end;
+    if (n_pass <= 0 || (!bitmaps_side0 && !bitmaps_side1)) return RT_OK;
+    HaloRegions R = {};
+    void* bm[2] = {bitmaps_side0, bitmaps_side1};
+    for (int side = 0; side < 2; ++side)
+    {
+        if (!bm[side]) continue;
+        int rc = halo_side_region(c, side, &R.row0[side], &R.rows[side]);
+        if (rc != RT_OK) return rc;
+        if (c->halo_flags_epoch[side] != c->epoch)
+            RT_FAIL(c, RT_ERR_STATE, "rt_halo_mark: the neighbour's shaded flags (rt_halo_flags_unpack of all %d halo rows on side %d) "
+                                     "must be refreshed after a camera, scene or option change", R.rows[side], side);
+        R.words[side] = rt_halo_bitmap_words(c, R.rows[side]);
+        R.bitmaps[side] = (uint32_t*)bm[side];
+    }
+    /* both sides in ONE allocation, side 0 first (rt_mg's arena): cleared with one memset, whatever lies between included */
+    const size_t bytes0 = R.words[0] * 4 * (size_t)n_pass, bytes1 = R.words[1] * 4 * (size_t)n_pass;
+    const bool together = bm[0] && bm[1] && (char*)bm[1] >= (char*)bm[0] + bytes0 && (size_t)((char*)bm[1] - (char*)bm[0]) <= 2 * bytes0 + (1u << 20);
+    if (together) RT_HIP(c, hipMemsetAsync(bm[0], 0, (size_t)((char*)bm[1] - (char*)bm[0]) + bytes1, c->stream));
+    else
+    {
+        if (bm[0]) RT_HIP(c, hipMemsetAsync(bm[0], 0, bytes0, c->stream));
+        if (bm[1]) RT_HIP(c, hipMemsetAsync(bm[1], 0, bytes1, c->stream));
+    }
+    /* only own rows within `halo` rows of a side can reach across it: one band per side, one launch over both (or
+     * over all own rows when the bands meet) */
+    const int lo_end = c->row_begin + c->halo < c->row_end ? c->row_begin + c->halo : c->row_end;
+    const int hi_beg = c->row_end - c->halo > c->row_begin ? c->row_end - c->halo : c->row_begin;
+    if (bm[0] && bm[1] && lo_end < hi_beg) { c->sub0 = c->row_begin; c->sub1 = lo_end; c->subb0 = hi_beg; c->subb1 = c->row_end; }
+    else if (bm[0] && bm[1]) { c->sub0 = c->row_begin; c->sub1 = c->row_end; c->subb0 = c->subb1 = 0; }
+    else if (bm[0]) { c->sub0 = c->row_begin; c->sub1 = lo_end; c->subb0 = c->subb1 = 0; }
+    else { c->sub0 = hi_beg; c->sub1 = c->row_end; c->subb0 = c->subb1 = 0; }
     const FrameParams P = make_params(c, frame, pass, K_OTHER);
     const int grid = launch_grid(c);
-    c->sub0 = c->sub1 = -1;
-    k_halo_mark<<<grid, BLOCK, 0, c->stream>>>(P, c->d_g1, r0, n, pass, n_pass, words, (uint32_t*)device_bitmaps);
+    c->sub0 = c->sub1 = -1; c->subb0 = c->subb1 = 0;
+    k_halo_mark<<<grid, BLOCK, 0, c->stream>>>(P, c->d_g1, R, pass, n_pass);
     RT_HIP(c, hipGetLastError());
-    k_halo_scan<<<n_pass, 1024, 0, c->stream>>>((uint32_t*)device_bitmaps, nw, words);
+    k_halo_scan_sides<<<dim3(n_pass, 2), 1024, 0, c->stream>>>(R);
     RT_HIP(c, hipGetLastError());
     return RT_OK;
+}
+int rt_halo_mark(rt_ctx* c, int frame, int pass, int n_pass, int side, void* device_bitmaps)
+{
+    RT_CHECK_CTX(c);
+    if (side != 0 && side != 1) RT_FAIL(c, RT_ERR_ARG, "side must be 0 or 1");
+    if (!device_bitmaps) RT_FAIL(c, RT_ERR_ARG, "null pointer");
+    return rt_halo_mark_sides(c, frame, pass, n_pass, side == 0 ? device_bitmaps : nullptr, side == 1 ? device_bitmaps : nullptr);
 }
 /* rebuild the prefix part of `count` consecutive bitmaps received from a neighbour */
 int rt_halo_scan(rt_ctx* c, int n_rows, int count, void* device_bitmaps)
@@ -1614,29 +1719,52 @@ int rt_halo_scan(rt_ctx* c, int n_rows, int count, void* device_bitmaps)
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }
-static int halo_sparse(rt_ctx* c, bool pack, int res, int row0, int n_rows, const void* device_bitmap, void* device_list)
+static int halo_sparse(rt_ctx* c, bool pack, int res, int n, const int* row0, const int* n_rows, const void* const* device_bitmap, void* const* device_list)
 {
     const int phys = halo_phys(c, res);
     if (phys < 0) RT_FAIL(c, RT_ERR_ARG, "bad reservoir buffer id %d", res);
-    int rc = halo_range(c, row0, n_rows);
-    if (rc != RT_OK) return rc;
-    const int n = n_rows * c->W;
-    const int nw = (int)((rt_halo_bitmap_words(c, n_rows) - 1) / 2);
-    const size_t off = (size_t)(row0 - c->lrow0) * c->W;
-    if (pack) k_halo_sparse<true><<<(n + 255) / 256, 256, 0, c->stream>>>((const uint32_t*)device_bitmap, nw, c->W, off, n, c->d_rec[phys], c->d_rad[phys], (float4*)device_list);
-    else k_halo_sparse<false><<<(n + 255) / 256, 256, 0, c->stream>>>((const uint32_t*)device_bitmap, nw, c->W, off, n, c->d_rec[phys], c->d_rad[phys], (float4*)device_list);
+    if (n <= 0) return RT_OK;
+    if (n > 2) RT_FAIL(c, RT_ERR_ARG, "at most two row ranges per call");
+    HaloLists Hh = {};
+    int most = 0;
+    for (int i = 0; i < n; ++i)
+    {
+        int rc = halo_range(c, row0[i], n_rows[i]);
+        if (rc != RT_OK) return rc;
+        Hh.bitmap[i] = (const uint32_t*)device_bitmap[i];
+        Hh.n_pix[i] = n_rows[i] * c->W;
+        Hh.nw[i] = (int)((rt_halo_bitmap_words(c, n_rows[i]) - 1) / 2);
+        Hh.region_off[i] = (size_t)(row0[i] - c->lrow0) * c->W;
+        Hh.list[i] = (float4*)device_list[i];
+        if (Hh.n_pix[i] > most) most = Hh.n_pix[i];
+    }
+    const dim3 grid((most + 255) / 256, n);
+    if (pack) k_halo_sparse<true><<<grid, 256, 0, c->stream>>>(Hh, c->d_rec[phys], c->d_rad[phys]);
+    else k_halo_sparse<false><<<grid, 256, 0, c->stream>>>(Hh, c->d_rec[phys], c->d_rad[phys]);
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }
 int rt_halo_pack_sparse(rt_ctx* c, int res, int row0, int n_rows, const void* device_bitmap, void* device_dst)
 {
     RT_CHECK_CTX(c);
-    return halo_sparse(c, true, res, row0, n_rows, device_bitmap, device_dst);
+    return halo_sparse(c, true, res, 1, &row0, &n_rows, &device_bitmap, &device_dst);
 }
 int rt_halo_unpack_sparse(rt_ctx* c, int res, int row0, int n_rows, const void* device_bitmap, const void* device_src)
 {
     RT_CHECK_CTX(c);
-    return halo_sparse(c, false, res, row0, n_rows, device_bitmap, const_cast<void*>(device_src));
+    void* src = const_cast<void*>(device_src);
+    return halo_sparse(c, false, res, 1, &row0, &n_rows, &device_bitmap, &src);
+}
+/* the same for up to two row ranges (both neighbours) in one launch */
+int rt_halo_pack_sparse_ranges(rt_ctx* c, int res, int n, const int* row0, const int* n_rows, const void* const* device_bitmaps, void* const* device_dsts)
+{
+    RT_CHECK_CTX(c);
+    return halo_sparse(c, true, res, n, row0, n_rows, device_bitmaps, device_dsts);
+}
+int rt_halo_unpack_sparse_ranges(rt_ctx* c, int res, int n, const int* row0, const int* n_rows, const void* const* device_bitmaps, const void* const* device_srcs)
+{
+    RT_CHECK_CTX(c);
+    return halo_sparse(c, false, res, n, row0, n_rows, device_bitmaps, const_cast<void* const*>(device_srcs));
 }
 
 /* ---- hooks of the native strip driver (strip_mg.cpp), plain C-ABI like everything else ---- */
@@ -1894,6 +2022,7 @@ int rt_tuning(rt_ctx* c, int key, int value)
     else if (key == 11 && (value == 0 || value == 1)) c->tune_defer_vis = value;
     else if (key == 12 && (value == 0 || value == 1)) c->tune_ris_pipe = value;
     else if (key == 13 && value >= -1 && value <= 1) c->tune_ws = value;
+    else if (key == 14 && (value == 0 || value == 1)) { c->tune_spec = value; if (!value) c->spec_valid = false; }
     else RT_FAIL(c, RT_ERR_ARG, "bad tuning key/value %d/%d", key, value);
     return RT_OK;
 }

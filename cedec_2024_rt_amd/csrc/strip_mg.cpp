@@ -160,11 +160,17 @@ struct rt_mg
         std::shared_ptr<LocalMsg> last_send[2], last_bm[2], last_flags; /* LOCAL: who may still be reading a buffer */
     };
     std::vector<Side> sides;
+    /* one arena per plan slot: [need side A][need side B][give side A][give side B], each max_passes bitmaps of
+     * bm_stride words, so that one memset clears the needs, one launch marks them and ONE strided copy brings every
+     * count (word 0 of each bitmap) to cnt_all; Side::need_bm / give_bm / cnt_h point into these */
+    uint32_t* bm_arena[2] = {nullptr, nullptr};
+    uint32_t* cnt_all[2] = {nullptr, nullptr}; /* pinned host: [need A][need B][give A][give B] x max_passes */
+    size_t bm_stride = 0;
     int bnd[2][2] = {{0, 0}, {0, 0}}, n_bnd = 0;   /* boundary row ranges (needed by a neighbour), computed first */
     int itr[2][2] = {{0, 0}, {0, 0}}, n_itr = 0;   /* interior row ranges, computed while halos travel */
 
     hipStream_t comm = nullptr, prep = nullptr; /* prep: the next frame's halo marks, beside this frame's passes */
-    hipEvent_t ev_packed = nullptr, ev_arrived = nullptr, ev_plan[2] = {nullptr, nullptr}, ev_gbuf = nullptr, ev_marked = nullptr;
+    hipEvent_t ev_packed = nullptr, ev_arrived = nullptr, ev_plan[2] = {nullptr, nullptr}, ev_gbuf = nullptr, ev_marked = nullptr, ev_carried = nullptr;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr; /* GPU-side clock of the frame loop: start of the first / latest frame since rt_mg_reset_stats */
     unsigned long long frames_timed = 0;
     ncclComm_t nccl = nullptr;
@@ -333,18 +339,32 @@ const char* rt_mg_last_error(rt_mg* m) { return m ? m->err.c_str() : "null rt_mg
 
 static int alloc_sides(rt_mg* m)
 {
+    const size_t ns = m->sides.size();
+    if (ns == 0) return RT_OK;
     for (auto& s : m->sides)
     {
         s.bm_words = rt_halo_bitmap_words(m->ctx, s.n_rows);
-        const size_t bm_bytes = s.bm_words * 4 * (size_t)m->max_passes;
+        if (s.bm_words > m->bm_stride) m->bm_stride = s.bm_words;
+    }
+    for (auto& s : m->sides)
+        if (s.bm_words != m->bm_stride) MG_FAIL(m, RT_ERR_STATE, "halo regions of different heights on the two sides");
+    const size_t per = m->bm_stride * (size_t)m->max_passes; /* words of one side's need (or give) bitmaps */
+    for (int k = 0; k < 2; ++k)
+    {
+        MG_HIP(m, hipMalloc(&m->bm_arena[k], per * 2 * ns * 4));
+        MG_HIP(m, hipMemset(m->bm_arena[k], 0, per * 2 * ns * 4));
+        MG_HIP(m, hipHostMalloc(&m->cnt_all[k], (size_t)m->max_passes * 2 * ns * 4, hipHostMallocDefault));
+        memset(m->cnt_all[k], 0, (size_t)m->max_passes * 2 * ns * 4);
+    }
+    for (size_t i = 0; i < ns; ++i)
+    {
+        auto& s = m->sides[i];
         const size_t list_bytes = rt_halo_bytes(m->ctx, s.n_rows) + 256;
         for (int k = 0; k < 2; ++k)
         {
-            MG_HIP(m, hipMalloc(&s.need_bm[k], bm_bytes));
-            MG_HIP(m, hipMalloc(&s.give_bm[k], bm_bytes));
-            MG_HIP(m, hipMemset(s.need_bm[k], 0, bm_bytes));
-            MG_HIP(m, hipMemset(s.give_bm[k], 0, bm_bytes));
-            MG_HIP(m, hipHostMalloc(&s.cnt_h[k], (size_t)m->max_passes * 2 * 4, hipHostMallocDefault));
+            s.need_bm[k] = m->bm_arena[k] + per * i;
+            s.give_bm[k] = m->bm_arena[k] + per * (ns + i);
+            s.cnt_h[k] = m->cnt_all[k] + (size_t)m->max_passes * i; /* give counts: + max_passes * ns */
             MG_HIP(m, hipMalloc(&s.send_buf[k], list_bytes));
         }
         MG_HIP(m, hipMalloc(&s.recv_buf, list_bytes));
@@ -404,6 +424,7 @@ int rt_mg_create(rt_ctx* ctx, int rank, int world, const int* bounds, int transp
     MG_HIP(m, hipEventCreateWithFlags(&m->ev_packed, hipEventDisableTiming));
     MG_HIP(m, hipEventCreateWithFlags(&m->ev_arrived, hipEventDisableTiming));
     for (auto& e : m->ev_plan) MG_HIP(m, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    MG_HIP(m, hipEventCreateWithFlags(&m->ev_carried, hipEventDisableTiming));
     MG_HIP(m, hipEventCreate(&m->ev_t0));
     MG_HIP(m, hipEventCreate(&m->ev_t1));
     int rc = alloc_sides(m);
@@ -455,12 +476,16 @@ int rt_mg_destroy(rt_mg* m)
     {
         for (int k = 0; k < 2; ++k)
         {
-            hipFree(s.need_bm[k]); hipFree(s.give_bm[k]); hipFree(s.send_buf[k]);
-            if (s.cnt_h[k]) hipHostFree(s.cnt_h[k]);
+            hipFree(s.send_buf[k]);
             s.last_send[k].reset(); s.last_bm[k].reset();
         }
         s.last_flags.reset();
         hipFree(s.recv_buf); hipFree(s.flags_send); hipFree(s.flags_recv);
+    }
+    for (int k = 0; k < 2; ++k)
+    {
+        hipFree(m->bm_arena[k]);
+        if (m->cnt_all[k]) hipHostFree(m->cnt_all[k]);
     }
     if (m->shm.base)
     {
@@ -473,6 +498,9 @@ int rt_mg_destroy(rt_mg* m)
     for (auto& e : m->ev_plan) if (e) hipEventDestroy(e);
     if (m->ev_gbuf) hipEventDestroy(m->ev_gbuf);
     if (m->ev_marked) hipEventDestroy(m->ev_marked);
+    if (m->ev_carried) hipEventDestroy(m->ev_carried);
+    if (m->ev_t0) hipEventDestroy(m->ev_t0);
+    if (m->ev_t1) hipEventDestroy(m->ev_t1);
     if (m->comm) hipStreamDestroy(m->comm);
     if (m->prep) hipStreamDestroy(m->prep);
     delete m;
@@ -645,25 +673,26 @@ static int complete(rt_mg* m)
 /* ------------------------------------------------------------------ the frame */
 static size_t list_bytes(uint32_t count) { return (size_t)(count > 0 ? count : 1) * 80; }
 
-/* record counts of the plan in `slot`: device bitmaps word 0 of each pass -> pinned host (async) */
+/* record counts of the plan in `slot`: word 0 of every bitmap of the arena -> pinned host, one strided copy */
 static int fetch_counts(rt_mg* m, int slot, hipStream_t st)
 {
-    for (auto& s : m->sides)
-    {
-        MG_HIP(m, hipMemcpy2DAsync(s.cnt_h[slot], 4, s.need_bm[slot], s.bm_words * 4, 4, (size_t)m->passes, hipMemcpyDeviceToHost, st));
-        MG_HIP(m, hipMemcpy2DAsync(s.cnt_h[slot] + m->passes, 4, s.give_bm[slot], s.bm_words * 4, 4, (size_t)m->passes, hipMemcpyDeviceToHost, st));
-    }
+    const size_t rows = (size_t)m->max_passes * 2 * m->sides.size();
+    MG_HIP(m, hipMemcpy2DAsync(m->cnt_all[slot], 4, m->bm_arena[slot], m->bm_stride * 4, 4, rows, hipMemcpyDeviceToHost, st));
     return RT_OK;
 }
+static uint32_t need_count(const rt_mg*, const rt_mg::Side& s, int slot, int k) { return s.cnt_h[slot][k]; }
+static uint32_t give_count(const rt_mg* m, const rt_mg::Side& s, int slot, int k) { return s.cnt_h[slot][(size_t)m->max_passes * m->sides.size() + k]; }
 
-/* need-bitmaps of `frame` for both neighbours (RNG replay on the device, rt_halo_mark) */
+/* need-bitmaps of `frame` for both neighbours (RNG replay on the device): one memset, one mark launch, one scan */
 static int mark_plan(rt_mg* m, int frame, int slot, hipStream_t writer)
 {
+    void* bm[2] = {nullptr, nullptr};
     for (auto& s : m->sides)
     {
         if (m->transport == RT_MG_TRANSPORT_LOCAL) { int rc = local_guard(m, s.last_bm[slot], writer); if (rc != RT_OK) return rc; }
-        MG_RT(m, rt_halo_mark(m->ctx, frame, 0, m->passes, s.side, s.need_bm[slot]));
+        bm[s.side] = s.need_bm[slot];
     }
+    MG_RT(m, rt_halo_mark_sides(m->ctx, frame, 0, m->passes, bm[0], bm[1]));
     return RT_OK;
 }
 
@@ -695,17 +724,30 @@ static int post_halo(rt_mg* m, int stage, int buf, bool with_plan)
     hipStream_t ms = main_stream(m);
     const int slot = m->frame & 1, nslot = slot ^ 1, k = stage;
     std::vector<Exchange> xs(m->sides.size());
+    if (m->use_sparse)
+    {
+        /* the marked records of both boundary bands -> two dense lists, one launch */
+        int row0[2], nrows[2];
+        const void* bms[2];
+        void* dsts[2];
+        for (size_t i = 0; i < m->sides.size(); ++i)
+        {
+            auto& s = m->sides[i];
+            if (m->transport == RT_MG_TRANSPORT_LOCAL) { int rc = local_guard(m, s.last_send[k & 1], ms); if (rc != RT_OK) return rc; }
+            row0[i] = s.send_row0; nrows[i] = s.n_rows;
+            bms[i] = s.give_bm[slot] + (size_t)k * s.bm_words;
+            dsts[i] = s.send_buf[k & 1];
+        }
+        MG_RT(m, rt_halo_pack_sparse_ranges(m->ctx, buf, (int)m->sides.size(), row0, nrows, bms, dsts));
+    }
     for (size_t i = 0; i < m->sides.size(); ++i)
     {
         auto& s = m->sides[i];
         xs[i].peer = s.peer;
         if (m->use_sparse)
         {
-            const uint32_t give = s.cnt_h[slot][m->passes + k], need = s.cnt_h[slot][k];
-            char* sb = s.send_buf[k & 1];
-            if (m->transport == RT_MG_TRANSPORT_LOCAL) { int rc = local_guard(m, s.last_send[k & 1], ms); if (rc != RT_OK) return rc; }
-            MG_RT(m, rt_halo_pack_sparse(m->ctx, buf, s.send_row0, s.n_rows, s.give_bm[slot] + (size_t)k * s.bm_words, sb));
-            xs[i].parts.push_back({sb, list_bytes(give), s.recv_buf, list_bytes(need)});
+            const uint32_t give = give_count(m, s, slot, k), need = need_count(m, s, slot, k);
+            xs[i].parts.push_back({s.send_buf[k & 1], list_bytes(give), s.recv_buf, list_bytes(need)});
             m->stats.records_sent += give;
         }
         else
@@ -740,14 +782,27 @@ static int finish_halo(rt_mg* m)
     if (rc != RT_OK) return rc;
     const int slot = m->frame & 1, nslot = slot ^ 1, k = m->pending_k;
     if (m->use_sparse)
-        for (auto& s : m->sides)
-            MG_RT(m, rt_halo_unpack_sparse(m->ctx, m->pending_buf, s.recv_row0, s.n_rows, s.need_bm[slot] + (size_t)k * s.bm_words, s.recv_buf));
+    {
+        int row0[2], nrows[2];
+        const void *bms[2], *srcs[2];
+        for (size_t i = 0; i < m->sides.size(); ++i)
+        {
+            auto& s = m->sides[i];
+            row0[i] = s.recv_row0; nrows[i] = s.n_rows;
+            bms[i] = s.need_bm[slot] + (size_t)k * s.bm_words;
+            srcs[i] = s.recv_buf;
+        }
+        MG_RT(m, rt_halo_unpack_sparse_ranges(m->ctx, m->pending_buf, (int)m->sides.size(), row0, nrows, bms, srcs));
+    }
     if (carried)
     {
-        /* the plan of frame + 1 is complete on the device: its counts travel to the host behind it */
-        rc = fetch_counts(m, nslot, ms);
+        /* the plan of frame + 1 is complete on the device: its counts travel to the host behind it, on the prep
+         * stream (the spatial passes of this frame do not wait for that copy) */
+        MG_HIP(m, hipEventRecord(m->ev_carried, ms));
+        MG_HIP(m, hipStreamWaitEvent(m->prep, m->ev_carried, 0));
+        rc = fetch_counts(m, nslot, m->prep);
         if (rc != RT_OK) return rc;
-        MG_HIP(m, hipEventRecord(m->ev_plan[nslot], ms));
+        MG_HIP(m, hipEventRecord(m->ev_plan[nslot], m->prep));
         m->plan_frame[nslot] = (long long)m->frame + 1;
         rt_state_epoch(m->ctx, &m->plan_epoch[nslot]);
         m->plan_passes = m->passes;

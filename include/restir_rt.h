@@ -205,6 +205,13 @@ int rt_halo_mark(rt_ctx* ctx, int frame, int first_pass, int n_passes, int side,
 int rt_halo_scan(rt_ctx* ctx, int n_rows, int n_bitmaps, void* device_bitmaps);
 int rt_halo_pack_sparse(rt_ctx* ctx, int res, int row0, int n_rows, const void* device_bitmap, void* device_dst);
 int rt_halo_unpack_sparse(rt_ctx* ctx, int res, int row0, int n_rows, const void* device_bitmap, const void* device_src);
+/* the same with both neighbours served by ONE launch each (the native strip driver: a strip's frame is a chain of small
+ * launches): rt_halo_mark_sides marks side 0 and / or side 1 (NULL = no neighbour there; if both pointers lie in one
+ * allocation, side 0 first and at most 1 MiB apart, everything from the first bitmap to the end of the last is cleared
+ * by one memset); the _ranges calls pack / unpack up to two row ranges. */
+int rt_halo_mark_sides(rt_ctx* ctx, int frame, int first_pass, int n_passes, void* device_bitmaps_side0, void* device_bitmaps_side1);
+int rt_halo_pack_sparse_ranges(rt_ctx* ctx, int res, int n, const int* row0, const int* n_rows, const void* const* device_bitmaps, void* const* device_dsts);
+int rt_halo_unpack_sparse_ranges(rt_ctx* ctx, int res, int n, const int* row0, const int* n_rows, const void* const* device_bitmaps, const void* const* device_srcs);
 
 /* ---- hooks used by the native strip driver below (and usable by any other driver) ---- */
 int rt_state_epoch(rt_ctx* ctx, uint64_t* epoch);   /* changes whenever camera, options, scene or an uploaded G-buffer change */
@@ -325,7 +332,12 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
  * key 12: 1 = software-pipelined RIS loop in the fused candidate kernel (A/B only, default 0).
  * key 13: shadow rays of generate_candidate / resolve walked with the work-sharing any-hit traversal (idle lanes of a
  * wavefront take over half of a busy lane's LDS stack): -1 (default) = for launches of at most ~one round of
- * wavefronts (strips of the multi-GPU frame), 0 = never, 1 = always. Same results.
+ * wavefronts (strips of the multi-GPU frame), 0 = never, 1 (default) = always. Same results.
+ * key 14: 1 (default) = rt_frame / rt_frame_stage trace the NEXT frame's primary rays on a stream of their own behind
+ * stage 0 of the current frame (they depend on the camera only), into a second G-buffer set, beside the HBM-bound
+ * spatial passes and the halo exchanges; the next frame uses them if camera, scene and options are still the same
+ * (rt_state_epoch) and traces its own otherwise. rt_sync waits for that launch too; rt_timing reports its duration as
+ * ms[1] although it is not part of ms[8]. 0 = every frame traces its primary rays first. Same results.
  * key 10 (before rt_scene_set): PLOC search radius of builder 2 (places in Morton order, default 16).
  * key 9: register budget of the unshadowed spatial pass, in wavefronts per SIMD (4, 5, 6; 0 = unbounded = 7; -1 = auto,
  * default: 4 for the gather kernel — fewer workgroups in flight keep its neighbour window inside the XCD's 4 MiB L2 —

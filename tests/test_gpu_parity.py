@@ -138,6 +138,18 @@ def test_lbvh_equals_brute_force(api, oracle, scenes, golden_scenes):
                 r.trace_mode(mode)
                 occ = r.trace_closest(rays)[:, 3].view(np.int32) >= 0
                 assert (occ == (ref[:, 3].view(np.int32) >= 0)).all(), f"{name} builder {builder} any-hit mode {mode}"
+            # 5: the work-sharing any-hit walk (idle lanes take over half of a busy lane's stack), also with a third
+            # of the lanes holding no ray at all (tmax < 0: they only help)
+            occ, passes, steals = r.trace_occluded_ws(rays)
+            assert (occ == (ref[:, 3].view(np.int32) >= 0)).all(), f"{name} builder {builder} work-sharing walk"
+            holes = rays.copy()
+            holes[::3, 7] = -1.0
+            occ_h, _, _ = r.trace_occluded_ws(holes)
+            want = ref[:, 3].view(np.int32) >= 0
+            want[::3] = False
+            assert (occ_h == want).all(), f"{name} builder {builder} work-sharing walk with idle lanes"
+            if name == "quad_room":
+                assert steals.sum() > 0, "no lane ever took over work: the walk under test is not exercised"
             r.close()
         assert (ref[:, 3].view(np.int32) >= 0).mean() > 0.2
 
@@ -181,6 +193,8 @@ def test_deep_traversal_stack_spills_past_lds(api, oracle):
             r.trace_mode(mode)
             occ = r.trace_closest(rays)[:, 3].view(np.int32) >= 0
             assert (occ == (ref[:, 3].view(np.int32) >= 0)).all(), f"builder {builder} any-hit mode {mode}"
+        occ, _, _ = r.trace_occluded_ws(rays)  # a stolen stack window never reaches into the spilled (per-lane) part
+        assert (occ == (ref[:, 3].view(np.int32) >= 0)).all(), f"builder {builder} work-sharing walk"
         r.close()
 
 
@@ -203,6 +217,9 @@ def test_lbvh_blocks_scene_vs_oracle_bvh(api, oracle, scenes):
             r.trace_mode(mode)
             dev = r.trace_closest(rays)
             assert _eq_bits(dev, ref), f"builder {builder} mode {mode}: {(dev.view(np.uint32) != ref.view(np.uint32)).any(axis=1).sum()} rays differ"
+        occ, passes, steals = r.trace_occluded_ws(rays)
+        assert (occ == (ref[:, 3].view(np.int32) >= 0)).all(), f"builder {builder} work-sharing walk"
+        assert steals.sum() > 1000, steals.sum()
         r.trace_mode(0)
         # a 2000-ray subset against true brute force
         sub = rays[:2000]
@@ -709,6 +726,36 @@ def test_candidate_kernel_variants_are_bit_identical(api, scenes):
         assert walked == shaded if frame == 1 else 0 < walked < shaded, (frame, walked, shaded)
     for r in rs:
         r.close()
+
+
+def test_work_sharing_shadow_walk_is_bit_identical(api, scenes):
+    """rt_tuning key 13: generate_candidate / resolve with the work-sharing shadow-ray walk (default) and with the
+    one-lane-one-ray walk give the same accumulation, pixels and reservoirs over 4 frames of the bench scene at quarter
+    resolution, whole frame and as a strip context."""
+    from cedec_2024_rt_amd.types import bench_options
+
+    tris = scenes.make_blocks_restir()
+    W, H = 480, 270
+    for rows, halo in ((None, 0), ((90, 180), 90)):
+        rs = []
+        for ws in (0, 1):
+            r = api.Renderer(W, H, rows=rows, halo=halo)
+            r.set_scene(tris)
+            r.lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)
+            r.set_options(bench_options())
+            r.tuning(13, ws)
+            rs.append(r)
+        for frame in (1, 2, 3, 4):
+            for r in rs:
+                if rows is None:
+                    r.frame(frame)
+                else:
+                    for k in range(5):
+                        r.frame_stage(frame, k, False)
+            for buf in (api.RT_BUF_ACCUMULATION, api.RT_BUF_PIXELS, api.RT_BUF_RES_0, api.RT_BUF_RES_1, api.RT_BUF_RES_TEMPORAL):
+                assert _eq_bits(rs[0].download(buf), rs[1].download(buf)), (rows, frame, buf)
+        for r in rs:
+            r.close()
 
 
 def test_camera_api_equals_the_references_camera_control(api, scenes, golden_dir):

@@ -71,7 +71,7 @@ import ctypes as C
 raw = np.zeros((len(shadow), 2), dtype=np.uint32)
 rr = np.ascontiguousarray(shadow, dtype=np.float32)
 r._ck(r.L.rt_trace_stats(r.h, rr.ctypes.data_as(C.c_void_p), len(rr), raw.ctypes.data_as(C.c_void_p)))
-wave = raw[:, 0].reshape(-1, 64).max(1).astype(np.int64)
+wave = (raw[:, 0] & 0x7fffffff).reshape(-1, 64).max(1).astype(np.int64)
 wave = wave[wave > 0]
 steals = (raw[:, 1] & 0xffff).astype(np.int64)
 steps = (raw[:, 1] >> 16).astype(np.int64)
