@@ -280,8 +280,13 @@ RT_DEV bool temporal_merge(const FrameParams& P, int x, int yi, f3 sp, f3 sn, Re
  * visibility is that sample's (reservoir.hpp:36) and the ray was dead work. In a steady sequence the history carries
  * M = 640 against the candidates' 32, so ~95 % of these rays are dead. Survivors are appended to a queue (wave
  * ballot + one atomic) and k_candidate_visibility walks them with full wavefronts and sets the bit. */
+/* the work-sharing variant allocates 102 VGPRs unconstrained (4 wavefronts per SIMD); held to the 96 of the plain
+ * kernel (5 per SIMD) it is 3 % faster (A/B on the GPU, profiles/r02_ws_register_budgets.txt) */
+#ifndef RT_GENERATE_WS_WAVES
+#define RT_GENERATE_WS_WAVES 5
+#endif
 template <bool FUSE_TEMPORAL, bool SHADOWED, bool DEFER = false, bool PIPE = false, bool WS = false>
-__global__ __launch_bounds__(TRACE_BLOCK, RT_TRACE_WAVES) void k_generate_candidate(
+__global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_WAVES) void k_generate_candidate(
     SceneView S, FrameParams P, const float4* __restrict__ g0, const float4* __restrict__ g1,
     const float4* __restrict__ prev_rec, const float4* __restrict__ prev_rad, float4* __restrict__ out_rec,
     float4* __restrict__ out_rad, uint32_t* __restrict__ vis_queue = nullptr, unsigned int* __restrict__ vis_count = nullptr)
@@ -1033,10 +1038,10 @@ __global__ void k_halo_flags(float4* __restrict__ g1, size_t off, int n_pix, uin
 
 /* -------------------------------------------------------------------- resolve */
 /* examples/10_restir_di/10_restir_di.cu:390-459 */
-/* 6 wavefronts per SIMD (what the 24 KB LDS stack allows): 86 -> 80 VGPRs, -3 % (A/B); the same bound
- * makes the candidate kernel spill (+6 %), so it is set here only */
+/* register budget in wavefronts per SIMD. r01 (one lane, one ray): 6 (86 -> 80 VGPRs) was 3 % faster than none.
+ * r02, with the work-sharing walk: 5 (96 VGPRs) is 3 % faster than 6 and equal to 4 (profiles/r02_ws_register_budgets.txt) */
 #ifndef RT_RESOLVE_WAVES
-#define RT_RESOLVE_WAVES 6
+#define RT_RESOLVE_WAVES 5
 #endif
 template <bool WS>
 __global__ __launch_bounds__(TRACE_BLOCK, RT_RESOLVE_WAVES) void k_resolve(SceneView S, FrameParams P, const float4* __restrict__ g0,

@@ -758,6 +758,39 @@ def test_work_sharing_shadow_walk_is_bit_identical(api, scenes):
             r.close()
 
 
+def test_next_frame_raycast_overlap_is_bit_identical(api, scenes):
+    """rt_tuning key 14: with the next frame's primary rays traced beside the current frame (and thrown away when the
+    camera moves, the options change or the per-kernel API is used in between) every buffer equals the run that traces
+    them at the start of each frame."""
+    from cedec_2024_rt_amd.types import bench_options
+
+    tris = scenes.make_quad_room()
+    W, H = 320, 180
+    rs = []
+    for spec in (0, 1):
+        r = api.Renderer(W, H)
+        r.set_scene(tris)
+        r.lookat((0.5, 2.5, 6.0), (0.0, 1.5, -1.0))
+        r.set_options(bench_options())
+        r.tuning(14, spec)
+        rs.append(r)
+    frame = 0
+    for step in ("still", "still", "orbit", "still", "options", "still", "kernels", "still", "still"):
+        frame += 1
+        for r in rs:
+            if step == "orbit":
+                r.orbit(37.0, -11.0)
+            if step == "options":
+                r.set_options(bench_options(spatial_resampling_passes=2))
+            if step == "kernels":  # the per-kernel API between two frames: its raycast writes the current G-buffer
+                r.raycast()
+            r.frame(frame, clear_first=(step in ("orbit", "options")))
+        for buf in (api.RT_BUF_VISIBILITY, api.RT_BUF_ACCUMULATION, api.RT_BUF_PIXELS, api.RT_BUF_RES_0, api.RT_BUF_RES_1, api.RT_BUF_RES_TEMPORAL):
+            assert _eq_bits(rs[0].download(buf), rs[1].download(buf)), (frame, step, buf)
+    for r in rs:
+        r.close()
+
+
 def test_camera_api_equals_the_references_camera_control(api, scenes, golden_dir):
     """rt_camera_orbit / _zoom / _pan + the RayGenerator they re-derive == the REFERENCE'S CameraControl
     (common/misc.hpp:108-224) + RayGenerator::lookat over the committed drag sequences (3 x 120 events, produced by
