@@ -318,6 +318,10 @@ class Renderer:
             raise RtError(f"rt_create -> {rc}: {msg} (no GPU visible? the HIP path has no CPU fallback)")
         if stream is not None:
             self._ck(self.L.rt_set_stream(self.h, C.c_void_p(int(stream))))
+        # A/B runs of the tools: RT_TUNING="8=0,14=0" applies rt_tuning keys to every context (results never depend on them)
+        for kv in filter(None, os.environ.get("RT_TUNING", "").split(",")):
+            k, v = kv.split("=")
+            self._ck(self.L.rt_tuning(self.h, int(k), int(v)))
         a, b = C.c_int(), C.c_int()
         self._ck(self.L.rt_local_rows(self.h, C.byref(a), C.byref(b)))
         self.local_row0, self.local_rows = a.value, b.value

@@ -743,8 +743,15 @@ __global__ __launch_bounds__(BLOCK) void k_spatial_lds(
     /* the tile of this workgroup (all its threads share it): window = rows [trow0 - 87, trow0 + 8 + 87), words [tw0, tw0 + 7) */
     int x = 0, row = P.row0;
     const bool ok = tile_pixel<BLOCK>(P, x, row);
-    /* every thread of a 32x8 tile derives the same tile origin from its own (x, row), in or out of the image */
-    const int tx0 = x & ~(TILE_W - 1), trow0 = P.row0 + ((row - P.row0) & ~(TILE_H - 1));
+    /* every thread of a 32x8 tile derives the same tile origin from its own (x, row), in or out of the image; the
+     * tile rows of a launch start at P.row0 or, for its second row range, at P.rowb0 (strips): row - (row within the
+     * tile). A workgroup beyond the last tile (x, row left at their defaults) stages a window nobody reads. */
+#if RT_WAVE_8X8 && RT_TILE_W == 32
+    const int in_tile_row = (threadIdx.x >> 3) & 7;
+#else
+    const int in_tile_row = threadIdx.x >> TILE_W_LOG2;
+#endif
+    const int tx0 = x & ~(TILE_W - 1), trow0 = row - in_tile_row;
     const int words = (P.W + 31) / 32, tw0 = (tx0 >> 5) - 3;
     for (int i = threadIdx.x; i < SPL_ROWS * SPL_WORDS; i += BLOCK)
     {

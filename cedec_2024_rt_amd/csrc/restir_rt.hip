@@ -1076,6 +1076,28 @@ static int halo_rows_needed(const rt_options& o)
 #ifndef RT_SHADOWED_SPATIAL_LDS
 #define RT_SHADOWED_SPATIAL_LDS 0 /* the walk's own LDS stack already limits the shadowed variant to 6 workgroups per CU */
 #endif
+/* the LDS-staged variant covers the default reach (87 px) and up to 5 neighbours. Whole-frame contexts only: the
+ * kernel itself handles strips (tile origins by row range, halo rows' bits from the neighbours' flags), but there it is
+ * no faster than the gather kernel (A/B r02: 0.517 / 0.517 ms per frame at 1080p in 8 strips, 1.308 / 1.289 at 4K) and
+ * it adds the bitmap launch to every frame */
+static bool use_lds_spatial(const rt_ctx* c)
+{
+    return c->tune_spatial_variant == 1 && c->opt.use_spatial_resampling && !c->opt.use_shadowed_target_function &&
+           halo_rows_needed(c->opt) <= SPL_HALO && c->opt.spatial_resampling_sample_count <= 5 &&
+           c->row_begin == 0 && c->row_end == c->H;
+}
+/* shaded bit per pixel of all local rows, rebuilt on the context's stream when the G-buffer or the halo flags changed.
+ * rt_frame_stage does this right behind the raycast, on the main stream, so that a stage's two lanes only read it. */
+static int refresh_shaded_bits(rt_ctx* c)
+{
+    if (!c->shaded_bits_stale || !c->has_gbuffer || !use_lds_spatial(c)) return RT_OK;
+    const int words = (c->W + 31) / 32;
+    if (!c->d_shaded_bits) RT_HIP(c, hipMalloc(&c->d_shaded_bits, (size_t)c->lrows * words * 4));
+    k_shaded_bitmap<<<dim3((c->W + 255) / 256, c->lrows), 256, 0, c->stream>>>(c->W, c->lrows, c->d_g1, c->d_shaded_bits);
+    RT_HIP(c, hipGetLastError());
+    c->shaded_bits_stale = false;
+    return RT_OK;
+}
 static int launch_spatial(rt_ctx* c, int frame, int pass, int in_phys, int out_phys)
 {
     const int need = halo_rows_needed(c->opt);
@@ -1085,22 +1107,13 @@ static int launch_spatial(rt_ctx* c, int frame, int pass, int in_phys, int out_p
                 c->opt.spatial_resampling_radius, need);
     const SceneView S = make_scene(c);
     const FrameParams P = make_params(c, frame, pass, K_SPATIAL);
-    /* the LDS-staged variant covers the default reach (87 px), up to 5 neighbours, whole-frame contexts */
-    const bool lds_variant = c->tune_spatial_variant == 1 && !c->opt.use_shadowed_target_function && need <= SPL_HALO &&
-                             c->opt.spatial_resampling_sample_count <= 5 && c->row_begin == 0 && c->row_end == c->H &&
-                             (c->sub0 < 0 || (c->sub0 == 0 && c->sub1 == c->H && c->subb1 <= c->subb0));
+    const bool lds_variant = use_lds_spatial(c);
     if (c->opt.use_shadowed_target_function)
         k_spatial<true><<<trace_grid(c), TRACE_BLOCK, (size_t)(RT_SHADOWED_SPATIAL_LDS), c->stream>>>(S, P, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys]);
     else if (lds_variant)
     {
-        const int words = (c->W + 31) / 32;
-        if (!c->d_shaded_bits) RT_HIP(c, hipMalloc(&c->d_shaded_bits, (size_t)c->lrows * words * 4));
-        if (c->shaded_bits_stale)
-        {
-            k_shaded_bitmap<<<dim3((c->W + 255) / 256, c->lrows), 256, 0, c->stream>>>(c->W, c->lrows, c->d_g1, c->d_shaded_bits);
-            RT_HIP(c, hipGetLastError());
-            c->shaded_bits_stale = false;
-        }
+        const int rc = refresh_shaded_bits(c); /* no-op inside rt_frame / rt_frame_stage: done behind the raycast */
+        if (rc != RT_OK) return rc;
 #define RT_SPL(WV) k_spatial_lds<WV><<<launch_grid(c), BLOCK, (size_t)c->tune_spatial_lds, c->stream>>>(P, c->d_shaded_bits, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys])
         switch (c->tune_spatial_waves) { case 4: RT_SPL(4); break; case 5: RT_SPL(5); break; case 6: RT_SPL(6); break; default: RT_SPL(0); break; }
 #undef RT_SPL
@@ -1237,6 +1250,9 @@ int rt_frame_stage_begin(rt_ctx* c, int frame, int stage, int clear_first)
     RT_CHECK_CTX(c);
     NEED_SCENE(c);
     c->last_frame = frame;
+    /* a spatial stage reads the shaded-bit rows from both lanes: (re)built here, on the main stream, if the halo flags
+     * arrived after the raycast (cold frame of a strip) */
+    if (stage >= 1) { const int rc = refresh_shaded_bits(c); if (rc != RT_OK) return rc; }
     RT_HIP(c, hipEventRecord(c->ev_stage, c->stream)); /* everything the stage reads is complete here */
     c->aux_used = false;
     const int passes = c->opt.spatial_resampling_passes;
@@ -1312,6 +1328,7 @@ static int stage_run_ranges(rt_ctx* c, int frame, int stage, int part, int row0,
         if (part != 2 && c->f_clear) rc = rt_clear(c);
         mark(1);
         if (part != 2 && rc == RT_OK) rc = raycast_or_take(c, row0 == c->row_begin && row1 == c->row_end && rowb0 >= rowb1);
+        if (part != 2 && rc == RT_OK && row0 == c->row_begin && row1 == c->row_end) rc = refresh_shaded_bits(c);
         mark(2);
         if (part != 1 && rc == RT_OK) rc = launch_generate(c, frame, c->fY, c->fX, c->opt.use_temporal_resampling != 0);
         mark(3);
@@ -1652,6 +1669,7 @@ int rt_halo_flags_unpack(rt_ctx* c, int row0, int n_rows, const void* device_src
         if (c->d_gset[set][2])
             k_halo_flags<false><<<(n + 255) / 256, 256, 0, c->stream>>>(c->d_gset[set][2], (size_t)(row0 - c->lrow0) * c->W, n, (uint8_t*)const_cast<void*>(device_src));
     RT_HIP(c, hipGetLastError());
+    c->shaded_bits_stale = true; /* the LDS-staged spatial pass reads these rows' bits too */
     if (row0 == c->lrow0 && row0 + n_rows == c->row_begin) c->halo_flags_epoch[0] = c->epoch;
     if (row0 == c->row_end && row0 + n_rows == c->lrow0 + c->lrows) c->halo_flags_epoch[1] = c->epoch;
     return RT_OK;

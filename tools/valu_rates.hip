@@ -187,6 +187,54 @@ __global__ __launch_bounds__(256) void k_rate_pk(float* out, uint64_t* cycles, f
     if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
+// binary64 (the portable sin/cos reduce and evaluate in double)
+template <int OP>
+__global__ __launch_bounds__(256) void k_rate_f64(float* out, uint64_t* cycles, double b, double c)
+{
+    double a[8];
+    for (int i = 0; i < 8; ++i) a[i] = 1.0 + 0.001 * (threadIdx.x + i);
+    uint64_t t0 = __builtin_amdgcn_s_memtime();
+    for (int r = 0; r < REP; ++r)
+    {
+#define OP_FMA64(i) "v_fma_f64 %" #i ", %" #i ", %8, %9\n"
+#define OP_MUL64(i) "v_mul_f64 %" #i ", %" #i ", %8\n"
+#define OP_ADD64(i) "v_add_f64 %" #i ", %" #i ", %8\n"
+#define F64CHAIN(OPSTR)                                                                                        \
+    asm volatile(OPSTR(0) OPSTR(1) OPSTR(2) OPSTR(3) OPSTR(4) OPSTR(5) OPSTR(6) OPSTR(7)                      \
+                 OPSTR(0) OPSTR(1) OPSTR(2) OPSTR(3) OPSTR(4) OPSTR(5) OPSTR(6) OPSTR(7)                      \
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) \
+                 : "v"(b), "v"(c))
+        if (OP == 0) F64CHAIN(OP_FMA64);
+        if (OP == 1) F64CHAIN(OP_MUL64);
+        if (OP == 2) F64CHAIN(OP_ADD64);
+    }
+    uint64_t t1 = __builtin_amdgcn_s_memtime();
+    double s = 0.0;
+    for (int i = 0; i < 8; ++i) s += a[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (float)s;
+    if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+// conversions between binary32 and binary64: a f32 -> f64 -> f32 round trip per chain step (2 instructions)
+__global__ __launch_bounds__(256) void k_rate_cvt64(float* out, uint64_t* cycles)
+{
+    float a[8];
+    double d[8];
+    for (int i = 0; i < 8; ++i) { a[i] = 1.0f + 0.001f * (threadIdx.x + i); d[i] = 0.0; }
+    uint64_t t0 = __builtin_amdgcn_s_memtime();
+    for (int r = 0; r < REP; ++r)
+    {
+#define OP_CVTRT(i, j) "v_cvt_f64_f32 %" #j ", %" #i "\nv_cvt_f32_f64 %" #i ", %" #j "\n"
+        asm volatile(OP_CVTRT(0, 8) OP_CVTRT(1, 9) OP_CVTRT(2, 10) OP_CVTRT(3, 11) OP_CVTRT(4, 12) OP_CVTRT(5, 13) OP_CVTRT(6, 14) OP_CVTRT(7, 15)
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                       "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]));
+    }
+    uint64_t t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.0f;
+    for (int i = 0; i < 8; ++i) s += a[i] + (float)d[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
 static const char* NAMES[] = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_add_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mul_u32_u24",
                               "v_rcp_f32", "v_sqrt_f32", "v_rsq_f32", "v_log_f32", "v_exp_f32", "v_div_fixup_f32", "v_div_fmas_f32",
                               "v_div_scale_f32", "v_cndmask_b32", "v_alignbit_b32", "v_lshrrev_b32", "v_xor_b32", "v_add3_u32",
@@ -246,7 +294,11 @@ int main()
     for (int f = 0; f < nfn; ++f) measure(NAMES[f], [&](int g) { fns[f](g, out, cyc); }, false);
     measure("v_mad_u64_u32", [&](int g) { k_rate_mad64<<<g, 256>>>(out, cyc, 12345u, 6789u); }, false);
     measure("v_pk_fma_f32", [&](int g) { k_rate_pk<0><<<g, 256>>>(out, cyc, 1.0001f, 0.5f); }, false);
-    measure("v_pk_mul_f32", [&](int g) { k_rate_pk<1><<<g, 256>>>(out, cyc, 1.0001f, 0.5f); }, true);
+    measure("v_pk_mul_f32", [&](int g) { k_rate_pk<1><<<g, 256>>>(out, cyc, 1.0001f, 0.5f); }, false);
+    measure("v_fma_f64", [&](int g) { k_rate_f64<0><<<g, 256>>>(out, cyc, 1.0001, 0.5); }, false);
+    measure("v_mul_f64", [&](int g) { k_rate_f64<1><<<g, 256>>>(out, cyc, 1.0001, 0.5); }, false);
+    measure("v_add_f64", [&](int g) { k_rate_f64<2><<<g, 256>>>(out, cyc, 1.0001, 0.5); }, false);
+    measure("v_cvt_f64_f32 + v_cvt_f32_f64 (per instruction)", [&](int g) { k_rate_cvt64<<<g, 256>>>(out, cyc); }, true);
     printf("}\n");
     return 0;
 }
