@@ -342,7 +342,13 @@ def main():
                 "scene": scene_desc,
                 "bvh_builder": "host binned SAH + 4-wide collapse", "build_ms": round(R["build_ms"], 1),
                 "rays_per_frame": total_rays,
-                "parallelism": f"row strips x{world}, {R['part']}, sparse 87-row halos over RCCL send/recv (native driver)" if world > 1 else "single GPU",
+                # strips (N > 1): every timed frame launches exactly one raycast, the one of the NEXT frame, on a second stream
+                # beside this frame's passes (rt_tuning key 14; rt_sync at the end of the timed region waits for it)
+                "frame_pipeline": ("raycast of frame f+1 beside the passes of frame f" if world > 1 else "kernels of a frame back to back on one stream"),
+                "parallelism": (f"row strips x{world}, {R['part']}, sparse 87-row halos over "
+                                + ("the SHM transport on ONE GPU (BENCH_DEV_SHM: protocol check, not a scaling number)" if dev_shm else
+                                   "self-loopback on ONE GPU (BENCH_DEV_MIRROR: per-rank overhead, not a scaling number)" if dev_mirror else
+                                   "RCCL send/recv") + " (native driver)") if world > 1 else "single GPU",
             },
             # what the parity chain cannot pin to the reference: HIPRT's device code is a missing binary
             # (DESIGN.md section 2); everything else is bit-exact against the reference's own sources

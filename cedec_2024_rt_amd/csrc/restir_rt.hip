@@ -60,7 +60,7 @@ struct rt_ctx
     int gcur = 0, timed_spec_set = -1;
     bool spec_valid = false, spec_timed[2] = {false, false};
     uint64_t spec_epoch = 0;
-    int tune_spec = 1; /* rt_tuning key 14 */
+    int tune_spec = -1; /* rt_tuning key 14: -1 auto = strip contexts only, 0 never, 1 always */
     bool lane_saved = false, lane_timing = false; /* rt_lane */
     hipStream_t lane_main = nullptr;
     std::string err;
@@ -919,10 +919,17 @@ int rt_raycast(rt_ctx* c)
     return RT_OK;
 }
 
+/* A/B r02 (profiles/r02_next_raycast_ab.txt): a strip's frame is a chain of small launches and exchanges with idle
+ * slots the raycast fills (-6 % at 1080p in 8 strips, -3 % at 4K); a whole frame gains < 1 % at 1080p (the overlapped
+ * spatial pass just waits for the machine) and its per-kernel times stop being comparable, so auto means strips only */
+static bool use_next_raycast(const rt_ctx* c)
+{
+    return c->tune_spec < 0 ? (c->row_begin != 0 || c->row_end != c->H) : c->tune_spec != 0;
+}
 /* the next frame's primary rays, behind everything enqueued on the main stream so far, on the stream of their own */
 static int launch_next_raycast(rt_ctx* c)
 {
-    if (!c->tune_spec) { c->spec_valid = false; return RT_OK; }
+    if (!use_next_raycast(c)) { c->spec_valid = false; return RT_OK; }
     const size_t n = local_pixels(c);
     if (!c->spec_stream)
     {
@@ -955,7 +962,7 @@ static int launch_next_raycast(rt_ctx* c)
 static int raycast_or_take(rt_ctx* c, bool whole)
 {
     c->timed_spec_set = -1;
-    if (whole && c->tune_spec && c->spec_valid && c->spec_epoch == c->epoch)
+    if (whole && use_next_raycast(c) && c->spec_valid && c->spec_epoch == c->epoch)
     {
         c->gcur ^= 1;
         c->d_vis = c->d_gset[c->gcur][0]; c->d_g0 = c->d_gset[c->gcur][1]; c->d_g1 = c->d_gset[c->gcur][2];
@@ -2040,7 +2047,7 @@ int rt_tuning(rt_ctx* c, int key, int value)
     else if (key == 11 && (value == 0 || value == 1)) c->tune_defer_vis = value;
     else if (key == 12 && (value == 0 || value == 1)) c->tune_ris_pipe = value;
     else if (key == 13 && value >= -1 && value <= 1) c->tune_ws = value;
-    else if (key == 14 && (value == 0 || value == 1)) { c->tune_spec = value; if (!value) c->spec_valid = false; }
+    else if (key == 14 && value >= -1 && value <= 1) { c->tune_spec = value; if (!use_next_raycast(c)) c->spec_valid = false; }
     else RT_FAIL(c, RT_ERR_ARG, "bad tuning key/value %d/%d", key, value);
     return RT_OK;
 }

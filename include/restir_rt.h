@@ -333,18 +333,12 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
  * key 13: shadow rays of generate_candidate / resolve walked with the work-sharing any-hit traversal (idle lanes of a
  * wavefront take over half of a busy lane's LDS stack): -1 (default) = for launches of at most ~one round of
  * wavefronts (strips of the multi-GPU frame), 0 = never, 1 (default) = always. Same results.
- * key 14: 1 (default) = rt_frame / rt_frame_stage trace the NEXT frame's primary rays on a stream of their own behind
- * stage 0 of the current frame (they depend on the camera only), into a second G-buffer set, beside the HBM-bound
- * spatial passes and the halo exchanges; the next frame uses them if camera, scene and options are still the same
- * (rt_state_epoch) and traces its own otherwise. rt_sync waits for that launch too; rt_timing reports its duration as
- * ms[1] although it is not part of ms[8]. 0 = every frame traces its primary rays first. Same results.
- * key 10 (before rt_scene_set): PLOC search radius of builder 2 (places in Morton order, default 16).
- * key 9: register budget of the unshadowed spatial pass, in wavefronts per SIMD (4, 5, 6; 0 = unbounded = 7; -1 = auto,
- * default: 4 for the gather kernel — fewer workgroups in flight keep its neighbour window inside the XCD's 4 MiB L2 —
- * and none for the LDS-staged kernel).
- * key 8: unshadowed spatial_resampling as 0 = dependent record gathers, 1 (default) = LDS-staged variant: the
- * tile's +-87-pixel window of shaded bits staged in LDS, neighbour addresses derived from LDS alone, the
- * record of neighbour k+1 in flight while neighbour k is merged (whole-frame contexts, radius <= 30). */
+ * key 14: rt_frame / rt_frame_stage trace the NEXT frame's primary rays on a stream of their own behind stage 0 of the
+ * current frame (they depend on the camera only), into a second G-buffer set, beside the spatial passes and the halo
+ * exchanges; the next frame uses them if camera, scene and options are still the same (rt_state_epoch) and traces its
+ * own otherwise. 1 = always, 0 = never (every frame traces its primary rays first), -1 (default) = strip contexts only
+ * (-6 % per frame at 1080p in 8 strips; < 1 % on a whole 1080p frame, where it only blurs the per-kernel times).
+ * rt_sync waits for that launch too; rt_timing reports its duration as ms[1] although it is not part of ms[8]. Same results. */
 int rt_tuning(rt_ctx* ctx, int key, int value);
 /* elementwise device evaluation of the portable math / IEEE div & sqrt (parity tests);
  * fn ids as in tests/test_portable_math.py */
