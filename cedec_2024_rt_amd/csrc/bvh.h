@@ -196,7 +196,10 @@ struct WideView
 #define RT_WIDE_LDS_STACK 24
 #endif
 constexpr int WIDE_LDS_STACK = RT_WIDE_LDS_STACK;
-constexpr int WIDE_OVF_STACK = 64 - RT_WIDE_LDS_STACK; /* total 64 >= 3 * wide height + 1 (checked at build) */
+#ifndef RT_WIDE_TOTAL_STACK
+#define RT_WIDE_TOTAL_STACK 64
+#endif
+constexpr int WIDE_OVF_STACK = RT_WIDE_TOTAL_STACK - RT_WIDE_LDS_STACK; /* total 64 >= 3 * wide height + 1 (checked at build) */
 constexpr uint32_t WIDE_LEAF_BIT = 0x80000000u;
 #ifndef WIDE_ANY_SORTED
 #define WIDE_ANY_SORTED 0 /* any-hit rays: visit children nearest-first (1) or in slot order (0) */

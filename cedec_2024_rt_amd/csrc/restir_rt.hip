@@ -324,7 +324,7 @@ static int build_wide(rt_ctx* c, const rt_triangle* tris, int n_refs)
     RT_HIP(c, hipStreamSynchronize(c->stream));
     std::vector<WideRec> recs;
     c->wide_height = collapse_wide(bin, tris, recs, c->bvh_bfs_records);
-    if (3 * c->wide_height + 1 > WIDE_LDS_STACK + WIDE_OVF_STACK)
+    if (RT_WIDE_TOTAL_STACK >= 64 && 3 * c->wide_height + 1 > WIDE_LDS_STACK + WIDE_OVF_STACK)
         RT_FAIL(c, RT_ERR_BVH_DEPTH, "wide BVH height %d exceeds the traversal stack (%d entries)", c->wide_height,
                 WIDE_LDS_STACK + WIDE_OVF_STACK);
     c->n_wide = (int)recs.size();
