@@ -103,6 +103,25 @@ def committed_pmc(sha):
     return out
 
 
+class _PythonStrips:
+    """bench.py's view of the round-1 Python strip schedule (fallback only): the rt_mg methods the loop uses"""
+
+    def __init__(self, sf):
+        self.sf = sf
+
+    def frame(self, frame, clear_first=False):
+        self.sf.frame(frame, clear_first)
+
+    def reset_stats(self):
+        pass
+
+    def stats(self):
+        return dict(frames=0, cold_frames=0, host_ns=0, plan_wait_ns=0, bytes_sent=0, messages=0, records_sent=0, gpu_ns_per_frame=0)
+
+    def close(self):
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -219,10 +238,40 @@ def main():
                 bounds = nb
                 r, build_ms = make_renderer(w, h, bounds[rank])
             part = "cost-weighted rows"
-        if dev_shm:
+        def python_strips(why):
+            """every rank TOGETHER: the round-1 schedule (Python StripFrame over torch.distributed send/recv: same HIP
+            kernels, same images, a slower host loop)"""
+            from cedec_2024_rt_amd import strips
+
+            if rank == 0:
+                sys.stderr.write("native strip driver not used (%s): Python strip schedule over torch.distributed\n" % why)
+            r.set_stream(torch.cuda.current_stream().cuda_stream)  # torch's stream orders packs, sends and unpacks
+            be = strips.HipStripBackend(r, dev, host_staging=dev_mirror)  # gloo (dev mode) moves host memory only
+            return _PythonStrips(strips.StripFrame(be, bounds, rank, transport=strips.DistTransport(dist), halo=HALO, sparse=True))
+
+        if os.environ.get("BENCH_FORCE_FALLBACK"):
+            mg = python_strips("BENCH_FORCE_FALLBACK")
+            part += ", FALLBACK: Python StripFrame over torch.distributed"
+        elif dev_shm:
             mg = api.MultiGpu(r, rank, bounds, transport=api.RT_MG_TRANSPORT_SHM, shm_name=uid[0])
+        elif dev_mirror:
+            mg = api.MultiGpu(r, rank, bounds, transport=api.RT_MG_TRANSPORT_MIRROR, unique_id=uid[0])
         else:
-            mg = api.MultiGpu(r, rank, bounds, transport=api.RT_MG_TRANSPORT_MIRROR if dev_mirror else api.RT_MG_TRANSPORT_RCCL, unique_id=uid[0])
+            # The RCCL transport of the native driver has only ever run on one rank (the development boxes have one
+            # GPU). If its communicator cannot be created on this node, every rank falls back together and the line
+            # says so, rather than losing the multi-GPU measurement.
+            mg, err = None, None
+            try:
+                mg = api.MultiGpu(r, rank, bounds, transport=api.RT_MG_TRANSPORT_RCCL, unique_id=uid[0])
+            except Exception as e:  # noqa: BLE001
+                err = f"rank {rank}: {e}"
+            errs = [None] * world
+            dist.all_gather_object(errs, err)
+            if any(errs):
+                if mg is not None:
+                    mg.close()
+                mg = python_strips(next(e for e in errs if e))
+                part += ", FALLBACK: Python StripFrame over torch.distributed (native RCCL driver failed to initialise)"
         return r, mg, bounds, build_ms, part
 
     def run(w, h, steps, warm):
@@ -346,9 +395,11 @@ def main():
                 # beside this frame's passes (rt_tuning key 14; rt_sync at the end of the timed region waits for it)
                 "frame_pipeline": ("raycast of frame f+1 beside the passes of frame f" if world > 1 else "kernels of a frame back to back on one stream"),
                 "parallelism": (f"row strips x{world}, {R['part']}, sparse 87-row halos over "
-                                + ("the SHM transport on ONE GPU (BENCH_DEV_SHM: protocol check, not a scaling number)" if dev_shm else
-                                   "self-loopback on ONE GPU (BENCH_DEV_MIRROR: per-rank overhead, not a scaling number)" if dev_mirror else
-                                   "RCCL send/recv") + " (native driver)") if world > 1 else "single GPU",
+                                + ("torch.distributed send/recv (Python schedule" + (", gloo on ONE GPU: not a scaling number)" if dev_mirror else ")")
+                                   if "FALLBACK" in R["part"] else
+                                   "the SHM transport on ONE GPU (BENCH_DEV_SHM: protocol check, not a scaling number) (native driver)" if dev_shm else
+                                   "self-loopback on ONE GPU (BENCH_DEV_MIRROR: per-rank overhead, not a scaling number) (native driver)" if dev_mirror else
+                                   "RCCL send/recv (native driver)")) if world > 1 else "single GPU",
             },
             # what the parity chain cannot pin to the reference: HIPRT's device code is a missing binary
             # (DESIGN.md section 2); everything else is bit-exact against the reference's own sources
