@@ -584,6 +584,230 @@ RT_DEV bool occluded_ws(const WideView& bvh, uint32_t* __restrict__ lds_generic,
     return s_hit[slot] != 0u;
 }
 
+/* ---- Shadow rays as a STREAM (r02). occluded_ws still starts 64 rays together and ends with the last one; the lanes
+ * that are done early can only help. Here a persistent wavefront pulls jobs (pixels) from a counter: whenever at
+ * least RT_STREAM_REFILL lanes are free, those lanes hand in their finished jobs and fetch new ones, so in steady
+ * state the wavefront holds rays of all ages and its passes are nearly full. When the counter runs dry the remaining
+ * rays are drained with the work-sharing rules of occluded_ws (idle lanes take half of a busy lane's stack).
+ *   fetch(job, ro, rd, tmin, tmax) -> bool : prepare job; false = the job needs no ray (fetch has dealt with it)
+ *   finish(job, occluded)                  : consume the answer of a job that had a ray
+ *   next_job(count, first, limit) -> bool  : called by ALL lanes of the wavefront together (wave-uniform result):
+ *                                            jobs [first, limit), limit - first <= count, or false when none are left
+ * Same answers as the one-lane walk: any-hit over the same triangles. ---- */
+#ifndef RT_STREAM_REFILL
+#define RT_STREAM_REFILL 24
+#endif
+#ifndef RT_STREAM_LEAF_NUM
+#define RT_STREAM_LEAF_NUM 1 /* leaf pass when lanes with a parked leaf * DEN >= lanes with a record to visit * NUM */
+#define RT_STREAM_LEAF_DEN 1
+#endif
+template <int STRIDE, class NextJob, class Fetch, class Finish>
+RT_DEV void occluded_stream(const WideView& bvh, uint32_t* __restrict__ lds_generic, NextJob next_job, Fetch fetch, Finish finish)
+{
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    lds_u32* lds_stack = (lds_u32*)lds_generic;
+    constexpr uint32_t NONE = 0x7fffffffu;
+    const int slot = threadIdx.x, lane = threadIdx.x & 63, wave0 = threadIdx.x & ~63;
+    lds_u32* s_hit = lds_stack + WIDE_LDS_STACK * STRIDE;
+    lds_u32* s_match = lds_stack + (WIDE_LDS_STACK + 1) * STRIDE;
+    s_hit[slot] = 0u;
+    f3 ro = F3(0.0f, 0.0f, 0.0f), rd = F3(0.0f, 0.0f, 1.0f), inv = F3(1.0f, 1.0f, 1.0f);
+    float tmin = 0.0f, tmax = 0.0f;
+    bool px = true, py = true, pz = true;
+    int owner = slot;
+    uint32_t ovf[WIDE_OVF_STACK];
+    int sp = 0, base = 0;
+    auto push = [&](uint32_t e) {
+        if (sp < WIDE_LDS_STACK) lds_stack[sp * STRIDE + slot] = e;
+        else ovf[sp - WIDE_LDS_STACK] = e;
+        ++sp;
+    };
+    auto pop = [&]() -> uint32_t {
+        --sp;
+        uint32_t e;
+        if (sp < WIDE_LDS_STACK) e = lds_stack[sp * STRIDE + slot];
+        else e = ovf[sp - WIDE_LDS_STACK];
+        if (sp == base) { sp = 0; base = 0; }
+        return e;
+    };
+    uint32_t cur = NONE, pend = NONE, pend2 = NONE;
+    int job = -1;           /* the job whose ray this lane OWNS (answer in s_hit[slot]), -1 = none */
+    bool exhausted = false; /* wave-uniform: the job counter has run dry, drain with work sharing */
+    uint32_t pass = 0u;
+    const bool empty_scene = bvh.n_tris <= 0;
+    for (;;)
+    {
+        if ((int)cur < 0 && pend2 == NONE)
+        {
+            if (pend == NONE) pend = cur; else pend2 = cur;
+            cur = sp > base ? pop() : NONE;
+        }
+        bool has_inner = cur < NONE;
+        bool has_pend = pend != NONE;
+        if (!exhausted)
+        {
+            /* no lane helps another yet: a ray is settled when its own lane has no work left or has found a hit */
+            const bool settled = job >= 0 && ((!has_inner && !has_pend) || s_hit[slot] != 0u);
+            const bool free_lane = job < 0 || settled;
+            const unsigned long long bf = __ballot(free_lane);
+            const int n_free = __popcll(bf);
+            if (n_free >= RT_STREAM_REFILL || __ballot(has_inner || has_pend) == 0ull)
+            {
+                if (settled)
+                {
+                    finish(job, s_hit[slot] != 0u);
+                    job = -1;
+                    cur = NONE; pend = NONE; pend2 = NONE; sp = 0; base = 0;
+                }
+                unsigned int first = 0u, limit = 0u;
+                const bool any = next_job((unsigned int)n_free, first, limit);
+                if (!any) exhausted = true;
+                if (any && free_lane)
+                {
+                    const unsigned int mine = first + (unsigned int)__popcll(bf & ((1ull << lane) - 1ull));
+                    if (mine < limit && fetch(mine, ro, rd, tmin, tmax))
+                    {
+                        if (empty_scene) finish(mine, false);
+                        else
+                        {
+                            job = (int)mine;
+                            s_hit[slot] = 0u;
+                            inv = F3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                            inv.x = fminf(fmaxf(inv.x, -1e30f), 1e30f);
+                            inv.y = fminf(fmaxf(inv.y, -1e30f), 1e30f);
+                            inv.z = fminf(fmaxf(inv.z, -1e30f), 1e30f);
+                            px = inv.x >= 0.0f; py = inv.y >= 0.0f; pz = inv.z >= 0.0f;
+                            owner = slot;
+                            cur = 0u; /* the root record */
+                        }
+                    }
+                }
+                has_inner = cur < NONE;
+                has_pend = pend != NONE;
+            }
+        }
+        const unsigned long long bl = __ballot(has_inner || has_pend);
+        if (bl == 0ull)
+        {
+            if (exhausted) break;
+            continue; /* every lane was handed a job without a ray: fetch again */
+        }
+        ++pass;
+        if (exhausted && (pass & ((1u << RT_WS_PERIOD) - 1u)) == 0u)
+        {
+            /* the drain: exactly the sharing step of occluded_ws */
+            if ((has_inner || has_pend) && s_hit[owner] != 0u)
+            {
+                cur = NONE; pend = NONE; pend2 = NONE; sp = 0; base = 0;
+                has_inner = false; has_pend = false;
+            }
+            const bool idle = !has_inner && !has_pend;
+            const bool rich = !idle && (sp - base) >= RT_WS_RICH && sp <= WIDE_LDS_STACK;
+            const unsigned long long bi = __ballot(idle), br = __ballot(rich);
+            const int nidle = __popcll(bi), nrich = __popcll(br);
+            if (nidle >= RT_WS_MIN && nrich > 0)
+            {
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                const int rank_i = __popcll(bi & lt), rank_r = __popcll(br & lt);
+                if (rich) s_match[wave0 + rank_r] = (uint32_t)lane;
+                const bool thief = idle && rank_i < nrich;
+                const bool robbed = rich && rank_r < nidle;
+                const int victim = thief ? (int)s_match[wave0 + rank_i] : lane;
+                const float vox = __shfl(ro.x, victim), voy = __shfl(ro.y, victim), voz = __shfl(ro.z, victim);
+                const float vdx = __shfl(rd.x, victim), vdy = __shfl(rd.y, victim), vdz = __shfl(rd.z, victim);
+                const float vix = __shfl(inv.x, victim), viy = __shfl(inv.y, victim), viz = __shfl(inv.z, victim);
+                const float vtmin = __shfl(tmin, victim), vtmax = __shfl(tmax, victim);
+                const int vbase = __shfl(base, victim), vsp = __shfl(sp, victim), vowner = __shfl(owner, victim);
+                if (thief)
+                {
+                    tmin = vtmin; tmax = vtmax;
+                    const int k = (vsp - vbase + 1) >> 1;
+                    ro = F3(vox, voy, voz); rd = F3(vdx, vdy, vdz); inv = F3(vix, viy, viz);
+                    px = inv.x >= 0.0f; py = inv.y >= 0.0f; pz = inv.z >= 0.0f;
+                    owner = vowner;
+                    const int vslot = wave0 + victim;
+                    for (int e = 0; e < k; ++e) lds_stack[e * STRIDE + slot] = lds_stack[(vbase + e) * STRIDE + vslot];
+                    base = 0; sp = k;
+                    cur = pop();
+                }
+                if (robbed) { base += (sp - base + 1) >> 1; if (base == sp) { base = 0; sp = 0; } }
+                has_inner = cur < NONE;
+            }
+        }
+        /* which pass: the rays of a stream have all ages, so "wait until every live lane has parked a leaf" (the rule of
+         * the one-shot walks) would leave lanes with two parked leaves stuck behind every newly fetched ray; run the
+         * triangle test when it has at least as many takers as the record visit */
+        const unsigned long long bi2 = __ballot(has_inner), bp = __ballot(has_pend);
+        if (bp != 0ull && (bi2 == 0ull || RT_STREAM_LEAF_DEN * __popcll(bp) >= RT_STREAM_LEAF_NUM * __popcll(bi2)))
+        {
+            if (has_pend)
+            {
+                const float4* g = bvh.rec + 3 * (size_t)(pend & ~WIDE_LEAF_BIT);
+                const float4 t0 = g[0], t1 = g[1], t2 = g[2];
+                pend = pend2; pend2 = NONE;
+                const f3 v0 = F3(t0.x, t0.y, t0.z), v1 = F3(t0.w, t1.x, t1.y), v2 = F3(t1.z, t1.w, t2.x);
+                float t, u, v;
+                if (intersect_ray_triangle(t, u, v, ro, rd, tmin, tmax, v0, v1, v2))
+                {
+                    s_hit[owner] = 1u;
+                    cur = NONE; pend = NONE; pend2 = NONE; sp = 0; base = 0;
+                }
+            }
+            continue;
+        }
+        if (has_inner)
+        {
+            const float4* g = bvh.rec + 3 * (size_t)cur;
+            const float4 q0 = g[0], q1f = g[1], q2f = g[2];
+            const uint32_t e = as_uint(q0.w);
+            const uint32_t cbase = as_uint(q1f.x), meta = as_uint(q1f.y);
+            const uint32_t lx = as_uint(q1f.z), ly = as_uint(q1f.w), lz = as_uint(q2f.x);
+            const uint32_t hx = as_uint(q2f.y), hy = as_uint(q2f.z), hz = as_uint(q2f.w);
+            const uint32_t nx = px ? lx : hx, ny = py ? ly : hy, nz = pz ? lz : hz;
+            const uint32_t fx = px ? hx : lx, fy = py ? hy : ly, fz = pz ? hz : lz;
+            const float sx = as_float((e & 0xffu) << 23), sy = as_float(((e >> 8) & 0xffu) << 23),
+                        sz = as_float(((e >> 16) & 0xffu) << 23);
+            const float Ax = (q0.x - ro.x) * inv.x, Ay = (q0.y - ro.y) * inv.y, Az = (q0.z - ro.z) * inv.z;
+            const float Bx = sx * inv.x, By = sy * inv.y, Bz = sz * inv.z;
+            bool h[4];
+            uint32_t ce[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+            {
+                const uint32_t m = (meta >> (8 * k)) & 0xffu;
+                float tn = fmaxf(fmaxf(__builtin_fmaf(wide_byte(nx, k), Bx, Ax), __builtin_fmaf(wide_byte(ny, k), By, Ay)),
+                                 __builtin_fmaf(wide_byte(nz, k), Bz, Az));
+                float tf = fminf(fminf(__builtin_fmaf(wide_byte(fx, k), Bx, Ax), __builtin_fmaf(wide_byte(fy, k), By, Ay)),
+                                 __builtin_fmaf(wide_byte(fz, k), Bz, Az));
+                tn = fmaxf(tn * (1.0f - 4e-7f), tmin);
+                tf = fminf(tf * (1.0f + 4e-7f), tmax);
+                h[k] = (m != 0u) && (tn <= tf);
+                ce[k] = (cbase + (uint32_t)k) | (m == 2u ? WIDE_LEAF_BIT : 0u);
+            }
+            if (h[0] || h[1] || h[2] || h[3])
+            {
+                const bool deep = __ballot(sp + 3 > WIDE_LDS_STACK) != 0ull;
+                cur = h[0] ? ce[0] : (h[1] ? ce[1] : (h[2] ? ce[2] : ce[3]));
+                if (__builtin_expect(deep, 0))
+                {
+                    if (h[1] && h[0]) push(ce[1]);
+                    if (h[2] && (h[0] || h[1])) push(ce[2]);
+                    if (h[3] && (h[0] || h[1] || h[2])) push(ce[3]);
+                }
+                else
+                {
+                    if (h[3] && (h[0] || h[1] || h[2])) { lds_stack[sp * STRIDE + slot] = ce[3]; ++sp; }
+                    if (h[2] && (h[0] || h[1])) { lds_stack[sp * STRIDE + slot] = ce[2]; ++sp; }
+                    if (h[1] && h[0]) { lds_stack[sp * STRIDE + slot] = ce[1]; ++sp; }
+                }
+            }
+            else cur = sp > base ? pop() : NONE;
+        }
+    }
+    /* the rays still owned when the wavefront ran out of work: their answers are in the flags */
+    if (job >= 0) finish(job, s_hit[slot] != 0u);
+}
+
 /* WS: walk with occluded_ws (idle lanes of the wavefront take over part of a busy lane's stack). The answer is the
  * same bit either way (any-hit of the same ray against the same triangles); it pays where a launch is a single round
  * of wavefronts, i.e. the strips of the multi-GPU frame, and costs ~1-3 % on the full frame (rt_tuning key 13). */

@@ -70,14 +70,14 @@ constexpr int TRACE_BLOCK = RT_TRACE_BLOCK;
 template <int TB> struct TileShape { static constexpr int W = TILE_W, H = TILE_H; };
 template <> struct TileShape<64> { static constexpr int W = 8, H = 8; };
 
+/* workgroup index b, thread index t (the persistent kernels walk a job counter instead of blockIdx / threadIdx) */
 template <int TB = BLOCK>
-RT_DEV bool tile_pixel(const FrameParams& P, int& x, int& row)
+RT_DEV bool tile_pixel_at(const FrameParams& P, const int b, const int t, int& x, int& row)
 {
     constexpr int TILE_W = TileShape<TB>::W, TILE_H = TileShape<TB>::H;
     const int tiles_x = (P.W + TILE_W - 1) / TILE_W;
     const int tiles_ya = (P.row1 - P.row0 + TILE_H - 1) / TILE_H;
     const int tiles_y = tiles_ya + (P.rowb1 > P.rowb0 ? (P.rowb1 - P.rowb0 + TILE_H - 1) / TILE_H : 0);
-    const int b = blockIdx.x;
     int tx, ty;
     if (P.tile_mode == 1)
     {
@@ -107,21 +107,26 @@ RT_DEV bool tile_pixel(const FrameParams& P, int& x, int& row)
     const int end = second ? P.rowb1 : P.row1;
     if (TB == 64)
     {
-        x = tx * 8 + (threadIdx.x & 7);
-        row = base + (threadIdx.x >> 3);
+        x = tx * 8 + (t & 7);
+        row = base + (t >> 3);
     }
     else
     {
 #if RT_WAVE_8X8 && RT_TILE_W == 32
         /* wavefront w of the workgroup covers the 8x8 sub-block w of the 32x8 tile */
-        x = tx * TILE_W + 8 * (threadIdx.x >> 6) + (threadIdx.x & 7);
-        row = base + ((threadIdx.x >> 3) & 7);
+        x = tx * TILE_W + 8 * (t >> 6) + (t & 7);
+        row = base + ((t >> 3) & 7);
 #else
-        x = tx * TILE_W + (threadIdx.x & (TILE_W - 1));
-        row = base + (threadIdx.x >> TILE_W_LOG2);
+        x = tx * TILE_W + (t & (TILE_W - 1));
+        row = base + (t >> TILE_W_LOG2);
 #endif
     }
     return x < P.W && row < end;
+}
+template <int TB = BLOCK>
+RT_DEV bool tile_pixel(const FrameParams& P, int& x, int& row)
+{
+    return tile_pixel_at<TB>(P, (int)blockIdx.x, (int)threadIdx.x, x, row);
 }
 static inline int tile_grid(int W, int rows, int tile_w = TILE_W, int tile_h = TILE_H, int rows_b = 0)
 {
@@ -1088,6 +1093,90 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_RESOLVE_WAVES) void k_resolve(Scene
 }
 
 
+/* resolve as a stream (bvh.h occluded_stream): persistent one-wavefront workgroups pull pixels from eight counters,
+ * one per XCD band of tiles (workgroup w starts on band w % 8 = the XCD it runs on, and moves on when a band is
+ * empty), in the tile order of the other tracing kernels: job i of a band = thread i % 64 of that band's tile i / 64.
+ * Sky / emissive pixels are written when they are fetched; a shaded pixel's ray is walked and the pixel is shaded when
+ * the ray is settled (its inputs are read again then: the walk keeps only the pixel's index). */
+#ifndef RT_RESOLVE_STREAM_WAVES
+#define RT_RESOLVE_STREAM_WAVES 5
+#endif
+#ifndef RT_STREAM_CHUNK
+#define RT_STREAM_CHUNK 256 /* jobs per atomic: four 8x8 tiles */
+#endif
+__global__ __launch_bounds__(TRACE_BLOCK, RT_RESOLVE_STREAM_WAVES) void k_resolve_stream(
+    SceneView S, FrameParams P, const float4* __restrict__ g0, const float4* __restrict__ g1, const float4* __restrict__ rec,
+    const float4* __restrict__ radb, float4* __restrict__ accum, int n_tiles)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_ROWS * TRACE_BLOCK];
+    /* No shared job counter: same-address device-scope atomics cost ~0.86 us EACH on this chip (they serialise at the
+     * memory side: 32 400 of them on 8 addresses took 3.5 ms), so workgroup w walks the tiles w, w + gridDim.x, ... of
+     * the launch's tile order (gridDim.x is a multiple of 8: the same XCD band every time); job = tile * 64 + thread. */
+    unsigned int tile_b = blockIdx.x;             /* wave-uniform */
+    unsigned int chunk_next = 0u, chunk_end = 0u; /* wave-uniform: job ids left of the current tile */
+    bool first_tile = true;
+    auto next_job = [&](unsigned int count, unsigned int& first, unsigned int& limit) -> bool {
+        if (chunk_next >= chunk_end)
+        {
+            if (!first_tile) tile_b += gridDim.x;
+            first_tile = false;
+            if (tile_b >= (unsigned int)n_tiles) return false;
+            chunk_next = tile_b * 64u;
+            chunk_end = chunk_next + 64u;
+        }
+        first = chunk_next;
+        limit = chunk_next + count < chunk_end ? chunk_next + count : chunk_end;
+        chunk_next = limit;
+        return true;
+    };
+    auto pixel_of = [&](unsigned int job, int& x, int& row) -> bool {
+        return tile_pixel_at<TRACE_BLOCK>(P, (int)(job >> 6), (int)(job & 63u), x, row);
+    };
+    auto fetch = [&](unsigned int job, f3& ro, f3& rd, float& tmin, float& tmax) -> bool {
+        int x, row;
+        if (!pixel_of(job, x, row)) return false;
+        const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
+        const float4 G0 = g0[li], G1 = g1[li];
+        const int tri = as_int(G0.w);
+        if (tri < 0) { accum[li] = make_float4(0.0f, 0.0f, 0.0f, 1.0f); return false; }
+        if (as_uint(G1.w) & GB_EMISSIVE)
+        {
+            const float4 ke = S.trimat[2 * (size_t)tri + 1];
+            accum[li] = make_float4(ke.x, ke.y, ke.z, 1.0f);
+            return false;
+        }
+        const float4 q0 = rec[4 * li + 0];
+        const f3 sp = F3(G0.x, G0.y, G0.z), sn = F3(G1.x, G1.y, G1.z), hp = F3(q0.x, q0.y, q0.z);
+        ro = sp + 0.001f * sn; /* check_visibility (common/raytrace.hpp:42-52) */
+        rd = hp - sp;
+        tmin = 0.0f; tmax = 0.99f;
+        return true;
+    };
+    auto finish = [&](unsigned int job, bool occluded) {
+        int x, row;
+        pixel_of(job, x, row);
+        const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
+        const float4 G0 = g0[li], G1 = g1[li];
+        const int tri = as_int(G0.w);
+        const f3 sp = F3(G0.x, G0.y, G0.z), sn = F3(G1.x, G1.y, G1.z);
+        const float4 q0 = rec[4 * li + 0], q1 = rec[4 * li + 1];
+        const float4 rq = radb[li];
+        const float4 kd = S.trimat[2 * (size_t)tri];
+        const f3 hp = F3(q0.x, q0.y, q0.z), hn = F3(q1.x, q1.y, q1.z);
+        const f3 brdf = (1.0f / kPI) * F3(kd.x, kd.y, kd.z);
+        const float G = geometry_term(sp, sn, hp, hn);
+        const float V = occluded ? 0.0f : 1.0f;
+        const f3 radiance = brdf * G * V * F3(rq.x, rq.y, rq.z) * q0.w;
+        if (P.accumulate)
+        {
+            const float4 a = accum[li];
+            accum[li] = make_float4(a.x + radiance.x, a.y + radiance.y, a.z + radiance.z, a.w + 1.0f);
+        }
+        else { accum[li] = make_float4(radiance.x, radiance.y, radiance.z, 1.0f); }
+    };
+    occluded_stream<TRACE_BLOCK>(S.wide, s_stack, next_job, fetch, finish);
+}
+
 /* ------------------------------------------------------- configs #2 / #3: path tracers */
 /* shadow rays of 08_nee / 09_ris through the work-sharing walk (bvh.h occluded_ws) */
 #ifndef RT_PT_WS
@@ -1566,6 +1655,24 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_stats_ws(SceneView S, con
     if (r[7] >= 0.0f) occ = occluded_ws<TRACE_BLOCK>(S.wide, s_stack, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7], st);
     stats[2 * (size_t)i] = st[0] | (occ ? 0x80000000u : 0u);
     stats[2 * (size_t)i + 1] = st[1];
+}
+/* shadow rays from a list, walked as the frame kernels walk theirs (one-wavefront workgroups): hits[i].w = 0 if
+ * occluded, -1 if not; rays with tmax < 0 are lanes without a ray. WS: the work-sharing walk, else one lane one ray. */
+template <bool WS>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_anyhit(SceneView S, const float* __restrict__ rays, int n, float* __restrict__ hits)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[(WS ? WIDE_LDS_ROWS : WIDE_LDS_STACK) * TRACE_BLOCK];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rays + 8 * (size_t)i;
+    bool occ = false;
+    if (r[7] >= 0.0f)
+    {
+        if (WS) occ = occluded_ws<TRACE_BLOCK>(S.wide, s_stack, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7]);
+        else { Hit h; occ = trace_wide<true, false, TRACE_BLOCK>(S.wide, s_stack, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7], h); }
+    }
+    float4* out = (float4*)hits;
+    out[i] = make_float4(0.0f, 0.0f, 0.0f, as_float(occ ? 0 : -1));
 }
 template <int MODE, bool ANY = false>
 __global__ __launch_bounds__(BLOCK) void k_trace_stats(SceneView S, const float* __restrict__ rays, int n, uint32_t* __restrict__ stats)

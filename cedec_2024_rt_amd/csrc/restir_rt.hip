@@ -60,6 +60,8 @@ struct rt_ctx
     int gcur = 0, timed_spec_set = -1;
     bool spec_valid = false, spec_timed[2] = {false, false};
     uint64_t spec_epoch = 0;
+    int tune_stream = 0; /* rt_tuning key 15: resolve as a stream of pixels through persistent wavefronts (A/B: slower) */
+    int n_cus = 256;
     int tune_spec = -1; /* rt_tuning key 14: -1 auto = strip contexts only, 0 never, 1 always */
     bool lane_saved = false, lane_timing = false; /* rt_lane */
     hipStream_t lane_main = nullptr;
@@ -217,6 +219,10 @@ int rt_create(int device, int width, int height, int row_begin, int row_end, int
     c->opt = default_options();
     memset(&c->rg, 0, sizeof(c->rg));
     RT_HIP(c, hipSetDevice(device));
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
+    }
     RT_HIP(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     /* default priority: with the lowest priority the lane was starved in some exchanges (A/B in DESIGN.md §7) */
     RT_HIP(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
@@ -1149,7 +1155,14 @@ int rt_spatial_resampling(rt_ctx* c, int frame, int pass, int in, int out)
 static int launch_resolve(rt_ctx* c, int phys)
 {
     const int g = trace_grid(c);
-    if (use_ws(c, g)) k_resolve<true><<<g, TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RESOLVE), c->d_g0, c->d_g1, c->d_rec[phys], c->d_rad[phys], c->d_accum);
+    if (c->tune_stream)
+    {
+        /* persistent wavefronts, tiles dealt out round-robin (no job counter) */
+        const int resident = c->n_cus * 4 * RT_RESOLVE_STREAM_WAVES; /* wavefronts the GPU holds at once: a multiple of 8 */
+        const int wgs = g < resident ? g : resident;
+        k_resolve_stream<<<wgs, TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RESOLVE), c->d_g0, c->d_g1, c->d_rec[phys], c->d_rad[phys], c->d_accum, g);
+    }
+    else if (use_ws(c, g)) k_resolve<true><<<g, TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RESOLVE), c->d_g0, c->d_g1, c->d_rec[phys], c->d_rad[phys], c->d_accum);
     else k_resolve<false><<<g, TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RESOLVE), c->d_g0, c->d_g1, c->d_rec[phys], c->d_rad[phys], c->d_accum);
     RT_HIP(c, hipGetLastError());
     return RT_OK;
@@ -1982,6 +1995,8 @@ int rt_trace_closest(rt_ctx* c, const float* rays, uint32_t n, float* hits)
     }
     else if (c->trace_mode == 0) k_trace_closest<0><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_h);
     else if (c->trace_mode == 4) k_trace_closest<0, true><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_h);
+    else if (c->trace_mode == 5) k_trace_anyhit<true><<<(n + TRACE_BLOCK - 1) / TRACE_BLOCK, TRACE_BLOCK, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_h);
+    else if (c->trace_mode == 6) k_trace_anyhit<false><<<(n + TRACE_BLOCK - 1) / TRACE_BLOCK, TRACE_BLOCK, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_h);
     else k_trace_closest<1><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_h);
     RT_HIP(c, hipGetLastError());
     RT_HIP(c, hipEventRecord(e1, c->stream));
@@ -2047,6 +2062,7 @@ int rt_tuning(rt_ctx* c, int key, int value)
     else if (key == 11 && (value == 0 || value == 1)) c->tune_defer_vis = value;
     else if (key == 12 && (value == 0 || value == 1)) c->tune_ris_pipe = value;
     else if (key == 13 && value >= -1 && value <= 1) c->tune_ws = value;
+    else if (key == 15 && (value == 0 || value == 1)) c->tune_stream = value;
     else if (key == 14 && value >= -1 && value <= 1) { c->tune_spec = value; if (!use_next_raycast(c)) c->spec_valid = false; }
     else RT_FAIL(c, RT_ERR_ARG, "bad tuning key/value %d/%d", key, value);
     return RT_OK;
@@ -2056,7 +2072,7 @@ int rt_tuning(rt_ctx* c, int key, int value)
 int rt_trace_mode(rt_ctx* c, int mode)
 {
     RT_CHECK_CTX(c);
-    if (mode < 0 || mode > 5) RT_FAIL(c, RT_ERR_ARG, "mode must be 0..5");
+    if (mode < 0 || mode > 6) RT_FAIL(c, RT_ERR_ARG, "mode must be 0..6");
     c->trace_mode = mode;
     return RT_OK;
 }

@@ -309,7 +309,9 @@ int rt_build_ms(rt_ctx* ctx, float* ms); /* wall time of the last rt_scene_set (
 /* which traversal rt_trace_closest / rt_trace_stats exercise: 0 = 4-wide quantised BVH + LDS stack
  * (what every frame kernel uses, default), 1 = binary LBVH + stackless trail (A/B measurements),
  * 2/3 = persistent lane-refill queue (closest / any hit), 4 = mode 0 with any-hit (shadow-ray)
- * semantics: hits[i].index >= 0 iff occluded. rt_trace_time: device ms of the last call's kernel. */
+ * semantics: hits[i].index >= 0 iff occluded; 5 / 6 = shadow rays in one-wavefront workgroups as the frame kernels
+ * walk them, with the work-sharing walk (5; rt_trace_stats then returns its pass / steal counters) or one lane per ray
+ * (6); rays with tmax < 0 are lanes without a ray. rt_trace_time: device ms of the last call's kernel. */
 int rt_trace_mode(rt_ctx* ctx, int mode);
 int rt_trace_time(rt_ctx* ctx, float* ms);
 /* performance knobs; results never depend on them. keys 0..3: workgroup->tile order inside an XCD
@@ -338,7 +340,12 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
  * exchanges; the next frame uses them if camera, scene and options are still the same (rt_state_epoch) and traces its
  * own otherwise. 1 = always, 0 = never (every frame traces its primary rays first), -1 (default) = strip contexts only
  * (-6 % per frame at 1080p in 8 strips; < 1 % on a whole 1080p frame, where it only blurs the per-kernel times).
- * rt_sync waits for that launch too; rt_timing reports its duration as ms[1] although it is not part of ms[8]. Same results. */
+ * rt_sync waits for that launch too; rt_timing reports its duration as ms[1] although it is not part of ms[8]. Same results.
+ * key 15: 1 = resolve as a STREAM: persistent wavefronts keep pulling pixels, a lane whose shadow ray is settled shades
+ * its pixel and fetches the next one while the other lanes keep walking (csrc/bvh.h occluded_stream). Evaluated and
+ * left off (default 0): same instruction count as the work-sharing kernel but 0.48 against 0.36 ms — a wavefront
+ * holding rays of several tiles and ages sends 1.5x the requests to L2 and misses 2.6x as often, see DESIGN.md
+ * section 5.2 and profiles/r02_stream_resolve_ab.txt. Same results. */
 int rt_tuning(rt_ctx* ctx, int key, int value);
 /* elementwise device evaluation of the portable math / IEEE div & sqrt (parity tests);
  * fn ids as in tests/test_portable_math.py */

@@ -758,6 +758,35 @@ def test_work_sharing_shadow_walk_is_bit_identical(api, scenes):
             r.close()
 
 
+def test_resolve_as_a_stream_is_bit_identical(api, scenes):
+    """rt_tuning key 15 (persistent wavefronts that refill finished lanes with the next pixels; evaluated, off by default):
+    same accumulation and pixels as the default resolve, with and without accumulation, whole frame and strip."""
+    from cedec_2024_rt_amd.types import bench_options
+
+    tris = scenes.make_blocks_restir()
+    W, H = 480, 270
+    for rows, halo, acc in ((None, 0, 0), (None, 0, 1), ((90, 200), 70, 0)):
+        rs = []
+        for stream in (0, 1):
+            r = api.Renderer(W, H, rows=rows, halo=halo)
+            r.set_scene(tris)
+            r.lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)
+            r.set_options(bench_options(accumulate=acc, spatial_resampling_radius=20.0))
+            r.tuning(15, stream)
+            rs.append(r)
+        for frame in (1, 2, 3):
+            for r in rs:
+                if rows is None:
+                    r.frame(frame)
+                else:
+                    for k in range(5):
+                        r.frame_stage(frame, k, False)
+            for buf in (api.RT_BUF_ACCUMULATION, api.RT_BUF_PIXELS):
+                assert _eq_bits(rs[0].download(buf), rs[1].download(buf)), (rows, acc, frame, buf)
+        for r in rs:
+            r.close()
+
+
 def test_next_frame_raycast_overlap_is_bit_identical(api, scenes):
     """rt_tuning key 14: with the next frame's primary rays traced beside the current frame (and thrown away when the
     camera moves, the options change or the per-kernel API is used in between) every buffer equals the run that traces

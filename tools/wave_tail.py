@@ -77,3 +77,14 @@ steals = (raw[:, 1] & 0xffff).astype(np.int64)
 steps = (raw[:, 1] >> 16).astype(np.int64)
 print("work-sharing shadow rays: per-wave passes mean %.1f p50 %d p90 %d p99 %d max %d; steals per wavefront %.1f; inner records per lane mean %.1f (sum over a wave / 64 = %.1f)" % (
     wave.mean(), *np.percentile(wave, [50, 90, 99]).astype(int), wave.max(), steals.reshape(-1, 64).sum(1).mean(), steps[sh].mean(), steps.reshape(-1, 64).sum(1).mean() / 64), flush=True)
+
+# device time of the same shadow rays from a list: persistent lane-refill queue (3), 256-thread workgroups one lane per
+# ray (4), one-wavefront workgroups with the work-sharing walk (5) and without (6)
+for mode, name in ((3, "persistent queue, lanes refilled with new rays"), (4, "one lane per ray, 256-thread workgroups"),
+                   (6, "one lane per ray, one-wavefront workgroups"), (5, "work-sharing walk, one-wavefront workgroups")):
+    r.trace_mode(mode)
+    ts = []
+    for _ in range(5):
+        r.trace_closest(shadow)
+        ts.append(r.trace_time())
+    print("shadow rays from a list, mode %d (%s): %.3f ms" % (mode, name, min(ts)), flush=True)
