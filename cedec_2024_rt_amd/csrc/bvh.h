@@ -584,6 +584,203 @@ RT_DEV bool occluded_ws(const WideView& bvh, uint32_t* __restrict__ lds_generic,
     return s_hit[slot] != 0u;
 }
 
+/* ---- Work-sharing CLOSEST-hit walk (r02). Same sharing rules as occluded_ws; the answer of a ray is the minimum over
+ * its subtrees of (t, then the larger triangle index), which is order-independent, so the pieces of a ray walked by
+ * different lanes are merged by one 64-bit LDS min per accepted triangle on the key (bits(t) << 32 | ~index). A lane
+ * culls boxes against its cached copy of the owner's best t (refreshed at every sharing check and after its own hits):
+ * a stale, larger value only prunes less. At the end the owner re-intersects the winning triangle to get (t, u, v):
+ * the same arithmetic on the same ray and triangle as the lane that found it. Rows WIDE_LDS_STACK .. +1 hold the
+ * keys, row +2 the thief/victim table: the caller's LDS array has WIDE_LDS_ROWS_CLOSEST rows. ---- */
+constexpr int WIDE_LDS_ROWS_CLOSEST = WIDE_LDS_STACK + 3;
+template <int STRIDE = BLOCK_THREADS>
+RT_DEV bool closest_ws(const WideView& bvh, const float4* __restrict__ tv, uint32_t* __restrict__ lds_generic, const f3 own_ro, const f3 own_rd,
+                       const float own_tmin, const float own_tmax, Hit& hit)
+{
+    if (bvh.n_tris <= 0) return false;
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+    lds_u32* lds_stack = (lds_u32*)lds_generic;
+    constexpr uint32_t NONE = 0x7fffffffu;
+    constexpr unsigned long long NOHIT = ~0ull;
+    const int slot = threadIdx.x, lane = threadIdx.x & 63, wave0 = threadIdx.x & ~63;
+    lds_u64* s_key = (lds_u64*)(lds_stack + WIDE_LDS_STACK * STRIDE);  /* [slot]: best (t, index) of the ray that lane owns */
+    lds_u32* s_match = lds_stack + (WIDE_LDS_STACK + 2) * STRIDE;
+    s_key[slot] = NOHIT;
+    f3 ro = own_ro, rd = own_rd;
+    float tmin = own_tmin, tmax = own_tmax;
+    f3 inv = F3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    inv.x = fminf(fmaxf(inv.x, -1e30f), 1e30f);
+    inv.y = fminf(fmaxf(inv.y, -1e30f), 1e30f);
+    inv.z = fminf(fmaxf(inv.z, -1e30f), 1e30f);
+    bool px = inv.x >= 0.0f, py = inv.y >= 0.0f, pz = inv.z >= 0.0f;
+    float best = tmax; /* cached: boxes beyond it cannot hold the answer */
+    int owner = slot;
+    uint32_t ovf[WIDE_OVF_STACK];
+    int sp = 0, base = 0;
+    auto push = [&](uint32_t e) {
+        if (sp < WIDE_LDS_STACK) lds_stack[sp * STRIDE + slot] = e;
+        else ovf[sp - WIDE_LDS_STACK] = e;
+        ++sp;
+    };
+    auto pop = [&]() -> uint32_t {
+        --sp;
+        uint32_t e;
+        if (sp < WIDE_LDS_STACK) e = lds_stack[sp * STRIDE + slot];
+        else e = ovf[sp - WIDE_LDS_STACK];
+        if (sp == base) { sp = 0; base = 0; }
+        return e;
+    };
+    /* order-preserving map of a float's bits onto unsigned integers (negative t included), and back */
+    auto sortable = [&](float f) -> uint32_t { const uint32_t b = as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); };
+    auto key_t = [&](unsigned long long k) -> float { const uint32_t u = (uint32_t)(k >> 32); return as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); };
+    uint32_t cur = 0u, pend = NONE, pend2 = NONE;
+    uint32_t pass = 0u;
+    for (;;)
+    {
+        if ((int)cur < 0 && pend2 == NONE)
+        {
+            if (pend == NONE) pend = cur; else pend2 = cur;
+            cur = sp > base ? pop() : NONE;
+        }
+        bool has_inner = cur < NONE;
+        bool has_pend = pend != NONE;
+        if (__ballot(has_inner || has_pend) == 0ull) break;
+        ++pass;
+        if ((pass & ((1u << RT_WS_PERIOD) - 1u)) == 0u)
+        {
+            /* what the other lanes have found for this ray meanwhile */
+            {
+                const unsigned long long k = s_key[owner];
+                if (k != NOHIT) best = fminf(best, key_t(k));
+            }
+            const bool idle = !has_inner && !has_pend;
+            const bool rich = !idle && (sp - base) >= RT_WS_RICH && sp <= WIDE_LDS_STACK;
+            const unsigned long long bi = __ballot(idle), br = __ballot(rich);
+            const int nidle = __popcll(bi), nrich = __popcll(br);
+            if (nidle >= RT_WS_MIN && nrich > 0)
+            {
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                const int rank_i = __popcll(bi & lt), rank_r = __popcll(br & lt);
+                if (rich) s_match[wave0 + rank_r] = (uint32_t)lane;
+                const bool thief = idle && rank_i < nrich;
+                const bool robbed = rich && rank_r < nidle;
+                const int victim = thief ? (int)s_match[wave0 + rank_i] : lane;
+                const float vox = __shfl(ro.x, victim), voy = __shfl(ro.y, victim), voz = __shfl(ro.z, victim);
+                const float vdx = __shfl(rd.x, victim), vdy = __shfl(rd.y, victim), vdz = __shfl(rd.z, victim);
+                const float vix = __shfl(inv.x, victim), viy = __shfl(inv.y, victim), viz = __shfl(inv.z, victim);
+                const float vtmin = __shfl(tmin, victim), vtmax = __shfl(tmax, victim), vbest = __shfl(best, victim);
+                const int vbase = __shfl(base, victim), vsp = __shfl(sp, victim), vowner = __shfl(owner, victim);
+                if (thief)
+                {
+                    tmin = vtmin; tmax = vtmax; best = vbest;
+                    const int k = (vsp - vbase + 1) >> 1; /* the bottom half: the far subtrees */
+                    ro = F3(vox, voy, voz); rd = F3(vdx, vdy, vdz); inv = F3(vix, viy, viz);
+                    px = inv.x >= 0.0f; py = inv.y >= 0.0f; pz = inv.z >= 0.0f;
+                    owner = vowner;
+                    const int vslot = wave0 + victim;
+                    for (int e = 0; e < k; ++e) lds_stack[e * STRIDE + slot] = lds_stack[(vbase + e) * STRIDE + vslot];
+                    base = 0; sp = k;
+                    cur = pop();
+                }
+                if (robbed) { base += (sp - base + 1) >> 1; if (base == sp) { base = 0; sp = 0; } }
+                has_inner = cur < NONE;
+            }
+        }
+        const unsigned long long bi2 = __ballot(has_inner), bp = __ballot(has_pend);
+        const int parked = __popcll(bp) + __popcll(__ballot(pend2 != NONE));
+        if (bp != 0ull && (bi2 == 0ull || RT_LEAF_DEN_CLOSEST * parked >= RT_LEAF_NUM_CLOSEST * __popcll(__ballot(has_inner || has_pend))))
+        {
+            if (has_pend)
+            {
+                const float4* g = bvh.rec + 3 * (size_t)(pend & ~WIDE_LEAF_BIT);
+                const float4 t0 = g[0], t1 = g[1], t2 = g[2];
+                pend = pend2; pend2 = NONE;
+                const f3 v0 = F3(t0.x, t0.y, t0.z), v1 = F3(t0.w, t1.x, t1.y), v2 = F3(t1.z, t1.w, t2.x);
+                const int pi = as_int(t2.y);
+                float t, u, v;
+                if (intersect_ray_triangle(t, u, v, ro, rd, tmin, tmax, v0, v1, v2) && t <= best)
+                {
+                    /* -0.0f and +0.0f are the same distance: one key for both */
+                    const unsigned long long key = ((unsigned long long)sortable(t + 0.0f) << 32) | (unsigned long long)(~(uint32_t)pi);
+                    atomicMin((unsigned long long*)&s_key[owner], key);
+                    best = t;
+                }
+            }
+            continue;
+        }
+        if (has_inner)
+        {
+            const float4* g = bvh.rec + 3 * (size_t)cur;
+            const float4 q0 = g[0], q1f = g[1], q2f = g[2];
+            const uint32_t e = as_uint(q0.w);
+            const uint32_t cbase = as_uint(q1f.x), meta = as_uint(q1f.y);
+            const uint32_t lx = as_uint(q1f.z), ly = as_uint(q1f.w), lz = as_uint(q2f.x);
+            const uint32_t hx = as_uint(q2f.y), hy = as_uint(q2f.z), hz = as_uint(q2f.w);
+            const uint32_t nx = px ? lx : hx, ny = py ? ly : hy, nz = pz ? lz : hz;
+            const uint32_t fx = px ? hx : lx, fy = py ? hy : ly, fz = pz ? hz : lz;
+            const float sx = as_float((e & 0xffu) << 23), sy = as_float(((e >> 8) & 0xffu) << 23),
+                        sz = as_float(((e >> 16) & 0xffu) << 23);
+            const float Ax = (q0.x - ro.x) * inv.x, Ay = (q0.y - ro.y) * inv.y, Az = (q0.z - ro.z) * inv.z;
+            const float Bx = sx * inv.x, By = sy * inv.y, Bz = sz * inv.z;
+            float td[4];
+            uint32_t ce[4];
+            int nhit = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+            {
+                const uint32_t m = (meta >> (8 * k)) & 0xffu;
+                float tn = fmaxf(fmaxf(__builtin_fmaf(wide_byte(nx, k), Bx, Ax), __builtin_fmaf(wide_byte(ny, k), By, Ay)),
+                                 __builtin_fmaf(wide_byte(nz, k), Bz, Az));
+                float tf = fminf(fminf(__builtin_fmaf(wide_byte(fx, k), Bx, Ax), __builtin_fmaf(wide_byte(fy, k), By, Ay)),
+                                 __builtin_fmaf(wide_byte(fz, k), Bz, Az));
+                tn = fmaxf(tn * (1.0f - 4e-7f), tmin);
+                tf = fminf(tf * (1.0f + 4e-7f), best);
+                const bool h = (m != 0u) && (tn <= tf);
+                td[k] = h ? tn : 3.0e38f;
+                ce[k] = (cbase + (uint32_t)k) | (m == 2u ? WIDE_LEAF_BIT : 0u);
+                nhit += h ? 1 : 0;
+            }
+            if (nhit > 0)
+            {
+                const bool deep = __ballot(sp + 3 > WIDE_LDS_STACK) != 0ull;
+#define RT_CSWAP(i, j)                                                     \
+    if (td[j] < td[i])                                                     \
+    {                                                                      \
+        const float _t = td[i]; td[i] = td[j]; td[j] = _t;                 \
+        const uint32_t _e = ce[i]; ce[i] = ce[j]; ce[j] = _e;             \
+    }
+                RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
+#undef RT_CSWAP
+                if (__builtin_expect(deep, 0))
+                {
+                    if (nhit > 3) push(ce[3]);
+                    if (nhit > 2) push(ce[2]);
+                    if (nhit > 1) push(ce[1]);
+                }
+                else if (nhit > 1)
+                {
+                    lds_u32* top = lds_stack + (sp + nhit - 2) * STRIDE + slot;
+                    top[0] = ce[1];
+                    if (nhit > 2) top[-STRIDE] = ce[2];
+                    if (nhit > 3) top[-2 * STRIDE] = ce[3];
+                    sp += nhit - 1;
+                }
+                cur = ce[0];
+            }
+            else cur = sp > base ? pop() : NONE;
+        }
+    }
+    const unsigned long long k = s_key[slot];
+    if (k == NOHIT) return false;
+    const int prim = (int)(~(uint32_t)k);
+    f3 v0, v1, v2;
+    load_tri(tv, prim, v0, v1, v2);
+    float t, u, v;
+    intersect_ray_triangle(t, u, v, own_ro, own_rd, own_tmin, own_tmax, v0, v1, v2);
+    hit.t = t; hit.u = u; hit.v = v; hit.prim = prim;
+    return true;
+}
+
 /* ---- Shadow rays as a STREAM (r02). occluded_ws still starts 64 rays together and ends with the last one; the lanes
  * that are done early can only help. Here a persistent wavefront pulls jobs (pixels) from a counter: whenever at
  * least RT_STREAM_REFILL lanes are free, those lanes hand in their finished jobs and fetch new ones, so in steady

@@ -169,10 +169,15 @@ RT_DEV void gbuffer_write(const SceneView& S, const FrameParams& P, float4* __re
 #ifndef RT_RAYCAST_WAVES
 #define RT_RAYCAST_WAVES RT_TRACE_WAVES
 #endif
-__global__ __launch_bounds__(TRACE_BLOCK, RT_RAYCAST_WAVES) void k_raycast(SceneView S, FrameParams P, float4* __restrict__ vis,
+#ifndef RT_RAYCAST_WS_WAVES
+#define RT_RAYCAST_WS_WAVES RT_RAYCAST_WAVES
+#endif
+/* WS: the work-sharing closest-hit walk (bvh.h closest_ws; rt_tuning key 16) */
+template <bool WS>
+__global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_RAYCAST_WS_WAVES : RT_RAYCAST_WAVES) void k_raycast(SceneView S, FrameParams P, float4* __restrict__ vis,
                                                     float4* __restrict__ g0, float4* __restrict__ g1)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_STACK * TRACE_BLOCK];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[(WS ? WIDE_LDS_ROWS_CLOSEST : WIDE_LDS_STACK) * TRACE_BLOCK];
     int x, row;
     if (!tile_pixel<TRACE_BLOCK>(P, x, row)) return;
     const int yi = P.H - 1 - row;
@@ -185,7 +190,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_RAYCAST_WAVES) void k_raycast(Scene
 
     Hit h;
     h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.prim = -1;
-    trace_wide<false, false, TRACE_BLOCK>(S.wide, s_stack, P.rg_origin, rd, 0.0f, kFltMax, h);
+    if (WS) closest_ws<TRACE_BLOCK>(S.wide, S.bvh.tv, s_stack, P.rg_origin, rd, 0.0f, kFltMax, h);
+    else trace_wide<false, false, TRACE_BLOCK>(S.wide, s_stack, P.rg_origin, rd, 0.0f, kFltMax, h);
     vis[li] = make_float4(h.u, h.v, as_float(h.prim), as_float(0));
     gbuffer_write(S, P, g0, g1, li, h.u, h.v, h.prim);
 }

@@ -60,6 +60,7 @@ struct rt_ctx
     int gcur = 0, timed_spec_set = -1;
     bool spec_valid = false, spec_timed[2] = {false, false};
     uint64_t spec_epoch = 0;
+    int tune_ws_primary = 0; /* rt_tuning key 16: primary rays with the work-sharing closest-hit walk (A/B: no gain) */
     int tune_stream = 0; /* rt_tuning key 15: resolve as a stream of pixels through persistent wavefronts (A/B: slower) */
     int n_cus = 256;
     int tune_spec = -1; /* rt_tuning key 14: -1 auto = strip contexts only, 0 never, 1 always */
@@ -916,7 +917,8 @@ int rt_raycast(rt_ctx* c)
 {
     RT_CHECK_CTX(c);
     NEED_SCENE(c);
-    k_raycast<<<trace_grid(c), TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_vis, c->d_g0, c->d_g1);
+    if (c->tune_ws_primary) k_raycast<true><<<trace_grid(c), TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_vis, c->d_g0, c->d_g1);
+    else k_raycast<false><<<trace_grid(c), TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_vis, c->d_g0, c->d_g1);
     RT_HIP(c, hipGetLastError());
     c->has_gbuffer = true;
     c->shaded_bits_stale = true;
@@ -954,7 +956,8 @@ static int launch_next_raycast(rt_ctx* c)
     const int s0 = c->sub0, s1 = c->sub1, b0 = c->subb0, b1 = c->subb1;
     c->sub0 = c->sub1 = -1; c->subb0 = c->subb1 = 0; /* all owned rows */
     if (c->timing) hipEventRecord(c->ev_spec_t[o][0], c->spec_stream);
-    k_raycast<<<trace_grid(c), TRACE_BLOCK, 0, c->spec_stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_gset[o][0], c->d_gset[o][1], c->d_gset[o][2]);
+    if (c->tune_ws_primary) k_raycast<true><<<trace_grid(c), TRACE_BLOCK, 0, c->spec_stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_gset[o][0], c->d_gset[o][1], c->d_gset[o][2]);
+    else k_raycast<false><<<trace_grid(c), TRACE_BLOCK, 0, c->spec_stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_gset[o][0], c->d_gset[o][1], c->d_gset[o][2]);
     c->sub0 = s0; c->sub1 = s1; c->subb0 = b0; c->subb1 = b1;
     RT_HIP(c, hipGetLastError());
     if (c->timing) hipEventRecord(c->ev_spec_t[o][1], c->spec_stream);
@@ -2063,6 +2066,7 @@ int rt_tuning(rt_ctx* c, int key, int value)
     else if (key == 12 && (value == 0 || value == 1)) c->tune_ris_pipe = value;
     else if (key == 13 && value >= -1 && value <= 1) c->tune_ws = value;
     else if (key == 15 && (value == 0 || value == 1)) c->tune_stream = value;
+    else if (key == 16 && (value == 0 || value == 1)) c->tune_ws_primary = value;
     else if (key == 14 && value >= -1 && value <= 1) { c->tune_spec = value; if (!use_next_raycast(c)) c->spec_valid = false; }
     else RT_FAIL(c, RT_ERR_ARG, "bad tuning key/value %d/%d", key, value);
     return RT_OK;

@@ -345,7 +345,11 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
  * its pixel and fetches the next one while the other lanes keep walking (csrc/bvh.h occluded_stream). Evaluated and
  * left off (default 0): same instruction count as the work-sharing kernel but 0.48 against 0.36 ms — a wavefront
  * holding rays of several tiles and ages sends 1.5x the requests to L2 and misses 2.6x as often, see DESIGN.md
- * section 5.2 and profiles/r02_stream_resolve_ab.txt. Same results. */
+ * section 5.2 and profiles/r02_stream_resolve_ab.txt. Same results.
+ * key 16: 1 = primary rays with the work-sharing CLOSEST-hit walk (csrc/bvh.h closest_ws: pieces of a ray walked by
+ * several lanes, merged by a 64-bit LDS min on (t, index)). Evaluated and left off (default 0): raycast 0.311 -> 0.318 ms
+ * at 1080p, 0.997 -> 1.029 at 4K — primary rays of an 8x8 tile are coherent (31.8 passes per wavefront for 23.1 steps
+ * per ray) and the walk needs 88 registers instead of 70. Same results. */
 int rt_tuning(rt_ctx* ctx, int key, int value);
 /* elementwise device evaluation of the portable math / IEEE div & sqrt (parity tests);
  * fn ids as in tests/test_portable_math.py */

@@ -758,6 +758,24 @@ def test_work_sharing_shadow_walk_is_bit_identical(api, scenes):
             r.close()
 
 
+def test_work_sharing_closest_hit_walk_is_bit_identical(api, scenes):
+    """rt_tuning key 16 (primary rays walked with closest_ws; evaluated, off by default): the Visibility buffer (u, v,
+    index per pixel) of the bench scene and of a scene with coplanar overlaps equals the default raycast, bit for bit."""
+    for tris, eye, at in ((scenes.make_blocks_restir(), scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT),
+                          (scenes.make_quad_room(), (0.5, 2.5, 6.0), (0.0, 1.5, -1.0))):
+        out = []
+        for ws in (0, 1):
+            r = api.Renderer(640, 360)
+            r.set_scene(tris)
+            r.lookat(eye, at)
+            r.tuning(16, ws)
+            r.raycast()
+            out.append(r.download(api.RT_BUF_VISIBILITY))
+            r.close()
+        assert _eq_bits(out[0], out[1])
+        assert (out[0]["index"] >= 0).mean() > 0.3
+
+
 def test_resolve_as_a_stream_is_bit_identical(api, scenes):
     """rt_tuning key 15 (persistent wavefronts that refill finished lanes with the next pixels; evaluated, off by default):
     same accumulation and pixels as the default resolve, with and without accumulation, whole frame and strip."""

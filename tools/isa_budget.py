@@ -160,7 +160,7 @@ def summarise(ops):
     return cls, cyc, buckets
 
 
-KERNELS = [("k_raycast", "k_raycast("), ("k_generate_candidate<true,false>", "k_generate_candidate<true, false, false, false, false>("),
+KERNELS = [("k_raycast", "k_raycast<false>("), ("k_raycast<WS>", "k_raycast<true>("), ("k_generate_candidate<true,false>", "k_generate_candidate<true, false, false, false, false>("),
            ("k_generate_candidate<true,false,WS>", "k_generate_candidate<true, false, false, false, true>("), ("k_resolve<WS>", "k_resolve<true>("), ("k_resolve_stream", "k_resolve_stream("),
            ("k_spatial_gather", "k_spatial_gather("), ("k_spatial_lds", "k_spatial_lds("), ("k_resolve", "k_resolve<false>("), ("k_spatial<true>", "k_spatial<true>("),
            ("k_temporal<false>", "k_temporal<false>("), ("k_tone_mapping", "k_tone_mapping("),
