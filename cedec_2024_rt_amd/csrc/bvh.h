@@ -419,7 +419,8 @@ RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3
 #endif
 template <int STRIDE = BLOCK_THREADS>
 RT_DEV bool occluded_ws(const WideView& bvh, uint32_t* __restrict__ lds_generic, f3 ro, f3 rd, float tmin, float tmax,
-                        uint32_t* stats = nullptr /* [0] passes of the wavefront, [1] steals by this lane | own steps << 16 */)
+                        uint32_t* stats = nullptr /* [0] passes of the wavefront, [1] steals by this lane | own steps << 16 */,
+                        const bool live = true /* false: this lane has no ray of its own and only helps (returns false) */)
 {
     if (bvh.n_tris <= 0) return false;
     /* an LDS-typed pointer: generic-pointer accesses in this loop (entries of another lane's slots) make the gfx950
@@ -453,7 +454,7 @@ RT_DEV bool occluded_ws(const WideView& bvh, uint32_t* __restrict__ lds_generic,
         return e;
     };
     const unsigned long long ba = __ballot(true); /* lanes that walk a ray of their own here */
-    uint32_t cur = 0u, pend = NONE, pend2 = NONE;
+    uint32_t cur = live ? 0u : NONE, pend = NONE, pend2 = NONE;
     uint32_t pass = 0u;
     for (;;)
     {
@@ -1008,12 +1009,15 @@ RT_DEV void occluded_stream(const WideView& bvh, uint32_t* __restrict__ lds_gene
 /* WS: walk with occluded_ws (idle lanes of the wavefront take over part of a busy lane's stack). The answer is the
  * same bit either way (any-hit of the same ray against the same triangles); it pays where a launch is a single round
  * of wavefronts, i.e. the strips of the multi-GPU frame, and costs ~1-3 % on the full frame (rt_tuning key 13). */
+/* live (work-sharing walk only): false = the caller does not need this lane's answer (returns true); the lane joins the
+ * wavefront's walk as a helper */
 template <int STRIDE = BLOCK_THREADS, bool WS = false>
-RT_DEV bool check_visibility_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3 p0, f3 n0, f3 p1)
+RT_DEV bool check_visibility_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3 p0, f3 n0, f3 p1, const bool live = true)
 {
     const f3 org = p0 + 0.001f * n0;
     const f3 dir = p1 - p0;
-    if (WS) return !occluded_ws<STRIDE>(bvh, lds_stack, org, dir, 0.0f, 0.99f);
+    if (WS) return !occluded_ws<STRIDE>(bvh, lds_stack, org, dir, 0.0f, 0.99f, nullptr, live);
+    if (!live) return true;
     Hit h;
     return !trace_wide<true, false, STRIDE>(bvh, lds_stack, org, dir, 0.0f, 0.99f, h);
 }

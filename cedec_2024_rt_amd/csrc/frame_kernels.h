@@ -303,13 +303,16 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_W
     float4* __restrict__ out_rad, uint32_t* __restrict__ vis_queue = nullptr, unsigned int* __restrict__ vis_count = nullptr)
 {
     static_assert(!DEFER || (FUSE_TEMPORAL && !SHADOWED), "deferred visibility: fused unshadowed kernel only");
+    constexpr bool LATE = WS && FUSE_TEMPORAL && !SHADOWED && !DEFER; /* the visibility-reuse ray after the temporal merge */
     __shared__ __attribute__((aligned(16))) uint32_t s_stack[DEFER ? 4 : (WS ? WIDE_LDS_ROWS : WIDE_LDS_STACK) * TRACE_BLOCK];
     int x = 0, row = P.row0;
     const bool in_image = tile_pixel<TRACE_BLOCK>(P, x, row);
-    if (!DEFER && !in_image) return;
+    if (!DEFER && !LATE && !in_image) return;
     const int yi = P.H - 1 - row;
     const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
     bool need_ray = false; /* DEFER: this lane's candidate survived and needs its visibility walked */
+    bool late_live = false;  /* LATE: this lane walks a visibility-reuse ray of its own */
+    f3 late_sp = F3(0.0f, 0.0f, 0.0f), late_sn = F3(0.0f, 1.0f, 0.0f);
     Res r = res_zero();
     float4 G0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), G1 = G0;
     if (in_image) { G0 = g0[li]; G1 = g1[li]; }
@@ -317,9 +320,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_W
     if (in_image && !(flags & GB_SHADED))
     {
         res_store(out_rec, out_rad, li, r, false); /* Reservoir{} (:56-70) */
-        if (!DEFER) return;
+        if (!DEFER && !LATE) return;
     }
-    /* DEFER keeps every lane to the end (the queue append is a wave-level operation) */
+    /* DEFER keeps every lane to the end (the queue append is a wave-level operation); so does LATE (every lane of the
+     * wavefront joins the walk, with or without a ray of its own) */
     if (in_image && (flags & GB_SHADED))
     {
     const f3 sp = F3(G0.x, G0.y, G0.z), sn = F3(G1.x, G1.y, G1.z);
@@ -432,13 +436,13 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_W
     if (FUSE_TEMPORAL && SHADOWED) load_prev(); /* its sample is a ray target */
     float V_cur = 1.0f, V_prev = 1.0f;
     if (SHADOWED) temporal_rays<TRACE_BLOCK>(S, s_stack, P, sp, sn, r, pr, FUSE_TEMPORAL, V_cur, V_prev);
-    else if (P.vis_reuse && !DEFER) V_cur = check_visibility_wide<TRACE_BLOCK, WS>(S.wide, s_stack, sp, sn, r.hit_p) ? 1.0f : 0.0f;
+    else if (P.vis_reuse && !DEFER && !LATE) V_cur = check_visibility_wide<TRACE_BLOCK, WS>(S.wide, s_stack, sp, sn, r.hit_p) ? 1.0f : 0.0f;
     {
         const float p_hat = SHADOWED ? target_shadowed(sp, sn, r.hit_p, r.hit_n, r.lum, V_cur)
                                      : target_unshadowed(sp, sn, r.hit_p, r.hit_n, r.lum);
         r.ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
     }
-    if (P.vis_reuse && !DEFER) r.vis = V_cur != 0.0f; /* :127-131 */
+    if (P.vis_reuse && !DEFER && !LATE) r.vis = V_cur != 0.0f; /* :127-131 */
 
     if (FUSE_TEMPORAL)
     {
@@ -447,8 +451,19 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_W
         /* unshadowed: neither the merge decision nor ucw depends on the candidate's visibility; the bit is stored
          * clear here and set by k_candidate_visibility if the ray finds the light unoccluded */
         if (DEFER) need_ray = P.vis_reuse && !took_prev;
+        if (LATE) { late_live = P.vis_reuse && !took_prev; late_sp = sp; late_sn = sn; }
     }
-    res_store(out_rec, out_rad, li, r, true);
+    if (!LATE) res_store(out_rec, out_rad, li, r, true);
+    }
+    if (LATE)
+    {
+        /* Work-sharing kernel: the merge first, the visibility-reuse ray of :127-131 after it, at ONE call site for the
+         * whole wavefront. The ray's answer is observable only if the candidate survived (otherwise the stored bit is
+         * the previous sample's, reservoir.hpp:36); lanes whose candidate did not survive, sky / emissive pixels and
+         * lanes outside the image walk no ray of their own and take over parts of the others' walks instead. */
+        const bool visible = check_visibility_wide<TRACE_BLOCK, true>(S.wide, s_stack, late_sp, late_sn, r.hit_p, late_live);
+        if (late_live) r.vis = visible;
+        if (in_image && (flags & GB_SHADED)) res_store(out_rec, out_rad, li, r, true);
     }
     if (DEFER)
     {

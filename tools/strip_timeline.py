@@ -16,7 +16,7 @@ for f in glob.glob(os.path.join(d, "**", "*memory_copy_trace.csv"), recursive=Tr
     for r in csv.DictReader(open(f)):
         ops.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "copy " + r.get("Direction", ""), "dma"))
 ops.sort()
-starts = [i for i, o in enumerate(ops) if o[2].startswith("k_raycast")]
+starts = [i for i, o in enumerate(ops) if "k_raycast" in o[2]]
 if len(starts) < 12:
     sys.exit("too few frames in the trace")
 steady = starts[len(starts) // 2:]
