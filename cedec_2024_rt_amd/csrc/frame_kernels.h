@@ -288,9 +288,10 @@ RT_DEV bool temporal_merge(const FrameParams& P, int x, int yi, f3 sp, f3 sn, Re
  * value still in registers (the reference round-trips it through reservoir_buffer0). */
 /* DEFER (fused, unshadowed only): the visibility-reuse ray of :127-131 is NOT walked here. Its answer is observable
  * only if the candidate's sample survives the temporal merge — if the previous frame's sample is taken, the stored
- * visibility is that sample's (reservoir.hpp:36) and the ray was dead work. In a steady sequence the history carries
- * M = 640 against the candidates' 32, so ~95 % of these rays are dead. Survivors are appended to a queue (wave
- * ballot + one atomic) and k_candidate_visibility walks them with full wavefronts and sets the bit. */
+ * visibility is that sample's (reservoir.hpp:36) and the ray was dead work (25 % of the rays in the bench scene:
+ * 1.465 M of 1.957 M candidates survive). Survivors are appended to a queue (wave ballot + one atomic) and
+ * k_candidate_visibility walks them with full wavefronts and sets the bit. A/B only (rt_tuning key 11): the work-sharing
+ * kernel gets the same saving without a queue (LATE below). */
 /* the work-sharing variant allocates 102 VGPRs unconstrained (4 wavefronts per SIMD); held to the 96 of the plain
  * kernel (5 per SIMD) it is 3 % faster (A/B on the GPU, profiles/r02_ws_register_budgets.txt) */
 #ifndef RT_GENERATE_WS_WAVES
