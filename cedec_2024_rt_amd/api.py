@@ -599,7 +599,7 @@ class Renderer:
             self._ck(self.L.rt_trace_stats(self.h, _p(rr), len(rr), _p(raw)))
         finally:
             self._ck(self.L.rt_trace_mode(self.h, 0))
-        return (raw[:, 0] >> 31).astype(bool), raw[:, 0] & 0x7fffffff, raw[:, 1] & 0xffff
+        return (raw[:, 0] >> 31).astype(bool), raw[:, 0] & 0x7fff, raw[:, 1] & 0xffff
 
     def bvh_config(self, split_factor):
         self._ck(self.L.rt_bvh_config(self.h, C.c_float(split_factor)))

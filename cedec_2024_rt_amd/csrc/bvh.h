@@ -419,7 +419,7 @@ RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3
 #endif
 template <int STRIDE = BLOCK_THREADS>
 RT_DEV bool occluded_ws(const WideView& bvh, uint32_t* __restrict__ lds_generic, f3 ro, f3 rd, float tmin, float tmax,
-                        uint32_t* stats = nullptr /* [0] passes of the wavefront, [1] steals by this lane | own steps << 16 */,
+                        uint32_t* stats = nullptr /* [0] passes of the wavefront, [1] steals by this lane | own steps << 16, [2] leaf passes, [3] own triangle tests */,
                         const bool live = true /* false: this lane has no ray of its own and only helps (returns false) */)
 {
     if (bvh.n_tris <= 0) return false;
@@ -515,8 +515,10 @@ RT_DEV bool occluded_ws(const WideView& bvh, uint32_t* __restrict__ lds_generic,
         const int parked = __popcll(bp) + __popcll(__ballot(pend2 != NONE));
         if (bp != 0ull && (bi2 == 0ull || RT_LEAF_DEN * parked >= RT_LEAF_NUM * __popcll(__ballot(has_inner || has_pend))))
         {
+            if (stats) stats[2] += 1u; /* leaf passes of the wavefront */
             if (has_pend)
             {
+                if (stats) stats[3] += 1u; /* triangle tests by this lane */
                 const float4* g = bvh.rec + 3 * (size_t)(pend & ~WIDE_LEAF_BIT);
                 const float4 t0 = g[0], t1 = g[1], t2 = g[2];
                 pend = pend2; pend2 = NONE;

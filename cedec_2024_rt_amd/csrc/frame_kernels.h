@@ -1664,18 +1664,19 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest(SceneView S, const floa
     o[0] = h.t; o[1] = h.u; o[2] = h.v; o[3] = as_float(h.prim);
 }
 /* statistics of the work-sharing shadow-ray walk: one-wavefront workgroups as in the frame kernels;
- * stats[2i] = passes the ray's wavefront ran | occluded << 31, stats[2i+1] = steals by this lane | inner records it
- * visited << 16 */
+ * stats[2i] = passes the ray's wavefront ran | leaf passes << 15 | this lane's triangle tests << 23 | occluded << 31,
+ * stats[2i+1] = steals by this lane | inner records it visited << 16 */
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_stats_ws(SceneView S, const float* __restrict__ rays, int n, uint32_t* __restrict__ stats)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_ROWS * TRACE_BLOCK];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* r = rays + 8 * (size_t)i;
-    uint32_t st[2] = {0u, 0u};
+    uint32_t st[4] = {0u, 0u, 0u, 0u};
     bool occ = false;
     if (r[7] >= 0.0f) occ = occluded_ws<TRACE_BLOCK>(S.wide, s_stack, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7], st);
-    stats[2 * (size_t)i] = st[0] | (occ ? 0x80000000u : 0u);
+    /* [0]: passes (15 bits) | leaf passes << 15 (8 bits) | triangle tests by this lane << 23 (8 bits) | occluded << 31 */
+    stats[2 * (size_t)i] = (st[0] & 0x7fffu) | ((st[2] > 255u ? 255u : st[2]) << 15) | ((st[3] > 255u ? 255u : st[3]) << 23) | (occ ? 0x80000000u : 0u);
     stats[2 * (size_t)i + 1] = st[1];
 }
 /* shadow rays from a list, walked as the frame kernels walk theirs (one-wavefront workgroups): hits[i].w = 0 if

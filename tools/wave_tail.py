@@ -71,10 +71,16 @@ import ctypes as C
 raw = np.zeros((len(shadow), 2), dtype=np.uint32)
 rr = np.ascontiguousarray(shadow, dtype=np.float32)
 r._ck(r.L.rt_trace_stats(r.h, rr.ctypes.data_as(C.c_void_p), len(rr), raw.ctypes.data_as(C.c_void_p)))
-wave = (raw[:, 0] & 0x7fffffff).reshape(-1, 64).max(1).astype(np.int64)
-wave = wave[wave > 0]
+wave = (raw[:, 0] & 0x7fff).reshape(-1, 64).max(1).astype(np.int64)
+leafp = ((raw[:, 0] >> 15) & 0xff).reshape(-1, 64).max(1).astype(np.int64)
+tests = ((raw[:, 0] >> 23) & 0xff).astype(np.int64)
 steals = (raw[:, 1] & 0xffff).astype(np.int64)
 steps = (raw[:, 1] >> 16).astype(np.int64)
+keep = wave > 0
+print("work-sharing shadow rays: of %.1f passes per wavefront %.1f are leaf passes (triangle tests per lane %.2f, i.e. %.0f %% of a leaf pass's lanes busy) and %.1f record visits (%.0f %% of their lanes busy)" % (
+    wave[keep].mean(), leafp[keep].mean(), tests.reshape(-1, 64).sum(1)[keep].mean() / 64, 100 * tests.reshape(-1, 64).sum(1)[keep].mean() / 64 / max(leafp[keep].mean(), 1e-9),
+    (wave - leafp)[keep].mean(), 100 * (raw[:, 1] >> 16).astype(np.int64).reshape(-1, 64).sum(1)[keep].mean() / 64 / (wave - leafp)[keep].mean()), flush=True)
+wave = wave[keep]
 print("work-sharing shadow rays: per-wave passes mean %.1f p50 %d p90 %d p99 %d max %d; steals per wavefront %.1f; inner records per lane mean %.1f (sum over a wave / 64 = %.1f)" % (
     wave.mean(), *np.percentile(wave, [50, 90, 99]).astype(int), wave.max(), steals.reshape(-1, 64).sum(1).mean(), steps[sh].mean(), steps.reshape(-1, 64).sum(1).mean() / 64), flush=True)
 
