@@ -235,6 +235,12 @@ __global__ void k_ploc_init(int n, const uint32_t* __restrict__ ids /* sorted po
     const float* b = prim_boxes + 6 * (size_t)ids[i];
     for (int k = 0; k < 6; ++k) cbox[6 * (size_t)i + k] = b[k];
 }
+/* parent links of the cluster roots under the host-built top of the tree */
+__global__ void k_scatter_int(int n, const int* __restrict__ idx, const int* __restrict__ val, int* __restrict__ dst)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[idx[i]] = val[i];
+}
 /* binary height: every leaf climbs to the root */
 __global__ void k_bvh_height(int n_leaves, const int2* __restrict__ children, const int* __restrict__ parent_inner, int* __restrict__ height)
 {

@@ -343,6 +343,9 @@ static int build_wide(rt_ctx* c, const rt_triangle* tris, int n_refs)
 
 /* The whole build on the device (bvh_build_device.h): pre-split, Morton sort, PLOC hierarchy, wide collapse.
  * The host only reads counters back. */
+#ifndef RT_PLOC_TOP
+#define RT_PLOC_TOP 8192 /* clusters left when the host builds the top of the tree (builder 2): 2048 / 8192 / 32768 -> build 10.4 / 13.3 / 25.3 ms, frame +3.5 / +1.5 / +0.5 % against the host SAH tree */
+#endif
 static int build_bvh_device(rt_ctx* c, int n_tris)
 {
     hipStream_t st = c->stream;
@@ -437,10 +440,13 @@ static int build_bvh_device(rt_ctx* c, int n_tris)
     k_ploc_init<<<grid, 256, 0, st>>>(n, d_ids2, d_boxes, d_cid[0], d_cbox[0], d_ps, d_parent);
     BD_HIP(hipGetLastError());
     int cur = 0;
-    bool done = false;
-    for (int batch = 0; batch < 64 && !done; ++batch)
+    bool done = n <= RT_PLOC_TOP;
+    PlocState ps = {(unsigned int)n, 0u};
+    for (int batch = 0; batch < 256 && !done; ++batch)
     {
-        for (int it = 0; it < 12; ++it)
+        /* 12 rounds between looks at the cluster count, 2 once the top is near */
+        const int rounds = ps.m > 16u * RT_PLOC_TOP ? 12 : 2;
+        for (int it = 0; it < rounds; ++it)
         {
             k_ploc_nn<<<grid, 256, 0, st>>>(d_ps, d_cbox[cur], d_nn, c->ploc_radius);
             k_ploc_merge<<<grid, 256, 0, st>>>(d_ps, n, d_cid[cur], d_cbox[cur], d_nn, d_children, d_parent, d_node_boxes, d_keep);
@@ -449,13 +455,120 @@ static int build_bvh_device(rt_ctx* c, int n_tris)
             cur ^= 1;
         }
         BD_HIP(hipGetLastError());
-        PlocState ps;
         BD_HIP(hipMemcpyAsync(&ps, d_ps, sizeof(ps), hipMemcpyDeviceToHost, st));
         BD_HIP(hipStreamSynchronize(st));
-        done = ps.m <= 1u;
-        if (done && ps.merges != (unsigned int)(n - 1)) BD_FAIL(RT_ERR_STATE, "internal: PLOC made %u nodes for %d references", ps.merges, n);
+        done = ps.m <= (unsigned int)RT_PLOC_TOP;
     }
     if (!done) BD_FAIL(RT_ERR_BVH_DEPTH, "PLOC did not converge");
+    if (ps.merges + ps.m != (unsigned int)n) BD_FAIL(RT_ERR_STATE, "internal: PLOC holds %u clusters after %u merges of %d references", ps.m, ps.merges, n);
+    if (ps.m > 1u)
+    {
+        /* The top of the tree — the levels every ray walks — by an exact top-down SAH sweep over the <= RT_PLOC_TOP
+         * clusters that are left, on the host (0.2 MB down, ~2 ms of host work, 0.3 MB up): mutual-nearest-neighbour
+         * merging in a +-16 window judges the last rounds poorly (frame +5.8 % against the host SAH tree, +1.5 % with
+         * this, r02). Node ids 0 .. m-2 are exactly the ones PLOC has not handed out (it counts down from n-2); the
+         * root is 0. */
+        const int m = (int)ps.m;
+        std::vector<int> h_cid((size_t)m);
+        std::vector<float> h_box((size_t)m * 6);
+        BD_HIP(hipMemcpyAsync(h_cid.data(), d_cid[cur], (size_t)m * 4, hipMemcpyDeviceToHost, st));
+        BD_HIP(hipMemcpyAsync(h_box.data(), d_cbox[cur], (size_t)m * 24, hipMemcpyDeviceToHost, st));
+        BD_HIP(hipStreamSynchronize(st));
+        std::vector<int2> t_children((size_t)m - 1);
+        std::vector<float> t_boxes(((size_t)m - 1) * 6);
+        std::vector<int> t_parent((size_t)m - 1, -1), s_idx, s_val;
+        int next_id = 0;
+        auto area = [](const float* b) { const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2]; return dx * dy + dy * dz + dz * dx; };
+        auto grow = [](float* b, const float* o) { for (int k = 0; k < 3; ++k) { b[k] = fminf(b[k], o[k]); b[3 + k] = fmaxf(b[3 + k], o[3 + k]); } };
+        auto centroid2 = [&](int item, int ax) { return h_box[(size_t)item * 6 + ax] + h_box[(size_t)item * 6 + 3 + ax]; };
+        /* exact sweep SAH with three presorted item lists (by centroid per axis) kept in step by stable partitions:
+         * O(m log m) in all; a range [lo, hi) holds the same items in all three lists */
+        std::vector<int> sorted[3], scratch((size_t)m);
+        for (int ax = 0; ax < 3; ++ax)
+        {
+            sorted[ax].resize((size_t)m);
+            for (int i = 0; i < m; ++i) sorted[ax][(size_t)i] = i;
+            std::sort(sorted[ax].begin(), sorted[ax].end(), [&](int x, int y) {
+                const float cx = centroid2(x, ax), cy = centroid2(y, ax);
+                return cx < cy || (cx == cy && x < y);
+            });
+        }
+        std::vector<unsigned char> goes_left((size_t)m);
+        std::vector<float> right_area((size_t)m);
+        struct Job { int lo, hi, parent, side; };
+        std::vector<Job> jobs;
+        jobs.push_back({0, m, -1, 0});
+        while (!jobs.empty())
+        {
+            const Job j = jobs.back();
+            jobs.pop_back();
+            int ref;
+            if (j.hi - j.lo == 1)
+            {
+                ref = h_cid[(size_t)sorted[0][(size_t)j.lo]];
+                if (ref >= 0) { s_idx.push_back(ref); s_val.push_back(j.parent); }
+            }
+            else
+            {
+                const int id = next_id++;
+                ref = id;
+                t_parent[(size_t)id] = j.parent;
+                const int cnt = j.hi - j.lo;
+                float best = INFINITY;
+                int best_axis = 0, best_i = cnt / 2;
+                float nb[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                for (int ax = 0; ax < 3; ++ax)
+                {
+                    const int* L = sorted[ax].data() + j.lo;
+                    float rb[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                    for (int i = cnt - 1; i >= 1; --i) { grow(rb, &h_box[(size_t)L[i] * 6]); right_area[(size_t)i] = area(rb); }
+                    float lb[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                    for (int i = 1; i < cnt; ++i)
+                    {
+                        grow(lb, &h_box[(size_t)L[i - 1] * 6]);
+                        const float cost = area(lb) * (float)i + right_area[(size_t)i] * (float)(cnt - i);
+                        if (cost < best) { best = cost; best_axis = ax; best_i = i; }
+                    }
+                    if (ax == 0) { for (int k = 0; k < 6; ++k) nb[k] = lb[k]; grow(nb, &h_box[(size_t)L[cnt - 1] * 6]); }
+                }
+                for (int k = 0; k < 6; ++k) t_boxes[(size_t)id * 6 + k] = nb[k];
+                /* the first best_i items of the best axis go left; the other two lists follow, order preserved */
+                for (int i = 0; i < cnt; ++i) goes_left[(size_t)sorted[best_axis][(size_t)(j.lo + i)]] = i < best_i ? 1 : 0;
+                for (int ax = 0; ax < 3; ++ax)
+                {
+                    if (ax == best_axis) continue;
+                    int* L = sorted[ax].data() + j.lo;
+                    int nl = 0, nr = 0;
+                    for (int i = 0; i < cnt; ++i)
+                    {
+                        if (goes_left[(size_t)L[i]]) L[nl++] = L[i];
+                        else scratch[(size_t)nr++] = L[i];
+                    }
+                    for (int i = 0; i < nr; ++i) L[nl + i] = scratch[(size_t)i];
+                }
+                jobs.push_back({j.lo, j.lo + best_i, id, 0});
+                jobs.push_back({j.lo + best_i, j.hi, id, 1});
+            }
+            if (j.parent >= 0)
+            {
+                if (j.side == 0) t_children[(size_t)j.parent].x = ref; else t_children[(size_t)j.parent].y = ref;
+            }
+        }
+        if (next_id != m - 1) BD_FAIL(RT_ERR_STATE, "internal: top-level build made %d nodes for %d clusters", next_id, m);
+        BD_HIP(hipMemcpyAsync(d_children, t_children.data(), ((size_t)m - 1) * 8, hipMemcpyHostToDevice, st));
+        BD_HIP(hipMemcpyAsync(d_node_boxes, t_boxes.data(), ((size_t)m - 1) * 24, hipMemcpyHostToDevice, st));
+        BD_HIP(hipMemcpyAsync(d_parent, t_parent.data(), ((size_t)m - 1) * 4, hipMemcpyHostToDevice, st));
+        if (!s_idx.empty())
+        {
+            int* d_si = (int*)dalloc(s_idx.size() * 4); BD_PTR(d_si);
+            int* d_sv = (int*)dalloc(s_idx.size() * 4); BD_PTR(d_sv);
+            BD_HIP(hipMemcpyAsync(d_si, s_idx.data(), s_idx.size() * 4, hipMemcpyHostToDevice, st));
+            BD_HIP(hipMemcpyAsync(d_sv, s_val.data(), s_idx.size() * 4, hipMemcpyHostToDevice, st));
+            k_scatter_int<<<((int)s_idx.size() + 255) / 256, 256, 0, st>>>((int)s_idx.size(), d_si, d_sv, d_parent);
+            BD_HIP(hipGetLastError());
+        }
+        BD_HIP(hipStreamSynchronize(st)); /* the host vectors go out of scope */
+    }
     int* d_height = (int*)dalloc(4); BD_PTR(d_height);
     BD_HIP(hipMemsetAsync(d_height, 0, 4, st));
     k_bvh_height<<<grid, 256, 0, st>>>(n, d_children, d_parent, d_height);

@@ -320,8 +320,10 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
  * A/B runs; the kernel now carries an explicit bound of 5 wavefronts per SIMD). Defaults: {1,0,1,0}, 0.
  * key 5 (before rt_scene_set): builder. 0 = device LBVH (Morton codes + Karras) with host pre-split and host
  * collapse (round 1), 1 = host binned SAH (the reference requests HIPRT's high-quality build,
- * common/loader.hpp:98-99), 2 = all on the device: pre-split, Morton sort, PLOC hierarchy, wide collapse
- * (no tree data crosses the host). All feed the same traversals; results never depend on the builder.
+ * common/loader.hpp:98-99), 2 = on the device: pre-split, Morton sort, PLOC hierarchy, wide collapse; only the boxes
+ * of the last <= 8 192 clusters visit the host, which builds the top of the tree over them by an exact SAH sweep
+ * (12 ms for 212 k triangles, frame +1.2 % against builder 1). All feed the same traversals; results never depend on
+ * the builder.
  * key 6: rt_path_trace as 0 = one launch per frame (the reference's shape), 1 = wavefront (one launch
  * per bounce over the list of live paths, compacted with wave ballots), 2 = auto (default: wavefront
  * for 09_ris, whose per-bounce RIS makes compaction pay; one launch for 07_pt). Same results.

@@ -15,7 +15,7 @@ from cedec_2024_rt_amd.types import bench_options  # noqa: E402
 W, H = 1920, 1080
 tris = scenes.make_blocks_restir()
 out = {}
-names = {0: "device LBVH (Karras) + host pre-split/collapse", 1: "host binned SAH", 2: "all-device: pre-split, PLOC, collapse"}
+names = {0: "device LBVH (Karras) + host pre-split/collapse", 1: "host binned SAH", 2: "device: pre-split, PLOC, host SAH sweep over the last 8192 clusters, collapse"}
 CASES = [(1, None), (0, None)] + [(2, rad) for rad in (8, 16, 32, 64, 128)]
 for builder, rad in CASES:
     r = api.Renderer(W, H)
