@@ -24,7 +24,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "cedec_2024_rt_amd", "csrc", "restir_rt.hip")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-gpu-flush-denormals-to-zero",
+FLAGS = ["--offload-arch=gfx950:xnack-", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-gpu-flush-denormals-to-zero",
          "-Wno-unused-value"]
 
 RATES = json.load(open(os.path.join(ROOT, "profiles", "r02_valu_rates.json")))
@@ -81,7 +81,7 @@ def what(op):
 def compile_asm(tmp):
     subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + ["--save-temps", "-c", SRC, "-o", os.path.join(tmp, "k.o")], cwd=tmp,
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    return open(os.path.join(tmp, "restir_rt-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+    return open(os.path.join(tmp, "restir_rt-hip-amdgcn-amd-amdhsa-gfx950:xnack-.s")).read()
 
 
 def resources(tmp):
