@@ -73,7 +73,9 @@ struct rt_ctx
      * pass's occupancy limiter (extra dynamic LDS). Defaults from the sweep in DESIGN.md §5. */
     int tune_tile_mode[5] = {1, 0, 1, 0, 0};
     int tune_spatial_lds = 0;     /* rt_tuning key 4: extra dynamic LDS per unshadowed spatial workgroup (A/B of the old throttle) */
-    int tune_spatial_variant = 1; /* rt_tuning key 8: 0 = k_spatial_gather, 1 = k_spatial_lds (staged shaded-bit window; falls back to 0 where it does not apply) */
+    int tune_spatial_variant = 0; /* rt_tuning key 8: 0 = k_spatial_gather (default since the xnack- build: 0.169 / 0.176 / 0.178 ms per pass
+                                     against 0.174 / 0.179 / 0.181), 1 = k_spatial_lds (staged shaded-bit window; falls back to 0 where it
+                                     does not apply) */
     int tune_spatial_waves = -1;  /* rt_tuning key 9: register budget of the unshadowed spatial pass in wavefronts per SIMD: 4, 5, 6, 0 = what the
                                      kernel needs (7), -1 = auto: 4 for the gather kernel (its neighbour window must stay in L2: 0.184 vs 0.202 ms
                                      per pass), none for the LDS-staged kernel (0.181 ms unbounded, 0.188 at 4) — profiles/r02_spatial_variants.json */
@@ -1227,6 +1229,12 @@ static int refresh_shaded_bits(rt_ctx* c)
     c->shaded_bits_stale = false;
     return RT_OK;
 }
+/* register budget of the gather kernel when rt_tuning key 9 is -1. xnack-any code (until late r02) wanted 4 wavefronts per
+ * SIMD to keep the neighbour window in L2 (0.184 against 0.202 ms unbounded); the xnack- build is flat across 4 / 5 / 6 /
+ * unbounded (0.170 / 0.169 / 0.168 / 0.170 ms), 6 a hair ahead */
+#ifndef RT_SPATIAL_GATHER_AUTO_WAVES
+#define RT_SPATIAL_GATHER_AUTO_WAVES 6
+#endif
 static int launch_spatial(rt_ctx* c, int frame, int pass, int in_phys, int out_phys)
 {
     const int need = halo_rows_needed(c->opt);
@@ -1250,7 +1258,7 @@ static int launch_spatial(rt_ctx* c, int frame, int pass, int in_phys, int out_p
     else
     {
 #define RT_SPG(WV) k_spatial_gather<WV><<<launch_grid(c), BLOCK, (size_t)c->tune_spatial_lds, c->stream>>>(S, P, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys])
-        switch (c->tune_spatial_waves < 0 ? 4 : c->tune_spatial_waves) { case 4: RT_SPG(4); break; case 5: RT_SPG(5); break; case 6: RT_SPG(6); break; default: RT_SPG(0); break; }
+        switch (c->tune_spatial_waves < 0 ? RT_SPATIAL_GATHER_AUTO_WAVES : c->tune_spatial_waves) { case 4: RT_SPG(4); break; case 5: RT_SPG(5); break; case 6: RT_SPG(6); break; default: RT_SPG(0); break; }
 #undef RT_SPG
     }
     RT_HIP(c, hipGetLastError());

@@ -329,6 +329,13 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
  * for 09_ris, whose per-bounce RIS makes compaction pay; one launch for 07_pt). Same results.
  * key 7 (before rt_scene_set): number of wide-BVH records emitted breadth-first before the
  * collapse switches to depth-first order (record order only; no measurable effect, default 2048).
+ * key 8: unshadowed spatial_resampling as 0 (default since the library is built for gfx950:xnack-, where it is the faster
+ * one) = dependent record gathers, 1 = LDS-staged variant: the tile's +-87-pixel window of shaded bits staged in LDS,
+ * neighbour addresses derived from LDS alone, the record of neighbour k+1 in flight while neighbour k is merged
+ * (whole-frame contexts, radius <= 30, <= 5 neighbours; the gather kernel otherwise).
+ * key 9: register budget of the unshadowed spatial pass, in wavefronts per SIMD (4, 5, 6; 0 = unbounded = 7; -1 = auto,
+ * default: 6 for the gather kernel, none for the LDS-staged kernel).
+ * key 10 (before rt_scene_set): PLOC search radius of builder 2 (places in Morton order, default 16).
  * key 11: rt_frame's fused generate_candidate + temporal_resampling (unshadowed target) walks the visibility-reuse ray
  * of 10_restir_di.cu:127-131 1 = only for candidates that survive the temporal merge — the ray's answer is
  * unobservable otherwise — through a compacted queue, 0 (default: 75 % survive in the bench scene, no gain) = for
