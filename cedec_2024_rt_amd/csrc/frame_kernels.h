@@ -1115,11 +1115,11 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_RESOLVE_WAVES) void k_resolve(Scene
 }
 
 
-/* resolve as a stream (bvh.h occluded_stream): persistent one-wavefront workgroups pull pixels from eight counters,
- * one per XCD band of tiles (workgroup w starts on band w % 8 = the XCD it runs on, and moves on when a band is
- * empty), in the tile order of the other tracing kernels: job i of a band = thread i % 64 of that band's tile i / 64.
- * Sky / emissive pixels are written when they are fetched; a shaded pixel's ray is walked and the pixel is shaded when
- * the ray is settled (its inputs are read again then: the walk keeps only the pixel's index). */
+/* resolve as a stream (bvh.h occluded_stream; rt_tuning key 15, evaluated and off by default): persistent one-wavefront
+ * workgroups walk the launch's tiles round-robin (workgroup w: tiles w, w + gridDim.x, ...: the XCD band of tile rows
+ * the other tracing kernels give it) and keep their lanes supplied with new pixels. Sky / emissive pixels are written
+ * when they are fetched; a shaded pixel's ray is walked and the pixel is shaded when the ray is settled (its inputs
+ * are read again then: the walk keeps only the pixel's index). */
 #ifndef RT_RESOLVE_STREAM_WAVES
 #define RT_RESOLVE_STREAM_WAVES 5
 #endif
