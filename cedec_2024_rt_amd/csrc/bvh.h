@@ -1035,8 +1035,8 @@ RT_DEV bool check_visibility_wide(const WideView& bvh, uint32_t* __restrict__ ld
 #define RT_BATCH_REFILL 1
 #endif
 template <int NR, int STRIDE = BLOCK_THREADS>
-RT_DEV uint32_t occluded_batch(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3 p0, f3 n0, const f3 (&tgt)[NR],
-                               uint32_t need)
+RT_DEV uint32_t occluded_batch_plain(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3 p0, f3 n0, const f3 (&tgt)[NR],
+                                     uint32_t need)
 {
     if (bvh.n_tris <= 0) return 0u;
     constexpr uint32_t NONE = 0x7fffffffu;
@@ -1166,6 +1166,206 @@ RT_DEV uint32_t occluded_batch(const WideView& bvh, uint32_t* __restrict__ lds_s
         }
     }
     return occluded;
+}
+
+/* The same with work sharing (r02, as occluded_ws): a lane whose batch is exhausted takes the bottom half of the stack
+ * of a lane that is still walking, with that lane's ray; hits go to a per-owner bit mask in LDS (bit k = ray k is
+ * occluded), so an owner may move on to its next ray while pieces of the previous one are still being walked by
+ * helpers. Rows WIDE_LDS_STACK and WIDE_LDS_STACK + 1 of the caller's array are used (WIDE_LDS_ROWS rows). */
+#ifndef RT_BATCH_WS
+#define RT_BATCH_WS 1
+#endif
+template <int NR, int STRIDE = BLOCK_THREADS>
+RT_DEV uint32_t occluded_batch_ws(const WideView& bvh, uint32_t* __restrict__ lds_generic, f3 p0, f3 n0, const f3 (&tgt)[NR], uint32_t need)
+{
+    if (bvh.n_tris <= 0) return 0u;
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    lds_u32* lds_stack = (lds_u32*)lds_generic;
+    constexpr uint32_t NONE = 0x7fffffffu;
+    const int slot = threadIdx.x, lane = threadIdx.x & 63, wave0 = threadIdx.x & ~63;
+    lds_u32* s_hit = lds_stack + WIDE_LDS_STACK * STRIDE;         /* [slot]: mask of occluded rays of the lane that owns them */
+    lds_u32* s_match = lds_stack + (WIDE_LDS_STACK + 1) * STRIDE;
+    s_hit[slot] = 0u;
+    f3 ro = p0 + 0.001f * n0;
+    const float tmin = 0.0f, tmax = 0.99f;
+    uint32_t ovf[WIDE_OVF_STACK];
+    int sp = 0, base = 0;
+    auto push = [&](uint32_t e) {
+        if (sp < WIDE_LDS_STACK) lds_stack[sp * STRIDE + slot] = e;
+        else ovf[sp - WIDE_LDS_STACK] = e;
+        ++sp;
+    };
+    auto pop = [&]() -> uint32_t {
+        --sp;
+        uint32_t e;
+        if (sp < WIDE_LDS_STACK) e = lds_stack[sp * STRIDE + slot];
+        else e = ovf[sp - WIDE_LDS_STACK];
+        if (sp == base) { sp = 0; base = 0; }
+        return e;
+    };
+    f3 rd = F3(0.0f, 0.0f, 1.0f), inv = F3(0.0f, 0.0f, 1.0f);
+    bool px = true, py = true, pz = true;
+    uint32_t ray_bit = 0u;
+    int owner = slot;
+    uint32_t cur = NONE, pend = NONE, pend2 = NONE;
+    uint32_t pass = 0u;
+    for (;;)
+    {
+        if ((int)cur < 0 && pend2 == NONE)
+        {
+            if (pend == NONE) pend = cur; else pend2 = cur;
+            cur = sp > base ? pop() : NONE;
+        }
+        bool has_inner = cur < NONE;
+        bool has_pend = pend != NONE;
+        bool live = has_inner || has_pend;
+        const bool want = !live && need != 0u;
+        unsigned long long bl = __ballot(live);
+        const unsigned long long bw = __ballot(want);
+        if (bl == 0ull && bw == 0ull) break; /* the whole wavefront is done */
+        if (bw != 0ull && (bl == 0ull || __popcll(bw) >= RT_BATCH_REFILL))
+        {
+            if (want)
+            {
+                const int k = __ffs((int)need) - 1;
+                ray_bit = 1u << k;
+                need &= ~ray_bit;
+                f3 t = tgt[0];
+#pragma unroll
+                for (int j = 1; j < NR; ++j)
+                    if (k == j) t = tgt[j];
+                rd = t - p0;
+                inv = F3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                inv.x = fminf(fmaxf(inv.x, -1e30f), 1e30f);
+                inv.y = fminf(fmaxf(inv.y, -1e30f), 1e30f);
+                inv.z = fminf(fmaxf(inv.z, -1e30f), 1e30f);
+                px = inv.x >= 0.0f; py = inv.y >= 0.0f; pz = inv.z >= 0.0f;
+                cur = 0u; sp = 0; base = 0;
+            }
+            continue;
+        }
+        ++pass;
+        if ((pass & ((1u << RT_WS_PERIOD) - 1u)) == 0u)
+        {
+            /* a ray that has been settled meanwhile: whoever still walks a piece of it drops it */
+            if (live && (s_hit[owner] & ray_bit) != 0u)
+            {
+                cur = NONE; pend = NONE; pend2 = NONE; sp = 0; base = 0;
+                has_inner = false; has_pend = false; live = false;
+            }
+            const bool idle = !live && need == 0u;
+            const bool rich = live && (sp - base) >= RT_WS_RICH && sp <= WIDE_LDS_STACK;
+            const unsigned long long bi = __ballot(idle), br = __ballot(rich);
+            const int nidle = __popcll(bi), nrich = __popcll(br);
+            if (nidle >= RT_WS_MIN && nrich > 0)
+            {
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                const int rank_i = __popcll(bi & lt), rank_r = __popcll(br & lt);
+                if (rich) s_match[wave0 + rank_r] = (uint32_t)lane;
+                const bool thief = idle && rank_i < nrich;
+                const bool robbed = rich && rank_r < nidle;
+                const int victim = thief ? (int)s_match[wave0 + rank_i] : lane;
+                const float vox = __shfl(ro.x, victim), voy = __shfl(ro.y, victim), voz = __shfl(ro.z, victim);
+                const float vdx = __shfl(rd.x, victim), vdy = __shfl(rd.y, victim), vdz = __shfl(rd.z, victim);
+                const float vix = __shfl(inv.x, victim), viy = __shfl(inv.y, victim), viz = __shfl(inv.z, victim);
+                const int vbase = __shfl(base, victim), vsp = __shfl(sp, victim), vowner = __shfl(owner, victim);
+                const uint32_t vbit = (uint32_t)__shfl((int)ray_bit, victim);
+                if (thief)
+                {
+                    const int k = (vsp - vbase + 1) >> 1;
+                    ro = F3(vox, voy, voz); rd = F3(vdx, vdy, vdz); inv = F3(vix, viy, viz);
+                    px = inv.x >= 0.0f; py = inv.y >= 0.0f; pz = inv.z >= 0.0f;
+                    owner = vowner; ray_bit = vbit;
+                    const int vslot = wave0 + victim;
+                    for (int e = 0; e < k; ++e) lds_stack[e * STRIDE + slot] = lds_stack[(vbase + e) * STRIDE + vslot];
+                    base = 0; sp = k;
+                    cur = pop();
+                }
+                if (robbed) { base += (sp - base + 1) >> 1; if (base == sp) { base = 0; sp = 0; } }
+                has_inner = cur < NONE;
+                live = has_inner || has_pend;
+                bl = __ballot(live);
+            }
+        }
+        if (!live) continue; /* waits for the refill pass, or for work to take over */
+        const unsigned long long bi = __ballot(has_inner), bp = __ballot(has_pend);
+        const int parked = __popcll(bp) + __popcll(__ballot(pend2 != NONE));
+        if (bp != 0ull && (bi == 0ull || RT_LEAF_DEN * parked >= RT_LEAF_NUM * __popcll(bl)))
+        {
+            if (has_pend)
+            {
+                const float4* g = bvh.rec + 3 * (size_t)(pend & ~WIDE_LEAF_BIT);
+                const float4 t0 = g[0], t1 = g[1], t2 = g[2];
+                pend = pend2; pend2 = NONE;
+                const f3 v0 = F3(t0.x, t0.y, t0.z), v1 = F3(t0.w, t1.x, t1.y), v2 = F3(t1.z, t1.w, t2.x);
+                float t, u, v;
+                if (intersect_ray_triangle(t, u, v, ro, rd, tmin, tmax, v0, v1, v2))
+                {
+                    atomicOr((uint32_t*)&s_hit[owner], ray_bit); /* any hit settles a shadow ray */
+                    cur = NONE; pend = NONE; pend2 = NONE; sp = 0; base = 0;
+                }
+            }
+            continue;
+        }
+        if (has_inner)
+        {
+            const float4* g = bvh.rec + 3 * (size_t)cur;
+            const float4 q0 = g[0], q1f = g[1], q2f = g[2];
+            const uint32_t e = as_uint(q0.w);
+            const uint32_t cbase = as_uint(q1f.x), meta = as_uint(q1f.y);
+            const uint32_t lx = as_uint(q1f.z), ly = as_uint(q1f.w), lz = as_uint(q2f.x);
+            const uint32_t hx = as_uint(q2f.y), hy = as_uint(q2f.z), hz = as_uint(q2f.w);
+            const uint32_t nx = px ? lx : hx, ny = py ? ly : hy, nz = pz ? lz : hz;
+            const uint32_t fx = px ? hx : lx, fy = py ? hy : ly, fz = pz ? hz : lz;
+            const float sx = as_float((e & 0xffu) << 23), sy = as_float(((e >> 8) & 0xffu) << 23),
+                        sz = as_float(((e >> 16) & 0xffu) << 23);
+            const float Ax = (q0.x - ro.x) * inv.x, Ay = (q0.y - ro.y) * inv.y, Az = (q0.z - ro.z) * inv.z;
+            const float Bx = sx * inv.x, By = sy * inv.y, Bz = sz * inv.z;
+            bool h[4];
+            uint32_t ce[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+            {
+                const uint32_t m = (meta >> (8 * k)) & 0xffu;
+                float tn = fmaxf(fmaxf(__builtin_fmaf(wide_byte(nx, k), Bx, Ax), __builtin_fmaf(wide_byte(ny, k), By, Ay)),
+                                 __builtin_fmaf(wide_byte(nz, k), Bz, Az));
+                float tf = fminf(fminf(__builtin_fmaf(wide_byte(fx, k), Bx, Ax), __builtin_fmaf(wide_byte(fy, k), By, Ay)),
+                                 __builtin_fmaf(wide_byte(fz, k), Bz, Az));
+                tn = fmaxf(tn * (1.0f - 4e-7f), tmin);
+                tf = fminf(tf * (1.0f + 4e-7f), tmax);
+                h[k] = (m != 0u) && (tn <= tf);
+                ce[k] = (cbase + (uint32_t)k) | (m == 2u ? WIDE_LEAF_BIT : 0u);
+            }
+            if (h[0] || h[1] || h[2] || h[3])
+            {
+                const bool deep = __ballot(sp + 3 > WIDE_LDS_STACK) != 0ull;
+                cur = h[0] ? ce[0] : (h[1] ? ce[1] : (h[2] ? ce[2] : ce[3]));
+                if (__builtin_expect(deep, 0))
+                {
+                    if (h[1] && h[0]) push(ce[1]);
+                    if (h[2] && (h[0] || h[1])) push(ce[2]);
+                    if (h[3] && (h[0] || h[1] || h[2])) push(ce[3]);
+                }
+                else
+                {
+                    if (h[3] && (h[0] || h[1] || h[2])) { lds_stack[sp * STRIDE + slot] = ce[3]; ++sp; }
+                    if (h[2] && (h[0] || h[1])) { lds_stack[sp * STRIDE + slot] = ce[2]; ++sp; }
+                    if (h[1] && h[0]) { lds_stack[sp * STRIDE + slot] = ce[1]; ++sp; }
+                }
+            }
+            else cur = sp > base ? pop() : NONE;
+        }
+    }
+    return s_hit[slot];
+}
+template <int NR, int STRIDE = BLOCK_THREADS>
+RT_DEV uint32_t occluded_batch(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3 p0, f3 n0, const f3 (&tgt)[NR], uint32_t need)
+{
+#if RT_BATCH_WS
+    return occluded_batch_ws<NR, STRIDE>(bvh, lds_stack, p0, n0, tgt, need);
+#else
+    return occluded_batch_plain<NR, STRIDE>(bvh, lds_stack, p0, n0, tgt, need);
+#endif
 }
 
 /* common/core.hpp:32-36 + common/raytrace.hpp:45-52: 1 = visible, 0 = occluded */

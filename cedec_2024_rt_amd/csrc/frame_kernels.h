@@ -305,7 +305,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_W
 {
     static_assert(!DEFER || (FUSE_TEMPORAL && !SHADOWED), "deferred visibility: fused unshadowed kernel only");
     constexpr bool LATE = WS && FUSE_TEMPORAL && !SHADOWED && !DEFER; /* the visibility-reuse ray after the temporal merge */
-    __shared__ __attribute__((aligned(16))) uint32_t s_stack[DEFER ? 4 : (WS ? WIDE_LDS_ROWS : WIDE_LDS_STACK) * TRACE_BLOCK];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[DEFER ? 4 : ((WS || (SHADOWED && RT_BATCH_WS)) ? WIDE_LDS_ROWS : WIDE_LDS_STACK) * TRACE_BLOCK];
     int x = 0, row = P.row0;
     const bool in_image = tile_pixel<TRACE_BLOCK>(P, x, row);
     if (!DEFER && !LATE && !in_image) return;
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_SHSPATIAL_WAVES) void k_spatial(Sce
                                                     float4* __restrict__ out_rad)
 {
     static_assert(SHADOWED, "the unshadowed pass is k_spatial_gather / k_spatial_lds");
-    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_STACK * TRACE_BLOCK];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[(RT_BATCH_WS ? WIDE_LDS_ROWS : WIDE_LDS_STACK) * TRACE_BLOCK];
     int x, row;
     if (!tile_pixel<TRACE_BLOCK>(P, x, row)) return;
     spatial_pixel<true, TRACE_BLOCK>(S, P, s_stack, x, row, g0, g1, in_rec, in_rad, out_rec, out_rad);
