@@ -27,6 +27,7 @@
  */
 #include <atomic>
 #include <cmath>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -211,7 +212,8 @@ static int rank_main(int rank, int ranks, bool mirror, bool shm, bool equal_stri
 {
     const float up[3] = {0, 1, 0};
     const int halo = 87, device = (mirror || shm) ? 0 : rank;
-    if (rank == 0 && shm) snprintf(sh->uid, sizeof(sh->uid), "rtmg_app_%d", (int)getppid());
+    if (rank == 0 && shm) snprintf(sh->uid, sizeof(sh->uid), "rtmg_app_%d_%llx", (int)getppid(),
+                                  (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count()); /* per-run nonce */
     if (rank == 0 && !mirror && !shm)
     {
         if (rt_mg_unique_id(sh->uid) != RT_OK) { fprintf(stderr, "rank 0: %s\n", rt_mg_load_error()); return 1; }

@@ -83,9 +83,10 @@ def lib_sha256():
     return h.hexdigest()
 
 
-def committed_pmc(sha):
-    """Counter data of THIS library build, if a PMC pass of it was committed (tools/profile_round.sh writes the
-    library's SHA-256 next to the counters). Nothing is reported for another build's counters."""
+def committed_pmc(sha, build_id):
+    """Counter data of THIS library build, if a PMC pass of it was committed. tools/profile_round.sh writes next to the
+    counters the library's rt_build_id (hash of sources + flags: survives a clean rebuild of the same sources) and the
+    SHA-256 of the .so file (differs between rebuilds). Nothing is reported for another build's counters."""
     out = dict(traffic=None, source=None, valu=None)
     p = os.path.join(ROOT, "profiles", "spatial_pmc_latest.json")
     if not os.path.exists(p):
@@ -95,12 +96,60 @@ def committed_pmc(sha):
             d = json.load(f)
     except Exception:
         return out
-    src = {"round": d.get("round"), "lib_sha256": d.get("lib_sha256"), "matches_this_build": d.get("lib_sha256") == sha}
+    same = (d.get("build_id") not in (None, "unknown") and d.get("build_id") == build_id) or d.get("lib_sha256") == sha
+    src = {"round": d.get("round"), "build_id": d.get("build_id"), "lib_sha256": d.get("lib_sha256"), "matches_this_build": bool(same)}
     out["source"] = src
     if src["matches_this_build"]:
         out["traffic"] = d.get("hbm_bytes_per_launch")
         out["valu"] = d.get("valu_issue_frac")
     return out
+
+
+class Watchdog:
+    """Progress watchdog of the multi-GPU run: the RCCL transport of the native strip
+    driver meets real neighbours for the first time in an unattended run. Every phase of the run ticks; if a rank makes no
+    progress for `limit` seconds (a grouped send/recv that never completes, a barrier a dead peer never reaches), the rank
+    says on stderr where it stalled, rank 0 prints ONE diagnostic JSON line (value null, "error"), and the process leaves
+    with os._exit(3) — no destructor may wait on a stuck stream, and a process that touched the GPU is never re-exec'ed."""
+
+    instance = None
+
+    def __init__(self, json_fd, rank, world, args):
+        import threading
+
+        Watchdog.instance = self
+        self.json_fd, self.rank, self.world, self.args = json_fd, rank, world, args
+        self.where, self.limit, self.t = "start-up", 600.0, time.monotonic()
+        self.done = False
+        self.th = threading.Thread(target=self._run, daemon=True)
+        self.th.start()
+
+    def tick(self, where, limit=None):
+        self.where, self.t = where, time.monotonic()
+        if limit is not None:
+            self.limit = float(limit)
+
+    def stop(self):
+        self.done = True
+
+    def _run(self):
+        while not self.done:
+            time.sleep(0.5)
+            idle = time.monotonic() - self.t
+            if not self.done and idle > self.limit:
+                self.fail(f"bench.py watchdog: rank {self.rank} of {self.world} made no progress for {idle:.0f} s in phase '{self.where}'")
+
+    def fail(self, msg):
+        self.done = True
+        sys.stderr.write(msg + "\n")
+        sys.stderr.flush()
+        if self.rank == 0:
+            line = {"metric": "Mray/s", "value": None, "unit": "Mray/s", "n_gpus": self.world, "steps": self.args.steps,
+                    "warmup": self.args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong",
+                    "vs_baseline": None, "dtype": "f32", "data": "synthetic", "error": msg,
+                    "config": {"workload": "10_restir_di blocks_restir stand-in ReSTIR DI (run aborted)"}}
+            os.write(self.json_fd, (json.dumps(line) + "\n").encode())
+        os._exit(3)
 
 
 class _PythonStrips:
@@ -123,6 +172,21 @@ class _PythonStrips:
 
 
 def main():
+    try:
+        _main()
+    except SystemExit:
+        raise
+    except BaseException as e:  # noqa: BLE001 — a failed rank must not leave the others waiting at a barrier for ever
+        import traceback
+
+        traceback.print_exc()
+        wd = Watchdog.instance
+        if wd is not None:
+            wd.fail(f"rank {wd.rank} of {wd.world} failed in phase '{wd.where}': {type(e).__name__}: {e}")
+        raise
+
+
+def _main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -147,6 +211,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    wd = Watchdog(json_fd, rank, world, args)
+    frame_limit = float(os.environ.get("BENCH_WATCHDOG_S", "60"))  # seconds without a completed step
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
@@ -210,7 +276,7 @@ def main():
         t0 = time.perf_counter()
         r = api.Renderer(w, h, device=local_rank, rows=rows, halo=HALO if world > 1 else 0)
         r.set_scene(tris)
-        build_ms = (time.perf_counter() - t0) * 1e3
+        build_ms = r.build_ms()  # rt_scene_set alone: upload + tables + BVH build, synchronised (not context creation)
         r.lookat(eye, center)
         r.set_options(opt)
         return r, build_ms
@@ -221,7 +287,7 @@ def main():
         that the most expensive one is as cheap as possible (>= 87 rows each)."""
         uid = [api.mg_unique_id() if rank == 0 and not dev_mirror else None]
         if dev_shm:
-            uid = [f"rtmg_{os.getpid()}_{w}x{h}" if rank == 0 else None]
+            uid = [f"rtmg_{os.getpid()}_{time.time_ns():x}_{w}x{h}" if rank == 0 else None]  # per-run nonce: never a stale segment
         dist.broadcast_object_list(uid, src=0)
         bounds = api.mg_partition(h, world, HALO)
         r, build_ms = make_renderer(w, h, bounds[rank])
@@ -285,7 +351,9 @@ def main():
         frame = 0
         for _ in range(warm):
             frame += 1
+            wd.tick(f"{w}x{h} warm-up frame {frame}", frame_limit)
             step(frame)
+        wd.tick(f"{w}x{h} synchronise after the warm-up", frame_limit)
         torch.cuda.synchronize()
         rays = reduce_sum(r.ray_count()[0])
         if mg is not None:
@@ -294,11 +362,15 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             frame += 1
+            wd.tick(f"{w}x{h} timed frame {frame}")  # one store per frame; the limit stays the frame limit
             step(frame)
+        wd.tick(f"{w}x{h} barrier at the end of the timed region")
         barrier()
         dt = reduce_max(time.perf_counter() - t0)
-        return dict(r=r, mg=mg, frame=frame, rays=rays, dt=dt, bounds=bounds, build_ms=build_ms, part=part)
+        wd.tick(f"{w}x{h} after the timed region", 600)
+        return dict(r=r, mg=mg, frame=frame, rays=rays, dt=dt, bounds=bounds, build_ms=build_ms, part=part, builder=r.bvh_builder())
 
+    wd.tick("scene + context set-up", 600)
     R = run(width, height, K, Wm)
     r, mg, frame, total_rays, elapsed = R["r"], R["mg"], R["frame"], R["rays"], R["dt"]
     info = r.scene_info()
@@ -343,7 +415,11 @@ def main():
         allst = [None] * world
         dist.all_gather_object(allst, mine)
         mg_stats = allst
-        if os.environ.get("BENCH_VERIFY"):
+        # N > 1 on real GPUs: the assembled image is compared with a single context by default (the RCCL transport has
+        # only ever run on one rank) — outside the timed region. BENCH_VERIFY=0 skips it; the MIRROR
+        # development transport cannot be verified (a rank receives what it sent).
+        want_verify = os.environ.get("BENCH_VERIFY", "0" if (dev_mirror and not dev_shm) else "1") not in ("", "0")
+        if want_verify:
             # development aid: the assembled N-rank image of the last frame must equal, bit for bit,
             # what a single full-frame context renders for the same frame sequence
             a, b = R["bounds"][rank]
@@ -389,7 +465,8 @@ def main():
                 "workload": f"10_restir_di blocks_restir {'stand-in' if scene_desc['stand_in'] else 'user OBJ'} {width}x{height} 1spp ReSTIR DI "
                             "(temporal+spatial reuse, 3 spatial passes, visibility reuse, unshadowed target)",
                 "scene": scene_desc,
-                "bvh_builder": "host binned SAH + 4-wide collapse", "build_ms": round(R["build_ms"], 1),
+                "bvh_builder": R["builder"], "build_ms": round(R["build_ms"], 1),
+                "rt_tuning_env": os.environ.get("RT_TUNING") or None,
                 "rays_per_frame": total_rays,
                 # strips (N > 1): every timed frame launches exactly one raycast, the one of the NEXT frame, on a second stream
                 # beside this frame's passes (rt_tuning key 14; rt_sync at the end of the timed region waits for it)
@@ -418,11 +495,14 @@ def main():
             out["also_3840x2160"] = also_4k
         if world == 1:
             sha = lib_sha256()
-            pmc = committed_pmc(sha)
+            pmc = committed_pmc(sha, api.build_id())
             ach = algo_bytes / (spatial_ms * 1e-3) / 1e9
             traffic = pmc["traffic"]
             out["roofline"] = {
-                "kernel": "k_spatial (spatial_resampling)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "kernel": "k_spatial (spatial_resampling)",
+                # the contract prices this kernel against HBM (bytes in reference-record sizes / time / 8 TB/s =
+                # `frac`); what really limits it is in `limiter` and `hbm_frac_measured` / `valu_issue_frac`
+                "bound": "hbm", "bound_measured": "valu+l2-latency", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": algo_bytes, "ms_per_launch": spatial_ms,
                 # the contract fraction counts reference-record bytes (16 + 76 B per neighbour); the kernel gathers
@@ -433,6 +513,7 @@ def main():
                 "valu_issue_frac": pmc["valu"],
             }
             out["lib_sha256"] = sha
+            out["build_id"] = api.build_id()
             out["kernel_ms"] = per_kernel
             out["gpu_event_median_ms"] = event_median
             out["pcie_inclusive"] = {"ms_per_frame": pcie_ms, "value": total_rays / pcie_ms / 1e3, "unit": "Mray/s",
@@ -443,7 +524,9 @@ def main():
             else:
                 out["cpu_baseline"] = None
         sys.stdout.flush()
+        wd.stop()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+    wd.stop()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

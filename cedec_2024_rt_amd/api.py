@@ -31,7 +31,7 @@ EXPORTS = [
     "rt_row_shaded", "rt_visibility_rays_walked", "rt_state_epoch", "rt_get_stream", "rt_geometry", "rt_res_region", "rt_lane",
     "rt_mg_partition", "rt_mg_bands", "rt_mg_unique_id", "rt_mg_load_error", "rt_mg_hub_create", "rt_mg_hub_destroy", "rt_mg_create",
     "rt_mg_destroy", "rt_mg_last_error", "rt_mg_frame", "rt_mg_frame_begin", "rt_mg_frame_step", "rt_mg_get_stats", "rt_mg_reset_stats",
-    "rt_mg_selftest_rccl",
+    "rt_mg_selftest_rccl", "rt_tuning_get", "rt_build_id",
 ]
 
 RT_MG_TRANSPORT_RCCL, RT_MG_TRANSPORT_LOCAL, RT_MG_TRANSPORT_MIRROR, RT_MG_TRANSPORT_SHM = 0, 1, 2, 3
@@ -137,6 +137,9 @@ def load_library():
     L.rt_trace_mode.argtypes = [vp, ci]
     L.rt_trace_time.argtypes = [vp, vp]
     L.rt_tuning.argtypes = [vp, ci, ci]
+    L.rt_tuning_get.argtypes = [vp, ci, vp]
+    L.rt_build_id.argtypes = []
+    L.rt_build_id.restype = C.c_char_p
     L.rt_row_shaded.argtypes = [vp, vp]
     L.rt_visibility_rays_walked.argtypes = [vp, vp]
     L.rt_state_epoch.argtypes = [vp, vp]
@@ -162,6 +165,11 @@ def load_library():
     L.rt_mg_selftest_rccl.argtypes = [C.c_size_t]
     _lib = L
     return L
+
+
+def build_id():
+    """rt_build_id(): hash of the sources + flags the loaded library was built from"""
+    return load_library().rt_build_id().decode()
 
 
 # ---- native multi-GPU strip driver (csrc/strip_mg.cpp) -------------------------------------------
@@ -614,6 +622,19 @@ class Renderer:
 
     def tuning(self, key, value):
         self._ck(self.L.rt_tuning(self.h, int(key), int(value)))
+
+    def tuning_get(self, key):
+        v = C.c_int()
+        self._ck(self.L.rt_tuning_get(self.h, int(key), C.byref(v)))
+        return v.value
+
+    BVH_BUILDERS = {0: "device Morton + Karras LBVH, host pre-split + 4-wide collapse",
+                    1: "host binned SAH + 4-wide collapse",
+                    2: "device pre-split + Morton sort + PLOC + top-level SAH sweep + 4-wide collapse"}
+
+    def bvh_builder(self):
+        """name of the builder this context's rt_scene_set used / will use (rt_tuning key 5)"""
+        return self.BVH_BUILDERS.get(self.tuning_get(5), "?")
 
     def build_ms(self):
         ms = C.c_float()

@@ -270,7 +270,10 @@ int rt_destroy(rt_ctx* c)
 {
     RT_CHECK_CTX(c);
     hipSetDevice(c->device);
+    if (c->stream && c->stream != c->own_stream) hipStreamSynchronize(c->stream);
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
+    if (c->spec_stream) hipStreamSynchronize(c->spec_stream); /* may still read the scene: before free_scene */
+    c->spec_valid = false;
     if (c->aux_stream) { hipStreamSynchronize(c->aux_stream); hipStreamDestroy(c->aux_stream); }
     if (c->ev_stage) hipEventDestroy(c->ev_stage);
     if (c->ev_aux) hipEventDestroy(c->ev_aux);
@@ -779,7 +782,12 @@ int rt_scene_set(rt_ctx* c, const rt_triangle* triangles, uint32_t count)
     RT_CHECK_CTX(c);
     if (!triangles && count) RT_FAIL(c, RT_ERR_ARG, "null triangles");
     RT_HIP(c, hipSetDevice(c->device));
-    RT_HIP(c, hipStreamSynchronize(c->stream));
+    /* every stream that may still read the old scene: the caller's / own stream, the speculative next-frame raycast
+     * (spec_stream) and the second lane */
+    { const int rs = rt_sync(c); if (rs != RT_OK) return rs; }
+    if (c->own_stream && c->own_stream != c->stream) RT_HIP(c, hipStreamSynchronize(c->own_stream));
+    if (c->aux_stream) RT_HIP(c, hipStreamSynchronize(c->aux_stream));
+    c->spec_valid = false;
     const auto t_build0 = std::chrono::steady_clock::now();
     free_scene(c);
     ++c->epoch;
@@ -2192,6 +2200,34 @@ int rt_tuning(rt_ctx* c, int key, int value)
     else RT_FAIL(c, RT_ERR_ARG, "bad tuning key/value %d/%d", key, value);
     return RT_OK;
 }
+int rt_tuning_get(rt_ctx* c, int key, int* value)
+{
+    RT_CHECK_CTX(c);
+    if (!value) return RT_ERR_ARG;
+    switch (key)
+    {
+        case 0: case 1: case 2: case 3: *value = c->tune_tile_mode[key]; break;
+        case 4: *value = c->tune_spatial_lds; break;
+        case 5: *value = c->bvh_builder; break;
+        case 6: *value = c->pt_wavefront; break;
+        case 7: *value = c->bvh_bfs_records; break;
+        case 8: *value = c->tune_spatial_variant; break;
+        case 9: *value = c->tune_spatial_waves; break;
+        case 10: *value = c->ploc_radius; break;
+        case 11: *value = c->tune_defer_vis; break;
+        case 12: *value = c->tune_ris_pipe; break;
+        case 13: *value = c->tune_ws; break;
+        case 14: *value = c->tune_spec; break;
+        case 15: *value = c->tune_stream; break;
+        case 16: *value = c->tune_ws_primary; break;
+        default: RT_FAIL(c, RT_ERR_ARG, "bad tuning key %d", key);
+    }
+    return RT_OK;
+}
+#ifndef RT_BUILD_ID
+#define RT_BUILD_ID "unknown"
+#endif
+const char* rt_build_id(void) { return RT_BUILD_ID; }
 /* which traversal rt_trace_closest / rt_trace_stats exercise: 0 = 4-wide quantised BVH with the
  * LDS stack (the one every frame kernel uses), 1 = binary LBVH with the stackless trail. */
 int rt_trace_mode(rt_ctx* c, int mode)

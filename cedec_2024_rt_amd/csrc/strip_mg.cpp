@@ -33,6 +33,7 @@
 #include <vector>
 
 #include <atomic>
+#include <cstdlib>
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -170,7 +171,7 @@ struct rt_mg
     int itr[2][2] = {{0, 0}, {0, 0}}, n_itr = 0;   /* interior row ranges, computed while halos travel */
 
     hipStream_t comm = nullptr, prep = nullptr; /* prep: the next frame's halo marks, beside this frame's passes */
-    hipEvent_t ev_packed = nullptr, ev_arrived = nullptr, ev_plan[2] = {nullptr, nullptr}, ev_gbuf = nullptr, ev_marked = nullptr, ev_carried = nullptr;
+    hipEvent_t ev_packed = nullptr, ev_arrived = nullptr, ev_arrived2 = nullptr, ev_plan[2] = {nullptr, nullptr}, ev_gbuf = nullptr, ev_marked = nullptr, ev_carried = nullptr;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr; /* GPU-side clock of the frame loop: start of the first / latest frame since rt_mg_reset_stats */
     unsigned long long frames_timed = 0;
     ncclComm_t nccl = nullptr;
@@ -374,6 +375,72 @@ static int alloc_sides(rt_mg* m)
     return RT_OK;
 }
 
+/* A stalled exchange must not hang the caller for ever: host waits on events of the exchange chain poll with a
+ * deadline (RT_MG_TIMEOUT_S seconds, default 30) and fail with the rank, the peer(s) and the step that stalled. The
+ * process cannot recover from that (the stream is stuck behind the collective): the caller reports and exits. */
+static double mg_timeout_s()
+{
+    const char* e = getenv("RT_MG_TIMEOUT_S");
+    const double t = e ? atof(e) : 0.0;
+    return t > 0.0 ? t : 30.0;
+}
+static int wait_event_deadline(rt_mg* m, hipEvent_t ev, const char* what)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    const double limit = mg_timeout_s();
+    for (long spins = 0;; ++spins)
+    {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return RT_OK;
+        if (e != hipErrorNotReady) MG_FAIL(m, RT_ERR_HIP, "hipEventQuery failed while waiting for %s: %s", what, hipGetErrorString(e));
+        if (spins > 2000) usleep(spins > 20000 ? 200 : 20);
+        if ((spins & 255) == 255 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
+            MG_FAIL(m, RT_ERR_COMM, "rank %d of %d (rows %d..%d): %s did not complete within %.0f s — the exchange with rank %d%s stalled (frame %d, stage %d)",
+                    m->rank, m->world, m->a, m->b, what, limit, m->sides.empty() ? -1 : m->sides[0].peer,
+                    m->sides.size() > 1 ? (std::string(" / ") + std::to_string(m->sides[1].peer)).c_str() : "", m->frame, m->stage);
+    }
+}
+
+/* first contact with the neighbours over RCCL: one grouped 16-byte send/recv with rank +-1 on the communication stream,
+ * checked on the host with a deadline. Proves, before any frame is enqueued, that the communicator, the grouped
+ * point-to-point path and the stream ordering work between THESE ranks; each rank also learns its neighbours' view of
+ * the partition (the row they believe the shared edge is at) and refuses a mismatch. */
+static int rccl_handshake(rt_mg* m)
+{
+    if (m->sides.empty()) return RT_OK;
+    int *d = nullptr, h_send[2][4], h_recv[2][4];
+    MG_HIP(m, hipMalloc(&d, 2 * 2 * 16));
+    for (size_t i = 0; i < m->sides.size(); ++i)
+    {
+        const auto& s = m->sides[i];
+        h_send[i][0] = 0x52544d47; /* "RTMG" */
+        h_send[i][1] = m->rank; h_send[i][2] = s.side == 0 ? m->a : m->b; /* the edge shared with this peer */
+        h_send[i][3] = m->halo;
+    }
+    MG_HIP(m, hipMemcpyAsync(d, h_send, sizeof(h_send), hipMemcpyHostToDevice, m->comm));
+    MG_HIP(m, hipMemsetAsync(d + 8, 0, 32, m->comm));
+    MG_NCCL(m, g_rccl.GroupStart());
+    for (size_t i = 0; i < m->sides.size(); ++i)
+    {
+        MG_NCCL(m, g_rccl.Send(d + 4 * i, 16, ncclUint8, m->sides[i].peer, m->nccl, m->comm));
+        MG_NCCL(m, g_rccl.Recv(d + 8 + 4 * i, 16, ncclUint8, m->sides[i].peer, m->nccl, m->comm));
+    }
+    MG_NCCL(m, g_rccl.GroupEnd());
+    MG_HIP(m, hipMemcpyAsync(h_recv, d + 8, sizeof(h_recv), hipMemcpyDeviceToHost, m->comm));
+    MG_HIP(m, hipEventRecord(m->ev_arrived, m->comm));
+    int rc = wait_event_deadline(m, m->ev_arrived, "the RCCL handshake (16-byte grouped send/recv with the neighbours)");
+    if (rc != RT_OK) return rc; /* d is leaked on purpose: the stream may still own it */
+    hipFree(d);
+    for (size_t i = 0; i < m->sides.size(); ++i)
+    {
+        const auto& s = m->sides[i];
+        if (h_recv[i][0] != 0x52544d47 || h_recv[i][1] != s.peer || h_recv[i][2] != (s.side == 0 ? m->a : m->b) || h_recv[i][3] != m->halo)
+            MG_FAIL(m, RT_ERR_COMM, "RCCL handshake: rank %d expected {rank %d, edge row %d, halo %d} from its neighbour, received {magic %08x, rank %d, edge row %d, halo %d}",
+                    m->rank, s.peer, s.side == 0 ? m->a : m->b, m->halo, (unsigned)h_recv[i][0], h_recv[i][1], h_recv[i][2], h_recv[i][3]);
+    }
+    return RT_OK;
+}
+
 /* ctx: the strip context of this rank, created with rows bounds[rank]..bounds[rank+1] and a halo of at
  * least the reach of the spatial pass (87 rows for the default radius). `arg`: RCCL: the 128-byte unique
  * id of rt_mg_unique_id (made by one rank, distributed by the caller); LOCAL: the hub. */
@@ -423,6 +490,7 @@ int rt_mg_create(rt_ctx* ctx, int rank, int world, const int* bounds, int transp
     MG_HIP(m, hipEventCreateWithFlags(&m->ev_marked, hipEventDisableTiming));
     MG_HIP(m, hipEventCreateWithFlags(&m->ev_packed, hipEventDisableTiming));
     MG_HIP(m, hipEventCreateWithFlags(&m->ev_arrived, hipEventDisableTiming));
+    MG_HIP(m, hipEventCreateWithFlags(&m->ev_arrived2, hipEventDisableTiming));
     for (auto& e : m->ev_plan) MG_HIP(m, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     MG_HIP(m, hipEventCreateWithFlags(&m->ev_carried, hipEventDisableTiming));
     MG_HIP(m, hipEventCreate(&m->ev_t0));
@@ -436,6 +504,8 @@ int rt_mg_create(rt_ctx* ctx, int rank, int world, const int* bounds, int transp
         ncclUniqueId id;
         memcpy(&id, arg, sizeof(id));
         MG_NCCL(m, g_rccl.CommInitRank(&m->nccl, world, id, rank));
+        rc = rccl_handshake(m);
+        if (rc != RT_OK) return rc;
     }
     else if (world > 1 && transport == RT_MG_TRANSPORT_LOCAL)
     {
@@ -453,13 +523,31 @@ int rt_mg_create(rt_ctx* ctx, int rank, int world, const int* bounds, int transp
         m->shm.world = world;
         m->shm.bytes = m->shm.slot * 2 * (size_t)(world - 1);
         m->shm.name = std::string("/") + (const char*)arg;
-        const int fd = shm_open(m->shm.name.c_str(), O_CREAT | O_RDWR, 0600);
-        if (fd < 0) MG_FAIL(m, RT_ERR_COMM, "shm_open(%s) failed", m->shm.name.c_str());
-        if (ftruncate(fd, (off_t)m->shm.bytes) != 0) { close(fd); MG_FAIL(m, RT_ERR_COMM, "ftruncate of the shared segment failed"); }
+        /* rank 0 creates the segment exclusively (a stale one of a crashed run with the same name is removed first, so
+         * every mailbox starts zero-filled: posted = consumed = 0); the other ranks wait until it exists at its full size.
+         * Callers put a per-run nonce in the name (bench.py, restir_app), so a rank never maps a predecessor's segment. */
+        int fd = -1;
+        if (rank == 0)
+        {
+            shm_unlink(m->shm.name.c_str());
+            fd = shm_open(m->shm.name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+            if (fd < 0) MG_FAIL(m, RT_ERR_COMM, "shm_open(%s, O_CREAT | O_EXCL) failed", m->shm.name.c_str());
+            if (ftruncate(fd, (off_t)m->shm.bytes) != 0) { close(fd); MG_FAIL(m, RT_ERR_COMM, "ftruncate of the shared segment failed"); }
+        }
+        else
+        {
+            for (int tries = 0; tries < 60000 && fd < 0; ++tries) /* <= 60 s */
+            {
+                fd = shm_open(m->shm.name.c_str(), O_RDWR, 0600);
+                struct stat sb;
+                if (fd >= 0 && (fstat(fd, &sb) != 0 || (size_t)sb.st_size != m->shm.bytes)) { close(fd); fd = -1; }
+                if (fd < 0) usleep(1000);
+            }
+            if (fd < 0) MG_FAIL(m, RT_ERR_COMM, "rank %d: the shared segment %s never appeared (rank 0 creates it)", rank, m->shm.name.c_str());
+        }
         m->shm.base = mmap(nullptr, m->shm.bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
         close(fd);
         if (m->shm.base == MAP_FAILED) { m->shm.base = nullptr; MG_FAIL(m, RT_ERR_COMM, "mmap of the shared segment failed"); }
-        /* a fresh segment is zero-filled: every mailbox starts at posted = consumed = 0 */
     }
     else if (world > 1 && transport != RT_MG_TRANSPORT_MIRROR) MG_FAIL(m, RT_ERR_ARG, "unknown transport %d", transport);
     return RT_OK;
@@ -495,6 +583,7 @@ int rt_mg_destroy(rt_mg* m)
     if (m->nccl) g_rccl.CommDestroy(m->nccl);
     if (m->ev_packed) hipEventDestroy(m->ev_packed);
     if (m->ev_arrived) hipEventDestroy(m->ev_arrived);
+    if (m->ev_arrived2) hipEventDestroy(m->ev_arrived2);
     for (auto& e : m->ev_plan) if (e) hipEventDestroy(e);
     if (m->ev_gbuf) hipEventDestroy(m->ev_gbuf);
     if (m->ev_marked) hipEventDestroy(m->ev_marked);
@@ -834,7 +923,7 @@ int rt_mg_frame_begin(rt_mg* m, int frame, int clear_first)
         {
             /* recorded in the middle of the previous frame: in a steady loop this returns at once */
             const auto t0 = std::chrono::steady_clock::now();
-            MG_HIP(m, hipEventSynchronize(m->ev_plan[slot]));
+            { const int wrc = wait_event_deadline(m, m->ev_plan[slot], "the halo plan of this frame (carried by the previous frame's first exchange)"); if (wrc != RT_OK) return wrc; }
             m->stats.plan_wait_ns += (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
             m->warm = true;
         }
@@ -907,7 +996,10 @@ static int frame_step(rt_mg* m, int* more)
         }
         case rt_mg::SEG_COLD_MARK:
         {
-            /* cold frame, 2: what I will gather from each neighbour in every pass of THIS frame */
+            /* cold frame, 2: what I will gather from each neighbour in every pass of THIS frame. A plan the previous
+             * frame carried for this slot may still be on its way to the host on the prep stream (counts copy into
+             * cnt_all[slot], reading bm_arena[slot]): the main stream waits for it before it re-marks the slot. */
+            MG_HIP(m, hipStreamWaitEvent(ms, m->ev_plan[slot], 0));
             rc = mark_plan(m, m->frame, slot, ms);
             if (rc != RT_OK) return rc;
             std::vector<Exchange> xs(m->sides.size());
@@ -926,7 +1018,10 @@ static int frame_step(rt_mg* m, int* more)
             if (rc != RT_OK) return rc;
             rc = fetch_counts(m, slot, ms);
             if (rc != RT_OK) return rc;
-            MG_HIP(m, hipStreamSynchronize(ms)); /* the one host wait of a cold frame: message sizes */
+            /* the one host wait of a cold frame: message sizes */
+            MG_HIP(m, hipEventRecord(m->ev_arrived2, ms));
+            rc = wait_event_deadline(m, m->ev_arrived2, "the cold frame's bitmap exchange");
+            if (rc != RT_OK) return rc;
             m->plan_frame[slot] = m->frame;
             rt_state_epoch(m->ctx, &m->plan_epoch[slot]);
             m->plan_passes = P;
@@ -1024,7 +1119,12 @@ int rt_mg_frame(rt_mg* m, int frame, int clear_first)
     int rc = rt_mg_frame_begin(m, frame, clear_first);
     int more = 1;
     while (rc == RT_OK && more) rc = rt_mg_frame_step(m, &more);
-    if (rc != RT_OK && m) m->seg = rt_mg::SEG_IDLE;
+    if (rc != RT_OK && m)
+    {
+        m->seg = rt_mg::SEG_IDLE;
+        m->pending = false; m->pending_carries_plan = false;
+        m->pending_x.clear(); m->pending_local.clear();
+    }
     return rc;
 }
 

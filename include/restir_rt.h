@@ -360,6 +360,13 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
  * at 1080p, 0.997 -> 1.029 at 4K — primary rays of an 8x8 tile are coherent (31.8 passes per wavefront for 23.1 steps
  * per ray) and the walk needs 88 registers instead of 70. Same results. */
 int rt_tuning(rt_ctx* ctx, int key, int value);
+/* the value a key holds now (measurement records name the builder / variants that were really used) */
+int rt_tuning_get(rt_ctx* ctx, int key, int* value);
+/* identity of the BUILD: the first 16 hex digits of a SHA-256 over the library's sources (csrc/ *.hip *.h *.cpp,
+ * include/restir_rt.h) and compiler flags, baked in by csrc/Makefile. Unlike a hash of the .so file it is the same for
+ * every clean rebuild of the same sources, so counter profiles (profiles/spatial_pmc_latest.json) can be matched to the
+ * library that is benchmarked. "unknown" if the library was built without the Makefile. */
+const char* rt_build_id(void);
 /* elementwise device evaluation of the portable math / IEEE div & sqrt (parity tests);
  * fn ids as in tests/test_portable_math.py */
 int rt_math_eval(rt_ctx* ctx, int fn, const float* in, uint32_t n, float* out);

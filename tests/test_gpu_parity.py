@@ -375,6 +375,72 @@ def test_frame_parity_blocks_restir_quarter_res(api, oracle, scenes, W, H):
     r.close()
 
 
+@pytest.mark.parametrize("W,H,frames,optkw", [
+    (480, 270, 3, dict(use_shadowed_target_function=1)),
+    (480, 270, 3, dict(use_shadowed_target_function=1, use_visibility_reuse=0)),
+    (1920, 1080, 1, dict(use_shadowed_target_function=1)),   # the size the shadowed-mode ms / Mray/s are quoted on
+])
+def test_shadowed_target_on_the_bench_scene(api, oracle, scenes, W, H, frames, optkw):
+    """README key 3 (common/reservoir.hpp:52-57, 10_restir_di.cu:195-199,346-350) on the blocks_restir stand-in —
+    the deep tree (29 levels, 380 k records) the batched work-sharing walks are quoted on: radiance, temporal history,
+    pixels and the reference's ray count against the oracle."""
+    tris = scenes.make_blocks_restir()
+    r, sc, rg, opt, eyev = _setup(api, oracle, tris, W, H, scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT, **optkw)
+    st = oracle.new_state(W, H)
+    for frame in range(1, frames + 1):
+        cnt = oracle.new_counters()
+        r.frame(frame)
+        sc.frame(W, H, frame, rg, eyev, opt, st, cnt)
+        acc = r.download(api.RT_BUF_ACCUMULATION)
+        ref = st["accum"].reshape(acc.shape)
+        nbad = int((acc.view(np.uint32) != ref.view(np.uint32)).any(axis=1).sum())
+        assert nbad == 0, f"{optkw} frame {frame}: {nbad} pixels differ, rel-L2 {_rel_l2(acc[:, :3], ref[:, :3])}"
+        rays, shaded_n = r.ray_count()
+        assert rays == int(cnt["rays"][0]) and shaded_n == int(cnt["shaded_pixels"][0])
+    shaded = (st["vis"]["index"] >= 0) & ~np.isin(st["vis"]["index"], sc.lights)
+    bad = _res_fields_equal(r.download(api.RT_BUF_RES_TEMPORAL), st["temporal"], mask=shaded)
+    assert not bad, f"temporal history: {bad}"
+    assert np.array_equal(r.download(api.RT_BUF_PIXELS).reshape(H, W, 4), st["pixels"])
+    r.close()
+
+
+def test_shadowed_target_three_strips_on_the_bench_scene(api, oracle, scenes):
+    """Three 90-row strips of a 480x270 shadowed-target frame of the bench scene == the oracle's frame (and so the
+    single context's, by the test above), two frames."""
+    import torch
+
+    from cedec_2024_rt_amd import strips
+    from cedec_2024_rt_amd.types import bench_options
+
+    W, H = 480, 270
+    optkw = dict(use_shadowed_target_function=1)
+    tris = scenes.make_blocks_restir()
+    oracle.set_math_mode(oracle.MATH_PORTABLE)
+    sc = oracle.Scene(tris, use_bvh=True)
+    rg = oracle.raygen_lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT, (0, 1, 0), FOVY, W, H)
+    eyev = np.asarray(scenes.BLOCKS_RESTIR_EYE, np.float32)
+    st = oracle.new_state(W, H)
+    bounds = strips.partition_rows(H, 3)
+    ctxs = []
+    for b in bounds:
+        c = api.Renderer(W, H, rows=b, halo=strips.HALO_ROWS)
+        c.set_scene(tris)
+        c.lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)
+        c.set_options(bench_options(**optkw))
+        ctxs.append(c)
+    for frame in (1, 2):
+        cnt = oracle.new_counters()
+        sc.frame(W, H, frame, rg, eyev, oracle.bench_options(**optkw), st, cnt)
+        ref = st["accum"].reshape(H, W, 4)
+        strips.run_frame_local(ctxs, bounds, frame, torch.device("cuda:0"), sparse=bool(frame % 2))
+        for c, (a, b) in zip(ctxs, bounds):
+            acc = c.download(api.RT_BUF_ACCUMULATION).reshape(c.local_rows, W, 4)
+            assert _eq_bits(acc[a - c.local_row0: b - c.local_row0], ref[a:b]), f"rows {a}:{b} frame {frame}"
+        assert sum(c.ray_count()[0] for c in ctxs) == int(cnt["rays"][0])
+    for c in ctxs:
+        c.close()
+
+
 @pytest.mark.parametrize("n_strips,H,sparse", [(2, 240, False), (3, 300, False), (2, 240, True), (3, 300, True)])
 def test_strip_contexts_match_full_frame(api, oracle, scenes, n_strips, H, sparse):
     """Two row-strip contexts on one GPU with an 87-row halo exchanged through the C-ABI halo
@@ -474,6 +540,10 @@ def test_random_strip_partitions_match_single_context(api, scenes, seed):
     (8, "quad_room", 96, 54, 2, dict(accumulate=1)),                           # 08_nee
     (8, "cornellbox2", 256, 256, 2, dict(accumulate=1, max_depth=3)),
     (8, "blocks", 320, 180, 1, dict()),
+    # SURVEY 8f rank 2 names 1920x1080: the sizes profiles/*_config_table.json quotes a time for
+    (7, "blocks_pt", 1920, 1080, 1, dict()),
+    (8, "blocks_pt", 1920, 1080, 1, dict()),
+    (9, "blocks_pt", 1920, 1080, 1, dict()),
 ])
 def test_path_tracers_07_and_09(api, oracle, scenes, golden_scenes, example, scene_name, W, H, frames, optkw):
     """Configs #2/#3 and 08_nee: the `path_trace` kernels of 07_pt, 08_nee and 09_ris, bit-identical

@@ -97,10 +97,14 @@ if sp:
     shaf = os.path.join(src, "lib.sha256")
     if os.path.exists(shaf):
         sha = open(shaf).read().split()[0]
+    bid = None
+    bidf = os.path.join(src, "lib.build_id")
+    if os.path.exists(bidf):
+        bid = open(bidf).read().split()[0]
     vfrac = {kk: round(e["valu_issue_fraction"], 3) for kk, e in out.items()
              if "valu_issue_fraction" in e and kk.split("<")[0] in ("k_raycast", "k_generate_candidate", "k_resolve", "k_spatial", "k_spatial_gather", "k_spatial_lds")}
     json.dump({
-        "kernel": k, "round": tag, "lib_sha256": sha, "valu_issue_frac": vfrac,
+        "kernel": k, "round": tag, "build_id": bid, "lib_sha256": sha, "valu_issue_frac": vfrac,
         "workload": "blocks_restir stand-in 1920x1080, bench options",
         "FETCH_SIZE_KB_per_launch": fetch / 1024, "WRITE_SIZE_KB_per_launch": write / 1024,
         "read_bytes_corrected": corrected, "streamed_read_bytes_known": streamed,

@@ -17,6 +17,7 @@ timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIV
 # where a wavefront's cycles go (quad-cycles; WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES, MI355X_MICROARCH.md PMC slots)
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS -d $OUT/pmc_stall -o pmc -- python3 bench.py --no-cpu-baseline --steps 16 --warmup 2 > $OUT/pmc_stall.log 2>&1
 sha256sum cedec_2024_rt_amd/librestir_rt.so > $OUT/lib.sha256
+python3 -c "from cedec_2024_rt_amd import api; print(api.build_id())" > $OUT/lib.build_id
 # summarise on the box (the raw rocprofv3 databases are too large to travel back) and keep the summaries only
 mkdir -p $OUT/summary
 cp -r profiles /tmp/profiles_before_$TAG
