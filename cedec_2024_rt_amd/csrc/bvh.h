@@ -186,6 +186,9 @@ done:
  * Traversal keeps a per-lane stack: the first WIDE_LDS_STACK entries in LDS (bank-conflict
  * free: entry i of lane t at word i*256+t), the rest in scratch (reached only by very deep trees).
  * ===================================================================================== */
+/* Lanes of one wavefront pass data through LDS in the work-sharing walks (hit flags, the rank -> lane table, a victim's
+ * stack slots): a wavefront executes its LDS operations in order, this keeps the COMPILER from moving or caching them. */
+#define RT_WAVE_LDS_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 struct WideView
 {
     const float4* __restrict__ rec; /* 3 per record */
@@ -417,6 +420,9 @@ RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3
 #ifndef RT_WS_RICH
 #define RT_WS_RICH 1 /* a lane can be robbed when its stack holds at least this many entries */
 #endif
+#ifndef RT_WS_MULTI
+#define RT_WS_MULTI 1 /* several thieves per victim (r03); 0 = one thief takes the bottom half (r02) */
+#endif
 template <int STRIDE = BLOCK_THREADS>
 RT_DEV bool occluded_ws(const WideView& bvh, uint32_t* __restrict__ lds_generic, f3 ro, f3 rd, float tmin, float tmax,
                         uint32_t* stats = nullptr /* [0] passes of the wavefront, [1] steals by this lane | own steps << 16, [2] leaf passes, [3] own triangle tests */,
@@ -429,8 +435,8 @@ RT_DEV bool occluded_ws(const WideView& bvh, uint32_t* __restrict__ lds_generic,
     lds_u32* lds_stack = (lds_u32*)lds_generic;
     constexpr uint32_t NONE = 0x7fffffffu;
     const int slot = threadIdx.x, lane = threadIdx.x & 63, wave0 = threadIdx.x & ~63;
-    lds_u32* s_hit = lds_stack + WIDE_LDS_STACK * STRIDE;         /* [slot]: ray owned by that lane is occluded */
-    lds_u32* s_match = lds_stack + (WIDE_LDS_STACK + 1) * STRIDE; /* [wave0 + rank]: lane of the rank-th rich lane */
+    volatile lds_u32* s_hit = lds_stack + WIDE_LDS_STACK * STRIDE;         /* [slot]: ray owned by that lane is occluded */
+    volatile lds_u32* s_match = lds_stack + (WIDE_LDS_STACK + 1) * STRIDE; /* [wave0 + rank]: lane of the rank-th rich lane */
     s_hit[slot] = 0u;
     f3 inv = F3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
     inv.x = fminf(fmaxf(inv.x, -1e30f), 1e30f);
@@ -480,11 +486,64 @@ RT_DEV bool occluded_ws(const WideView& bvh, uint32_t* __restrict__ lds_generic,
             const bool rich = !idle && (sp - base) >= RT_WS_RICH && sp <= WIDE_LDS_STACK;
             const unsigned long long bi = __ballot(idle), br = __ballot(rich);
             const int nidle = __popcll(bi), nrich = __popcll(br);
+#if RT_WS_MULTI
+            if (nidle >= RT_WS_MIN && nrich > 0)
+            {
+                /* Several thieves per victim (r03): idle lane j serves rich lane j mod nrich as its (j / nrich)-th helper.
+                 * A victim with n stack entries and T helpers is cut into T + 1 runs of c ~ n / (T + 1) entries from the
+                 * bottom (the largest pending subtrees first); the victim keeps what is left on top. With one thief per
+                 * victim a long ray spreads over the idle lanes in log2 steps of RT_WS_PERIOD passes each; this way it
+                 * spreads as far as its stack allows in one step. Small integer quotients by reciprocal: operands
+                 * < 128, the +0.5 guard is far above the 1-ulp error of v_rcp_f32. */
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                const int rank_i = __popcll(bi & lt), rank_r = __popcll(br & lt);
+                if (rich) s_match[wave0 + rank_r] = (uint32_t)lane;
+                RT_WAVE_LDS_FENCE(); /* the table and the victims' stack slots are read by OTHER lanes below */
+                const float inv_rich = __builtin_amdgcn_rcpf((float)nrich);
+                const int t_idx = (int)(((float)rank_i + 0.5f) * inv_rich);
+                const int v_rank = idle ? rank_i - t_idx * nrich : rank_r;
+                const int helpers = v_rank < nidle ? (int)(((float)(nidle - 1 - v_rank) + 0.5f) * inv_rich) + 1 : 0;
+                const int victim = idle ? (int)s_match[wave0 + v_rank] : lane;
+                const float vox = __shfl(ro.x, victim), voy = __shfl(ro.y, victim), voz = __shfl(ro.z, victim);
+                const float vdx = __shfl(rd.x, victim), vdy = __shfl(rd.y, victim), vdz = __shfl(rd.z, victim);
+                const float vix = __shfl(inv.x, victim), viy = __shfl(inv.y, victim), viz = __shfl(inv.z, victim);
+                const float vtmin = __shfl(tmin, victim), vtmax = __shfl(tmax, victim);
+                const int vbase = __shfl(base, victim), vsp = __shfl(sp, victim), vowner = __shfl(owner, victim);
+                const int n = vsp - vbase; /* a rich lane looks at itself: victim == lane */
+                const int t_eff = helpers < n ? helpers : n;
+                const int c = (int)(((float)(n + t_eff) + 0.5f) * __builtin_amdgcn_rcpf((float)(t_eff + 1)));
+                if (idle)
+                {
+                    const int lo = t_idx * c;
+                    const int hi = lo + c < n ? lo + c : n;
+                    if (t_idx < t_eff && lo < n)
+                    {
+                        tmin = vtmin; tmax = vtmax;
+                        ro = F3(vox, voy, voz); rd = F3(vdx, vdy, vdz); inv = F3(vix, viy, viz);
+                        px = inv.x >= 0.0f; py = inv.y >= 0.0f; pz = inv.z >= 0.0f;
+                        owner = vowner;
+                        const int vslot = wave0 + victim;
+                        for (int e = lo; e < hi; ++e) lds_stack[(e - lo) * STRIDE + slot] = lds_stack[(vbase + e) * STRIDE + vslot];
+                        base = 0; sp = hi - lo;
+                        cur = pop();
+                        if (stats) stats[1] += 1u;
+                    }
+                }
+                else if (rich && t_eff > 0)
+                {
+                    const int taken = t_eff * c < n ? t_eff * c : n;
+                    base += taken;
+                    if (base == sp) { base = 0; sp = 0; }
+                }
+                has_inner = cur < NONE;
+            }
+#else
             if (nidle >= RT_WS_MIN && nrich > 0)
             {
                 const unsigned long long lt = (1ull << lane) - 1ull;
                 const int rank_i = __popcll(bi & lt), rank_r = __popcll(br & lt);
                 if (rich) s_match[wave0 + rank_r] = (uint32_t)lane;
+                RT_WAVE_LDS_FENCE(); /* the table and the victims' stack slots are read by OTHER lanes below */
                 const bool thief = idle && rank_i < nrich;
                 const bool robbed = rich && rank_r < nidle;
                 const int victim = thief ? (int)s_match[wave0 + rank_i] : lane;
@@ -510,6 +569,7 @@ RT_DEV bool occluded_ws(const WideView& bvh, uint32_t* __restrict__ lds_generic,
                 if (robbed) { base += (sp - base + 1) >> 1; if (base == sp) { base = 0; sp = 0; } }
                 has_inner = cur < NONE;
             }
+#endif
         }
         const unsigned long long bi2 = __ballot(has_inner), bp = __ballot(has_pend);
         const int parked = __popcll(bp) + __popcll(__ballot(pend2 != NONE));
@@ -607,7 +667,7 @@ RT_DEV bool closest_ws(const WideView& bvh, const float4* __restrict__ tv, uint3
     constexpr unsigned long long NOHIT = ~0ull;
     const int slot = threadIdx.x, lane = threadIdx.x & 63, wave0 = threadIdx.x & ~63;
     lds_u64* s_key = (lds_u64*)(lds_stack + WIDE_LDS_STACK * STRIDE);  /* [slot]: best (t, index) of the ray that lane owns */
-    lds_u32* s_match = lds_stack + (WIDE_LDS_STACK + 2) * STRIDE;
+    volatile lds_u32* s_match = lds_stack + (WIDE_LDS_STACK + 2) * STRIDE;
     s_key[slot] = NOHIT;
     f3 ro = own_ro, rd = own_rd;
     float tmin = own_tmin, tmax = own_tmax;
@@ -665,6 +725,7 @@ RT_DEV bool closest_ws(const WideView& bvh, const float4* __restrict__ tv, uint3
                 const unsigned long long lt = (1ull << lane) - 1ull;
                 const int rank_i = __popcll(bi & lt), rank_r = __popcll(br & lt);
                 if (rich) s_match[wave0 + rank_r] = (uint32_t)lane;
+                RT_WAVE_LDS_FENCE(); /* the table and the victims' stack slots are read by OTHER lanes below */
                 const bool thief = idle && rank_i < nrich;
                 const bool robbed = rich && rank_r < nidle;
                 const int victim = thief ? (int)s_match[wave0 + rank_i] : lane;
@@ -808,8 +869,8 @@ RT_DEV void occluded_stream(const WideView& bvh, uint32_t* __restrict__ lds_gene
     lds_u32* lds_stack = (lds_u32*)lds_generic;
     constexpr uint32_t NONE = 0x7fffffffu;
     const int slot = threadIdx.x, lane = threadIdx.x & 63, wave0 = threadIdx.x & ~63;
-    lds_u32* s_hit = lds_stack + WIDE_LDS_STACK * STRIDE;
-    lds_u32* s_match = lds_stack + (WIDE_LDS_STACK + 1) * STRIDE;
+    volatile lds_u32* s_hit = lds_stack + WIDE_LDS_STACK * STRIDE;
+    volatile lds_u32* s_match = lds_stack + (WIDE_LDS_STACK + 1) * STRIDE;
     s_hit[slot] = 0u;
     f3 ro = F3(0.0f, 0.0f, 0.0f), rd = F3(0.0f, 0.0f, 1.0f), inv = F3(1.0f, 1.0f, 1.0f);
     float tmin = 0.0f, tmax = 0.0f;
@@ -910,6 +971,7 @@ RT_DEV void occluded_stream(const WideView& bvh, uint32_t* __restrict__ lds_gene
                 const unsigned long long lt = (1ull << lane) - 1ull;
                 const int rank_i = __popcll(bi & lt), rank_r = __popcll(br & lt);
                 if (rich) s_match[wave0 + rank_r] = (uint32_t)lane;
+                RT_WAVE_LDS_FENCE(); /* the table and the victims' stack slots are read by OTHER lanes below */
                 const bool thief = idle && rank_i < nrich;
                 const bool robbed = rich && rank_r < nidle;
                 const int victim = thief ? (int)s_match[wave0 + rank_i] : lane;
@@ -1183,8 +1245,8 @@ RT_DEV uint32_t occluded_batch_ws(const WideView& bvh, uint32_t* __restrict__ ld
     lds_u32* lds_stack = (lds_u32*)lds_generic;
     constexpr uint32_t NONE = 0x7fffffffu;
     const int slot = threadIdx.x, lane = threadIdx.x & 63, wave0 = threadIdx.x & ~63;
-    lds_u32* s_hit = lds_stack + WIDE_LDS_STACK * STRIDE;         /* [slot]: mask of occluded rays of the lane that owns them */
-    lds_u32* s_match = lds_stack + (WIDE_LDS_STACK + 1) * STRIDE;
+    volatile lds_u32* s_hit = lds_stack + WIDE_LDS_STACK * STRIDE;         /* [slot]: mask of occluded rays of the lane that owns them */
+    volatile lds_u32* s_match = lds_stack + (WIDE_LDS_STACK + 1) * STRIDE;
     s_hit[slot] = 0u;
     f3 ro = p0 + 0.001f * n0;
     const float tmin = 0.0f, tmax = 0.99f;
@@ -1262,6 +1324,7 @@ RT_DEV uint32_t occluded_batch_ws(const WideView& bvh, uint32_t* __restrict__ ld
                 const unsigned long long lt = (1ull << lane) - 1ull;
                 const int rank_i = __popcll(bi & lt), rank_r = __popcll(br & lt);
                 if (rich) s_match[wave0 + rank_r] = (uint32_t)lane;
+                RT_WAVE_LDS_FENCE(); /* the table and the victims' stack slots are read by OTHER lanes below */
                 const bool thief = idle && rank_i < nrich;
                 const bool robbed = rich && rank_r < nidle;
                 const int victim = thief ? (int)s_match[wave0 + rank_i] : lane;

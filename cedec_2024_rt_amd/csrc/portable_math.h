@@ -7,18 +7,19 @@
  * Device libm (ocml) and glibc disagree in the last bits, and ONE flipped
  * reservoir decision changes a whole pixel (SURVEY.md §7 "discrete-decision
  * parity"), so the GPU path and its CPU checker must evaluate these functions
- * with identical results. Everything here is built from IEEE-754 +,-,*,/ and
+ * with identical results. Everything here is built from IEEE-754 +,-,*,/, fma and
  * integer bit manipulation only, in a fixed operation order; it must be compiled
  * with -ffp-contract=off on both sides (no FMA contraction, no fast-math).
  *
- * The polynomial kernels are the classic fdlibm/msun ones (Sun Microsystems,
+ * The log/exp kernels are the classic fdlibm/msun ones (Sun Microsystems,
  * "Permission to use, copy, modify, and distribute this software is freely
  * granted, provided that this notice is preserved"), restated for this file;
- * sin/cos reduce and evaluate in binary64, log/exp in binary32.
+ * everything is binary32 (sin/cos since round 3: Cody-Waite reduction with fma and
+ * a carried tail, own minimax coefficients; rounds 1-2 used binary64 there).
  *
  * Accuracy (checked in tests/test_portable_math.py against glibc): <= 1 ulp for
  * logf/expf on the ranges the renderer uses, <= 1 ulp for sinf/cosf on
- * [-2*pi, 4*pi].
+ * [-2*pi, 4*pi] (exhaustively: tools/sincos_exhaustive.c).
  *
  * This header is dual-use: C99 (the oracle includes it for its "portable"
  * math mode) and HIP device code (the product).
@@ -155,93 +156,74 @@ PM_FN float pm_expf(float x)
     return pm_scale2f(y, k);
 }
 
-/* binary64 kernels on [-pi/4, pi/4] */
-PM_FN double pm_sin_kernel(double x)
-{
-    const double S1 = -0.166666666416265235595;    /* -0x15555554cbac77.0p-55 */
-    const double S2 = 0.0083333293858894631756;    /*  0x111110896efbb2.0p-59 */
-    const double S3 = -0.000198393348360966317347; /* -0x1a00f9e2cae774.0p-65 */
-    const double S4 = 0.0000027183114939898219064; /*  0x16cd878c3b46a7.0p-71 */
-    const double z = x * x;
-    const double w = z * z;
-    const double r = S3 + z * S4;
-    const double s = z * x;
-    return (x + s * (S1 + z * S2)) + (s * w) * r;
-}
-PM_FN double pm_cos_kernel(double x)
-{
-    const double C0 = -0.499999997251031003120;    /* -0x1ffffffd0c5e81.0p-54 */
-    const double C1 = 0.0416666233237390631894;    /*  0x155553e1053a42.0p-57 */
-    const double C2 = -0.00138867637746099294692;  /* -0x16c087e80f1e27.0p-62 */
-    const double C3 = 0.0000243904487962774090654; /*  0x199342e0ee5069.0p-68 */
-    const double z = x * x;
-    const double w = z * z;
-    const double r = C2 + z * C3;
-    return ((1.0 + z * C0) + w * C1) + (w * z) * r;
-}
-
-/* quadrant reduction in binary64; valid (sub-ulp) for |x| < ~1e6 */
-PM_FN int pm_rem_pio2(float x, double* y)
-{
-    const double invpio2 = 6.36619772367581382433e-01;
-    const double pio2_1 = 1.57079631090164184570e+00;  /* first 25 bits of pi/2 */
-    const double pio2_1t = 1.58932547735281966916e-08; /* pi/2 - pio2_1 */
-    const double xd = (double)x;
-    const double q = xd * invpio2;
-    const int n = (int)(q + (q < 0.0 ? -0.5 : 0.5));
-    const double fn = (double)n;
-    *y = (xd - fn * pio2_1) - fn * pio2_1t;
-    return n;
-}
-
-PM_FN float pm_sinf(float x)
-{
-    const uint32_t ax = pm_f2u(x) & 0x7fffffffu;
-    if (ax >= 0x7f800000u) return pm_u2f(0x7fc00000u);
-    if (ax > 0x4e000000u) return 0.0f; /* |x| > 2^29: out of contract, defined as 0 */
-    double y;
-    const int n = pm_rem_pio2(x, &y);
-    switch (n & 3)
-    {
-        case 0: return (float)pm_sin_kernel(y);
-        case 1: return (float)pm_cos_kernel(y);
-        case 2: return (float)(-pm_sin_kernel(y));
-        default: return (float)(-pm_cos_kernel(y));
-    }
-}
-
-PM_FN float pm_cosf(float x)
-{
-    const uint32_t ax = pm_f2u(x) & 0x7fffffffu;
-    if (ax >= 0x7f800000u) return pm_u2f(0x7fc00000u);
-    if (ax > 0x4e000000u) return 1.0f; /* out of contract, defined as 1 */
-    double y;
-    const int n = pm_rem_pio2(x, &y);
-    switch (n & 3)
-    {
-        case 0: return (float)pm_cos_kernel(y);
-        case 1: return (float)(-pm_sin_kernel(y));
-        case 2: return (float)(-pm_cos_kernel(y));
-        default: return (float)pm_sin_kernel(y);
-    }
-}
-
-/* pm_sinf(x) and pm_cosf(x) at once: one reduction and one evaluation of each kernel instead of two
- * of each (callers always need both of the same angle, and on a wavefront the quadrants of the lanes
- * differ, so the separate functions evaluate both kernels twice). Bit-identical to the two calls:
- * same reduced argument, same kernels, and (float)(-k) == -(float)k. */
+/* ---- sin / cos, binary32 throughout (r03; rounds 1-2 reduced and evaluated in binary64: 33 half-rate instructions
+ * per call on the device, five calls per pixel and spatial pass). IEEE +, -, * and fma (one rounding: the same bits
+ * on every IEEE machine; __builtin_fmaf is v_fma_f32 on the device and glibc's correctly rounded fmaf on the host).
+ *
+ * Reduction (Cody-Waite, three constants): n = rint(x * 2/pi), r = x - n*pi/2 carried as hi + lo.
+ *   P1 has 8 significant bits, so t1 = fma(-n, P1, x) is exact for |x| <= 2^15;
+ *   hi = fma(-n, P2, t1) rounds once; its rounding error is recovered (lo = fma(-n, P2, t1 - hi), t1 - hi exact) and
+ *   the third constant is folded in (lo = fma(-n, P3, lo)): r = hi + lo to ~2^-48 relative, pi/2 = P1+P2+P3 to 8e-20.
+ * Kernels on |r| <= pi/4 (+ a rounding): fdlibm's k_sin / k_cos shape with the tail `lo`, minimax coefficients for
+ * binary32 (sin: 4 terms, |error| < 3.3e-11 relative; cos: 3 terms after 1 - z/2, < 1e-9 absolute); the last operation
+ * of each is one addition whose second operand is < 0.11 |result|, so the result is within ~0.8 ulp of the exact one.
+ * Accuracy against glibc, checked exhaustively over every binary32 in [-2 pi, 4 pi] (tools/sincos_exhaustive.c) and in
+ * tests/test_portable_math.py: <= 1 ulp. Contract range |x| <= 32768; beyond it the functions are defined as (0, 1). */
 PM_FN void pm_sincosf(float x, float* sn, float* cs)
 {
     const uint32_t ax = pm_f2u(x) & 0x7fffffffu;
     if (ax >= 0x7f800000u) { *sn = pm_u2f(0x7fc00000u); *cs = pm_u2f(0x7fc00000u); return; }
-    if (ax > 0x4e000000u) { *sn = 0.0f; *cs = 1.0f; return; }
-    double y;
-    const int n = pm_rem_pio2(x, &y);
-    const float s = (float)pm_sin_kernel(y), c = (float)pm_cos_kernel(y);
+    if (ax > 0x47000000u) { *sn = 0.0f; *cs = 1.0f; return; } /* |x| > 32768: out of contract */
+    const float INVPIO2 = 0.6366197466850281f; /* 0x3f22f983 */
+    const float P1 = 1.5703125f;               /* 0x3fc90000: 8 significant bits of pi/2 */
+    const float P2 = 4.838267923332751e-4f;    /* 0x39fdaa22: pi/2 - P1 */
+    const float P3 = 2.5633440682570896e-12f;  /* 0x2c34611a: pi/2 - P1 - P2 */
+    const float S1 = -0.1666666716337204f, S2 = 0.008333331905305386f, S3 = -1.983999100048095e-4f, S4 = 2.723765874179662e-6f;
+    const float C1 = 0.0416666641831398f, C2 = -0.001388825592584908f, C3 = 2.4537857825635e-5f;
+
+    const float q = x * INVPIO2;
+    /* round to nearest integer, ties away from zero (exact: |q| < 2^15): trunc(q +- 0.5) */
+    const int n = (int)(q + (q < 0.0f ? -0.5f : 0.5f));
+    const float fn = (float)n;
+    const float t1 = __builtin_fmaf(-fn, P1, x);
+    const float hi = __builtin_fmaf(-fn, P2, t1);
+    float lo = __builtin_fmaf(-fn, P2, t1 - hi);
+    lo = __builtin_fmaf(-fn, P3, lo);
+
+    const float z = hi * hi;
+    /* sin(hi + lo) = hi - ((z*(lo/2 - v*r) - lo) - v*S1),  v = z*hi,  r = S2 + z*(S3 + z*S4) */
+    const float v = z * hi;
+    float r = __builtin_fmaf(z, S4, S3);
+    r = __builtin_fmaf(z, r, S2);
+    float ts = __builtin_fmaf(-v, r, 0.5f * lo);
+    ts = __builtin_fmaf(z, ts, -lo);
+    ts = __builtin_fmaf(-v, S1, ts);
+    const float s = hi - ts;
+    /* cos(hi + lo) = w + (((1 - w) - z/2) + (z*(z*rc) - hi*lo)),  w = 1 - z/2,  rc = C1 + z*(C2 + z*C3) */
+    float rc = __builtin_fmaf(z, C3, C2);
+    rc = __builtin_fmaf(z, rc, C1);
+    const float hz = 0.5f * z;
+    const float w = 1.0f - hz;
+    const float tc = __builtin_fmaf(z, z * rc, -(hi * lo));
+    const float c = w + (((1.0f - w) - hz) + tc);
+
     const float a = (n & 1) ? c : s;  /* |sin| source */
     const float b = (n & 1) ? s : c;  /* |cos| source */
     *sn = (n & 2) ? -a : a;
     *cs = ((n + 1) & 2) ? -b : b;
+}
+/* the single functions are the fused one (bit-identical by construction) */
+PM_FN float pm_sinf(float x)
+{
+    float s, c;
+    pm_sincosf(x, &s, &c);
+    return s;
+}
+PM_FN float pm_cosf(float x)
+{
+    float s, c;
+    pm_sincosf(x, &s, &c);
+    return c;
 }
 
 /* x^8 by three squarings: the portable definition of powf(x, 8.0f)

@@ -63,7 +63,8 @@ struct rt_ctx
     int tune_ws_primary = 0; /* rt_tuning key 16: primary rays with the work-sharing closest-hit walk (A/B: no gain) */
     int tune_stream = 0; /* rt_tuning key 15: resolve as a stream of pixels through persistent wavefronts (A/B: slower) */
     int n_cus = 256;
-    int tune_spec = -1; /* rt_tuning key 14: -1 auto = strip contexts only, 0 never, 1 always */
+    int tune_spec = -1; /* rt_tuning key 14: -1 auto = strip contexts: primary rays AND candidates of the next frame, 0 never,
+                           1 = the next frame's primary rays only, 2 = primary rays and candidates */
     bool lane_saved = false, lane_timing = false; /* rt_lane */
     hipStream_t lane_main = nullptr;
     std::string err;
@@ -110,12 +111,34 @@ struct rt_ctx
 
     float4 *d_vis = nullptr, *d_g0 = nullptr, *d_g1 = nullptr, *d_accum = nullptr;
     uint32_t* d_pixels = nullptr;
-    float4* d_rec[3] = {nullptr, nullptr, nullptr};
-    float4* d_rad[3] = {nullptr, nullptr, nullptr};
+    /* three reservoir buffers carry the reference's names (res_map); a fourth, allocated when the pipelined stage 0 is
+     * first used, receives the NEXT frame's candidates while this frame's passes still read the other three */
+    float4* d_rec[4] = {nullptr, nullptr, nullptr, nullptr};
+    float4* d_rad[4] = {nullptr, nullptr, nullptr, nullptr};
     int res_map[3] = {0, 1, 2};
+    /* Pipelined stage 0 (rt_tuning key 14 = 2, r03): frame f+1's generate_candidate(+temporal_resampling) depends on frame
+     * f only through the temporal history, and the reference saves that history right after temporal_resampling, BEFORE
+     * the spatial passes (10_restir_di.cpp:314-321) — so stage 0 of frame f+1 (primary rays, candidates, temporal merge)
+     * can run beside the spatial passes, halo exchanges and resolve of frame f. It is launched on spec_stream behind
+     * stage 0 of frame f, reads the history frame f just wrote, writes the spare buffer, and frame f+1 takes it if it
+     * is frame f+1 indeed and nothing it read has changed meanwhile (epoch: camera / scene / options / uploads;
+     * res_epoch: any call that writes a reservoir buffer outside the staged frame). Same launches, same results. */
+    /* Tail stream (rt_tuning key 17, r03): resolve + tone_mapping of frame f read only frame f's final reservoirs and
+     * G-buffer, so a strip's main stream does not wait for them — it goes on with frame f+1's first halo exchange while
+     * they run on a stream of their own. Whatever could overwrite what they read waits for ev_tail first: the next frame's
+     * first spatial pass (its output buffer can be this frame's final one), the next-but-one frame's pipelined stage 0 (same
+     * G-buffer set, spare reservoir buffer), and every call outside the staged frame (join_tail). */
+    hipStream_t tail_stream = nullptr;
+    hipEvent_t ev_tail_go = nullptr, ev_tail = nullptr;
+    bool tail_pending_main = false, tail_pending_spec = false;
+    int tune_tail = -1; /* -1 auto = strip contexts, 0 never, 1 always */
+    int spare = 3;             /* physical buffer not named by res_map */
+    bool spec_gen_valid = false, gen_taken = false;
+    int spec_gen_frame = 0, spec_gen_hist = -1;
+    uint64_t res_epoch = 1, spec_res_epoch = 0;
     int sub0 = -1, sub1 = -1; /* row sub-range of the running rt_frame_stage_run (-1: all owned rows) */
     int subb0 = 0, subb1 = 0; /* optional second row range of the same launches (rt_frame_stage_run_ranges) */
-    int fX = 0, fY = 1, fZ = 2, f_in = 0, f_out = 1, f_stage = 0, f_final = RT_RES_1;
+    int fX = 0, fY = 1, fZ = 2, f_in = 0, f_out = 1, f_stage = 0, f_final = RT_RES_1, f_frame = 0;
     bool f_clear = false;
     uint64_t halo_flags_epoch[2] = {0, 0}; /* epoch at which the neighbour's shaded flags were unpacked (valid while it is the current one) */
     unsigned long long* d_counter = nullptr;
@@ -273,6 +296,9 @@ int rt_destroy(rt_ctx* c)
     if (c->stream && c->stream != c->own_stream) hipStreamSynchronize(c->stream);
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     if (c->spec_stream) hipStreamSynchronize(c->spec_stream); /* may still read the scene: before free_scene */
+    if (c->tail_stream) { hipStreamSynchronize(c->tail_stream); hipStreamDestroy(c->tail_stream); }
+    if (c->ev_tail_go) hipEventDestroy(c->ev_tail_go);
+    if (c->ev_tail) hipEventDestroy(c->ev_tail);
     c->spec_valid = false;
     if (c->aux_stream) { hipStreamSynchronize(c->aux_stream); hipStreamDestroy(c->aux_stream); }
     if (c->ev_stage) hipEventDestroy(c->ev_stage);
@@ -284,7 +310,7 @@ int rt_destroy(rt_ctx* c)
     for (auto& es : c->ev_spec_t) for (auto& e : es) if (e) hipEventDestroy(e);
     for (auto& gs : c->d_gset) for (auto& p : gs) hipFree(p);
     hipFree(c->d_accum); hipFree(c->d_pixels);
-    for (int k = 0; k < 3; ++k) { hipFree(c->d_rec[k]); hipFree(c->d_rad[k]); }
+    for (int k = 0; k < 4; ++k) { hipFree(c->d_rec[k]); hipFree(c->d_rad[k]); }
     hipFree(c->d_shaded_bits);
     hipFree(c->d_visq[0]); hipFree(c->d_visq[1]); hipFree(c->d_visq_count);
     if (c->h_visq_count) hipHostFree(c->h_visq_count);
@@ -316,6 +342,8 @@ int rt_sync(rt_ctx* c)
     RT_CHECK_CTX(c);
     RT_HIP(c, hipStreamSynchronize(c->stream));
     if (c->spec_stream) RT_HIP(c, hipStreamSynchronize(c->spec_stream)); /* the next frame's raycast is work of this call too */
+    if (c->tail_stream) RT_HIP(c, hipStreamSynchronize(c->tail_stream));
+    c->tail_pending_main = false; c->tail_pending_spec = false;
     return RT_OK;
 }
 
@@ -1022,6 +1050,21 @@ static int launch_grid(const rt_ctx* c)
 #endif
 static bool use_ws(const rt_ctx* c, int grid) { return c->tune_ws < 0 ? grid <= RT_WS_AUTO_WAVES : c->tune_ws != 0; }
 /* grid of the tracing kernels: TRACE_BLOCK threads on TileShape<TRACE_BLOCK> tiles */
+static bool use_tail(const rt_ctx* c)
+{
+    if (c->timing) return false; /* rt_timing brackets the kernels with events on the main stream */
+    return c->tune_tail < 0 ? (c->row_begin != 0 || c->row_end != c->H) : c->tune_tail != 0;
+}
+/* the stream about to be used waits for the previous frame's resolve + tone_mapping (no-op unless they are in flight) */
+static int join_tail(rt_ctx* c)
+{
+    if (!c->tail_pending_main) return RT_OK;
+    RT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_tail, 0));
+    /* the second lane of a stage waits for itself; the main stream still has to */
+    if (c->stream != c->aux_stream) c->tail_pending_main = false;
+    return RT_OK;
+}
+#define JOIN_TAIL(c) do { const int _jt = join_tail(c); if (_jt != RT_OK) return _jt; } while (0)
 static int trace_grid(const rt_ctx* c)
 {
     const int rows = c->sub0 >= 0 ? c->sub1 - c->sub0 : c->row_end - c->row_begin;
@@ -1031,6 +1074,7 @@ static int trace_grid(const rt_ctx* c)
 int rt_clear(rt_ctx* c)
 {
     RT_CHECK_CTX(c);
+    JOIN_TAIL(c);
     k_clear<<<launch_grid(c), BLOCK, 0, c->stream>>>(make_params(c, 0, 0), c->d_accum);
     RT_HIP(c, hipGetLastError());
     return RT_OK;
@@ -1039,6 +1083,7 @@ int rt_clear(rt_ctx* c)
 int rt_raycast(rt_ctx* c)
 {
     RT_CHECK_CTX(c);
+    JOIN_TAIL(c);
     NEED_SCENE(c);
     if (c->tune_ws_primary) k_raycast<true><<<trace_grid(c), TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_vis, c->d_g0, c->d_g1);
     else k_raycast<false><<<trace_grid(c), TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_vis, c->d_g0, c->d_g1);
@@ -1057,9 +1102,18 @@ static bool use_next_raycast(const rt_ctx* c)
 {
     return c->tune_spec < 0 ? (c->row_begin != 0 || c->row_end != c->H) : c->tune_spec != 0;
 }
-/* the next frame's primary rays, behind everything enqueued on the main stream so far, on the stream of their own */
-static int launch_next_raycast(rt_ctx* c)
+/* the next frame's generate_candidate(+temporal) too. Not while per-kernel timing is on (rt_timing attributes events of the
+ * main stream to kernels) and not with the deferred-visibility queue (its counters live per lane of the main frame). */
+static bool use_next_generate(const rt_ctx* c)
 {
+    if (!use_next_raycast(c) || c->timing || c->tune_defer_vis) return false;
+    return c->tune_spec < 0 || c->tune_spec == 2;
+}
+static int launch_generate(rt_ctx* c, int frame, int dst_phys, int prev_phys, bool fuse);
+/* the next frame's primary rays, behind everything enqueued on the main stream so far, on the stream of their own */
+static int launch_next_raycast(rt_ctx* c, int frame)
+{
+    c->spec_gen_valid = false;
     if (!use_next_raycast(c)) { c->spec_valid = false; return RT_OK; }
     const size_t n = local_pixels(c);
     if (!c->spec_stream)
@@ -1076,29 +1130,74 @@ static int launch_next_raycast(rt_ctx* c)
     const int o = c->gcur ^ 1;
     RT_HIP(c, hipEventRecord(c->ev_spec_go, c->stream));
     RT_HIP(c, hipStreamWaitEvent(c->spec_stream, c->ev_spec_go, 0));
+    if (c->tail_pending_spec)
+    {
+        /* the G-buffer set and the spare reservoir buffer written below are what the previous frame's resolve reads */
+        RT_HIP(c, hipStreamWaitEvent(c->spec_stream, c->ev_tail, 0));
+        c->tail_pending_spec = false;
+    }
     const int s0 = c->sub0, s1 = c->sub1, b0 = c->subb0, b1 = c->subb1;
     c->sub0 = c->sub1 = -1; c->subb0 = c->subb1 = 0; /* all owned rows */
     if (c->timing) hipEventRecord(c->ev_spec_t[o][0], c->spec_stream);
     if (c->tune_ws_primary) k_raycast<true><<<trace_grid(c), TRACE_BLOCK, 0, c->spec_stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_gset[o][0], c->d_gset[o][1], c->d_gset[o][2]);
     else k_raycast<false><<<trace_grid(c), TRACE_BLOCK, 0, c->spec_stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_gset[o][0], c->d_gset[o][1], c->d_gset[o][2]);
-    c->sub0 = s0; c->sub1 = s1; c->subb0 = b0; c->subb1 = b1;
     RT_HIP(c, hipGetLastError());
     if (c->timing) hipEventRecord(c->ev_spec_t[o][1], c->spec_stream);
     c->spec_timed[o] = c->timing;
+    int rc = RT_OK;
+    if (use_next_generate(c) && c->n_lights > 0)
+    {
+        /* candidates (+ temporal merge) of frame + 1: G-buffer = the set just traced, history = the buffer this frame's
+         * stage 0 wrote (c->fY), output = the spare buffer; all owned rows, on the same stream behind the raycast */
+        const size_t npx = local_pixels(c);
+        if (!c->d_rec[3])
+        {
+            RT_HIP(c, hipMalloc(&c->d_rec[3], npx * 64));
+            RT_HIP(c, hipMalloc(&c->d_rad[3], npx * 16));
+            RT_HIP(c, hipMemsetAsync(c->d_rec[3], 0, npx * 64, c->spec_stream));
+            RT_HIP(c, hipMemsetAsync(c->d_rad[3], 0, npx * 16, c->spec_stream));
+        }
+        hipStream_t ms = c->stream;
+        float4 *g0 = c->d_g0, *g1 = c->d_g1;
+        c->stream = c->spec_stream; c->d_g0 = c->d_gset[o][1]; c->d_g1 = c->d_gset[o][2];
+        rc = launch_generate(c, frame + 1, c->spare, c->fY, c->opt.use_temporal_resampling != 0);
+        c->stream = ms; c->d_g0 = g0; c->d_g1 = g1;
+        if (rc == RT_OK)
+        {
+            c->spec_gen_valid = true;
+            c->spec_gen_frame = frame + 1;
+            c->spec_gen_hist = c->fY;
+            c->spec_res_epoch = c->res_epoch;
+        }
+    }
+    c->sub0 = s0; c->sub1 = s1; c->subb0 = b0; c->subb1 = b1;
+    if (rc != RT_OK) return rc;
     RT_HIP(c, hipEventRecord(c->ev_spec_done, c->spec_stream));
     c->spec_valid = true;
     c->spec_epoch = c->epoch;
     return RT_OK;
 }
 /* stage 0's raycast over all owned rows: the G-buffer traced beside the previous frame if it is still the right one */
-static int raycast_or_take(rt_ctx* c, bool whole)
+static int raycast_or_take(rt_ctx* c, bool whole, int frame)
 {
     c->timed_spec_set = -1;
+    c->gen_taken = false;
     if (whole && use_next_raycast(c) && c->spec_valid && c->spec_epoch == c->epoch)
     {
         c->gcur ^= 1;
         c->d_vis = c->d_gset[c->gcur][0]; c->d_g0 = c->d_gset[c->gcur][1]; c->d_g1 = c->d_gset[c->gcur][2];
         RT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_spec_done, 0));
+        if (c->spec_gen_valid && use_next_generate(c) && c->spec_gen_frame == frame && c->spec_res_epoch == c->res_epoch &&
+            c->spec_gen_hist == c->fX)
+        {
+            /* this frame's candidates are in the spare buffer already: it becomes Y, the buffer Y would have been is the
+             * new spare (stage 0's generate is skipped; rt_frame_stage_output / _end see the swapped role) */
+            const int old = c->fY;
+            c->fY = c->spare; c->spare = old;
+            c->f_in = c->fY;
+            c->gen_taken = true;
+        }
+        c->spec_gen_valid = false;
         c->spec_valid = false;
         c->has_gbuffer = true;
         c->shaded_bits_stale = true;
@@ -1106,6 +1205,7 @@ static int raycast_or_take(rt_ctx* c, bool whole)
         return RT_OK;
     }
     c->spec_valid = false;
+    c->spec_gen_valid = false;
     return rt_raycast(c);
 }
 
@@ -1166,8 +1266,10 @@ static int launch_generate(rt_ctx* c, int frame, int dst_phys, int prev_phys, bo
 int rt_generate_candidate(rt_ctx* c, int frame, int dst)
 {
     RT_CHECK_CTX(c);
+    JOIN_TAIL(c);
     NEED_SCENE(c);
     NEED_RES(c, dst);
+    ++c->res_epoch; /* a reservoir buffer changes outside the staged frame: a pipelined stage 0 is stale */
     if (!c->has_gbuffer) RT_FAIL(c, RT_ERR_STATE, "no G-buffer: call rt_raycast or upload RT_BUF_VISIBILITY first");
     return launch_generate(c, frame, c->res_map[dst], 0, false);
 }
@@ -1175,9 +1277,11 @@ int rt_generate_candidate(rt_ctx* c, int frame, int dst)
 int rt_temporal_resampling(rt_ctx* c, int frame, int prev, int inout)
 {
     RT_CHECK_CTX(c);
+    JOIN_TAIL(c);
     NEED_SCENE(c);
     NEED_RES(c, prev);
     NEED_RES(c, inout);
+    ++c->res_epoch; /* a reservoir buffer changes outside the staged frame: a pipelined stage 0 is stale */
     if (prev == inout) RT_FAIL(c, RT_ERR_ARG, "prev and inout must differ");
     const SceneView S = make_scene(c);
     const FrameParams P = make_params(c, frame, 0);
@@ -1194,8 +1298,10 @@ int rt_temporal_resampling(rt_ctx* c, int frame, int prev, int inout)
 int rt_save_temporal_reservoir(rt_ctx* c, int src, int dst)
 {
     RT_CHECK_CTX(c);
+    JOIN_TAIL(c);
     NEED_RES(c, src);
     NEED_RES(c, dst);
+    ++c->res_epoch; /* a reservoir buffer changes outside the staged frame: a pipelined stage 0 is stale */
     if (src == dst) return RT_OK;
     const size_t off = (size_t)(c->row_begin - c->lrow0) * c->W;
     const size_t n = (size_t)(c->row_end - c->row_begin) * c->W;
@@ -1276,9 +1382,11 @@ static int launch_spatial(rt_ctx* c, int frame, int pass, int in_phys, int out_p
 int rt_spatial_resampling(rt_ctx* c, int frame, int pass, int in, int out)
 {
     RT_CHECK_CTX(c);
+    JOIN_TAIL(c);
     NEED_SCENE(c);
     NEED_RES(c, in);
     NEED_RES(c, out);
+    ++c->res_epoch; /* a reservoir buffer changes outside the staged frame: a pipelined stage 0 is stale */
     if (in == out) RT_FAIL(c, RT_ERR_ARG, "in and out must differ");
     c->last_frame = frame;
     return launch_spatial(c, frame, pass, c->res_map[in], c->res_map[out]);
@@ -1302,23 +1410,30 @@ static int launch_resolve(rt_ctx* c, int phys)
 int rt_resolve(rt_ctx* c, int res)
 {
     RT_CHECK_CTX(c);
+    JOIN_TAIL(c);
     NEED_SCENE(c);
     NEED_RES(c, res);
     return launch_resolve(c, c->res_map[res]);
 }
 
-int rt_tone_mapping(rt_ctx* c)
+static int launch_tone_mapping(rt_ctx* c)
 {
-    RT_CHECK_CTX(c);
     k_tone_mapping<<<launch_grid(c), BLOCK, 0, c->stream>>>(make_params(c, 0, 0), c->d_accum, c->d_pixels);
     RT_HIP(c, hipGetLastError());
     return RT_OK;
+}
+int rt_tone_mapping(rt_ctx* c)
+{
+    RT_CHECK_CTX(c);
+    JOIN_TAIL(c);
+    return launch_tone_mapping(c);
 }
 
 /* `path_trace` of examples/07_pt/07_pt.cu (example 7), examples/08_nee/08_nee.cu (8) or examples/09_ris/09_ris.cu (9) */
 int rt_path_trace(rt_ctx* c, int example, int frame)
 {
     RT_CHECK_CTX(c);
+    JOIN_TAIL(c);
     NEED_SCENE(c);
     if (example != 7 && example != 8 && example != 9) RT_FAIL(c, RT_ERR_ARG, "example must be 7 (07_pt), 8 (08_nee) or 9 (09_ris)");
     if (example != 7 && c->n_lights == 0) RT_FAIL(c, RT_ERR_STATE, "08_nee / 09_ris need at least one emissive triangle");
@@ -1415,6 +1530,8 @@ int rt_frame_stage_begin(rt_ctx* c, int frame, int stage, int clear_first)
         c->f_in = c->fY; c->f_out = c->fZ;
         c->f_clear = clear_first != 0;
         c->f_stage = 0;
+        c->gen_taken = false;
+        c->f_frame = frame;
         return RT_OK;
     }
     if (stage != c->f_stage) RT_FAIL(c, RT_ERR_STATE, "rt_frame_stage: expected stage %d, got %d", c->f_stage, stage);
@@ -1479,16 +1596,21 @@ static int stage_run_ranges(rt_ctx* c, int frame, int stage, int part, int row0,
         mark(0);
         if (part != 2 && c->f_clear) rc = rt_clear(c);
         mark(1);
-        if (part != 2 && rc == RT_OK) rc = raycast_or_take(c, row0 == c->row_begin && row1 == c->row_end && rowb0 >= rowb1);
+        if (part != 2 && rc == RT_OK) rc = raycast_or_take(c, row0 == c->row_begin && row1 == c->row_end && rowb0 >= rowb1, frame);
         if (part != 2 && rc == RT_OK && row0 == c->row_begin && row1 == c->row_end) rc = refresh_shaded_bits(c);
         mark(2);
-        if (part != 1 && rc == RT_OK) rc = launch_generate(c, frame, c->fY, c->fX, c->opt.use_temporal_resampling != 0);
+        if (part != 1 && rc == RT_OK && !c->gen_taken)
+        {
+            rc = join_tail(c); /* this frame's candidates may go where the previous frame's resolve still reads */
+            if (rc == RT_OK) rc = launch_generate(c, frame, c->fY, c->fX, c->opt.use_temporal_resampling != 0);
+        }
         mark(3);
     }
     else if (stage <= passes)
     {
         const int k = stage - 1;
-        rc = launch_spatial(c, frame, k, c->f_in, c->f_out);
+        rc = join_tail(c); /* the pass's output buffer can be the one the previous frame's resolve reads */
+        if (rc == RT_OK) rc = launch_spatial(c, frame, k, c->f_in, c->f_out);
         if (k < 3) mark(4 + k);
     }
     else
@@ -1500,10 +1622,36 @@ static int stage_run_ranges(rt_ctx* c, int frame, int stage, int part, int row0,
          * (rt_frame_stage_end keeps the logical names on the reference's buffers), so the result is the
          * reference's, stale data included. */
         const int final_phys = passes > 0 ? c->f_out : c->fZ;
-        rc = launch_resolve(c, final_phys);
+        const bool tail = whole && use_tail(c);
+        hipStream_t ms = c->stream;
+        if (tail)
+        {
+            /* resolve + tone_mapping on the tail stream, behind everything enqueued so far (and behind the previous
+             * frame's tail: same stream); the main stream does not wait for them */
+            if (!c->tail_stream)
+            {
+                RT_HIP(c, hipStreamCreateWithFlags(&c->tail_stream, hipStreamNonBlocking));
+                RT_HIP(c, hipEventCreateWithFlags(&c->ev_tail_go, hipEventDisableTiming));
+                RT_HIP(c, hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
+            }
+            RT_HIP(c, hipEventRecord(c->ev_tail_go, ms));
+            RT_HIP(c, hipStreamWaitEvent(c->tail_stream, c->ev_tail_go, 0));
+            c->stream = c->tail_stream;
+        }
+        else rc = join_tail(c);
+        if (rc == RT_OK) rc = launch_resolve(c, final_phys);
         mark(7);
-        if (rc == RT_OK) rc = rt_tone_mapping(c);
+        if (rc == RT_OK) rc = launch_tone_mapping(c);
         mark(8);
+        if (tail)
+        {
+            c->stream = ms;
+            if (rc == RT_OK)
+            {
+                RT_HIP(c, hipEventRecord(c->ev_tail, c->tail_stream));
+                c->tail_pending_main = true; c->tail_pending_spec = true;
+            }
+        }
     }
     c->sub0 = c->sub1 = -1;
     c->subb0 = c->subb1 = 0;
@@ -1556,7 +1704,7 @@ int rt_frame_stage_end(rt_ctx* c, int stage)
         c->aux_used = false;
     }
     const int passes = c->opt.spatial_resampling_passes;
-    if (stage == 0) { const int rc = launch_next_raycast(c); if (rc != RT_OK) return rc; }
+    if (stage == 0) { const int rc = launch_next_raycast(c, c->f_frame); if (rc != RT_OK) return rc; }
     if (stage <= passes) { c->f_stage = stage + 1; return RT_OK; }
     const int X = c->fX, Y = c->fY, Z = c->fZ;
     if (passes < 2)
@@ -1564,6 +1712,7 @@ int rt_frame_stage_end(rt_ctx* c, int stage)
         /* logical RT_RES_0 still equals the post-temporal reservoirs: materialise the copy the
          * reference's save_temporal_reservoir makes (10_restir_di.cpp:314-321) */
         const size_t n = local_pixels(c);
+        JOIN_TAIL(c);
         RT_HIP(c, hipMemcpyAsync(c->d_rec[X], c->d_rec[Y], n * 64, hipMemcpyDeviceToDevice, c->stream));
         RT_HIP(c, hipMemcpyAsync(c->d_rad[X], c->d_rad[Y], n * 16, hipMemcpyDeviceToDevice, c->stream));
     }
@@ -1656,6 +1805,7 @@ int rt_local_rows(rt_ctx* c, int* first_row, int* n_rows)
 int rt_download(rt_ctx* c, int buf, void* dst, size_t bytes)
 {
     RT_CHECK_CTX(c);
+    JOIN_TAIL(c);
     if (!dst) RT_FAIL(c, RT_ERR_ARG, "null dst");
     const size_t n = local_pixels(c);
     switch (buf)
@@ -1694,6 +1844,7 @@ int rt_download(rt_ctx* c, int buf, void* dst, size_t bytes)
 int rt_upload(rt_ctx* c, int buf, const void* src, size_t bytes)
 {
     RT_CHECK_CTX(c);
+    JOIN_TAIL(c);
     if (!src) RT_FAIL(c, RT_ERR_ARG, "null src");
     const size_t n = local_pixels(c);
     switch (buf)
@@ -1722,6 +1873,7 @@ int rt_upload(rt_ctx* c, int buf, const void* src, size_t bytes)
         {
             if (bytes != n * 76) RT_FAIL(c, RT_ERR_ARG, "size mismatch: want %zu", n * 76);
             if (!c->has_gbuffer) RT_FAIL(c, RT_ERR_STATE, "upload RT_BUF_VISIBILITY (or rt_raycast) before reservoirs");
+            ++c->res_epoch;
             const int phys = c->res_map[buf - RT_BUF_RES_0];
             /* the record keeps M in 30 bits: refuse what it cannot hold rather than truncate */
             for (size_t i = 0; i < n; ++i)
@@ -1754,13 +1906,14 @@ static int halo_range(rt_ctx* c, int row0, int n_rows)
  * rt_frame_stage_input reported */
 static int halo_phys(rt_ctx* c, int res)
 {
-    if (res >= RT_RES_PHYS && res < RT_RES_PHYS + 3) return res - RT_RES_PHYS;
+    if (res >= RT_RES_PHYS && res < RT_RES_PHYS + 4 && c->d_rec[res - RT_RES_PHYS]) return res - RT_RES_PHYS;
     if (res >= 0 && res <= 2) return c->res_map[res];
     return -1;
 }
 int rt_halo_pack(rt_ctx* c, int res, int row0, int n_rows, void* device_dst)
 {
     RT_CHECK_CTX(c);
+    JOIN_TAIL(c);
     const int phys = halo_phys(c, res);
     if (phys < 0) RT_FAIL(c, RT_ERR_ARG, "bad reservoir buffer id %d", res);
     int rc = halo_range(c, row0, n_rows);
@@ -1773,6 +1926,7 @@ int rt_halo_pack(rt_ctx* c, int res, int row0, int n_rows, void* device_dst)
 int rt_halo_unpack(rt_ctx* c, int res, int row0, int n_rows, const void* device_src)
 {
     RT_CHECK_CTX(c);
+    JOIN_TAIL(c);
     const int phys = halo_phys(c, res);
     if (phys < 0) RT_FAIL(c, RT_ERR_ARG, "bad reservoir buffer id %d", res);
     int rc = halo_range(c, row0, n_rows);
@@ -2196,7 +2350,8 @@ int rt_tuning(rt_ctx* c, int key, int value)
     else if (key == 13 && value >= -1 && value <= 1) c->tune_ws = value;
     else if (key == 15 && (value == 0 || value == 1)) c->tune_stream = value;
     else if (key == 16 && (value == 0 || value == 1)) c->tune_ws_primary = value;
-    else if (key == 14 && value >= -1 && value <= 1) { c->tune_spec = value; if (!use_next_raycast(c)) c->spec_valid = false; }
+    else if (key == 14 && value >= -1 && value <= 2) { c->tune_spec = value; if (!use_next_raycast(c)) c->spec_valid = false; if (!use_next_generate(c)) c->spec_gen_valid = false; }
+    else if (key == 17 && value >= -1 && value <= 1) c->tune_tail = value;
     else RT_FAIL(c, RT_ERR_ARG, "bad tuning key/value %d/%d", key, value);
     return RT_OK;
 }
@@ -2220,6 +2375,7 @@ int rt_tuning_get(rt_ctx* c, int key, int* value)
         case 14: *value = c->tune_spec; break;
         case 15: *value = c->tune_stream; break;
         case 16: *value = c->tune_ws_primary; break;
+        case 17: *value = c->tune_tail; break;
         default: RT_FAIL(c, RT_ERR_ARG, "bad tuning key %d", key);
     }
     return RT_OK;

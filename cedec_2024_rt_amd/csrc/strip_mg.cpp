@@ -139,6 +139,13 @@ struct LocalHub
 
 struct rt_mg
 {
+    /* Halo plans live in three slots (slot = frame mod 3): while frame f runs with plan f, plan f+1 (marked during frame
+     * f-1) rides on frame f's first halo message, and plan f+2 is being marked on the prep stream. Marking two frames
+     * ahead (r03) takes the mark kernel off the critical path: since the next frame's stage 0 runs beside this frame's
+     * passes (rt_tuning key 14), a frame starts with its first exchange, and a plan marked in the same frame would have
+     * to be waited for right there. */
+    static constexpr int NSLOT = 3;
+    static int slot_of(long long frame) { return (int)(((frame % NSLOT) + NSLOT) % NSLOT); }
     rt_ctx* ctx = nullptr;
     int rank = 0, world = 1, W = 0, H = 0, halo = 0, a = 0, b = 0;
     std::vector<int> bounds;
@@ -152,36 +159,39 @@ struct rt_mg
         int peer = -1, side = 0;
         int send_row0 = 0, recv_row0 = 0, n_rows = 0;
         size_t bm_words = 0;                                /* rt_halo_bitmap_words(n_rows): count, bits, prefix */
-        uint32_t* need_bm[2] = {nullptr, nullptr};          /* [plan slot] passes x bm_words: what I gather from the peer */
-        uint32_t* give_bm[2] = {nullptr, nullptr};          /* what the peer gathers from me */
-        uint32_t* cnt_h[2] = {nullptr, nullptr};            /* pinned host, [slot][0..P) need counts, [P..2P) give counts */
+        uint32_t* need_bm[NSLOT] = {nullptr, nullptr, nullptr}; /* [plan slot] passes x bm_words: what I gather from the peer */
+        uint32_t* give_bm[NSLOT] = {nullptr, nullptr, nullptr}; /* what the peer gathers from me */
+        uint32_t* cnt_h[NSLOT] = {nullptr, nullptr, nullptr};   /* pinned host, [slot][0..P) need counts, [P..2P) give counts */
         char* send_buf[2] = {nullptr, nullptr};             /* sparse record lists, by exchange parity */
         char* recv_buf = nullptr;
         uint8_t *flags_send = nullptr, *flags_recv = nullptr;
-        std::shared_ptr<LocalMsg> last_send[2], last_bm[2], last_flags; /* LOCAL: who may still be reading a buffer */
+        std::shared_ptr<LocalMsg> last_send[2], last_bm[NSLOT], last_flags; /* LOCAL: who may still be reading a buffer */
     };
     std::vector<Side> sides;
     /* one arena per plan slot: [need side A][need side B][give side A][give side B], each max_passes bitmaps of
      * bm_stride words, so that one memset clears the needs, one launch marks them and ONE strided copy brings every
      * count (word 0 of each bitmap) to cnt_all; Side::need_bm / give_bm / cnt_h point into these */
-    uint32_t* bm_arena[2] = {nullptr, nullptr};
-    uint32_t* cnt_all[2] = {nullptr, nullptr}; /* pinned host: [need A][need B][give A][give B] x max_passes */
+    uint32_t* bm_arena[NSLOT] = {nullptr, nullptr, nullptr};
+    uint32_t* cnt_all[NSLOT] = {nullptr, nullptr, nullptr}; /* pinned host: [need A][need B][give A][give B] x max_passes */
     size_t bm_stride = 0;
     int bnd[2][2] = {{0, 0}, {0, 0}}, n_bnd = 0;   /* boundary row ranges (needed by a neighbour), computed first */
     int itr[2][2] = {{0, 0}, {0, 0}}, n_itr = 0;   /* interior row ranges, computed while halos travel */
 
     hipStream_t comm = nullptr, prep = nullptr; /* prep: the next frame's halo marks, beside this frame's passes */
-    hipEvent_t ev_packed = nullptr, ev_arrived = nullptr, ev_arrived2 = nullptr, ev_plan[2] = {nullptr, nullptr}, ev_gbuf = nullptr, ev_marked = nullptr, ev_carried = nullptr;
+    hipEvent_t ev_packed = nullptr, ev_arrived = nullptr, ev_arrived2 = nullptr, ev_plan[NSLOT] = {nullptr, nullptr, nullptr}, ev_gbuf = nullptr,
+               ev_marked[NSLOT] = {nullptr, nullptr, nullptr}, ev_carried = nullptr;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr; /* GPU-side clock of the frame loop: start of the first / latest frame since rt_mg_reset_stats */
     unsigned long long frames_timed = 0;
     ncclComm_t nccl = nullptr;
     LocalHub* hub = nullptr;
     ShmSegment shm;
 
-    /* cached halo plans, slot = frame & 1 */
+    /* cached halo plans, slot = frame mod 3: marked_* = need-bitmaps marked on the device (event ev_marked), plan_* =
+     * bitmaps exchanged and counts on their way to the host (event ev_plan) */
     int plan_passes = 0, max_passes = 0;
-    long long plan_frame[2] = {-1, -1};
-    uint64_t plan_epoch[2] = {0, 0}, flags_epoch = 0;
+    long long plan_frame[NSLOT] = {-1, -1, -1}, marked_frame[NSLOT] = {-1, -1, -1};
+    uint64_t plan_epoch[NSLOT] = {0, 0, 0}, marked_epoch[NSLOT] = {0, 0, 0}, flags_epoch = 0;
+    int marked_passes[NSLOT] = {0, 0, 0};
 
     /* frame state machine (rt_mg_frame_begin / _step) */
     enum Seg { SEG_IDLE, SEG_RAYCAST, SEG_COLD_FLAGS, SEG_COLD_MARK, SEG_COLD_BITMAPS, SEG_GENERATE, SEG_PASS, SEG_FINAL };
@@ -350,7 +360,7 @@ static int alloc_sides(rt_mg* m)
     for (auto& s : m->sides)
         if (s.bm_words != m->bm_stride) MG_FAIL(m, RT_ERR_STATE, "halo regions of different heights on the two sides");
     const size_t per = m->bm_stride * (size_t)m->max_passes; /* words of one side's need (or give) bitmaps */
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < rt_mg::NSLOT; ++k)
     {
         MG_HIP(m, hipMalloc(&m->bm_arena[k], per * 2 * ns * 4));
         MG_HIP(m, hipMemset(m->bm_arena[k], 0, per * 2 * ns * 4));
@@ -361,13 +371,13 @@ static int alloc_sides(rt_mg* m)
     {
         auto& s = m->sides[i];
         const size_t list_bytes = rt_halo_bytes(m->ctx, s.n_rows) + 256;
-        for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < rt_mg::NSLOT; ++k)
         {
             s.need_bm[k] = m->bm_arena[k] + per * i;
             s.give_bm[k] = m->bm_arena[k] + per * (ns + i);
             s.cnt_h[k] = m->cnt_all[k] + (size_t)m->max_passes * i; /* give counts: + max_passes * ns */
-            MG_HIP(m, hipMalloc(&s.send_buf[k], list_bytes));
         }
+        for (int k = 0; k < 2; ++k) MG_HIP(m, hipMalloc(&s.send_buf[k], list_bytes));
         MG_HIP(m, hipMalloc(&s.recv_buf, list_bytes));
         MG_HIP(m, hipMalloc(&s.flags_send, rt_halo_flags_bytes(m->ctx, s.n_rows) + 16));
         MG_HIP(m, hipMalloc(&s.flags_recv, rt_halo_flags_bytes(m->ctx, s.n_rows) + 16));
@@ -487,7 +497,7 @@ int rt_mg_create(rt_ctx* ctx, int rank, int world, const int* bounds, int transp
     MG_HIP(m, hipStreamCreateWithFlags(&m->comm, hipStreamNonBlocking));
     MG_HIP(m, hipStreamCreateWithFlags(&m->prep, hipStreamNonBlocking));
     MG_HIP(m, hipEventCreateWithFlags(&m->ev_gbuf, hipEventDisableTiming));
-    MG_HIP(m, hipEventCreateWithFlags(&m->ev_marked, hipEventDisableTiming));
+    for (auto& e : m->ev_marked) MG_HIP(m, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     MG_HIP(m, hipEventCreateWithFlags(&m->ev_packed, hipEventDisableTiming));
     MG_HIP(m, hipEventCreateWithFlags(&m->ev_arrived, hipEventDisableTiming));
     MG_HIP(m, hipEventCreateWithFlags(&m->ev_arrived2, hipEventDisableTiming));
@@ -562,15 +572,12 @@ int rt_mg_destroy(rt_mg* m)
     m->pending_local.clear();
     for (auto& s : m->sides)
     {
-        for (int k = 0; k < 2; ++k)
-        {
-            hipFree(s.send_buf[k]);
-            s.last_send[k].reset(); s.last_bm[k].reset();
-        }
+        for (int k = 0; k < 2; ++k) { hipFree(s.send_buf[k]); s.last_send[k].reset(); }
+        for (auto& l : s.last_bm) l.reset();
         s.last_flags.reset();
         hipFree(s.recv_buf); hipFree(s.flags_send); hipFree(s.flags_recv);
     }
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < rt_mg::NSLOT; ++k)
     {
         hipFree(m->bm_arena[k]);
         if (m->cnt_all[k]) hipHostFree(m->cnt_all[k]);
@@ -586,7 +593,7 @@ int rt_mg_destroy(rt_mg* m)
     if (m->ev_arrived2) hipEventDestroy(m->ev_arrived2);
     for (auto& e : m->ev_plan) if (e) hipEventDestroy(e);
     if (m->ev_gbuf) hipEventDestroy(m->ev_gbuf);
-    if (m->ev_marked) hipEventDestroy(m->ev_marked);
+    for (auto& e : m->ev_marked) if (e) hipEventDestroy(e);
     if (m->ev_carried) hipEventDestroy(m->ev_carried);
     if (m->ev_t0) hipEventDestroy(m->ev_t0);
     if (m->ev_t1) hipEventDestroy(m->ev_t1);
@@ -811,7 +818,7 @@ static int run_rows(rt_mg* m, int stage, int part, const int (*ranges)[2], int n
 static int post_halo(rt_mg* m, int stage, int buf, bool with_plan)
 {
     hipStream_t ms = main_stream(m);
-    const int slot = m->frame & 1, nslot = slot ^ 1, k = stage;
+    const int slot = rt_mg::slot_of(m->frame), nslot = rt_mg::slot_of((long long)m->frame + 1), k = stage;
     std::vector<Exchange> xs(m->sides.size());
     if (m->use_sparse)
     {
@@ -869,7 +876,7 @@ static int finish_halo(rt_mg* m)
     const bool carried = m->pending_carries_plan;
     int rc = complete(m);
     if (rc != RT_OK) return rc;
-    const int slot = m->frame & 1, nslot = slot ^ 1, k = m->pending_k;
+    const int slot = rt_mg::slot_of(m->frame), nslot = rt_mg::slot_of((long long)m->frame + 1), k = m->pending_k;
     if (m->use_sparse)
     {
         int row0[2], nrows[2];
@@ -918,7 +925,7 @@ int rt_mg_frame_begin(rt_mg* m, int frame, int clear_first)
     {
         uint64_t epoch = 0;
         rt_state_epoch(m->ctx, &epoch);
-        const int slot = frame & 1;
+        const int slot = rt_mg::slot_of(frame);
         if (m->plan_frame[slot] == (long long)frame && m->plan_epoch[slot] == epoch && m->plan_passes == m->passes)
         {
             /* recorded in the middle of the previous frame: in a steady loop this returns at once */
@@ -950,7 +957,7 @@ int rt_mg_frame_step(rt_mg* m, int* more)
 static int frame_step(rt_mg* m, int* more)
 {
     hipStream_t ms = main_stream(m);
-    const int slot = m->frame & 1, nslot = slot ^ 1, P = m->passes;
+    const int slot = rt_mg::slot_of(m->frame), nslot = rt_mg::slot_of((long long)m->frame + 1), P = m->passes;
     const bool exchanges = !m->sides.empty() && P > 0;
     const int all[1][2] = {{m->a, m->b}};
     *more = 1;
@@ -1000,6 +1007,8 @@ static int frame_step(rt_mg* m, int* more)
              * frame carried for this slot may still be on its way to the host on the prep stream (counts copy into
              * cnt_all[slot], reading bm_arena[slot]): the main stream waits for it before it re-marks the slot. */
             MG_HIP(m, hipStreamWaitEvent(ms, m->ev_plan[slot], 0));
+            MG_HIP(m, hipStreamWaitEvent(ms, m->ev_marked[slot], 0)); /* a stale mark of this slot (other epoch) on the prep stream */
+            m->marked_frame[slot] = -1;
             rc = mark_plan(m, m->frame, slot, ms);
             if (rc != RT_OK) return rc;
             std::vector<Exchange> xs(m->sides.size());
@@ -1039,16 +1048,26 @@ static int frame_step(rt_mg* m, int* more)
             }
             if (m->use_sparse)
             {
-                /* The plan of the NEXT frame (valid if the camera stays): marked on a stream of its own behind
-                 * this frame's raycast, so that its bitmaps can ride on the FIRST halo message and its counts
-                 * reach the host while most of this frame is still to run. */
+                /* Plans of the frames to come (valid while the camera stays), marked on a stream of their own from this
+                 * frame's G-buffer: frame + 2 in every frame; frame + 1 too if the previous frame did not mark it (a cold
+                 * frame: then the first exchange below waits for that mark, once). */
+                uint64_t epoch = 0;
+                rt_state_epoch(m->ctx, &epoch);
                 MG_HIP(m, hipEventRecord(m->ev_gbuf, ms));
                 MG_HIP(m, hipStreamWaitEvent(m->prep, m->ev_gbuf, 0));
                 MG_RT(m, rt_set_stream(m->ctx, m->prep));
-                rc = mark_plan(m, m->frame + 1, nslot, m->prep);
+                for (int ahead = 1; ahead <= 2 && rc == RT_OK; ++ahead)
+                {
+                    const long long tf = (long long)m->frame + ahead;
+                    const int ts = rt_mg::slot_of(tf);
+                    if (ahead == 1 && m->marked_frame[ts] == tf && m->marked_epoch[ts] == epoch && m->marked_passes[ts] == P) continue;
+                    rc = mark_plan(m, (int)tf, ts, m->prep);
+                    if (rc != RT_OK) break;
+                    if (hipEventRecord(m->ev_marked[ts], m->prep) != hipSuccess) { rc = RT_ERR_HIP; m->err = "hipEventRecord(ev_marked) failed"; break; }
+                    m->marked_frame[ts] = tf; m->marked_epoch[ts] = epoch; m->marked_passes[ts] = P;
+                }
                 rt_set_stream(m->ctx, ms);
                 if (rc != RT_OK) return rc;
-                MG_HIP(m, hipEventRecord(m->ev_marked, m->prep));
             }
             if (exchanges)
             {
@@ -1063,7 +1082,7 @@ static int frame_step(rt_mg* m, int* more)
                 const bool carry = m->use_sparse;
                 int buf = 0;
                 MG_RT(m, rt_frame_stage_output(m->ctx, 0, &buf));
-                if (carry) MG_HIP(m, hipStreamWaitEvent(ms, m->ev_marked, 0));
+                if (carry) MG_HIP(m, hipStreamWaitEvent(ms, m->ev_marked[nslot], 0)); /* marked during the previous frame: long done */
                 rc = post_halo(m, 0, RT_RES_PHYS + buf, carry);
                 if (rc != RT_OK) return rc;
                 MG_RT(m, rt_frame_stage_end(m->ctx, 0));

@@ -344,12 +344,17 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
  * key 13: shadow rays of generate_candidate / resolve walked with the work-sharing any-hit traversal (idle lanes of a
  * wavefront take over half of a busy lane's LDS stack): -1 (default) = for launches of at most ~one round of
  * wavefronts (strips of the multi-GPU frame), 0 = never, 1 (default) = always. Same results.
- * key 14: rt_frame / rt_frame_stage trace the NEXT frame's primary rays on a stream of their own behind stage 0 of the
- * current frame (they depend on the camera only), into a second G-buffer set, beside the spatial passes and the halo
- * exchanges; the next frame uses them if camera, scene and options are still the same (rt_state_epoch) and traces its
- * own otherwise. 1 = always, 0 = never (every frame traces its primary rays first), -1 (default) = strip contexts only
- * (-6 % per frame at 1080p in 8 strips; < 1 % on a whole 1080p frame, where it only blurs the per-kernel times).
- * rt_sync waits for that launch too; rt_timing reports its duration as ms[1] although it is not part of ms[8]. Same results.
+ * key 14: rt_frame / rt_frame_stage run the NEXT frame's stage 0 on a stream of its own behind stage 0 of the current frame,
+ * beside the spatial passes, the halo exchanges and resolve. 1 = its primary rays (they depend on the camera only), into a
+ * second G-buffer set; 2 (r03) = its generate_candidate + temporal_resampling as well, into a fourth reservoir buffer: the
+ * reference saves the temporal history right after temporal_resampling, before the spatial passes (10_restir_di.cpp:314-321),
+ * so frame f+1's candidates depend on frame f only through a buffer that is final when frame f's stage 0 ends. The next frame
+ * takes the results if it is the next frame number and camera, scene, options (rt_state_epoch) and the reservoir buffers
+ * (uploads, per-kernel calls) are unchanged, and runs its own stage 0 otherwise. 0 = never; -1 (default) = strip contexts
+ * only, level 2 (a strip's frame is a chain of small launches: 1080p in 8 strips 0.51 -> ms per frame see DESIGN.md section 7;
+ * a whole 1080p frame keeps its kernels back to back, which keeps the per-kernel times of rt_timing meaningful; with
+ * rt_timing_enabled level 2 behaves as level 1). rt_sync waits for that stream too; every frame's launches run exactly
+ * once per frame in a steady loop. Same results.
  * key 15: 1 = resolve as a STREAM: persistent wavefronts keep pulling pixels, a lane whose shadow ray is settled shades
  * its pixel and fetches the next one while the other lanes keep walking (csrc/bvh.h occluded_stream). Evaluated and
  * left off (default 0): same instruction count as the work-sharing kernel but 0.48 against 0.36 ms — a wavefront
@@ -358,7 +363,12 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
  * key 16: 1 = primary rays with the work-sharing CLOSEST-hit walk (csrc/bvh.h closest_ws: pieces of a ray walked by
  * several lanes, merged by a 64-bit LDS min on (t, index)). Evaluated and left off (default 0): raycast 0.311 -> 0.318 ms
  * at 1080p, 0.997 -> 1.029 at 4K — primary rays of an 8x8 tile are coherent (31.8 passes per wavefront for 23.1 steps
- * per ray) and the walk needs 88 registers instead of 70. Same results. */
+ * per ray) and the walk needs 88 registers instead of 70. Same results.
+ * key 17 (r03): resolve + tone_mapping of a staged frame on a stream of their own ("tail"): they read only the frame's final
+ * reservoirs and G-buffer, so the main stream goes on with the next frame's first halo exchange meanwhile; whatever could
+ * overwrite what they read (the next frame's first spatial pass, the pipelined stage 0 after next, any call outside the
+ * staged frame, downloads) waits for them. -1 (default) = strip contexts only, 0 = never, 1 = always. Off while
+ * rt_timing is enabled. Same results. */
 int rt_tuning(rt_ctx* ctx, int key, int value);
 /* the value a key holds now (measurement records name the builder / variants that were really used) */
 int rt_tuning_get(rt_ctx* ctx, int key, int* value);

@@ -884,26 +884,44 @@ def test_next_frame_raycast_overlap_is_bit_identical(api, scenes):
     tris = scenes.make_quad_room()
     W, H = 320, 180
     rs = []
-    for spec in (0, 1):
+    # key 14 = 2 (r03): the next frame's generate_candidate + temporal_resampling too (pipelined stage 0);
+    # key 17 = 1 (r03): resolve + tone_mapping on their own stream, the next frame does not wait for them
+    for spec, tail in ((0, 0), (1, 0), (2, 0), (2, 1), (0, 1)):
         r = api.Renderer(W, H)
         r.set_scene(tris)
         r.lookat((0.5, 2.5, 6.0), (0.0, 1.5, -1.0))
         r.set_options(bench_options())
         r.tuning(14, spec)
+        r.tuning(17, tail)
         rs.append(r)
     frame = 0
-    for step in ("still", "still", "orbit", "still", "options", "still", "kernels", "still", "still"):
-        frame += 1
+    steps = ("still", "still", "orbit", "still", "options", "still", "kernels", "still", "still", "upload", "still", "jump", "still",
+             "temporal_off", "still", "shadowed", "still", "still", "accumulate", "still", "still", "orbit", "still")
+    for step in steps:
+        frame += 3 if step == "jump" else 1  # a frame number the pipelined stage 0 was not made for
+        saved = rs[0].download(api.RT_BUF_RES_TEMPORAL) if step == "upload" else None
         for r in rs:
             if step == "orbit":
                 r.orbit(37.0, -11.0)
             if step == "options":
                 r.set_options(bench_options(spatial_resampling_passes=2))
-            if step == "kernels":  # the per-kernel API between two frames: its raycast writes the current G-buffer
-                r.raycast()
+            if step == "temporal_off":
+                r.set_options(bench_options(use_temporal_resampling=0))
+            if step == "shadowed":
+                r.set_options(bench_options(use_shadowed_target_function=1))
+            if step == "accumulate":
+                r.set_options(bench_options(accumulate=1, spatial_resampling_passes=2))
+            if step == "kernels":  # the per-kernel API between two frames: its raycast writes the current G-buffer,
+                r.raycast()        # its generate_candidate a reservoir buffer the next frame's history could be
+                r.generate_candidate(frame, api.RT_RES_TEMPORAL)
+            if step == "upload":   # fixture injection into the temporal history between two frames
+                h = saved.copy()
+                h["M"] = np.minimum(h["M"], 3)
+                r.upload(api.RT_BUF_RES_TEMPORAL, h)
             r.frame(frame, clear_first=(step in ("orbit", "options")))
         for buf in (api.RT_BUF_VISIBILITY, api.RT_BUF_ACCUMULATION, api.RT_BUF_PIXELS, api.RT_BUF_RES_0, api.RT_BUF_RES_1, api.RT_BUF_RES_TEMPORAL):
-            assert _eq_bits(rs[0].download(buf), rs[1].download(buf)), (frame, step, buf)
+            for other in rs[1:]:
+                assert _eq_bits(rs[0].download(buf), other.download(buf)), (frame, step, buf)
     for r in rs:
         r.close()
 

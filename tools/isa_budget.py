@@ -8,7 +8,7 @@ reads the gfx950 assembly and prints, as Markdown,
     class and their issue cost in SIMD cycles, priced with the per-instruction costs MEASURED on the MI355X
     (profiles/r02_valu_rates.json, tools/valu_rates.hip: wall time per wave64 instruction per SIMD at 8 waves/SIMD).
 
-  python tools/isa_budget.py > profiles/r02_isa_budget.md        (CPU only: hipcc cross-compiles)
+  python tools/isa_budget.py > profiles/r03_isa_budget.md        (CPU only: hipcc cross-compiles)
 
 Classes: F = full rate (v_add/sub/mul/fma/fmac_f32, v_mov, integer add/shift/logic: ~2.5 cycles per wave64
 instruction), C = half rate (min/max/cmp/cndmask/cvt/bfe/perm/alignbit/add3/mul_lo/mad_u64/div_scale/div_fmas/
@@ -69,6 +69,8 @@ def what(op):
         return "PCG (64-bit LCG step, rotate)"
     if op.startswith("v_sqrt"):
         return "sqrt"
+    if op.endswith(("_f64", "_f64_e32", "_f64_e64")) or "_f64_" in op:
+        return "binary64 (sin / cos of rounds 1-2)"
     if op.startswith(("v_cvt_f32_ubyte", "v_cvt_f32_u")):
         return "byte -> float (quantised boxes)"
     if op.startswith(("v_max", "v_min", "v_med3")):
@@ -162,10 +164,10 @@ def summarise(ops):
 
 KERNELS = [("k_raycast", "k_raycast<false>("), ("k_raycast<WS>", "k_raycast<true>("), ("k_generate_candidate<true,false>", "k_generate_candidate<true, false, false, false, false>("),
            ("k_generate_candidate<true,false,WS>", "k_generate_candidate<true, false, false, false, true>("), ("k_resolve<WS>", "k_resolve<true>("), ("k_resolve_stream", "k_resolve_stream("),
-           ("k_spatial_gather", "k_spatial_gather("), ("k_spatial_lds", "k_spatial_lds("), ("k_resolve", "k_resolve<false>("), ("k_spatial<true>", "k_spatial<true>("),
+           ("k_spatial_gather", "k_spatial_gather<6>("), ("k_halo_mark", "k_halo_mark("), ("k_spatial_lds", "k_spatial_lds("), ("k_resolve", "k_resolve<false>("), ("k_spatial<true>", "k_spatial<true>("),
            ("k_temporal<false>", "k_temporal<false>("), ("k_tone_mapping", "k_tone_mapping("),
            ("k_path_trace<9,false>", "k_path_trace<9, false>(")]
-LOOP_KERNELS = {"k_raycast", "k_generate_candidate<true,false>", "k_spatial_gather", "k_resolve"}
+LOOP_KERNELS = {"k_raycast", "k_generate_candidate<true,false>", "k_spatial_gather", "k_halo_mark", "k_resolve", "k_spatial<true>"}
 
 
 def main():
