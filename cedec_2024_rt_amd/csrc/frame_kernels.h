@@ -551,7 +551,7 @@ __global__ __launch_bounds__(BLOCK) void k_temporal(SceneView S, FrameParams P, 
 #endif
 /* one pixel of the pass (x, row already resolved by the caller's tile mapping) */
 template <bool SHADOWED, int TB>
-RT_DEV void spatial_pixel(const SceneView& S, const FrameParams& P, uint32_t* s_stack, int x, int row, const float4* __restrict__ g0,
+RT_DEV void spatial_pixel(const SceneView& S, const FrameParams& P, const HaloFuse& F, uint32_t* s_stack, int x, int row, const float4* __restrict__ g0,
                           const float4* __restrict__ g1, const float4* __restrict__ in_rec, const float4* __restrict__ in_rad,
                           float4* __restrict__ out_rec, float4* __restrict__ out_rad)
 {
@@ -561,7 +561,7 @@ RT_DEV void spatial_pixel(const SceneView& S, const FrameParams& P, uint32_t* s_
     if (!(as_uint(G1.w) & GB_SHADED))
     {
         /* the reference stores nothing here (:275-287); we keep the shaded bit valid */
-        res_store(out_rec, out_rad, li, res_zero(), false);
+        res_store_give(F, P.W, out_rec, out_rad, li, x, row, res_zero(), false);
         return;
     }
     const f3 sp = F3(G0.x, G0.y, G0.z), sn = F3(G1.x, G1.y, G1.z);
@@ -569,7 +569,7 @@ RT_DEV void spatial_pixel(const SceneView& S, const FrameParams& P, uint32_t* s_
 
     bool own_shaded;
     Res r = res_load(in_rec, li, own_shaded);
-    size_t rad_from = li;
+    const float4* rad_from = in_rad + li; /* radiance side record of the selected sample: a buffer entry or a halo list entry */
 
     if (SHADOWED && P.use_spatial && P.spatial_count <= 5)
     {
@@ -582,14 +582,15 @@ RT_DEV void spatial_pixel(const SceneView& S, const FrameParams& P, uint32_t* s_
          * (ucw == 0, or visibility reuse with an occluded sample). Same results, same reference ray
          * count (rt_ray_count counts raytrace() calls of the reference, not walks). */
         const float scale = P.spatial_radius / 1.96f;
-        long long pid[5];
+        const float4* prec[5]; /* the neighbour's record (reservoir buffer or received halo list), nullptr = none */
+        const float4* prad[5];
         float ud[5];
         f3 tgt[6];
         uint32_t need = 0u;
 #pragma unroll
         for (int k = 0; k < 5; ++k)
         {
-            pid[k] = -1; ud[k] = 0.0f; tgt[k] = F3(0.0f, 0.0f, 0.0f);
+            prec[k] = nullptr; prad[k] = nullptr; ud[k] = 0.0f; tgt[k] = F3(0.0f, 0.0f, 0.0f);
             if (k < P.spatial_count)
             {
                 const float rv0 = rng.uniformf();
@@ -606,11 +607,13 @@ RT_DEV void spatial_pixel(const SceneView& S, const FrameParams& P, uint32_t* s_
                 if (ok)
                 {
                     const size_t id = (size_t)nx + (size_t)lr * P.W;
-                    const float4 q0 = in_rec[4 * id + 0], q1 = in_rec[4 * id + 1];
+                    const float4* nrad;
+                    const float4* nq = halo_record(F, P.W, in_rec, in_rad, id, nx, P.H - 1 - ny, nrad);
+                    const float4 q0 = nq[0], q1 = nq[1];
                     const uint32_t mb = as_uint(q1.w);
                     if (mb & RES_SHADED_BIT)
                     {
-                        pid[k] = (long long)id;
+                        prec[k] = nq; prad[k] = nrad;
                         ud[k] = rng.uniformf();
                         tgt[k] = F3(q0.x, q0.y, q0.z);
                         const bool moot = (q0.w == 0.0f) || (P.vis_reuse && !(mb & RES_VIS_BIT));
@@ -626,10 +629,10 @@ RT_DEV void spatial_pixel(const SceneView& S, const FrameParams& P, uint32_t* s_
 #pragma unroll
         for (int k = 0; k < 5; ++k)
         {
-            if (pid[k] >= 0)
+            if (prec[k])
             {
                 bool n_shaded;
-                Res nr = res_load(in_rec, (size_t)pid[k], n_shaded);
+                Res nr = res_load_at(prec[k], n_shaded);
                 /* evaluate_target_function with the shadow term (common/reservoir.hpp:42-59) */
                 const float V = (occl >> k) & 1u ? 0.0f : 1.0f;
                 float p_hat_y = (1.0f / kPI) * geometry_term(sp, sn, nr.hit_p, nr.hit_n) * V * nr.lum;
@@ -641,7 +644,7 @@ RT_DEV void spatial_pixel(const SceneView& S, const FrameParams& P, uint32_t* s_
                 if (ud[k] < weight / r.w_sum)
                 {
                     res_take_sample(r, nr);
-                    rad_from = (size_t)pid[k];
+                    rad_from = prad[k];
                     sel = k;
                 }
             }
@@ -672,7 +675,8 @@ RT_DEV void spatial_pixel(const SceneView& S, const FrameParams& P, uint32_t* s_
             if (lr < 0 || lr >= P.lrows) continue; /* only when halo < 87: outside the contract */
             const size_t pid = (size_t)nx + (size_t)lr * P.W;
             bool n_shaded;
-            Res nr = res_load(in_rec, pid, n_shaded);
+            const float4* nrad;
+            Res nr = res_load_at(halo_record(F, P.W, in_rec, in_rad, pid, nx, nrow, nrad), n_shaded);
             if (!n_shaded) continue; /* sky or emissive neighbour (:326-338) */
 
             float p_hat_y = target_function<SHADOWED, TB>(S, s_stack, sp, sn, nr.hit_p, nr.hit_n, nr.lum);
@@ -685,20 +689,20 @@ RT_DEV void spatial_pixel(const SceneView& S, const FrameParams& P, uint32_t* s_
             if (u < weight / r.w_sum)
             {
                 res_take_sample(r, nr);
-                rad_from = pid;
+                rad_from = nrad;
             }
         }
         const float p_hat = target_function<SHADOWED, TB>(S, s_stack, sp, sn, r.hit_p, r.hit_n, r.lum);
         r.ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
     }
-    const float4 rq = in_rad[rad_from];
+    const float4 rq = *rad_from;
     r.rad = F3(rq.x, rq.y, rq.z);
-    res_store(out_rec, out_rad, li, r, true);
+    res_store_give(F, P.W, out_rec, out_rad, li, x, row, r, true);
 }
 
 /* shadowed target function: a tracing kernel (one-wavefront workgroups, LDS traversal stack) */
 template <bool SHADOWED>
-__global__ __launch_bounds__(TRACE_BLOCK, RT_SHSPATIAL_WAVES) void k_spatial(SceneView S, FrameParams P, const float4* __restrict__ g0,
+__global__ __launch_bounds__(TRACE_BLOCK, RT_SHSPATIAL_WAVES) void k_spatial(SceneView S, FrameParams P, HaloFuse F, const float4* __restrict__ g0,
                                                     const float4* __restrict__ g1, const float4* __restrict__ in_rec,
                                                     const float4* __restrict__ in_rad, float4* __restrict__ out_rec,
                                                     float4* __restrict__ out_rad)
@@ -707,7 +711,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_SHSPATIAL_WAVES) void k_spatial(Sce
     __shared__ __attribute__((aligned(16))) uint32_t s_stack[(RT_BATCH_WS ? WIDE_LDS_ROWS : WIDE_LDS_STACK) * TRACE_BLOCK];
     int x, row;
     if (!tile_pixel<TRACE_BLOCK>(P, x, row)) return;
-    spatial_pixel<true, TRACE_BLOCK>(S, P, s_stack, x, row, g0, g1, in_rec, in_rad, out_rec, out_rad);
+    spatial_pixel<true, TRACE_BLOCK>(S, P, F, s_stack, x, row, g0, g1, in_rec, in_rad, out_rec, out_rad);
 }
 
 /* Unshadowed target function = the roofline kernel: no rays, five dependent 64-B record gathers per pixel.
@@ -730,13 +734,13 @@ template <int WAVES> RT_DEV void occupancy_bound()
 }
 template <int WAVES>
 __global__ __launch_bounds__(BLOCK) void k_spatial_gather(
-    SceneView S, FrameParams P, const float4* __restrict__ g0, const float4* __restrict__ g1, const float4* __restrict__ in_rec,
+    SceneView S, FrameParams P, HaloFuse F, const float4* __restrict__ g0, const float4* __restrict__ g1, const float4* __restrict__ in_rec,
     const float4* __restrict__ in_rad, float4* __restrict__ out_rec, float4* __restrict__ out_rad)
 {
     occupancy_bound<WAVES>();
     int x, row;
     if (!tile_pixel<BLOCK>(P, x, row)) return;
-    spatial_pixel<false, BLOCK>(S, P, nullptr, x, row, g0, g1, in_rec, in_rad, out_rec, out_rad);
+    spatial_pixel<false, BLOCK>(S, P, F, nullptr, x, row, g0, g1, in_rec, in_rad, out_rec, out_rad);
 }
 
 /* LDS-staged variant of the same pass (north star: "LDS-staged neighbour reservoirs"; rt_tuning key 8 = 1).

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <string>
@@ -132,6 +133,7 @@ struct rt_ctx
     hipEvent_t ev_tail_go = nullptr, ev_tail = nullptr;
     bool tail_pending_main = false, tail_pending_spec = false;
     int tune_tail = -1; /* -1 auto = strip contexts, 0 never, 1 always */
+    HaloFuse fuse = {};        /* rt_halo_fuse_set: halo lists read / written by the running stage's spatial pass itself */
     int spare = 3;             /* physical buffer not named by res_map */
     bool spec_gen_valid = false, gen_taken = false;
     int spec_gen_frame = 0, spec_gen_hist = -1;
@@ -1050,6 +1052,15 @@ static int launch_grid(const rt_ctx* c)
 #endif
 static bool use_ws(const rt_ctx* c, int grid) { return c->tune_ws < 0 ? grid <= RT_WS_AUTO_WAVES : c->tune_ws != 0; }
 /* grid of the tracing kernels: TRACE_BLOCK threads on TileShape<TRACE_BLOCK> tiles */
+/* priority of a side stream: 0 = default, +1 = lowest, -1 = highest (the range HIP reports), overridable for A/B runs */
+static int stream_priority(const char* env, int dflt)
+{
+    const char* e = getenv(env);
+    int want = e ? atoi(e) : dflt;
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return 0;
+    return want > 0 ? least : (want < 0 ? greatest : 0);
+}
 static bool use_tail(const rt_ctx* c)
 {
     if (c->timing) return false; /* rt_timing brackets the kernels with events on the main stream */
@@ -1118,7 +1129,7 @@ static int launch_next_raycast(rt_ctx* c, int frame)
     const size_t n = local_pixels(c);
     if (!c->spec_stream)
     {
-        RT_HIP(c, hipStreamCreateWithFlags(&c->spec_stream, hipStreamNonBlocking));
+        RT_HIP(c, hipStreamCreateWithPriority(&c->spec_stream, hipStreamNonBlocking, stream_priority("RT_SPEC_PRIORITY", 0)));
         RT_HIP(c, hipEventCreateWithFlags(&c->ev_spec_go, hipEventDisableTiming));
         RT_HIP(c, hipEventCreateWithFlags(&c->ev_spec_done, hipEventDisableTiming));
         for (auto& es : c->ev_spec_t) for (auto& e : es) RT_HIP(c, hipEventCreate(&e));
@@ -1360,7 +1371,7 @@ static int launch_spatial(rt_ctx* c, int frame, int pass, int in_phys, int out_p
     const FrameParams P = make_params(c, frame, pass, K_SPATIAL);
     const bool lds_variant = use_lds_spatial(c);
     if (c->opt.use_shadowed_target_function)
-        k_spatial<true><<<trace_grid(c), TRACE_BLOCK, (size_t)(RT_SHADOWED_SPATIAL_LDS), c->stream>>>(S, P, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys]);
+        k_spatial<true><<<trace_grid(c), TRACE_BLOCK, (size_t)(RT_SHADOWED_SPATIAL_LDS), c->stream>>>(S, P, c->fuse, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys]);
     else if (lds_variant)
     {
         const int rc = refresh_shaded_bits(c); /* no-op inside rt_frame / rt_frame_stage: done behind the raycast */
@@ -1371,7 +1382,7 @@ static int launch_spatial(rt_ctx* c, int frame, int pass, int in_phys, int out_p
     }
     else
     {
-#define RT_SPG(WV) k_spatial_gather<WV><<<launch_grid(c), BLOCK, (size_t)c->tune_spatial_lds, c->stream>>>(S, P, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys])
+#define RT_SPG(WV) k_spatial_gather<WV><<<launch_grid(c), BLOCK, (size_t)c->tune_spatial_lds, c->stream>>>(S, P, c->fuse, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys])
         switch (c->tune_spatial_waves < 0 ? RT_SPATIAL_GATHER_AUTO_WAVES : c->tune_spatial_waves) { case 4: RT_SPG(4); break; case 5: RT_SPG(5); break; case 6: RT_SPG(6); break; default: RT_SPG(0); break; }
 #undef RT_SPG
     }
@@ -1389,6 +1400,7 @@ int rt_spatial_resampling(rt_ctx* c, int frame, int pass, int in, int out)
     ++c->res_epoch; /* a reservoir buffer changes outside the staged frame: a pipelined stage 0 is stale */
     if (in == out) RT_FAIL(c, RT_ERR_ARG, "in and out must differ");
     c->last_frame = frame;
+    c->fuse = HaloFuse{};
     return launch_spatial(c, frame, pass, c->res_map[in], c->res_map[out]);
 }
 
@@ -1522,6 +1534,7 @@ int rt_frame_stage_begin(rt_ctx* c, int frame, int stage, int clear_first)
     if (stage >= 1) { const int rc = refresh_shaded_bits(c); if (rc != RT_OK) return rc; }
     RT_HIP(c, hipEventRecord(c->ev_stage, c->stream)); /* everything the stage reads is complete here */
     c->aux_used = false;
+    c->fuse = HaloFuse{};
     const int passes = c->opt.spatial_resampling_passes;
     if (stage == 0)
     {
@@ -1630,7 +1643,7 @@ static int stage_run_ranges(rt_ctx* c, int frame, int stage, int part, int row0,
              * frame's tail: same stream); the main stream does not wait for them */
             if (!c->tail_stream)
             {
-                RT_HIP(c, hipStreamCreateWithFlags(&c->tail_stream, hipStreamNonBlocking));
+                RT_HIP(c, hipStreamCreateWithPriority(&c->tail_stream, hipStreamNonBlocking, stream_priority("RT_TAIL_PRIORITY", 0)));
                 RT_HIP(c, hipEventCreateWithFlags(&c->ev_tail_go, hipEventDisableTiming));
                 RT_HIP(c, hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
             }
@@ -1704,6 +1717,7 @@ int rt_frame_stage_end(rt_ctx* c, int stage)
         c->aux_used = false;
     }
     const int passes = c->opt.spatial_resampling_passes;
+    c->fuse = HaloFuse{};
     if (stage == 0) { const int rc = launch_next_raycast(c, c->f_frame); if (rc != RT_OK) return rc; }
     if (stage <= passes) { c->f_stage = stage + 1; return RT_OK; }
     const int X = c->fX, Y = c->fY, Z = c->fZ;
@@ -2066,6 +2080,43 @@ static int halo_sparse(rt_ctx* c, bool pack, int res, int n, const int* row0, co
     if (pack) k_halo_sparse<true><<<grid, 256, 0, c->stream>>>(Hh, c->d_rec[phys], c->d_rad[phys]);
     else k_halo_sparse<false><<<grid, 256, 0, c->stream>>>(Hh, c->d_rec[phys], c->d_rad[phys]);
     RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+/* The running spatial stage reads its halo records from the received lists and writes the records its neighbours marked
+ * to the send lists itself (no rt_halo_unpack_sparse before / rt_halo_pack_sparse after it): call between
+ * rt_frame_stage_begin(stage in 1..passes) and the _run calls it shall apply to; rt_frame_stage_end clears it. Regions
+ * are the context's own: received records belong to the halo rows below (side 0) / above (side 1) the strip, sent ones to
+ * the first / last `halo` owned rows. Lists and bitmaps as for the separate calls. */
+int rt_halo_fuse_set(rt_ctx* c, const rt_halo_fuse* f)
+{
+    RT_CHECK_CTX(c);
+    c->fuse = HaloFuse{};
+    if (!f) return RT_OK;
+    if (c->f_stage < 1 || c->f_stage > c->opt.spatial_resampling_passes) RT_FAIL(c, RT_ERR_STATE, "rt_halo_fuse_set outside a spatial stage");
+    if (use_lds_spatial(c)) RT_FAIL(c, RT_ERR_UNSUPPORTED, "the LDS-staged spatial variant reads halo rows, not lists");
+    HaloFuse F = {};
+    F.rows = c->halo;
+    F.nw = (int)(((size_t)c->halo * c->W + 31) / 32);
+    for (int side = 0; side < 2; ++side)
+    {
+        const bool has = side == 0 ? c->row_begin > 0 : c->row_end < c->H;
+        if ((f->need_bitmap[side] || f->recv_list[side] || f->give_bitmap[side] || f->send_list[side]) && !has)
+            RT_FAIL(c, RT_ERR_ARG, "no neighbour on side %d", side);
+        if (!has) continue;
+        int r0 = 0, n = 0;
+        const int rc = halo_side_region(c, side, &r0, &n);
+        if (rc != RT_OK) return rc;
+        if (n != c->halo || c->row_end - c->row_begin < c->halo) RT_FAIL(c, RT_ERR_STATE, "fused halos need full %d-row regions", c->halo);
+        if ((f->need_bitmap[side] != nullptr) != (f->recv_list[side] != nullptr) || (f->give_bitmap[side] != nullptr) != (f->send_list[side] != nullptr))
+            RT_FAIL(c, RT_ERR_ARG, "bitmap and list go together");
+        F.need_bm[side] = (const uint32_t*)f->need_bitmap[side];
+        F.recv[side] = (const float4*)f->recv_list[side];
+        F.need_row0[side] = r0;
+        F.give_bm[side] = (const uint32_t*)f->give_bitmap[side];
+        F.send[side] = (float4*)f->send_list[side];
+        F.give_row0[side] = side == 0 ? c->row_begin : c->row_end - c->halo;
+    }
+    c->fuse = F;
     return RT_OK;
 }
 int rt_halo_pack_sparse(rt_ctx* c, int res, int row0, int n_rows, const void* device_bitmap, void* device_dst)

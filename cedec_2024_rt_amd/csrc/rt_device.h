@@ -216,13 +216,13 @@ RT_DEV void res_store(float4* __restrict__ rec, float4* __restrict__ radb, size_
     rec[4 * i + 3] = make_float4(r.org_n.x, r.org_n.y, r.org_n.z, r.w_sum);
     radb[i] = make_float4(r.rad.x, r.rad.y, r.rad.z, 0.0f);
 }
-/* loads everything except radiance */
-RT_DEV Res res_load(const float4* __restrict__ rec, size_t i, bool& shaded)
+/* loads everything except radiance; q = the record's four float4 (in a reservoir buffer or in a halo list) */
+RT_DEV Res res_load_at(const float4* __restrict__ q, bool& shaded)
 {
-    const float4 q0 = rec[4 * i + 0];
-    const float4 q1 = rec[4 * i + 1];
-    const float4 q2 = rec[4 * i + 2];
-    const float4 q3 = rec[4 * i + 3];
+    const float4 q0 = q[0];
+    const float4 q1 = q[1];
+    const float4 q2 = q[2];
+    const float4 q3 = q[3];
     Res r;
     r.hit_p = F3(q0.x, q0.y, q0.z);
     r.ucw = q0.w;
@@ -237,6 +237,69 @@ RT_DEV Res res_load(const float4* __restrict__ rec, size_t i, bool& shaded)
     r.w_sum = q3.w;
     r.rad = F3(0.0f, 0.0f, 0.0f);
     return r;
+}
+RT_DEV Res res_load(const float4* __restrict__ rec, size_t i, bool& shaded) { return res_load_at(rec + 4 * i, shaded); }
+
+/* Halo records without pack / unpack launches (multi-GPU strips, r03). A strip exchanges with each neighbour the records
+ * marked in a bitmap (frame_kernels.h, k_halo_mark), as a dense list in bitmap order: list entry = the 4 float4 of the
+ * record + its radiance side record. UNPACK side: a spatial pass that gathers a neighbour from a halo row reads it from
+ * the received list (index = prefix count of the bitmap word + bits below) instead of from halo rows an unpack kernel
+ * filled. PACK side: a pass that writes a record of a row its neighbour's halo covers also writes it to the send list if
+ * the neighbour marked it. Bitmap layout: [0] count, [1 .. nw] bits, [1+nw .. 1+2nw) exclusive prefix per word. */
+struct HaloFuse
+{
+    const uint32_t* need_bm[2]; /* side 0 = rows below the strip, 1 = above; nullptr = none */
+    const float4* recv[2];
+    const uint32_t* give_bm[2];
+    float4* send[2];
+    int need_row0[2], give_row0[2];
+    int rows, nw; /* rows per region, bitmap words = ceil(rows * W / 32) */
+};
+RT_DEV uint32_t halo_list_index(const uint32_t* __restrict__ bm, int nw, uint32_t i, bool& marked)
+{
+    const uint32_t word = bm[1 + (i >> 5)];
+    marked = (word >> (i & 31u)) & 1u;
+    return bm[1 + nw + (i >> 5)] + (uint32_t)__popc(word & ((1u << (i & 31u)) - 1u));
+}
+/* where the record of pixel (nx, nrow) = buffer index pid lives: the reservoir buffer, or the received list */
+RT_DEV const float4* halo_record(const HaloFuse& F, int W, const float4* __restrict__ in_rec, const float4* __restrict__ in_rad, size_t pid,
+                                 int nx, int nrow, const float4*& rad)
+{
+    const float4* q = in_rec + 4 * pid;
+    rad = in_rad + pid;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+        if (F.recv[s] && (unsigned)(nrow - F.need_row0[s]) < (unsigned)F.rows)
+        {
+            bool marked;
+            const uint32_t idx = halo_list_index(F.need_bm[s], F.nw, (uint32_t)(nrow - F.need_row0[s]) * (uint32_t)W + (uint32_t)nx, marked);
+            q = F.recv[s] + 5 * (size_t)idx; /* marked by construction: the plan replays exactly these draws */
+            rad = q + 4;
+        }
+    return q;
+}
+/* res_store + the send list, for a record of pixel (x, row) */
+RT_DEV void res_store_give(const HaloFuse& F, int W, float4* __restrict__ rec, float4* __restrict__ radb, size_t i, int x, int row, const Res& r,
+                           bool shaded)
+{
+    res_store(rec, radb, i, r, shaded);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+        if (F.send[s] && (unsigned)(row - F.give_row0[s]) < (unsigned)F.rows)
+        {
+            bool marked;
+            const uint32_t idx = halo_list_index(F.give_bm[s], F.nw, (uint32_t)(row - F.give_row0[s]) * (uint32_t)W + (uint32_t)x, marked);
+            if (marked)
+            {
+                const uint32_t mbits = ((uint32_t)r.M & RES_M_MASK) | (r.vis ? RES_VIS_BIT : 0u) | (shaded ? RES_SHADED_BIT : 0u);
+                float4* L = F.send[s] + 5 * (size_t)idx;
+                L[0] = make_float4(r.hit_p.x, r.hit_p.y, r.hit_p.z, r.ucw);
+                L[1] = make_float4(r.hit_n.x, r.hit_n.y, r.hit_n.z, as_float(mbits));
+                L[2] = make_float4(r.org_p.x, r.org_p.y, r.org_p.z, r.lum);
+                L[3] = make_float4(r.org_n.x, r.org_n.y, r.org_n.z, r.w_sum);
+                L[4] = make_float4(r.rad.x, r.rad.y, r.rad.z, 0.0f);
+            }
+        }
 }
 
 }  // namespace rt

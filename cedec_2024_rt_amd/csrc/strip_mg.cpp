@@ -151,6 +151,7 @@ struct rt_mg
     std::vector<int> bounds;
     int transport = RT_MG_TRANSPORT_RCCL;
     bool sparse = true, two_lanes = true;
+    bool fuse_halos = true; /* sparse halos packed / unpacked by the spatial passes themselves (rt_halo_fuse_set, r03) */
     std::string err;
 
     /* neighbours: side 0 = the strip below (rank - 1, smaller rows), side 1 = the strip above */
@@ -463,6 +464,7 @@ int rt_mg_create(rt_ctx* ctx, int rank, int world, const int* bounds, int transp
     m->bounds.assign(bounds, bounds + world + 1);
     m->sparse = !(flags & RT_MG_DENSE);
     m->two_lanes = !(flags & RT_MG_ONE_LANE);
+    m->fuse_halos = !(flags & RT_MG_SEPARATE_PACK);
     memset(&m->stats, 0, sizeof(m->stats));
     int ra = 0, rb = 0;
     MG_RT(m, rt_geometry(ctx, &m->W, &m->H, &ra, &rb, &m->halo));
@@ -495,7 +497,13 @@ int rt_mg_create(rt_ctx* ctx, int rank, int world, const int* bounds, int transp
     int dev = 0;
     MG_HIP(m, hipGetDevice(&dev));
     MG_HIP(m, hipStreamCreateWithFlags(&m->comm, hipStreamNonBlocking));
-    MG_HIP(m, hipStreamCreateWithFlags(&m->prep, hipStreamNonBlocking));
+    {
+        /* the plans are needed a frame later: RT_PREP_PRIORITY=1 gives their stream the lowest priority (A/B runs) */
+        const char* e = getenv("RT_PREP_PRIORITY");
+        int least = 0, greatest = 0, prio = 0;
+        if (e && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess) prio = atoi(e) > 0 ? least : (atoi(e) < 0 ? greatest : 0);
+        MG_HIP(m, hipStreamCreateWithPriority(&m->prep, hipStreamNonBlocking, prio));
+    }
     MG_HIP(m, hipEventCreateWithFlags(&m->ev_gbuf, hipEventDisableTiming));
     for (auto& e : m->ev_marked) MG_HIP(m, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     MG_HIP(m, hipEventCreateWithFlags(&m->ev_packed, hipEventDisableTiming));
@@ -820,9 +828,10 @@ static int post_halo(rt_mg* m, int stage, int buf, bool with_plan)
     hipStream_t ms = main_stream(m);
     const int slot = rt_mg::slot_of(m->frame), nslot = rt_mg::slot_of((long long)m->frame + 1), k = stage;
     std::vector<Exchange> xs(m->sides.size());
-    if (m->use_sparse)
+    if (m->use_sparse && !(m->fuse_halos && k >= 1))
     {
-        /* the marked records of both boundary bands -> two dense lists, one launch */
+        /* the marked records of both boundary bands -> two dense lists, one launch (exchange 0: the candidates come from
+         * the pipelined stage 0; later exchanges: the spatial pass that produced the records has filled the lists) */
         int row0[2], nrows[2];
         const void* bms[2];
         void* dsts[2];
@@ -876,8 +885,9 @@ static int finish_halo(rt_mg* m)
     const bool carried = m->pending_carries_plan;
     int rc = complete(m);
     if (rc != RT_OK) return rc;
+    const bool fused = m->use_sparse && m->fuse_halos; /* the consuming pass reads the received lists itself */
     const int slot = rt_mg::slot_of(m->frame), nslot = rt_mg::slot_of((long long)m->frame + 1), k = m->pending_k;
-    if (m->use_sparse)
+    if (m->use_sparse && !fused)
     {
         int row0[2], nrows[2];
         const void *bms[2], *srcs[2];
@@ -1099,6 +1109,25 @@ static int frame_step(rt_mg* m, int* more)
             MG_RT(m, rt_frame_stage_begin(m->ctx, m->frame, s, 0));
             if (lanes) { rc = run_rows(m, s, 0, m->itr, m->n_itr, true); if (rc != RT_OK) return rc; }
             if (exchanges) { rc = finish_halo(m); if (rc != RT_OK) return rc; }
+            if (exchanges && m->use_sparse && m->fuse_halos)
+            {
+                /* this pass gathers its halo records from the lists that just arrived and fills the lists of the next
+                 * exchange as it writes its boundary rows: no unpack launch before it, no pack launch after it */
+                rt_halo_fuse f;
+                memset(&f, 0, sizeof(f));
+                for (auto& sd : m->sides)
+                {
+                    f.need_bitmap[sd.side] = sd.need_bm[slot] + (size_t)(s - 1) * sd.bm_words;
+                    f.recv_list[sd.side] = sd.recv_buf;
+                    if (s < P)
+                    {
+                        if (m->transport == RT_MG_TRANSPORT_LOCAL) { rc = local_guard(m, sd.last_send[s & 1], ms); if (rc != RT_OK) return rc; }
+                        f.give_bitmap[sd.side] = sd.give_bm[slot] + (size_t)s * sd.bm_words;
+                        f.send_list[sd.side] = sd.send_buf[s & 1];
+                    }
+                }
+                MG_RT(m, rt_halo_fuse_set(m->ctx, &f));
+            }
             if (exchanges)
             {
                 rc = run_rows(m, s, 0, m->bnd, m->n_bnd, false);

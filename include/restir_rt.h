@@ -213,6 +213,17 @@ int rt_halo_mark_sides(rt_ctx* ctx, int frame, int first_pass, int n_passes, voi
 int rt_halo_pack_sparse_ranges(rt_ctx* ctx, int res, int n, const int* row0, const int* n_rows, const void* const* device_bitmaps, void* const* device_dsts);
 int rt_halo_unpack_sparse_ranges(rt_ctx* ctx, int res, int n, const int* row0, const int* n_rows, const void* const* device_bitmaps, const void* const* device_srcs);
 
+/* The same without pack / unpack launches (r03): the running spatial stage gathers halo records straight from the received
+ * lists (per side: the need-bitmap the receiver marked + the list that arrived) and writes the records its neighbours marked
+ * (give-bitmap) into the send lists as it produces them. Call between rt_frame_stage_begin(stage in 1..passes) and the _run
+ * calls it applies to; rt_frame_stage_end clears it; NULL clears it. Same results as the separate calls. */
+typedef struct
+{
+    const void* need_bitmap[2]; const void* recv_list[2]; /* side 0 = strip below, 1 = above; NULL = none */
+    const void* give_bitmap[2]; void* send_list[2];
+} rt_halo_fuse;
+int rt_halo_fuse_set(rt_ctx* ctx, const rt_halo_fuse* fuse);
+
 /* ---- hooks used by the native strip driver below (and usable by any other driver) ---- */
 int rt_state_epoch(rt_ctx* ctx, uint64_t* epoch);   /* changes whenever camera, options, scene or an uploaded G-buffer change */
 int rt_get_stream(rt_ctx* ctx, void** hip_stream);  /* the stream calls are enqueued on right now */
@@ -237,7 +248,8 @@ typedef struct rt_mg rt_mg;
 enum { RT_MG_TRANSPORT_RCCL = 0, RT_MG_TRANSPORT_LOCAL = 1, RT_MG_TRANSPORT_MIRROR = 2 /* a rank receives what it sent: one rank alone, for overhead measurements (results are not a frame) */,
        RT_MG_TRANSPORT_SHM = 3 /* N processes of one node through a POSIX shared-memory segment (arg = its name, the same string on every
                                   rank): host-staged and blocking, for exact multi-process runs where RCCL cannot go (N ranks on ONE GPU) */ };
-enum { RT_MG_DENSE = 1 /* whole 87-row bands, sent from the buffers in place */, RT_MG_ONE_LANE = 2 /* no second stream */ };
+enum { RT_MG_DENSE = 1 /* whole 87-row bands, sent from the buffers in place */, RT_MG_ONE_LANE = 2 /* no second stream */,
+       RT_MG_SEPARATE_PACK = 4 /* sparse halos packed / unpacked by launches of their own (r02) instead of by the spatial passes */ };
 typedef struct
 {
     unsigned long long frames, cold_frames; /* cold = built its halo plan on the spot (one host wait) */

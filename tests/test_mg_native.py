@@ -153,6 +153,9 @@ class _Rig:
     (3, 330, 0, dict(use_shadowed_target_function=1, spatial_resampling_passes=2)),
     (2, 240, 0, dict(use_spatial_resampling=0)),
     (4, 700, 0, dict(accumulate=1, use_visibility_reuse=0, spatial_resampling_sample_count=3)),
+    (3, 600, 4, dict()),                                         # sparse halos packed / unpacked by launches of their own (r02 form)
+    (3, 330, 4, dict(use_shadowed_target_function=1, spatial_resampling_passes=2)),
+    (3, 600, 4 | 2, dict()),
 ])
 def test_native_strips_match_single_context(n, H, flags, optkw):
     """Frames 1..6 with a camera move before frame 4 (cold frame + clear) and a frame-number jump after

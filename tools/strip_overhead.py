@@ -58,14 +58,14 @@ def measure(W, H, N, flags, tris, frames=40, warm=6, rank=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
-    ap.add_argument("--only", default=None, help="WxH:N:sparse|dense|onelane, e.g. 3840x2160:8:sparse (for a kernel trace of one case)")
+    ap.add_argument("--only", default=None, help="WxH:N:sparse|dense|onelane|separate, e.g. 3840x2160:8:sparse (for a kernel trace of one case)")
     args = ap.parse_args()
     tris = scenes.make_blocks_restir()
     res = {}
     if args.only:
         wh, n, mode = args.only.split(":")
         w, h = (int(v) for v in wh.split("x"))
-        flags = {"sparse": 0, "dense": api.RT_MG_DENSE, "onelane": api.RT_MG_ONE_LANE}[mode]
+        flags = {"sparse": 0, "dense": api.RT_MG_DENSE, "onelane": api.RT_MG_ONE_LANE, "separate": api.RT_MG_SEPARATE_PACK}[mode]
         print(json.dumps({args.only: measure(w, h, int(n), flags, tris)}), flush=True)
         return
     for (W, H) in ((1920, 1080), (3840, 2160)):
