@@ -470,7 +470,13 @@ def _main():
                 "rays_per_frame": total_rays,
                 # strips (N > 1): every timed frame launches exactly one raycast, the one of the NEXT frame, on a second stream
                 # beside this frame's passes (rt_tuning key 14; rt_sync at the end of the timed region waits for it)
-                "frame_pipeline": ("raycast of frame f+1 beside the passes of frame f" if world > 1 else "kernels of a frame back to back on one stream"),
+                # every timed frame launches each kernel of a frame exactly once; stage 0 of frame f+1 (primary rays, candidates +
+                # temporal merge: they depend on frame f only through the history frame f's stage 0 wrote) runs on a second
+                # stream beside the spatial passes and resolve of frame f (rt_tuning key 14; the sync at the end of the
+                # timed region waits for it). kernel_ms / gpu_event_median_ms below are of frames run back to back on one stream.
+                "frame_pipeline": "stage 0 (raycast, generate_candidate + temporal) of frame f+1 beside the spatial passes and resolve of frame f"
+                                  + ("; resolve + tone mapping of frame f beside the first halo exchange of frame f+1; halo records read from / "
+                                     "written to the exchange lists by the spatial passes" if world > 1 else ""),
                 "parallelism": (f"row strips x{world}, {R['part']}, sparse 87-row halos over "
                                 + ("torch.distributed send/recv (Python schedule" + (", gloo on ONE GPU: not a scaling number)" if dev_mirror else ")")
                                    if "FALLBACK" in R["part"] else

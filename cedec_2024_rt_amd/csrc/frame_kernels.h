@@ -211,13 +211,13 @@ __global__ __launch_bounds__(BLOCK) void k_gbuffer_from_vis(SceneView S, FramePa
 /* ------------------------------------------------------- target function helper */
 /* common/reservoir.hpp:42-59 */
 template <bool SHADOWED, int STRIDE = BLOCK>
-RT_DEV float target_function(const SceneView& S, uint32_t* s_stack, f3 op, f3 on, f3 hp, f3 hn, float lum)
+RT_DEV float target_function(const SceneView& S, uint32_t* s_stack, f3 op, f3 on, f3 hp, f3 hn, float lum, int own_tri = -1)
 {
     if (SHADOWED)
     {
         const float brdf = 1.0f / kPI;
         const float G = geometry_term(op, on, hp, hn);
-        const float V = check_visibility_wide<STRIDE>(S.wide, s_stack, op, on, hp) ? 1.0f : 0.0f;
+        const float V = check_visibility_wide<STRIDE>(S.wide, s_stack, op, on, hp, true, S.bvh.tv, own_tri) ? 1.0f : 0.0f;
         return brdf * G * V * lum;
     }
     return target_unshadowed(op, on, hp, hn, lum);
@@ -243,11 +243,11 @@ RT_DEV float target_shadowed(f3 op, f3 on, f3 hp, f3 hn, float lum, float V)
  * when its weight is 0 whatever the answer. V = 1 visible, 0 occluded. */
 template <int STRIDE = BLOCK>
 RT_DEV void temporal_rays(const SceneView& S, uint32_t* s_stack, const FrameParams& P, f3 sp, f3 sn, const Res& r,
-                          const Res& pr, bool with_prev, float& V_cur, float& V_prev)
+                          const Res& pr, bool with_prev, float& V_cur, float& V_prev, int own_tri = -1)
 {
     const f3 tgt[2] = {r.hit_p, pr.hit_p};
     const bool moot = !with_prev || pr.ucw == 0.0f || (P.vis_reuse && !pr.vis);
-    const uint32_t occl = occluded_batch<2, STRIDE>(S.wide, s_stack, sp, sn, tgt, moot ? 1u : 3u);
+    const uint32_t occl = occluded_batch<2, STRIDE>(S.wide, s_stack, sp, sn, tgt, moot ? 1u : 3u, S.bvh.tv, own_tri);
     V_cur = (occl & 1u) ? 0.0f : 1.0f;
     V_prev = (occl & 2u) ? 0.0f : 1.0f;
 }
@@ -436,8 +436,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_W
     };
     if (FUSE_TEMPORAL && SHADOWED) load_prev(); /* its sample is a ray target */
     float V_cur = 1.0f, V_prev = 1.0f;
-    if (SHADOWED) temporal_rays<TRACE_BLOCK>(S, s_stack, P, sp, sn, r, pr, FUSE_TEMPORAL, V_cur, V_prev);
-    else if (P.vis_reuse && !DEFER && !LATE) V_cur = check_visibility_wide<TRACE_BLOCK, WS>(S.wide, s_stack, sp, sn, r.hit_p) ? 1.0f : 0.0f;
+    if (SHADOWED) temporal_rays<TRACE_BLOCK>(S, s_stack, P, sp, sn, r, pr, FUSE_TEMPORAL, V_cur, V_prev, as_int(G0.w));
+    else if (P.vis_reuse && !DEFER && !LATE) V_cur = check_visibility_wide<TRACE_BLOCK, WS>(S.wide, s_stack, sp, sn, r.hit_p, true, S.bvh.tv, as_int(G0.w)) ? 1.0f : 0.0f;
     {
         const float p_hat = SHADOWED ? target_shadowed(sp, sn, r.hit_p, r.hit_n, r.lum, V_cur)
                                      : target_unshadowed(sp, sn, r.hit_p, r.hit_n, r.lum);
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_W
          * whole wavefront. The ray's answer is observable only if the candidate survived (otherwise the stored bit is
          * the previous sample's, reservoir.hpp:36); lanes whose candidate did not survive, sky / emissive pixels and
          * lanes outside the image walk no ray of their own and take over parts of the others' walks instead. */
-        const bool visible = check_visibility_wide<TRACE_BLOCK, true>(S.wide, s_stack, late_sp, late_sn, r.hit_p, late_live);
+        const bool visible = check_visibility_wide<TRACE_BLOCK, true>(S.wide, s_stack, late_sp, late_sn, r.hit_p, late_live, S.bvh.tv, as_int(G0.w));
         if (late_live) r.vis = visible;
         if (in_image && (flags & GB_SHADED)) res_store(out_rec, out_rad, li, r, true);
     }
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_RESOLVE_WAVES_FWD) void k_candidate
             const size_t li = vis_queue[i];
             const float4 G0 = g0[li], G1 = g1[li];
             const float4 q0 = rec[4 * li + 0];
-            const bool visible = check_visibility_wide<TRACE_BLOCK>(S.wide, s_stack, F3(G0.x, G0.y, G0.z), F3(G1.x, G1.y, G1.z), F3(q0.x, q0.y, q0.z));
+            const bool visible = check_visibility_wide<TRACE_BLOCK>(S.wide, s_stack, F3(G0.x, G0.y, G0.z), F3(G1.x, G1.y, G1.z), F3(q0.x, q0.y, q0.z), true, S.bvh.tv, as_int(G0.w));
             if (visible)
             {
                 uint32_t* w = reinterpret_cast<uint32_t*>(rec) + 16 * li + 7; /* q1.w = M | vis << 31 | shaded << 30 */
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(BLOCK) void k_temporal(SceneView S, FrameParams P, 
     const float4 pq = prev_rad[li];
     pr.rad = F3(pq.x, pq.y, pq.z);
     float V_cur = 1.0f, V_prev = 1.0f;
-    if (SHADOWED) temporal_rays(S, s_stack, P, sp, sn, r, pr, true, V_cur, V_prev);
+    if (SHADOWED) temporal_rays(S, s_stack, P, sp, sn, r, pr, true, V_cur, V_prev, as_int(G0.w));
     temporal_merge<SHADOWED>(P, x, yi, sp, sn, r, pr, V_cur, V_prev);
     res_store(rec, radb, li, r, true);
 }
@@ -624,7 +624,7 @@ RT_DEV void spatial_pixel(const SceneView& S, const FrameParams& P, const HaloFu
         }
         tgt[5] = r.hit_p;
         need |= 1u << 5;
-        const uint32_t occl = occluded_batch<6, TB>(S.wide, s_stack, sp, sn, tgt, need);
+        const uint32_t occl = occluded_batch<6, TB>(S.wide, s_stack, sp, sn, tgt, need, S.bvh.tv, as_int(G0.w));
         int sel = 5;
 #pragma unroll
         for (int k = 0; k < 5; ++k)
@@ -679,7 +679,7 @@ RT_DEV void spatial_pixel(const SceneView& S, const FrameParams& P, const HaloFu
             Res nr = res_load_at(halo_record(F, P.W, in_rec, in_rad, pid, nx, nrow, nrad), n_shaded);
             if (!n_shaded) continue; /* sky or emissive neighbour (:326-338) */
 
-            float p_hat_y = target_function<SHADOWED, TB>(S, s_stack, sp, sn, nr.hit_p, nr.hit_n, nr.lum);
+            float p_hat_y = target_function<SHADOWED, TB>(S, s_stack, sp, sn, nr.hit_p, nr.hit_n, nr.lum, as_int(G0.w));
             if (P.vis_reuse) p_hat_y *= nr.vis ? 1.0f : 0.0f;
             nr.M = scale_M(nr.M, rejection_heuristics(r.org_p, r.org_n, nr.org_p, nr.org_n, P.eye));
             const float weight = p_hat_y * nr.ucw * (float)nr.M;
@@ -692,7 +692,7 @@ RT_DEV void spatial_pixel(const SceneView& S, const FrameParams& P, const HaloFu
                 rad_from = nrad;
             }
         }
-        const float p_hat = target_function<SHADOWED, TB>(S, s_stack, sp, sn, r.hit_p, r.hit_n, r.lum);
+        const float p_hat = target_function<SHADOWED, TB>(S, s_stack, sp, sn, r.hit_p, r.hit_n, r.lum, as_int(G0.w));
         r.ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
     }
     const float4 rq = *rad_from;
@@ -1108,7 +1108,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_RESOLVE_WAVES) void k_resolve(Scene
     const f3 hp = F3(q0.x, q0.y, q0.z), hn = F3(q1.x, q1.y, q1.z);
     const f3 brdf = (1.0f / kPI) * F3(kd.x, kd.y, kd.z);
     const float G = geometry_term(sp, sn, hp, hn);
-    const float V = check_visibility_wide<TRACE_BLOCK, WS>(S.wide, s_stack, sp, sn, hp) ? 1.0f : 0.0f;
+    const float V = check_visibility_wide<TRACE_BLOCK, WS>(S.wide, s_stack, sp, sn, hp, true, S.bvh.tv, tri) ? 1.0f : 0.0f;
     const f3 radiance = brdf * G * V * F3(rq.x, rq.y, rq.z) * q0.w;
     if (P.accumulate)
     {
@@ -1282,7 +1282,7 @@ RT_DEV bool path_bounce(const SceneView& S, uint32_t* s_stack, const FrameParams
         warp_unit_triangle(bx, by);
         const f3 lp = (1.0f - bx - by) * a0 + bx * a1 + by * a2;
         const f3 ln = tri_normal(a0, a1, a2);
-        const float V = check_visibility_wide<STRIDE, RT_PT_WS>(S.wide, s_stack, sp, sn, lp) ? 1.0f : 0.0f;
+        const float V = check_visibility_wide<STRIDE, RT_PT_WS>(S.wide, s_stack, sp, sn, lp, true, S.bvh.tv, h.prim) ? 1.0f : 0.0f;
         ++nrays;
         const f3 brdf = (1.0f / kPI) * kd;
         const float G = geometry_term(sp, sn, lp, ln);
@@ -1332,7 +1332,7 @@ RT_DEV bool path_bounce(const SceneView& S, uint32_t* s_stack, const FrameParams
                     if (target_unshadowed(sp, sn, lp, ln, L2.y) != 0.0f) need |= 1u << j; /* weight 0 whatever V says otherwise */
                 }
             }
-            const uint32_t occl = occluded_batch<8, STRIDE>(S.wide, s_stack, sp, sn, tgt, need);
+            const uint32_t occl = occluded_batch<8, STRIDE>(S.wide, s_stack, sp, sn, tgt, need, S.bvh.tv, h.prim);
 #pragma unroll
             for (int j = 0; j < 8; ++j)
             {
@@ -1360,7 +1360,7 @@ RT_DEV bool path_bounce(const SceneView& S, uint32_t* s_stack, const FrameParams
         const f3 brdf = (1.0f / kPI) * kd;
         const float G = geometry_term(sp, sn, r.hit_p, r.hit_n);
         /* no candidate selected (all weights 0): the reference still walks surface -> Reservoir{}'s zero position */
-        const float V = have_sel ? V_sel : (check_visibility_wide<STRIDE, RT_PT_WS>(S.wide, s_stack, sp, sn, r.hit_p) ? 1.0f : 0.0f);
+        const float V = have_sel ? V_sel : (check_visibility_wide<STRIDE, RT_PT_WS>(S.wide, s_stack, sp, sn, r.hit_p, true, S.bvh.tv, h.prim) ? 1.0f : 0.0f);
         nrays += 2; /* :110-113 and :116-120 */
         const float p_hat = target_shadowed(sp, sn, r.hit_p, r.hit_n, r.lum, V);
         const float ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
@@ -1398,7 +1398,7 @@ RT_DEV bool path_bounce(const SceneView& S, uint32_t* s_stack, const FrameParams
         }
         const f3 brdf = (1.0f / kPI) * kd;
         const float G = geometry_term(sp, sn, r.hit_p, r.hit_n);
-        const float V = check_visibility_wide<STRIDE, RT_PT_WS>(S.wide, s_stack, sp, sn, r.hit_p) ? 1.0f : 0.0f;
+        const float V = check_visibility_wide<STRIDE, RT_PT_WS>(S.wide, s_stack, sp, sn, r.hit_p, true, S.bvh.tv, h.prim) ? 1.0f : 0.0f;
         ++nrays;
         const float p_hat = target_unshadowed(sp, sn, r.hit_p, r.hit_n, r.lum);
         const float ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;

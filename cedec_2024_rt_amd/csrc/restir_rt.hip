@@ -1111,7 +1111,10 @@ int rt_raycast(rt_ctx* c)
  * spatial pass just waits for the machine) and its per-kernel times stop being comparable, so auto means strips only */
 static bool use_next_raycast(const rt_ctx* c)
 {
-    return c->tune_spec < 0 ? (c->row_begin != 0 || c->row_end != c->H) : c->tune_spec != 0;
+    if (c->tune_spec >= 0) return c->tune_spec != 0;
+    /* auto: strips always; whole frames too (r03: with the candidates pipelined as well a 1080p frame gains 3 %), except
+     * while rt_timing brackets the kernels of a frame with events — then they run back to back on one stream */
+    return (c->row_begin != 0 || c->row_end != c->H) || !c->timing;
 }
 /* the next frame's generate_candidate(+temporal) too. Not while per-kernel timing is on (rt_timing attributes events of the
  * main stream to kernels) and not with the deferred-visibility queue (its counters live per lane of the main frame). */

@@ -362,11 +362,11 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
  * reference saves the temporal history right after temporal_resampling, before the spatial passes (10_restir_di.cpp:314-321),
  * so frame f+1's candidates depend on frame f only through a buffer that is final when frame f's stage 0 ends. The next frame
  * takes the results if it is the next frame number and camera, scene, options (rt_state_epoch) and the reservoir buffers
- * (uploads, per-kernel calls) are unchanged, and runs its own stage 0 otherwise. 0 = never; -1 (default) = strip contexts
- * only, level 2 (a strip's frame is a chain of small launches: 1080p in 8 strips 0.51 -> ms per frame see DESIGN.md section 7;
- * a whole 1080p frame keeps its kernels back to back, which keeps the per-kernel times of rt_timing meaningful; with
- * rt_timing_enabled level 2 behaves as level 1). rt_sync waits for that stream too; every frame's launches run exactly
- * once per frame in a steady loop. Same results.
+ * (uploads, per-kernel calls) are unchanged, and runs its own stage 0 otherwise. 0 = never; -1 (default) = level 2, except
+ * that a whole-frame context with rt_timing enabled keeps its kernels back to back on one stream (per-kernel times stay
+ * meaningful); strips: 1080p in 8 strips 0.47 -> 0.44 ms per frame, 4K 1.24 -> 1.15; a whole 1080p frame 1.86 -> 1.81 ms
+ * (DESIGN.md sections 6-7). With rt_timing enabled level 2 behaves as level 1. rt_sync waits for that stream too; in a
+ * steady loop every frame's launches run exactly once. Same results.
  * key 15: 1 = resolve as a STREAM: persistent wavefronts keep pulling pixels, a lane whose shadow ray is settled shades
  * its pixel and fetches the next one while the other lanes keep walking (csrc/bvh.h occluded_stream). Evaluated and
  * left off (default 0): same instruction count as the work-sharing kernel but 0.48 against 0.36 ms — a wavefront
