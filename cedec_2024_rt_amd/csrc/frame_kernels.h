@@ -444,11 +444,15 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_W
         r.ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
     }
     if (P.vis_reuse && !DEFER && !LATE) r.vis = V_cur != 0.0f; /* :127-131 */
+    /* the ray surface point -> candidate has been walked from this pixel (shadowed target: always; else the visibility-reuse ray) */
+    if (SHADOWED || (P.vis_reuse && !DEFER && !LATE)) r.ownv = ownv_of(V_cur != 0.0f);
 
     if (FUSE_TEMPORAL)
     {
         if (!SHADOWED) load_prev(); /* after the walk: not live across it */
         const bool took_prev = temporal_merge<SHADOWED>(P, x, yi, sp, sn, r, pr, V_cur, V_prev);
+        /* the previous frame's sample won: its ray from THIS surface point is known under the shadowed target only */
+        if (took_prev) r.ownv = SHADOWED ? ownv_of(V_prev != 0.0f) : 0u;
         /* unshadowed: neither the merge decision nor ucw depends on the candidate's visibility; the bit is stored
          * clear here and set by k_candidate_visibility if the ray finds the light unoccluded */
         if (DEFER) need_ray = P.vis_reuse && !took_prev;
@@ -463,7 +467,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_W
          * the previous sample's, reservoir.hpp:36); lanes whose candidate did not survive, sky / emissive pixels and
          * lanes outside the image walk no ray of their own and take over parts of the others' walks instead. */
         const bool visible = check_visibility_wide<TRACE_BLOCK, true>(S.wide, s_stack, late_sp, late_sn, r.hit_p, late_live, S.bvh.tv, as_int(G0.w));
-        if (late_live) r.vis = visible;
+        if (late_live) { r.vis = visible; r.ownv = ownv_of(visible); }
         if (in_image && (flags & GB_SHADED)) res_store(out_rec, out_rad, li, r, true);
     }
     if (DEFER)
@@ -531,12 +535,15 @@ __global__ __launch_bounds__(BLOCK) void k_temporal(SceneView S, FrameParams P, 
     Res r = res_load(rec, li, dummy);
     const float4 rq = radb[li];
     r.rad = F3(rq.x, rq.y, rq.z);
+    r.ownv = as_uint(rq.w);
     Res pr = res_load(prev_rec, li, dummy);
     const float4 pq = prev_rad[li];
     pr.rad = F3(pq.x, pq.y, pq.z);
     float V_cur = 1.0f, V_prev = 1.0f;
     if (SHADOWED) temporal_rays(S, s_stack, P, sp, sn, r, pr, true, V_cur, V_prev, as_int(G0.w));
-    temporal_merge<SHADOWED>(P, x, yi, sp, sn, r, pr, V_cur, V_prev);
+    const bool took_prev = temporal_merge<SHADOWED>(P, x, yi, sp, sn, r, pr, V_cur, V_prev);
+    if (SHADOWED) r.ownv = ownv_of((took_prev ? V_prev : V_cur) != 0.0f);
+    else if (took_prev) r.ownv = 0u;
     res_store(rec, radb, li, r, true);
 }
 
@@ -570,6 +577,7 @@ RT_DEV void spatial_pixel(const SceneView& S, const FrameParams& P, const HaloFu
     bool own_shaded;
     Res r = res_load(in_rec, li, own_shaded);
     const float4* rad_from = in_rad + li; /* radiance side record of the selected sample: a buffer entry or a halo list entry */
+    bool took_other = false;
 
     if (SHADOWED && P.use_spatial && P.spatial_count <= 5)
     {
@@ -623,8 +631,11 @@ RT_DEV void spatial_pixel(const SceneView& S, const FrameParams& P, const HaloFu
             }
         }
         tgt[5] = r.hit_p;
-        need |= 1u << 5;
-        const uint32_t occl = occluded_batch<6, TB>(S.wide, s_stack, sp, sn, tgt, need, S.bvh.tv, as_int(G0.w));
+        /* the own sample's ray: walked by the kernel that wrote this record if the flag says so (see rt_device.h) */
+        const uint32_t own_flags = as_uint(in_rad[li].w);
+        if (!(own_flags & OWNV_KNOWN)) need |= 1u << 5;
+        uint32_t occl = occluded_batch<6, TB>(S.wide, s_stack, sp, sn, tgt, need, S.bvh.tv, as_int(G0.w));
+        if ((own_flags & OWNV_KNOWN) && !(own_flags & OWNV_VISIBLE)) occl |= 1u << 5;
         int sel = 5;
 #pragma unroll
         for (int k = 0; k < 5; ++k)
@@ -652,6 +663,8 @@ RT_DEV void spatial_pixel(const SceneView& S, const FrameParams& P, const HaloFu
         const float Vf = (occl >> sel) & 1u ? 0.0f : 1.0f;
         const float p_hat = (1.0f / kPI) * geometry_term(sp, sn, r.hit_p, r.hit_n) * Vf * r.lum;
         r.ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
+        r.ownv = ownv_of(Vf != 0.0f);
+        took_other = true; /* flags set above */
     }
     else if (P.use_spatial)
     {
@@ -690,6 +703,7 @@ RT_DEV void spatial_pixel(const SceneView& S, const FrameParams& P, const HaloFu
             {
                 res_take_sample(r, nr);
                 rad_from = nrad;
+                took_other = true;
             }
         }
         const float p_hat = target_function<SHADOWED, TB>(S, s_stack, sp, sn, r.hit_p, r.hit_n, r.lum, as_int(G0.w));
@@ -697,6 +711,10 @@ RT_DEV void spatial_pixel(const SceneView& S, const FrameParams& P, const HaloFu
     }
     const float4 rq = *rad_from;
     r.rad = F3(rq.x, rq.y, rq.z);
+    /* unshadowed passes and the one-ray-at-a-time shadowed form: the own sample keeps what is known about it, a sample
+     * taken from a neighbour has not been tested from here */
+    if (!took_other) r.ownv = as_uint(rq.w);
+    else if (!(SHADOWED && P.use_spatial && P.spatial_count <= 5)) r.ownv = 0u;
     res_store_give(F, P.W, out_rec, out_rad, li, x, row, r, true);
 }
 
@@ -867,6 +885,7 @@ __global__ __launch_bounds__(BLOCK) void k_spatial_lds(
     }
     const float4 rq = in_rad[rad_from];
     r.rad = F3(rq.x, rq.y, rq.z);
+    r.ownv = rad_from == li ? as_uint(rq.w) : 0u; /* own sample: what is known stays known; a neighbour's: untested from here */
     res_store(out_rec, out_rad, li, r, true);
 }
 
@@ -1108,7 +1127,12 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_RESOLVE_WAVES) void k_resolve(Scene
     const f3 hp = F3(q0.x, q0.y, q0.z), hn = F3(q1.x, q1.y, q1.z);
     const f3 brdf = (1.0f / kPI) * F3(kd.x, kd.y, kd.z);
     const float G = geometry_term(sp, sn, hp, hn);
-    const float V = check_visibility_wide<TRACE_BLOCK, WS>(S.wide, s_stack, sp, sn, hp, true, S.bvh.tv, tri) ? 1.0f : 0.0f;
+    /* the "fresh shadow ray" of :443-444 repeats the ray an earlier kernel of this frame walked from this pixel to this
+     * sample if the record says so (rt_device.h, own-visibility flags): those lanes only help the others' walks */
+    const uint32_t ownv = as_uint(rq.w);
+    const bool known = (ownv & OWNV_KNOWN) != 0u;
+    const bool walked = check_visibility_wide<TRACE_BLOCK, WS>(S.wide, s_stack, sp, sn, hp, !known, S.bvh.tv, tri);
+    const float V = (known ? (ownv & OWNV_VISIBLE) != 0u : walked) ? 1.0f : 0.0f;
     const f3 radiance = brdf * G * V * F3(rq.x, rq.y, rq.z) * q0.w;
     if (P.accumulate)
     {
@@ -1593,6 +1617,7 @@ __global__ void k_res_from_ref(int n, const uint32_t* __restrict__ in, const flo
     r.w_sum = as_float(s[16]);
     r.ucw = as_float(s[17]);
     r.M = (int)s[18];
+    r.ownv = 0u; /* an uploaded reservoir: nothing is known about its sample's visibility from this pixel */
     r.lum = luminance(r.rad);
     const bool shaded = (as_uint(g1[i].w) & GB_SHADED) != 0u;
     res_store(rec, radb, (size_t)i, r, shaded);

@@ -180,15 +180,29 @@ RT_HD bool intersect_ray_triangle(float& tOut, float& uOut, float& vOut, f3 ro, 
  *   q1 = { hit_normal.xyz,   bits(M | visibility << 31 | shaded << 30) }
  *   q2 = { origin_position.xyz, luminance(radiance) }
  *   q3 = { origin_normal.xyz,   w_sum }
- * plus a 16-B side record { radiance.xyz, 0 } that only moves with the finally selected
- * sample. Together they hold every field of the reference's 76-B Reservoir
+ * plus a 16-B side record { radiance.xyz, bits(own-visibility flags) } that only moves with the finally
+ * selected sample. Together they hold every field of the reference's 76-B Reservoir
  * (common/reservoir.hpp:5-38) losslessly for 0 <= M < 2^30.
+ *
+ * Own-visibility flags (r03; not part of the reference's Reservoir, never downloaded): OWNV_KNOWN = a kernel of THIS frame
+ * has already evaluated the shadow ray from THIS pixel's surface point to the sample the record holds, OWNV_VISIBLE =
+ * its answer. The reference traces that same ray again in the next kernel (the own sample's p-hat of the next spatial pass
+ * under the shadowed target function, 10_restir_di.cu:370-378; resolve's "fresh" ray, :443-444): same origin, same
+ * target, same frame, same scene => same answer, so the kernels that find the flag set skip the walk. Every kernel
+ * rewrites the flags with the record (clear whenever it did not evaluate that ray itself), so they can never be stale;
+ * uploads and the per-kernel API start from "unknown".
  */
 constexpr uint32_t GB_SHADED = 1u;
 constexpr uint32_t GB_EMISSIVE = 2u;
 constexpr uint32_t RES_VIS_BIT = 0x80000000u;
 constexpr uint32_t RES_SHADED_BIT = 0x40000000u;
 constexpr uint32_t RES_M_MASK = 0x3fffffffu;
+constexpr uint32_t OWNV_KNOWN = 1u;
+constexpr uint32_t OWNV_VISIBLE = 2u;
+#ifndef RT_OWNV
+#define RT_OWNV 1 /* 0: never set the flags (A/B) */
+#endif
+RT_HD uint32_t ownv_of(bool visible) { return RT_OWNV ? (OWNV_KNOWN | (visible ? OWNV_VISIBLE : 0u)) : 0u; }
 
 struct Res
 {
@@ -196,6 +210,7 @@ struct Res
     float ucw, lum, w_sum;
     int M;
     bool vis;
+    uint32_t ownv; /* own-visibility flags of the side record (not loaded by res_load) */
 };
 RT_HD Res res_zero()
 {
@@ -204,6 +219,7 @@ RT_HD Res res_zero()
     r.ucw = r.lum = r.w_sum = 0.0f;
     r.M = 0;
     r.vis = false;
+    r.ownv = 0u;
     return r;
 }
 
@@ -214,7 +230,7 @@ RT_DEV void res_store(float4* __restrict__ rec, float4* __restrict__ radb, size_
     rec[4 * i + 1] = make_float4(r.hit_n.x, r.hit_n.y, r.hit_n.z, as_float(mbits));
     rec[4 * i + 2] = make_float4(r.org_p.x, r.org_p.y, r.org_p.z, r.lum);
     rec[4 * i + 3] = make_float4(r.org_n.x, r.org_n.y, r.org_n.z, r.w_sum);
-    radb[i] = make_float4(r.rad.x, r.rad.y, r.rad.z, 0.0f);
+    radb[i] = make_float4(r.rad.x, r.rad.y, r.rad.z, as_float(r.ownv));
 }
 /* loads everything except radiance; q = the record's four float4 (in a reservoir buffer or in a halo list) */
 RT_DEV Res res_load_at(const float4* __restrict__ q, bool& shaded)
@@ -236,6 +252,7 @@ RT_DEV Res res_load_at(const float4* __restrict__ q, bool& shaded)
     r.org_n = F3(q3.x, q3.y, q3.z);
     r.w_sum = q3.w;
     r.rad = F3(0.0f, 0.0f, 0.0f);
+    r.ownv = 0u;
     return r;
 }
 RT_DEV Res res_load(const float4* __restrict__ rec, size_t i, bool& shaded) { return res_load_at(rec + 4 * i, shaded); }
