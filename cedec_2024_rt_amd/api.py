@@ -631,7 +631,8 @@ class Renderer:
 
     BVH_BUILDERS = {0: "device Morton + Karras LBVH, host pre-split + 4-wide collapse",
                     1: "host binned SAH + 4-wide collapse",
-                    2: "device pre-split + Morton sort + PLOC + top-level SAH sweep + 4-wide collapse"}
+                    2: "device pre-split + Morton sort + PLOC + top-level SAH sweep + 4-wide collapse",
+                    3: "device pre-split + top-down binned SAH (32 bins) + 4-wide collapse, all on the GPU"}
 
     def bvh_builder(self):
         """name of the builder this context's rt_scene_set used / will use (rt_tuning key 5)"""

@@ -98,7 +98,9 @@ struct rt_ctx
     int trace_mode = 0; /* rt_trace_closest / rt_trace_stats: 0 = wide (what the frame kernels use), 1 = binary stackless */
     float bvh_split_factor = 10.0f; /* fragment length in median triangle extents; 0 = no pre-split */
     int bvh_bfs_records = 2048; /* rt_tuning key 7: records emitted breadth-first (top of the tree contiguous) */
-    int bvh_builder = 1; /* 0 = device LBVH (Morton/Karras, host pre-split + collapse), 1 = host binned SAH (high quality), 2 = all-device: pre-split, PLOC, wide collapse */
+    int bvh_builder = 3; /* 0 = device LBVH (Morton/Karras, host pre-split + collapse), 1 = host binned SAH (high quality), 2 = device: pre-split, PLOC,
+                            host SAH sweep over the top, wide collapse, 3 (default, r03) = device: pre-split, top-down binned SAH (the host builder's
+                            algorithm and tree), wide collapse */
     float build_ms = 0.0f; /* wall time of the last rt_scene_set */
     int ploc_radius = RT_PLOC_RADIUS; /* rt_tuning key 10 */
     float* d_tris = nullptr;
@@ -447,8 +449,71 @@ static int build_bvh_device(rt_ctx* c, int n_tris)
     k_bvh_tv<<<gt, 256, 0, st>>>(c->d_tris, n_tris, c->d_tv);
     BD_HIP(hipGetLastError());
     if (n < 2) BD_FAIL(RT_ERR_STATE, "internal: the device build needs at least two references");
-    /* 3. Morton order */
     const int grid = (n + 255) / 256;
+    int2* d_children = (int2*)dalloc((size_t)n * 8); BD_PTR(d_children);
+    int* d_parent = (int*)dalloc((size_t)n * 4); BD_PTR(d_parent);
+    float* d_node_boxes = (float*)dalloc((size_t)n * 24); BD_PTR(d_node_boxes);
+    const uint32_t* d_leaf_ids = nullptr; /* leaf position -> reference, for k_bvh_emit */
+    SahState* d_sah_state = nullptr;
+    if (c->bvh_builder == 3)
+    {
+        /* 3b. top-down binned SAH on the device (bvh_build_device.h): the host enqueues levels and, from level 16 on,
+         * looks every fourth level whether large nodes are left (24 bytes of counters; a balanced tree over 2^24 references
+         * is done by then, deeper ones keep going up to SAH_MAX_LEVELS) */
+        const int max_active = n / (SAH_SMALL + 1) + 2, max_small = n / 2 + 2;
+        uint32_t* d_order[2] = {(uint32_t*)dalloc((size_t)n * 4), (uint32_t*)dalloc((size_t)n * 4)}; BD_PTR(d_order[0]); BD_PTR(d_order[1]);
+        int* d_seg[2] = {(int*)dalloc((size_t)n * 4), (int*)dalloc((size_t)n * 4)}; BD_PTR(d_seg[0]); BD_PTR(d_seg[1]);
+        unsigned int* d_flag = (unsigned int*)dalloc((size_t)n * 4); BD_PTR(d_flag);
+        unsigned int* d_pre = (unsigned int*)dalloc((size_t)n * 4); BD_PTR(d_pre);
+        SahNode* d_act[2] = {(SahNode*)dalloc((size_t)max_active * sizeof(SahNode)), (SahNode*)dalloc((size_t)max_active * sizeof(SahNode))}; BD_PTR(d_act[0]); BD_PTR(d_act[1]);
+        SahSplit* d_splits = (SahSplit*)dalloc((size_t)max_active * sizeof(SahSplit)); BD_PTR(d_splits);
+        const size_t bin_words = (size_t)max_active * SAH_NODE_BIN_WORDS;
+        unsigned int* d_bins = (unsigned int*)dalloc(bin_words * 4); BD_PTR(d_bins);
+        SahSmallRoot* d_small = (SahSmallRoot*)dalloc((size_t)max_small * sizeof(SahSmallRoot)); BD_PTR(d_small);
+        d_sah_state = (SahState*)dalloc(sizeof(SahState)); BD_PTR(d_sah_state);
+        size_t scan_bytes = 0;
+        BD_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, d_flag, d_pre, 0u, (size_t)n, rocprim::plus<unsigned int>(), st));
+        void* d_scan_tmp = dalloc(scan_bytes); BD_PTR(d_scan_tmp);
+        BD_HIP(hipMemsetAsync(d_parent, 0xff, 4, st)); /* the root has no parent */
+        const int big_grid = (n + SAH_BLOCK - 1) / SAH_BLOCK;
+        k_sah_begin<<<1, 1, 0, st>>>(d_sah_state);
+        k_sah_root_bounds<<<big_grid, SAH_BLOCK, 0, st>>>(n, d_boxes, d_order[0], d_seg[0], d_sah_state);
+        k_sah_root<<<1, 1, 0, st>>>(n, d_sah_state, d_act[0], d_small);
+        BD_HIP(hipGetLastError());
+        constexpr int SAH_MAX_LEVELS = 4096;
+        const int clear_grid = (int)std::min<size_t>((bin_words + 255) / 256, 4096);
+        int levels_run = 0;
+        bool large_left = n > SAH_SMALL;
+        while (large_left && levels_run < SAH_MAX_LEVELS)
+        {
+            const int level = levels_run, r = level & 1, w = r ^ 1;
+            k_sah_clear_bins<<<clear_grid, 256, 0, st>>>(level, d_sah_state, d_bins, bin_words);
+            k_sah_bin<<<big_grid, SAH_BLOCK, 0, st>>>(n, level, d_sah_state, d_act[r], d_boxes, d_order[r], d_seg[r], d_bins);
+            k_sah_split<<<max_active, 64, 0, st>>>(level, d_sah_state, d_act[r], d_act[w], d_bins, d_splits, d_small, d_children, d_parent, d_node_boxes, max_active, max_small);
+            k_sah_medium<<<max_active, SAH_BLOCK, 0, st>>>(level, d_sah_state, d_act[r], d_act[w], d_boxes, d_order[r], d_splits, d_small, d_children, d_parent, d_node_boxes, max_active, max_small);
+            k_sah_classify<<<grid, 256, 0, st>>>(n, level, d_sah_state, d_splits, d_boxes, d_order[r], d_seg[r], d_flag);
+            BD_HIP(rocprim::exclusive_scan(d_scan_tmp, scan_bytes, d_flag, d_pre, 0u, (size_t)n, rocprim::plus<unsigned int>(), st));
+            k_sah_scatter<<<grid, 256, 0, st>>>(n, level, d_sah_state, d_splits, d_flag, d_pre, d_order[r], d_seg[r], d_order[w], d_seg[w]);
+            k_sah_next_level<<<1, 1, 0, st>>>(level, d_sah_state);
+            ++levels_run;
+            if (levels_run >= 16 && (levels_run & 3) == 0)
+            {
+                SahState probe;
+                BD_HIP(hipGetLastError());
+                BD_HIP(hipMemcpyAsync(&probe, d_sah_state, sizeof(probe), hipMemcpyDeviceToHost, st));
+                BD_HIP(hipStreamSynchronize(st));
+                large_left = probe.n_active[levels_run & 1] != 0u;
+            }
+        }
+        BD_HIP(hipGetLastError());
+        uint32_t* d_final = d_order[levels_run & 1];
+        k_sah_small<<<max_small, 64, 0, st>>>(d_sah_state, d_small, d_boxes, d_final, d_children, d_parent, d_node_boxes);
+        BD_HIP(hipGetLastError());
+        d_leaf_ids = d_final;
+    }
+    else
+    {
+    /* 3. Morton order */
     uint64_t* d_keys = (uint64_t*)dalloc((size_t)n * 8); BD_PTR(d_keys);
     uint64_t* d_keys2 = (uint64_t*)dalloc((size_t)n * 8); BD_PTR(d_keys2);
     uint32_t* d_ids = (uint32_t*)dalloc((size_t)n * 4); BD_PTR(d_ids);
@@ -460,9 +525,6 @@ static int build_bvh_device(rt_ctx* c, int n_tris)
     void* d_t2 = dalloc(rb); BD_PTR(d_t2);
     BD_HIP(rocprim::radix_sort_pairs(d_t2, rb, d_keys, d_keys2, d_ids, d_ids2, (size_t)n, 0, 64, st));
     /* 4. PLOC hierarchy */
-    int2* d_children = (int2*)dalloc((size_t)n * 8); BD_PTR(d_children);
-    int* d_parent = (int*)dalloc((size_t)n * 4); BD_PTR(d_parent);
-    float* d_node_boxes = (float*)dalloc((size_t)n * 24); BD_PTR(d_node_boxes);
     int* d_cid[2] = {(int*)dalloc((size_t)n * 4), (int*)dalloc((size_t)n * 4)}; BD_PTR(d_cid[0]); BD_PTR(d_cid[1]);
     float* d_cbox[2] = {(float*)dalloc((size_t)n * 24), (float*)dalloc((size_t)n * 24)}; BD_PTR(d_cbox[0]); BD_PTR(d_cbox[1]);
     int* d_nn = (int*)dalloc((size_t)n * 4); BD_PTR(d_nn);
@@ -604,11 +666,13 @@ static int build_bvh_device(rt_ctx* c, int n_tris)
         }
         BD_HIP(hipStreamSynchronize(st)); /* the host vectors go out of scope */
     }
+    d_leaf_ids = d_ids2;
+    } /* builder 2 */
     int* d_height = (int*)dalloc(4); BD_PTR(d_height);
     BD_HIP(hipMemsetAsync(d_height, 0, 4, st));
     k_bvh_height<<<grid, 256, 0, st>>>(n, d_children, d_parent, d_height);
     BD_HIP(hipMalloc(&c->d_nodes, (size_t)(n - 1) * sizeof(BvhNode)));
-    k_bvh_emit<<<grid, 256, 0, st>>>(n, d_ids2, d_ref_tri, d_boxes, d_children, d_parent, d_node_boxes, c->d_nodes);
+    k_bvh_emit<<<grid, 256, 0, st>>>(n, d_leaf_ids, d_ref_tri, d_boxes, d_children, d_parent, d_node_boxes, c->d_nodes);
     BD_HIP(hipGetLastError());
     /* 5. wide collapse, level by level */
     const size_t rec_cap = (size_t)n * 2 + 8;
@@ -626,9 +690,21 @@ static int build_bvh_device(rt_ctx* c, int n_tris)
     BD_HIP(hipGetLastError());
     CollapseState cs;
     int bh = 0;
+    SahState sah_final;
+    memset(&sah_final, 0, sizeof(sah_final));
     BD_HIP(hipMemcpyAsync(&cs, d_cs, sizeof(cs), hipMemcpyDeviceToHost, st));
     BD_HIP(hipMemcpyAsync(&bh, d_height, 4, hipMemcpyDeviceToHost, st));
+    if (d_sah_state) BD_HIP(hipMemcpyAsync(&sah_final, d_sah_state, sizeof(sah_final), hipMemcpyDeviceToHost, st));
     BD_HIP(hipStreamSynchronize(st));
+    if (d_sah_state)
+    {
+        /* the counters that came back with the heights: every level reached the small-subtree size, no table overflowed,
+         * and exactly n - 1 inner nodes were made */
+        if (sah_final.n_active[0] != 0u || sah_final.n_active[1] != 0u)
+            BD_FAIL(RT_ERR_BVH_DEPTH, "device SAH build: large nodes left after the enqueued levels (tree deeper than expected)");
+        if (sah_final.overflow != 0u || sah_final.next_node != (unsigned int)(n - 1))
+            BD_FAIL(RT_ERR_STATE, "internal: device SAH build made %u inner nodes for %d references (overflow %u)", sah_final.next_node, n, sah_final.overflow);
+    }
     if (cs.count[0] != 0u || cs.count[1] != 0u || 3 * (int)cs.height + 1 > WIDE_LDS_STACK + WIDE_OVF_STACK)
         BD_FAIL(RT_ERR_BVH_DEPTH, "wide BVH height %u exceeds the traversal stack (%d entries)", cs.height, WIDE_LDS_STACK + WIDE_OVF_STACK);
     if (cs.n_rec > rec_cap) BD_FAIL(RT_ERR_STATE, "internal: %u wide records for %d references", cs.n_rec, n);
@@ -646,7 +722,7 @@ static int build_bvh_device(rt_ctx* c, int n_tris)
 /* LBVH build, see bvh.h */
 static int build_bvh(rt_ctx* c, const rt_triangle* tris, int n_tris)
 {
-    if (c->bvh_builder == 2 && n_tris >= 2) return build_bvh_device(c, n_tris);
+    if (c->bvh_builder >= 2 && n_tris >= 2) return build_bvh_device(c, n_tris);
     hipStream_t st = c->stream;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     std::vector<float> extents((size_t)n_tris);
@@ -2393,7 +2469,7 @@ int rt_tuning(rt_ctx* c, int key, int value)
     RT_CHECK_CTX(c);
     if (key >= 0 && key <= 3 && (value == 0 || value == 1)) c->tune_tile_mode[key] = value;
     else if (key == 4 && value >= 0 && value <= 160 * 1024) c->tune_spatial_lds = value;
-    else if (key == 5 && value >= 0 && value <= 2) c->bvh_builder = value; /* before rt_scene_set */
+    else if (key == 5 && value >= 0 && value <= 3) c->bvh_builder = value; /* before rt_scene_set */
     else if (key == 6 && value >= 0 && value <= 2) c->pt_wavefront = value;
     else if (key == 7 && value >= 0) c->bvh_bfs_records = value; /* before rt_scene_set */
     else if (key == 8 && (value == 0 || value == 1)) c->tune_spatial_variant = value;

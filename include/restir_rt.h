@@ -330,11 +330,14 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
  * band for raycast / generate_candidate / spatial_resampling / resolve (0 row-major, 1 column-major);
  * key 4: extra LDS bytes per unshadowed spatial_resampling workgroup (round 1's occupancy throttle, kept for
  * A/B runs; the kernel now carries an explicit bound of 5 wavefronts per SIMD). Defaults: {1,0,1,0}, 0.
- * key 5 (before rt_scene_set): builder. 0 = device LBVH (Morton codes + Karras) with host pre-split and host
+ * key 5 (before rt_scene_set): builder (default 3). 0 = device LBVH (Morton codes + Karras) with host pre-split and host
  * collapse (round 1), 1 = host binned SAH (the reference requests HIPRT's high-quality build,
  * common/loader.hpp:98-99), 2 = on the device: pre-split, Morton sort, PLOC hierarchy, wide collapse; only the boxes
  * of the last <= 8 192 clusters visit the host, which builds the top of the tree over them by an exact SAH sweep
- * (12 ms for 212 k triangles, frame +1.2 % against builder 1). All feed the same traversals; results never depend on
+ * (12 ms for 212 k triangles, frame +1.2 % against builder 1), 3 (default since r03) = builder 1's algorithm on the device:
+ * pre-split, top-down binned SAH (32 centroid bins per axis, level by level over the large nodes, one wavefront per
+ * subtree of <= 64 references), wide collapse — the same tree as builder 1 (380 779 records, 15 levels on the benchmark
+ * scene) in 11 ms instead of 230; the host reads back counters only. All feed the same traversals; results never depend on
  * the builder.
  * key 6: rt_path_trace as 0 = one launch per frame (the reference's shape), 1 = wavefront (one launch
  * per bounce over the list of live paths, compacted with wave ballots), 2 = auto (default: wavefront

@@ -123,7 +123,7 @@ def test_lbvh_equals_brute_force(api, oracle, scenes, golden_scenes):
         rays = _random_rays(rng, 60000 if len(tris) < 1000 else 20000, lo - 0.5, hi + 0.5)
         sc = oracle.Scene(tris, use_bvh=False)
         ref = sc.trace_closest(rays, force_brute=True)
-        for builder in (0, 1, 2):  # 0: device LBVH (Morton + Karras), 1: host binned SAH, 2: all-device (pre-split, PLOC, collapse)
+        for builder in (0, 1, 2, 3):  # 0: device LBVH (Morton + Karras), 1: host binned SAH, 2: device PLOC, 3: device binned SAH
             r = api.Renderer(8, 8)
             r.tuning(5, builder)
             r.set_scene(tris)
@@ -180,7 +180,7 @@ def test_deep_traversal_stack_spills_past_lds(api, oracle):
     sc = oracle.Scene(tris, use_bvh=False)
     ref = sc.trace_closest(rays, force_brute=True)
     assert (ref[:, 3].view(np.int32) >= 0).mean() > 0.5
-    for builder in (0, 1, 2):
+    for builder in (0, 1, 2, 3):
         r = api.Renderer(8, 8)
         r.tuning(5, builder)
         r.set_scene(tris)
@@ -206,7 +206,7 @@ def test_lbvh_blocks_scene_vs_oracle_bvh(api, oracle, scenes):
     rays = _random_rays(rng, 200000, np.float32([-20, 0, -10]), np.float32([40, 40, 60]))
     sc = oracle.Scene(tris, use_bvh=True)
     ref = sc.trace_closest(rays)
-    for builder in (0, 1, 2):
+    for builder in (0, 1, 2, 3):
         r = api.Renderer(8, 8)
         r.tuning(5, builder)
         r.set_scene(tris)

@@ -191,6 +191,59 @@ def test_native_strips_match_single_context(n, H, flags, optkw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("RT_MG_SEEDS", "6")))))
+def test_native_strips_random(seed):
+    """Random image sizes, 2-5 strips of irregular heights, random option sets and driver flags (dense / one lane / halo
+    records packed by launches of their own or by the spatial passes), the blocks scene or the room, a camera move and an
+    option change somewhere in the sequence: every frame of the native driver == the single context."""
+    api = _api()
+    from cedec_2024_rt_amd import scenes
+    from cedec_2024_rt_amd.types import bench_options
+
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.integers(2, 6))
+    cuts = np.sort(rng.integers(0, 120, size=n))
+    H = int(87 * n + cuts.sum() + rng.integers(0, 60))
+    extra = H - 87 * n
+    # irregular strip heights, each >= 87 rows
+    parts = rng.multinomial(extra, np.ones(n) / n)
+    edges = np.concatenate([[0], np.cumsum(87 + parts)])
+    bounds = [(int(edges[i]), int(edges[i + 1])) for i in range(n)]
+    W = int(rng.integers(40, 200))
+    flags = int(rng.choice([0, 0, 0, 1, 2, 4, 6]))
+
+    def options():
+        return dict(use_temporal_resampling=int(rng.integers(0, 2)), use_visibility_reuse=int(rng.integers(0, 2)),
+                    use_shadowed_target_function=int(rng.integers(0, 3) == 0), ris_sample_count=int(rng.integers(1, 9)),
+                    spatial_resampling_passes=int(rng.integers(1, 4)), spatial_resampling_sample_count=int(rng.integers(1, 6)),
+                    accumulate=int(rng.integers(0, 2)))
+
+    if rng.integers(0, 2):
+        tris, eye, at = scenes.make_quad_room(), (0.5 + float(rng.normal()) * 0.4, 2.5, 6.0), (0.0, 1.5, -1.0)
+    else:
+        tris, eye, at = scenes.make_blocks_restir(), scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT
+    optkw = options()
+    rig = _Rig(api, tris, W, H, n, eye, at, optkw, flags, bounds=bounds)
+    move_at, change_at = int(rng.integers(2, 7)), int(rng.integers(2, 7))
+    for frame in range(1, 8):
+        clear = False
+        if frame == move_at:
+            for r in rig.everyone():
+                r.orbit(float(20 + 10 * seed), -9.0)
+            clear = True
+        if frame == change_at:
+            new = bench_options(**options())
+            for r in rig.everyone():
+                r.set_options(new)
+        rig.frame(frame, clear)
+        what = f"seed {seed}: {n} strips {bounds} of {W}x{H}, flags {flags}, frame {frame} (move at {move_at}, options at {change_at})"
+        rig.check(what)
+        rig.check_history(what)
+    assert sum(c.ray_count()[0] for c in rig.ctxs) == rig.full.ray_count()[0]
+    rig.close()
+
+
+@pytest.mark.gpu
 def test_native_strips_option_change_and_irregular_bounds():
     """Cost-weighted (irregular) strip heights and an option change between frames (new plan)."""
     api = _api()

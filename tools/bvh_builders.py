@@ -1,4 +1,4 @@
-"""The three BVH builders on the benchmark scene (211 916 triangles): rt_scene_set wall time (upload + tables +
+"""The four BVH builders on the benchmark scene (211 916 triangles): rt_scene_set wall time (upload + tables +
 build, synchronised), tree statistics, and the frame time each tree gives (1920x1080, bench options, HIP events).
   python tools/bvh_builders.py"""
 import json
@@ -15,8 +15,9 @@ from cedec_2024_rt_amd.types import bench_options  # noqa: E402
 W, H = 1920, 1080
 tris = scenes.make_blocks_restir()
 out = {}
-names = {0: "device LBVH (Karras) + host pre-split/collapse", 1: "host binned SAH", 2: "device: pre-split, PLOC, host SAH sweep over the last 8192 clusters, collapse"}
-CASES = [(1, None), (0, None)] + [(2, rad) for rad in (8, 16, 32, 64, 128)]
+names = {0: "device LBVH (Karras) + host pre-split/collapse", 1: "host binned SAH", 2: "device: pre-split, PLOC, host SAH sweep over the last 8192 clusters, collapse",
+         3: "device: pre-split, top-down binned SAH (32 bins), collapse"}
+CASES = [(1, None), (3, None), (0, None), (2, 16)] if not os.environ.get("BVH_PLOC_SWEEP") else [(2, rad) for rad in (8, 16, 32, 64, 128)]
 for builder, rad in CASES:
     r = api.Renderer(W, H)
     r.tuning(5, builder)

@@ -84,6 +84,36 @@ json.dump(out, open(os.path.join(dst, f"{tag}_pmc_valu.json"), "w"), indent=1)
 
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
 
+# ---- shadowed-target mode (tools/shadowed_frames.py under the same passes): per-kernel trace + counters
+scon = db("sh_stats")
+if scon is not None:
+    srows = collections.defaultdict(list)
+    for name, dur in scon.execute("select name, duration from kernels"):
+        srows[short(name)].append(dur)
+    stot = sum(sum(v) for v in srows.values())
+    with open(os.path.join(dst, f"{tag}_shadowed_kernel_stats.csv"), "w") as f:
+        f.write("Name,Calls,TotalDurationNs,AverageNs,MinNs,MaxNs,Percentage\n")
+        for k, v in sorted(srows.items(), key=lambda kv: -sum(kv[1])):
+            f.write(f'"{k}",{len(v)},{sum(v)},{sum(v)/len(v):.1f},{min(v)},{max(v)},{100.0*sum(v)/stot:.3f}\n')
+    s_avg = {k: sum(v) / len(v) * 1e-6 for k, v in srows.items()}
+    sh = {}
+    for path in ("sh_pmc_FETCH_SIZE", "sh_pmc_WRITE_SIZE", "sh_pmc_valu", "sh_pmc_stall"):
+        for k, cs in counters(path).items():
+            if k.startswith("k_") and "bvh" not in k:
+                sh.setdefault(k, {}).update({c: v["mean"] for c, v in cs.items()})
+    for k, e in sh.items():
+        if k in s_avg:
+            e["avg_ms_kernel_trace"] = s_avg[k]
+            if e.get("SQ_INSTS_VALU"):
+                e["valu_issue_fraction"] = e["SQ_INSTS_VALU"] * 4 / 1024 / 2.4e6 / s_avg[k]
+                if e.get("SQ_WAVES"):
+                    e["valu_insts_per_wave"] = e["SQ_INSTS_VALU"] / e["SQ_WAVES"]
+            if e.get("SQ_WAVE_CYCLES"):
+                for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+                    if e.get(c) is not None:
+                        e[c + "_share_of_wave_cycles"] = e[c] / e["SQ_WAVE_CYCLES"]
+    json.dump(sh, open(os.path.join(dst, f"{tag}_shadowed_pmc.json"), "w"), indent=1)
+
 # spatial kernel HBM traffic, corrected as calibrated in profiles/r01_fetch_calibration.json
 sp = [k for k in fw["FETCH_SIZE"] if k.startswith(("k_spatial_gather", "k_spatial_lds", "k_spatial<false"))]
 if sp:

@@ -8,6 +8,10 @@ export TMPDIR=/tmp
 OUT=gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 timeout 300 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+# per-kernel profiles are of frames whose kernels run back to back on one stream (RT_TUNING=14=0: without the pipelined stage 0
+# the kernels of consecutive frames do not overlap, so a kernel's duration and counters are its own; the bench line records
+# rt_tuning_env). The headline bench.json above is the default (pipelined) run.
+export RT_TUNING=14=0
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o st -- python3 bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c -d $OUT/pmc_$c -o pmc -- python3 bench.py --no-cpu-baseline --steps 16 --warmup 2 > $OUT/pmc_$c.log 2>&1
@@ -16,6 +20,14 @@ timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES
 timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU -d $OUT/pmc_mix -o pmc -- python3 bench.py --no-cpu-baseline --steps 16 --warmup 2 > $OUT/pmc_mix.log 2>&1
 # where a wavefront's cycles go (quad-cycles; WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES, MI355X_MICROARCH.md PMC slots)
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS -d $OUT/pmc_stall -o pmc -- python3 bench.py --no-cpu-baseline --steps 16 --warmup 2 > $OUT/pmc_stall.log 2>&1
+# the shadowed-target mode (README key 3): kernel trace + the same counter passes, 20 frames
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/sh_stats -o st -- python3 tools/shadowed_frames.py 20 > $OUT/sh_stats.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --pmc $c -d $OUT/sh_pmc_$c -o pmc -- python3 tools/shadowed_frames.py 12 > $OUT/sh_pmc_$c.log 2>&1
+done
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/sh_pmc_valu -o pmc -- python3 tools/shadowed_frames.py 12 > $OUT/sh_pmc_valu.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS -d $OUT/sh_pmc_stall -o pmc -- python3 tools/shadowed_frames.py 12 > $OUT/sh_pmc_stall.log 2>&1
+unset RT_TUNING
 sha256sum cedec_2024_rt_amd/librestir_rt.so > $OUT/lib.sha256
 python3 -c "from cedec_2024_rt_amd import api; print(api.build_id())" > $OUT/lib.build_id
 # summarise on the box (the raw rocprofv3 databases are too large to travel back) and keep the summaries only
@@ -23,5 +35,5 @@ mkdir -p $OUT/summary
 cp -r profiles /tmp/profiles_before_$TAG
 python3 tools/profile_collect.py $TAG > $OUT/summary/collect.log 2>&1
 for f in profiles/${TAG}_* profiles/spatial_pmc_latest.json; do cp $f $OUT/summary/; done
-rm -rf $OUT/stats $OUT/pmc_* 
+rm -rf $OUT/stats $OUT/pmc_* $OUT/sh_stats $OUT/sh_pmc_*
 cat $OUT/bench.json
