@@ -733,16 +733,14 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_SHSPATIAL_WAVES) void k_spatial(Sce
 }
 
 /* Unshadowed target function = the roofline kernel: no rays, five dependent 64-B record gathers per pixel.
- * Its neighbour window must stay in the XCD's 4 MiB L2, which bounds the workgroups in flight per CU: the
- * register allocation is told to allow at most RT_SPATIAL_MAX_WAVES wavefronts per SIMD (round 1 did this
- * with a dummy 32 KB LDS allocation; rt_tuning key 4 still adds LDS for A/B runs, default 0). */
-#ifndef RT_SPATIAL_MAX_WAVES
-#define RT_SPATIAL_MAX_WAVES 5
-#endif
-/* amdgpu_waves_per_eu(1, 5) alone leaves .vgpr_count at the 70 registers the kernel uses (7 wavefronts per SIMD at
- * dispatch: measured 0.200 ms per pass against 0.188 with 5). Naming the last register of the 96-register
- * allocation step as clobbered makes the descriptor ask for 96 VGPRs = floor(512 / 96) = 5 wavefronts per SIMD
- * (MI355X_MICROARCH.md, register-file table) — an explicit register budget instead of round 1's dummy LDS. */
+ * The register allocation can be told to admit at most WAVES wavefronts per SIMD (template parameter; rt_tuning key 9;
+ * round 1 did this with a dummy 32 KB LDS allocation, and rt_tuning key 4 still adds LDS for A/B runs, default 0): the
+ * xnack-any code of rounds 1-2 wanted 4-5 to keep the neighbour window in the XCD's 4 MiB L2 (0.184 against 0.202 ms per
+ * pass unbounded); the xnack- code the library ships is flat across 4 / 5 / 6 / unbounded (0.170 / 0.169 / 0.168 / 0.170 ms),
+ * and the default is 6 (RT_SPATIAL_GATHER_AUTO_WAVES in restir_rt.hip).
+ * amdgpu_waves_per_eu alone leaves .vgpr_count at the registers the kernel uses (7 wavefronts per SIMD at dispatch).
+ * Naming the last register of an allocation step as clobbered makes the descriptor ask for that step: 128 / 96 / 80 VGPRs
+ * = 4 / 5 / 6 wavefronts per SIMD (MI355X_MICROARCH.md, register-file table). */
 template <int WAVES> RT_DEV void occupancy_bound()
 {
     /* the last register of the allocation step that admits WAVES wavefronts per SIMD: 512 / {128, 96, 80} */

@@ -329,7 +329,7 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
 /* performance knobs; results never depend on them. keys 0..3: workgroup->tile order inside an XCD
  * band for raycast / generate_candidate / spatial_resampling / resolve (0 row-major, 1 column-major);
  * key 4: extra LDS bytes per unshadowed spatial_resampling workgroup (round 1's occupancy throttle, kept for
- * A/B runs; the kernel now carries an explicit bound of 5 wavefronts per SIMD). Defaults: {1,0,1,0}, 0.
+ * A/B runs; the kernel carries an explicit register budget instead, key 9: 6 wavefronts per SIMD by default). Defaults: {1,0,1,0}, 0.
  * key 5 (before rt_scene_set): builder (default 3). 0 = device LBVH (Morton codes + Karras) with host pre-split and host
  * collapse (round 1), 1 = host binned SAH (the reference requests HIPRT's high-quality build,
  * common/loader.hpp:98-99), 2 = on the device: pre-split, Morton sort, PLOC hierarchy, wide collapse; only the boxes

@@ -1,7 +1,7 @@
 #!/bin/bash
-# A/B builds of librestir_rt.so with different -D flags, for RT_LIB_PATH (tools/experiments/*.py).
-#   tools/experiments/build_variants.sh name1 "-DX=1" name2 "-DX=2 -DY=3" ...
-cd "$(dirname "$0")/../../cedec_2024_rt_amd/csrc"
+# A/B builds of librestir_rt.so with different -D flags, for RT_LIB_PATH (the tools).
+#   tools/build_variants.sh name1 "-DX=1" name2 "-DX=2 -DY=3" ...
+cd "$(dirname "$0")/../cedec_2024_rt_amd/csrc"
 mkdir -p ../../gpurun_variants
 pids=()
 while [ $# -ge 2 ]; do

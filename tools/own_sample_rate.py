@@ -2,7 +2,7 @@
 whose FINAL reservoir sample (what resolve shades) originates from the pixel itself (origin_position / origin_normal
 bit-equal to the pixel's surface point), config #4 at 1080p, frame 10 of a static sequence."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from cedec_2024_rt_amd import api, scenes

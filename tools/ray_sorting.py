@@ -2,7 +2,7 @@
 frame 3) as a list in 8x8-tile order, walked by the list kernels (rt_trace_mode 6 = one lane per ray, 5 = work-sharing),
 as they are and re-ordered inside blocks of 256 / 1024 consecutive rays (4 / 16 tiles) by target."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from cedec_2024_rt_amd import api, scenes

@@ -1,6 +1,6 @@
 """Dev tool: per-kernel times with use_shadowed_target_function on (README key 3)."""
 import sys, os, json
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from cedec_2024_rt_amd import api, scenes
 from cedec_2024_rt_amd.types import bench_options

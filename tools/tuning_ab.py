@@ -1,7 +1,7 @@
 """A/B of one rt_tuning key on rt_frame (config #4, whole frame on one GPU): throughput (wall clock over 60 frames, one
-sync at the end) and the HIP-event time per kernel.   python tools/experiments/tuning_ab.py KEY V0 V1 [...]"""
+sync at the end) and the HIP-event time per kernel.   python tools/tuning_ab.py KEY V0 V1 [...]"""
 import sys, os, json, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from cedec_2024_rt_amd import api, scenes
 from cedec_2024_rt_amd.types import bench_options
