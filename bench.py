@@ -213,6 +213,7 @@ def _main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     wd = Watchdog(json_fd, rank, world, args)
     frame_limit = float(os.environ.get("BENCH_WATCHDOG_S", "60"))  # seconds without a completed step
+    stall_at = tuple(int(v) for v in os.environ["BENCH_TEST_STALL"].split(":")) if os.environ.get("BENCH_TEST_STALL") else None
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
@@ -363,6 +364,8 @@ def _main():
         for _ in range(steps):
             frame += 1
             wd.tick(f"{w}x{h} timed frame {frame}")  # one store per frame; the limit stays the frame limit
+            if stall_at == (rank, frame):  # BENCH_TEST_STALL="rank:frame": this rank stops here (watchdog self-test)
+                time.sleep(1e6)
             step(frame)
         wd.tick(f"{w}x{h} barrier at the end of the timed region")
         barrier()
