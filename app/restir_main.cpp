@@ -309,6 +309,7 @@ static int rank_main(int rank, int ranks, bool mirror, bool shm, bool equal_stri
 
 int main(int argc, char** argv)
 {
+    setenv("GPU_MAX_HW_QUEUES", "8", 0); /* five streams side by side per rank: before the first HIP call */
     int W = 1920, H = 1080, frames = 8; /* 10_restir_di.cpp:26-27 */
     /* camera "blocks_restir.obj 1", 10_restir_di.cpp:188-189 */
     float eye[3] = {-0.579885f, 22.194597f, -6.567105f}, lookat[3] = {5.224952f, 20.847435f, 1.431192f};

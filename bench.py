@@ -25,8 +25,14 @@ Prints ONE JSON line on rank 0 (contract in the task statement) including
 """
 import argparse
 import hashlib
-import json
 import os
+
+# HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4). The frame uses five streams that must run
+# beside each other (main, pipelined stage 0, tail, second lane, RCCL): with 4 queues two of them share one and which two
+# depends on creation order (profiles/r03_hw_queue_mapping.txt: 0.40 or 0.60 ms per frame at 1080p in 8 strips). The
+# runtime reads the variable when it initialises, i.e. before torch touches the GPU: set here, first thing.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import json
 import sys
 import time
 

@@ -186,6 +186,7 @@ struct rt_ctx
         if (_e != hipSuccess) RT_FAIL(ctx, RT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(_e)); \
     } while (0)
 
+static int stream_priority(const char* env, int dflt);
 static rt_options default_options()
 {
     rt_options o;
@@ -237,6 +238,9 @@ int rt_create(int device, int width, int height, int row_begin, int row_end, int
 {
     if (!out || width <= 0 || height <= 0 || row_begin < 0 || row_end > height || row_begin >= row_end || halo < 0)
         return RT_ERR_ARG;
+    /* five streams of a context want a hardware queue each (see below); effective if this is the process's first HIP call,
+     * harmless otherwise — hosts that initialise HIP earlier export GPU_MAX_HW_QUEUES=8 themselves */
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device >= ndev) return RT_ERR_NO_DEVICE;
     rt_ctx* c = new rt_ctx();
@@ -253,9 +257,21 @@ int rt_create(int device, int width, int height, int row_begin, int row_end, int
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
     }
+    /* All streams of the context are created here, in a fixed order: HIP maps streams onto a small pool of hardware queues
+     * (GPU_MAX_HW_QUEUES, 4 unless the environment says otherwise) and hands a new stream the least-used one, so streams
+     * created lazily, after a host has destroyed and re-created contexts, can land on the queue of the very stream they are
+     * meant to run beside (measured: the pipelined stage 0 on the main stream's queue, 0.39 -> 0.51 ms per frame at 1080p
+     * in 8 strips, profiles/r03_hw_queue_mapping.txt). Order of importance: main, pipelined stage 0, tail, second lane. */
     RT_HIP(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    RT_HIP(c, hipStreamCreateWithPriority(&c->spec_stream, hipStreamNonBlocking, stream_priority("RT_SPEC_PRIORITY", 0)));
+    RT_HIP(c, hipStreamCreateWithPriority(&c->tail_stream, hipStreamNonBlocking, stream_priority("RT_TAIL_PRIORITY", 0)));
     /* default priority: with the lowest priority the lane was starved in some exchanges (A/B in DESIGN.md §7) */
     RT_HIP(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    RT_HIP(c, hipEventCreateWithFlags(&c->ev_spec_go, hipEventDisableTiming));
+    RT_HIP(c, hipEventCreateWithFlags(&c->ev_spec_done, hipEventDisableTiming));
+    for (auto& es : c->ev_spec_t) for (auto& e : es) RT_HIP(c, hipEventCreate(&e));
+    RT_HIP(c, hipEventCreateWithFlags(&c->ev_tail_go, hipEventDisableTiming));
+    RT_HIP(c, hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
     RT_HIP(c, hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming));
     RT_HIP(c, hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming));
     c->stream = c->own_stream;
@@ -1206,12 +1222,8 @@ static int launch_next_raycast(rt_ctx* c, int frame)
     c->spec_gen_valid = false;
     if (!use_next_raycast(c)) { c->spec_valid = false; return RT_OK; }
     const size_t n = local_pixels(c);
-    if (!c->spec_stream)
+    if (!c->d_gset[c->gcur ^ 1][0])
     {
-        RT_HIP(c, hipStreamCreateWithPriority(&c->spec_stream, hipStreamNonBlocking, stream_priority("RT_SPEC_PRIORITY", 0)));
-        RT_HIP(c, hipEventCreateWithFlags(&c->ev_spec_go, hipEventDisableTiming));
-        RT_HIP(c, hipEventCreateWithFlags(&c->ev_spec_done, hipEventDisableTiming));
-        for (auto& es : c->ev_spec_t) for (auto& e : es) RT_HIP(c, hipEventCreate(&e));
         const int o = c->gcur ^ 1;
         for (int k = 0; k < 3; ++k) RT_HIP(c, hipMalloc(&c->d_gset[o][k], n * 16));
         /* halo rows of g1 hold the neighbours' shaded flags (rt_halo_flags_unpack keeps both sets current from here on) */
@@ -1720,12 +1732,6 @@ static int stage_run_ranges(rt_ctx* c, int frame, int stage, int part, int row0,
         {
             /* resolve + tone_mapping on the tail stream, behind everything enqueued so far (and behind the previous
              * frame's tail: same stream); the main stream does not wait for them */
-            if (!c->tail_stream)
-            {
-                RT_HIP(c, hipStreamCreateWithPriority(&c->tail_stream, hipStreamNonBlocking, stream_priority("RT_TAIL_PRIORITY", 0)));
-                RT_HIP(c, hipEventCreateWithFlags(&c->ev_tail_go, hipEventDisableTiming));
-                RT_HIP(c, hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
-            }
             RT_HIP(c, hipEventRecord(c->ev_tail_go, ms));
             RT_HIP(c, hipStreamWaitEvent(c->tail_stream, c->ev_tail_go, 0));
             c->stream = c->tail_stream;
@@ -2227,6 +2233,15 @@ int rt_state_epoch(rt_ctx* c, uint64_t* epoch)
     RT_CHECK_CTX(c);
     if (!epoch) return RT_ERR_ARG;
     *epoch = c->epoch;
+    return RT_OK;
+}
+/* the context's tail stream (resolve + tone_mapping of a staged frame, rt_tuning key 17): a strip driver enqueues its halo-plan
+ * marks there instead of on a stream of its own — one hardware queue less to compete for, and a plan is needed a frame later */
+int rt_side_stream(rt_ctx* c, int which, void** hip_stream)
+{
+    RT_CHECK_CTX(c);
+    if (!hip_stream || which != 0) RT_FAIL(c, RT_ERR_ARG, "which: 0 = tail stream");
+    *hip_stream = (void*)c->tail_stream;
     return RT_OK;
 }
 int rt_get_stream(rt_ctx* c, void** hip_stream)

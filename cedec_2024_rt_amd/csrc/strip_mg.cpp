@@ -178,7 +178,8 @@ struct rt_mg
     int bnd[2][2] = {{0, 0}, {0, 0}}, n_bnd = 0;   /* boundary row ranges (needed by a neighbour), computed first */
     int itr[2][2] = {{0, 0}, {0, 0}}, n_itr = 0;   /* interior row ranges, computed while halos travel */
 
-    hipStream_t comm = nullptr, prep = nullptr; /* prep: the next frame's halo marks, beside this frame's passes */
+    hipStream_t comm = nullptr, prep = nullptr; /* prep: the halo marks of the frames to come, beside this frame's passes */
+    bool own_prep = false;
     hipEvent_t ev_packed = nullptr, ev_arrived = nullptr, ev_arrived2 = nullptr, ev_plan[NSLOT] = {nullptr, nullptr, nullptr}, ev_gbuf = nullptr,
                ev_marked[NSLOT] = {nullptr, nullptr, nullptr}, ev_carried = nullptr;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr; /* GPU-side clock of the frame loop: start of the first / latest frame since rt_mg_reset_stats */
@@ -498,11 +499,13 @@ int rt_mg_create(rt_ctx* ctx, int rank, int world, const int* bounds, int transp
     MG_HIP(m, hipGetDevice(&dev));
     MG_HIP(m, hipStreamCreateWithFlags(&m->comm, hipStreamNonBlocking));
     {
-        /* the plans are needed a frame later: RT_PREP_PRIORITY=1 gives their stream the lowest priority (A/B runs) */
-        const char* e = getenv("RT_PREP_PRIORITY");
-        int least = 0, greatest = 0, prio = 0;
-        if (e && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess) prio = atoi(e) > 0 ? least : (atoi(e) < 0 ? greatest : 0);
-        MG_HIP(m, hipStreamCreateWithPriority(&m->prep, hipStreamNonBlocking, prio));
+        /* the halo plans are marked on the context's tail stream (behind the previous frame's resolve + tone mapping, which
+         * are short and long done when the marks are enqueued): HIP multiplexes streams onto few hardware queues, and every
+         * stream this driver does not create is one chance less for the main stream and the pipelined stage 0 to share one */
+        void* ts = nullptr;
+        MG_RT(m, rt_side_stream(ctx, 0, &ts));
+        m->prep = (hipStream_t)ts;
+        if (!m->prep) { MG_HIP(m, hipStreamCreateWithFlags(&m->prep, hipStreamNonBlocking)); m->own_prep = true; }
     }
     MG_HIP(m, hipEventCreateWithFlags(&m->ev_gbuf, hipEventDisableTiming));
     for (auto& e : m->ev_marked) MG_HIP(m, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -606,7 +609,7 @@ int rt_mg_destroy(rt_mg* m)
     if (m->ev_t0) hipEventDestroy(m->ev_t0);
     if (m->ev_t1) hipEventDestroy(m->ev_t1);
     if (m->comm) hipStreamDestroy(m->comm);
-    if (m->prep) hipStreamDestroy(m->prep);
+    if (m->prep && m->own_prep) hipStreamDestroy(m->prep);
     delete m;
     return RT_OK;
 }

@@ -227,6 +227,7 @@ int rt_halo_fuse_set(rt_ctx* ctx, const rt_halo_fuse* fuse);
 /* ---- hooks used by the native strip driver below (and usable by any other driver) ---- */
 int rt_state_epoch(rt_ctx* ctx, uint64_t* epoch);   /* changes whenever camera, options, scene or an uploaded G-buffer change */
 int rt_get_stream(rt_ctx* ctx, void** hip_stream);  /* the stream calls are enqueued on right now */
+int rt_side_stream(rt_ctx* ctx, int which, void** hip_stream); /* which = 0: the tail stream (rt_tuning key 17); the strip driver marks its halo plans there */
 int rt_geometry(rt_ctx* ctx, int* width, int* height, int* row_begin, int* row_end, int* halo);
 /* device addresses of n_rows storage rows of a reservoir buffer: 64-B records and 16-B radiance side
  * records; dense halos travel from / into the buffers themselves */

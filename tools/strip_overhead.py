@@ -58,10 +58,13 @@ def measure(W, H, N, flags, tris, frames=40, warm=6, rank=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
+    ap.add_argument("--churn", type=int, default=0, help="create and destroy this many strip contexts + drivers first (stream -> hardware queue mapping after a host has re-created its contexts, as bench.py does for cost-weighted strips)")
     ap.add_argument("--only", default=None, help="WxH:N:sparse|dense|onelane|separate, e.g. 3840x2160:8:sparse (for a kernel trace of one case)")
     args = ap.parse_args()
     tris = scenes.make_blocks_restir()
     res = {}
+    for _ in range(args.churn):
+        measure(1920, 1080, 8, 0, tris, frames=3, warm=1)
     if args.only:
         wh, n, mode = args.only.split(":")
         w, h = (int(v) for v in wh.split("x"))
