@@ -134,6 +134,7 @@ struct rt_ctx
     hipStream_t tail_stream = nullptr;
     hipEvent_t ev_tail_go = nullptr, ev_tail = nullptr;
     bool tail_pending_main = false, tail_pending_spec = false;
+    int tail_phys = -1; /* reservoir buffer the tail in flight reads (the frame's final one) */
     int tune_tail = -1; /* -1 auto = strip contexts, 0 never, 1 always */
     HaloFuse fuse = {};        /* rt_halo_fuse_set: halo lists read / written by the running stage's spatial pass itself */
     int spare = 3;             /* physical buffer not named by res_map */
@@ -1168,6 +1169,9 @@ static int join_tail(rt_ctx* c)
     return RT_OK;
 }
 #define JOIN_TAIL(c) do { const int _jt = join_tail(c); if (_jt != RT_OK) return _jt; } while (0)
+/* a kernel of the staged frame that WRITES reservoir buffer `phys` (and reads only what the tail reads too): it waits for the
+ * tail only if that is the buffer the tail reads */
+static int join_tail_for(rt_ctx* c, int phys) { return (c->tail_pending_main && phys == c->tail_phys) ? join_tail(c) : RT_OK; }
 static int trace_grid(const rt_ctx* c)
 {
     const int rows = c->sub0 >= 0 ? c->sub1 - c->sub0 : c->row_end - c->row_begin;
@@ -1292,11 +1296,18 @@ static int raycast_or_take(rt_ctx* c, bool whole, int frame)
         if (c->spec_gen_valid && use_next_generate(c) && c->spec_gen_frame == frame && c->spec_res_epoch == c->res_epoch &&
             c->spec_gen_hist == c->fX)
         {
-            /* this frame's candidates are in the spare buffer already: it becomes Y, the buffer Y would have been is the
-             * new spare (stage 0's generate is skipped; rt_frame_stage_output / _end see the swapped role) */
-            const int old = c->fY;
-            c->fY = c->spare; c->spare = old;
-            c->f_in = c->fY;
+            /* this frame's candidates are in the spare buffer already: it becomes Y (stage 0's generate is skipped;
+             * rt_frame_stage_output / _end see the swapped roles). Of the two buffers the passes ping-pong through, the one the
+             * previous frame's resolve may still be reading on the tail stream (its final buffer) becomes the new spare — the
+             * pipelined stage 0 after next waits for the tail anyway — and pass 0 writes the other one, so that no spatial pass
+             * of this frame has to wait for the previous frame's resolve. With no spatial pass, logical RES_1 keeps its buffer
+             * (the reference resolves a buffer that frame did not write: its content must carry over). */
+            const int r0 = c->fY, r1 = c->fZ;
+            const int prev_final = c->res_map[c->f_final == RT_RES_1 ? RT_RES_1 : RT_RES_0];
+            c->fY = c->spare;
+            if (c->opt.spatial_resampling_passes >= 1 && prev_final == r1) { c->fZ = r0; c->spare = r1; }
+            else c->spare = r0;
+            c->f_in = c->fY; c->f_out = c->fZ;
             c->gen_taken = true;
         }
         c->spec_gen_valid = false;
@@ -1705,7 +1716,7 @@ static int stage_run_ranges(rt_ctx* c, int frame, int stage, int part, int row0,
         mark(2);
         if (part != 1 && rc == RT_OK && !c->gen_taken)
         {
-            rc = join_tail(c); /* this frame's candidates may go where the previous frame's resolve still reads */
+            rc = join_tail_for(c, c->fY); /* this frame's candidates may go where the previous frame's resolve still reads */
             if (rc == RT_OK) rc = launch_generate(c, frame, c->fY, c->fX, c->opt.use_temporal_resampling != 0);
         }
         mark(3);
@@ -1713,7 +1724,7 @@ static int stage_run_ranges(rt_ctx* c, int frame, int stage, int part, int row0,
     else if (stage <= passes)
     {
         const int k = stage - 1;
-        rc = join_tail(c); /* the pass's output buffer can be the one the previous frame's resolve reads */
+        rc = join_tail_for(c, c->f_out); /* the pass's output buffer can be the one the previous frame's resolve reads */
         if (rc == RT_OK) rc = launch_spatial(c, frame, k, c->f_in, c->f_out);
         if (k < 3) mark(4 + k);
     }
@@ -1748,6 +1759,7 @@ static int stage_run_ranges(rt_ctx* c, int frame, int stage, int part, int row0,
             {
                 RT_HIP(c, hipEventRecord(c->ev_tail, c->tail_stream));
                 c->tail_pending_main = true; c->tail_pending_spec = true;
+                c->tail_phys = final_phys;
             }
         }
     }
@@ -1811,7 +1823,7 @@ int rt_frame_stage_end(rt_ctx* c, int stage)
         /* logical RT_RES_0 still equals the post-temporal reservoirs: materialise the copy the
          * reference's save_temporal_reservoir makes (10_restir_di.cpp:314-321) */
         const size_t n = local_pixels(c);
-        JOIN_TAIL(c);
+        { const int jr = join_tail_for(c, X); if (jr != RT_OK) return jr; }
         RT_HIP(c, hipMemcpyAsync(c->d_rec[X], c->d_rec[Y], n * 64, hipMemcpyDeviceToDevice, c->stream));
         RT_HIP(c, hipMemcpyAsync(c->d_rad[X], c->d_rad[Y], n * 16, hipMemcpyDeviceToDevice, c->stream));
     }
