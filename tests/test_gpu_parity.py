@@ -688,6 +688,49 @@ def test_edge_cases_and_error_codes(api, oracle, scenes):
     r4.close()
 
 
+def test_round3_entry_points(api, scenes):
+    """rt_tuning_get reads back what rt_tuning set (and the defaults), rt_build_id names the build, rt_side_stream hands out
+    the tail stream, rt_halo_fuse_set refuses to be called outside a spatial stage or for a side without a neighbour."""
+    import ctypes as C
+
+    L = api.load_library()
+    r = api.Renderer(64, 48)
+    assert r.tuning_get(5) == 3 and "SAH" in r.bvh_builder()          # default builder: the device SAH build
+    assert r.tuning_get(14) == -1 and r.tuning_get(17) == -1 and r.tuning_get(13) == 1
+    for key, val in ((5, 1), (14, 2), (17, 1), (9, 5), (13, 0)):
+        r.tuning(key, val)
+        assert r.tuning_get(key) == val
+    with pytest.raises(api.RtError):
+        r.tuning(5, 4)
+    with pytest.raises(api.RtError):
+        r.tuning_get(99)
+    assert len(api.build_id()) == 16
+    s = C.c_void_p()
+    assert L.rt_side_stream(r.h, 0, C.byref(s)) == 0 and s.value
+    assert L.rt_side_stream(r.h, 1, C.byref(s)) != 0
+    r.set_scene(scenes.make_quad_room())
+    r.lookat((0.5, 2.5, 6.0), (0.0, 1.5, -1.0))
+    fuse = (C.c_void_p * 8)()
+    assert L.rt_halo_fuse_set(r.h, None) == 0                         # NULL clears
+    assert L.rt_halo_fuse_set(r.h, fuse) == 3                         # RT_ERR_STATE: no spatial stage is running
+    r.close()
+    # a strip without a neighbour below: side 0 must stay empty
+    top = api.Renderer(64, 200, rows=(0, 100), halo=87)
+    top.set_scene(scenes.make_quad_room())
+    top.lookat((0.5, 2.5, 6.0), (0.0, 1.5, -1.0))
+    from cedec_2024_rt_amd.types import bench_options
+
+    top.set_options(bench_options())
+    for st in (0,):
+        assert L.rt_frame_stage(top.h, 1, st, 0) == 0
+    assert L.rt_frame_stage_begin(top.h, 1, 1, 0) == 0
+    dummy = (C.c_uint32 * 4)()
+    fuse[0] = C.addressof(dummy)   # need_bitmap[0]: the strip below — there is none
+    fuse[2] = C.addressof(dummy)   # recv_list[0]
+    assert L.rt_halo_fuse_set(top.h, fuse) == 1                       # RT_ERR_ARG
+    top.close()
+
+
 def test_interactive_camera_and_accumulation_reset(api, oracle, scenes):
     """CameraControl (common/misc.hpp:108-224) as C-ABI calls: orbit keeps the distance, zoom scales it,
     pan moves eye and look-at together; a moved camera raises `updated`, which the frame loop turns into
