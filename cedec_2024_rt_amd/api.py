@@ -31,7 +31,7 @@ EXPORTS = [
     "rt_row_shaded", "rt_visibility_rays_walked", "rt_state_epoch", "rt_get_stream", "rt_geometry", "rt_res_region", "rt_lane",
     "rt_mg_partition", "rt_mg_bands", "rt_mg_unique_id", "rt_mg_load_error", "rt_mg_hub_create", "rt_mg_hub_destroy", "rt_mg_create",
     "rt_mg_destroy", "rt_mg_last_error", "rt_mg_frame", "rt_mg_frame_begin", "rt_mg_frame_step", "rt_mg_get_stats", "rt_mg_reset_stats",
-    "rt_mg_selftest_rccl", "rt_tuning_get", "rt_build_id", "rt_halo_fuse_set", "rt_side_stream",
+    "rt_mg_selftest_rccl", "rt_tuning_get", "rt_build_id", "rt_halo_fuse_set", "rt_side_stream", "rt_copy_parts",
 ]
 
 RT_MG_TRANSPORT_RCCL, RT_MG_TRANSPORT_LOCAL, RT_MG_TRANSPORT_MIRROR, RT_MG_TRANSPORT_SHM = 0, 1, 2, 3
@@ -140,6 +140,7 @@ def load_library():
     L.rt_tuning_get.argtypes = [vp, ci, vp]
     L.rt_halo_fuse_set.argtypes = [vp, vp]
     L.rt_side_stream.argtypes = [vp, ci, vp]
+    L.rt_copy_parts.argtypes = [vp, ci, vp, vp, vp]
     L.rt_build_id.argtypes = []
     L.rt_build_id.restype = C.c_char_p
     L.rt_row_shaded.argtypes = [vp, vp]

@@ -970,6 +970,7 @@ struct HaloRegions
     int row0[2], rows[2];
     size_t words[2]; /* rt_halo_bitmap_words of the region = distance between the bitmaps of consecutive passes */
     uint32_t* bitmaps[2];
+    int quick; /* 1 = rows far from the regions test their draws against a radius bound first (rt_tuning key 18) */
 };
 __global__ __launch_bounds__(BLOCK) void k_halo_mark(FrameParams P, const float4* __restrict__ g1, HaloRegions R, int pass0, int n_pass)
 {
@@ -979,9 +980,39 @@ __global__ __launch_bounds__(BLOCK) void k_halo_mark(FrameParams P, const float4
     const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
     if (!(as_uint(g1[li].w) & GB_SHADED) || !P.use_spatial) return;
     const float scale = P.spatial_radius / 1.96f;
+    /* Quick reject (r03): a neighbour lands at most scale * radius + 1 rows from this pixel (|sin| <= 1, one unit for the
+     * float add and the truncation), radius = sqrt(-2 log rv0); rv0 of neighbour k is draw 2k .. 3k of the pass's stream
+     * (two or three draws per neighbour). A pixel dmin rows from the nearest region can therefore mark something only if
+     * one of the first 3 (count - 1) + 1 draws is below exp(-((dmin - 1.01) / scale)^2 / 2) — taken 0.1 % larger, far more
+     * than the <= 1 ulp of the portable log / exp / sqrt; rv0 = 0 (radius = inf, the reference's off-screen case) is below
+     * any threshold and takes the full path. Rows more than ~3 sigma from the edge (half of a band) skip the log / sqrt /
+     * sincos replay for 9 passes in 10: -30 % of the kernel at 4K. The marks are those of the full replay. */
+    int dmin = 0x7fffffff;
+#pragma unroll
+    for (int sd = 0; sd < 2; ++sd)
+        if (R.rows[sd] > 0)
+        {
+            const int d = row < R.row0[sd] ? R.row0[sd] - row : (row >= R.row0[sd] + R.rows[sd] ? row - (R.row0[sd] + R.rows[sd] - 1) : 0);
+            dmin = d < dmin ? d : dmin;
+        }
+    const bool far_row = R.quick && dmin >= 40 && P.spatial_count >= 1 && P.spatial_count <= 8;
+    float thr = 2.0f;
+    if (far_row)
+    {
+        const float q = ((float)dmin - 1.01f) / scale;
+        thr = pm_expf(-0.5f * q * q) * 1.001f;
+    }
     for (int pi = 0; pi < n_pass; ++pi) /* one bitmap per spatial pass, same launch */
     {
         PCG rng = pcg_init(hashPCG4((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame, (uint32_t)(2 + pass0 + pi)), 0);
+        if (far_row)
+        {
+            PCG probe = rng;
+            float lowest = 2.0f;
+            const int n_draws = 3 * (P.spatial_count - 1) + 1;
+            for (int k = 0; k < n_draws; ++k) lowest = fminf(lowest, probe.uniformf());
+            if (!(lowest < thr)) continue; /* no neighbour of this pass can reach a region */
+        }
         for (int k = 0; k < P.spatial_count; ++k)
         {
             const float rv0 = rng.uniformf();
@@ -1081,6 +1112,41 @@ __global__ void k_halo_sparse(HaloLists H, float4* __restrict__ rec, float4* __r
         radb[p] = L[4];
     }
 }
+/* up to 8 device-to-device copies in ONE launch (blockIdx.y = part): the stand-in transports of the strip driver move the
+ * parts of an exchange with it, as one grouped RCCL send/recv is one launch */
+struct CopyParts
+{
+    const char* src[8];
+    char* dst[8];
+    size_t bytes[8];
+};
+__global__ void k_copy_parts(CopyParts P)
+{
+    const int part = blockIdx.y;
+    const char* __restrict__ s = P.src[part];
+    char* __restrict__ d = P.dst[part];
+    const size_t n = P.bytes[part];
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    if ((((uintptr_t)s | (uintptr_t)d) & 15u) == 0u)
+    {
+        const size_t n16 = n / 16;
+        const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(s);
+        uint4* __restrict__ d4 = reinterpret_cast<uint4*>(d);
+        for (size_t i = tid; i < n16; i += stride) d4[i] = s4[i];
+        for (size_t i = n16 * 16 + tid; i < n; i += stride) d[i] = s[i];
+    }
+    else if ((((uintptr_t)s | (uintptr_t)d) & 3u) == 0u)
+    {
+        const size_t n4 = n / 4;
+        const uint32_t* __restrict__ s1 = reinterpret_cast<const uint32_t*>(s);
+        uint32_t* __restrict__ d1 = reinterpret_cast<uint32_t*>(d);
+        for (size_t i = tid; i < n4; i += stride) d1[i] = s1[i];
+        for (size_t i = n4 * 4 + tid; i < n; i += stride) d[i] = s[i];
+    }
+    else
+        for (size_t i = tid; i < n; i += stride) d[i] = s[i];
+}
+
 /* shaded flags of rows as bytes (halo rows of the G-buffer only ever hold these flags) */
 template <bool PACK>
 __global__ void k_halo_flags(float4* __restrict__ g1, size_t off, int n_pix, uint8_t* __restrict__ bytes)

@@ -749,12 +749,19 @@ static int complete(rt_mg* m)
     {
         /* every rank receives what it sent (a neighbour that mirrors it): same launches and bytes as a
          * real exchange with no peer to wait for — the overhead measurements of tools/strip_overhead.py */
+        /* one launch for the whole group, as one grouped ncclSend/ncclRecv is */
+        const void* src[8];
+        void* dst[8];
+        size_t nb[8];
+        int n = 0;
         for (auto& x : m->pending_x)
             for (auto& p : x.parts)
             {
                 if (p.send_bytes != p.recv_bytes) MG_FAIL(m, RT_ERR_STATE, "MIRROR transport: %zu bytes out, %zu in", p.send_bytes, p.recv_bytes);
-                MG_HIP(m, hipMemcpyAsync(p.recv, p.send, p.recv_bytes, hipMemcpyDeviceToDevice, ms));
+                if (n == 8) { MG_RT(m, rt_copy_parts(m->ctx, n, src, dst, nb)); n = 0; }
+                src[n] = p.send; dst[n] = p.recv; nb[n] = p.recv_bytes; ++n;
             }
+        MG_RT(m, rt_copy_parts(m->ctx, n, src, dst, nb));
         return RT_OK;
     }
     for (auto& x : m->pending_x)
@@ -765,12 +772,17 @@ static int complete(rt_mg* m)
         q.pop_front();
         if (msg->parts.size() != x.parts.size()) MG_FAIL(m, RT_ERR_STATE, "LOCAL transport: message shape mismatch between ranks %d and %d", x.peer, m->rank);
         MG_HIP(m, hipStreamWaitEvent(ms, msg->ready, 0));
+        if (x.parts.size() > 8) MG_FAIL(m, RT_ERR_STATE, "LOCAL transport: more than 8 parts in a message");
+        const void* src[8];
+        void* dst[8];
+        size_t nb[8];
         for (size_t i = 0; i < x.parts.size(); ++i)
         {
             if (msg->parts[i].second != x.parts[i].recv_bytes)
                 MG_FAIL(m, RT_ERR_STATE, "LOCAL transport: rank %d sends %zu bytes, rank %d expects %zu", x.peer, msg->parts[i].second, m->rank, x.parts[i].recv_bytes);
-            MG_HIP(m, hipMemcpyAsync(x.parts[i].recv, msg->parts[i].first, x.parts[i].recv_bytes, hipMemcpyDeviceToDevice, ms));
+            src[i] = msg->parts[i].first; dst[i] = x.parts[i].recv; nb[i] = x.parts[i].recv_bytes;
         }
+        MG_RT(m, rt_copy_parts(m->ctx, (int)x.parts.size(), src, dst, nb));
         MG_HIP(m, hipEventRecord(msg->consumed, ms));
         msg->consumed_recorded = true;
     }

@@ -228,6 +228,9 @@ int rt_halo_fuse_set(rt_ctx* ctx, const rt_halo_fuse* fuse);
 int rt_state_epoch(rt_ctx* ctx, uint64_t* epoch);   /* changes whenever camera, options, scene or an uploaded G-buffer change */
 int rt_get_stream(rt_ctx* ctx, void** hip_stream);  /* the stream calls are enqueued on right now */
 int rt_side_stream(rt_ctx* ctx, int which, void** hip_stream); /* which = 0: the tail stream (rt_tuning key 17); the strip driver marks its halo plans there */
+/* n <= 8 device-to-device copies in ONE launch on the context's current stream: what the strip driver's stand-in transports
+ * (LOCAL, MIRROR) move the parts of an exchange with, as one grouped ncclSend/ncclRecv is one launch */
+int rt_copy_parts(rt_ctx* ctx, int n, const void* const* src, void* const* dst, const size_t* bytes);
 int rt_geometry(rt_ctx* ctx, int* width, int* height, int* row_begin, int* row_end, int* halo);
 /* device addresses of n_rows storage rows of a reservoir buffer: 64-B records and 16-B radiance side
  * records; dense halos travel from / into the buffers themselves */
@@ -383,8 +386,11 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
  * key 17 (r03): resolve + tone_mapping of a staged frame on a stream of their own ("tail"): they read only the frame's final
  * reservoirs and G-buffer, so the main stream goes on with the next frame's first halo exchange meanwhile; whatever could
  * overwrite what they read (the next frame's first spatial pass, the pipelined stage 0 after next, any call outside the
- * staged frame, downloads) waits for them. -1 (default) = strip contexts only, 0 = never, 1 = always. Off while
- * rt_timing is enabled. Same results. */
+ * staged frame, downloads) waits for them. -1 (default) = 1 = on (a whole 1080p frame 1.68 -> 1.63 ms, 8 strips 0.44 -> 0.37 ms),
+ * 0 = never. Off while rt_timing is enabled. Same results.
+ * key 18 (r03): 1 (default) = rt_halo_mark lets rows more than 40 rows from a neighbour's region test the pass's first draws
+ * against a bound on the neighbour distance (radius = sqrt(-2 log rv0) <= the rows to go) before replaying log / sqrt / sincos
+ * for every neighbour: nine passes in ten are skipped there. 0 = full replay everywhere. Same marks (tested bit for bit). */
 int rt_tuning(rt_ctx* ctx, int key, int value);
 /* the value a key holds now (measurement records name the builder / variants that were really used) */
 int rt_tuning_get(rt_ctx* ctx, int key, int* value);

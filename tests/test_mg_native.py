@@ -268,6 +268,61 @@ def test_native_strips_option_change_and_irregular_bounds():
 
 
 @pytest.mark.gpu
+def test_halo_mark_quick_reject_marks_the_same_records():
+    """rt_tuning key 18: the quick reject of k_halo_mark (rows far from a neighbour's region test the pass's first draws
+    against a bound on the neighbour distance before replaying log / sqrt / sincos) marks exactly the records of the full
+    replay: need-bitmaps, counts and prefix words of both sides, three passes, four frames, a 270-row strip of the
+    benchmark frame and a 135-row one (bands that meet)."""
+    import ctypes as C
+
+    import torch
+
+    api = _api()
+    from cedec_2024_rt_amd import scenes
+    from cedec_2024_rt_amd.types import bench_options
+
+    L = api.load_library()
+    tris = scenes.make_blocks_restir()
+    W, H = 1920, 1080
+    for n in (4, 8):
+        bounds = api.mg_partition(H, n)
+        ctxs = []
+        for k in (0, 1, 2):
+            c = api.Renderer(W, H, rows=bounds[k], halo=87)
+            c.set_scene(tris)
+            c.lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)
+            c.set_options(bench_options())
+            c.raycast()
+            ctxs.append(c)
+        mid = ctxs[1]
+        a, b = bounds[1]
+        buf = torch.zeros(87 * W + 64, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        for src, row0 in ((ctxs[0], a - 87), (ctxs[2], b)):
+            src.halo_flags_pack(row0, 87, buf.data_ptr())
+            src.sync()
+            mid.halo_flags_unpack(row0, 87, buf.data_ptr())
+            mid.sync()
+        words = mid.halo_bitmap_words(87)
+        marked = 0
+        for frame in (1, 2, 3, 4):
+            got = []
+            for quick in (0, 1):
+                mid.tuning(18, quick)
+                bm = torch.full((2, 3 * words), -1, dtype=torch.int32, device="cuda")
+                torch.cuda.synchronize()  # torch fills on its own stream; the context marks on its non-blocking stream
+                rc = L.rt_halo_mark_sides(mid.h, frame, 0, 3, C.c_void_p(bm[0].data_ptr()), C.c_void_p(bm[1].data_ptr()))
+                assert rc == 0, mid.last_error() if hasattr(mid, "last_error") else rc
+                mid.sync()
+                got.append(bm.cpu().numpy().copy())
+            assert np.array_equal(got[0], got[1]), f"{n} strips, frame {frame}: {(got[0] != got[1]).sum()} words differ"
+            marked += int(got[0][0, 0]) + int(got[0][1, 0])
+        assert marked > 10000, marked
+        for c in ctxs:
+            c.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("W,H", [(1920, 1080), (3840, 2160)])  # BASELINE configs #4 and #5, the 8-GPU partition
 def test_native_strips_full_size(W, H):
     api = _api()
