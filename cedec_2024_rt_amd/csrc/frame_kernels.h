@@ -888,6 +888,217 @@ __global__ __launch_bounds__(BLOCK) void k_spatial_lds(
 }
 
 
+/* Cooperative gather variant of the same pass (rt_tuning key 8 = 2). What bounds k_spatial_gather is not bytes but
+ * address-processing slots of the CU's vector L1: a per-lane gather of a 64-B record is 4 dwordx4 wave-instructions that
+ * each touch 64 different cache lines (TCP_TOTAL_CACHE_ACCESSES = 1 521 per wavefront, 0.47 per cycle and CU). Here the
+ * wavefront fetches its 64 records together: in round j lane l loads one 16-B part of the record lane 16 j + l / 4 wants,
+ * so the four lanes of a quad read ONE 64-B segment (16 segments per wave-instruction instead of 64), as an LDS-DMA load
+ * whose lane-linear destination puts the four parts of a record next to each other; every lane then reads its own
+ * record back with 4 ds_read_b128. Bank conflicts: which part a lane fetches is rotated by the record's lane (the
+ * source address is free, the destination is not), and the reader applies the same rotation.
+ * Same decisions, same arithmetic, same results as spatial_pixel<false>. */
+#ifndef RT_COOP_DMA
+#define RT_COOP_DMA 1 /* 0: stage through VGPRs (global_load_dwordx4 + ds_write_b128) */
+#endif
+/* the common tail: the wavefront's loads have been issued; wait, then every lane reads its own record */
+RT_DEV void wave_gather_finish(float4* s_wave, const int lane, float4& q0, float4& q1, float4& q2, float4& q3)
+{
+#if RT_COOP_DMA
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    RT_WAVE_LDS_FENCE();
+    const int rot = (lane >> 2) & 3;
+    q0 = s_wave[4 * lane + (0 ^ rot)];
+    q1 = s_wave[4 * lane + (1 ^ rot)];
+    q2 = s_wave[4 * lane + (2 ^ rot)];
+    q3 = s_wave[4 * lane + (3 ^ rot)];
+    RT_WAVE_LDS_FENCE(); /* the next round overwrites the image */
+}
+RT_DEV void wave_gather_issue(const float4* p, float4* s_dst, const int lane)
+{
+#if RT_COOP_DMA
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p, (__attribute__((address_space(3))) void*)s_dst, 16, 0, 0);
+#else
+    s_dst[lane] = *p;
+#endif
+}
+/* Every lane names a record (never null: a lane that wants none names any valid one, e.g. its own, and ignores what comes
+ * back - no branches around the loads). By address (records in halo lists), or by index into one buffer (half the lane
+ * exchanges). */
+RT_DEV void wave_gather_records(const float4* q, float4* s_wave, const int lane, float4& q0, float4& q1, float4& q2, float4& q3)
+{
+    const unsigned long long a = (unsigned long long)q;
+    const int lo = (int)(uint32_t)a, hi = (int)(uint32_t)(a >> 32);
+    const float4* p[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) /* all lane exchanges first: they wait on one counter */
+    {
+        const int src = 16 * j + (lane >> 2);
+        const uint32_t slo = (uint32_t)__shfl(lo, src), shi = (uint32_t)__shfl(hi, src);
+        p[j] = (const float4*)(((unsigned long long)shi << 32) | slo);
+    }
+    const int part = (lane & 3) ^ ((lane >> 4) & 3); /* rotation by the record's lane: (src >> 2) & 3 = (lane >> 4) & 3 for every j */
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wave_gather_issue(p[j] + part, s_wave + 64 * j, lane);
+    wave_gather_finish(s_wave, lane, q0, q1, q2, q3);
+}
+RT_DEV void wave_gather_records_at(const float4* __restrict__ rec, const uint32_t idx, float4* s_wave, const int lane, float4& q0, float4& q1,
+                                   float4& q2, float4& q3)
+{
+    uint32_t from[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) from[j] = (uint32_t)__shfl((int)idx, 16 * j + (lane >> 2));
+    const int part = (lane & 3) ^ ((lane >> 4) & 3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wave_gather_issue(rec + 4 * (size_t)from[j] + part, s_wave + 64 * j, lane);
+    wave_gather_finish(s_wave, lane, q0, q1, q2, q3);
+}
+/* the reverse for the 64 records a wavefront writes: every lane puts its record into the image, then in round j lane l
+ * stores one 16-B part of the record of lane 16 j + l / 4: a quad writes one whole 64-B segment (64 write requests per
+ * wavefront reach L2 instead of 256 partial ones). idx = the record's index in rec, < 0: this lane stores nothing. */
+RT_DEV void wave_scatter_records(float4* __restrict__ rec, const int idx, float4* s_wave, const int lane, const float4& q0, const float4& q1,
+                                 const float4& q2, const float4& q3)
+{
+    const int rot = (lane >> 2) & 3;
+    s_wave[4 * lane + (0 ^ rot)] = q0;
+    s_wave[4 * lane + (1 ^ rot)] = q1;
+    s_wave[4 * lane + (2 ^ rot)] = q2;
+    s_wave[4 * lane + (3 ^ rot)] = q3;
+    int to[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) to[j] = __shfl(idx, 16 * j + (lane >> 2));
+    RT_WAVE_LDS_FENCE();
+    const int part = (lane & 3) ^ ((lane >> 4) & 3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (to[j] >= 0) rec[4 * (size_t)to[j] + part] = s_wave[64 * j + lane];
+    RT_WAVE_LDS_FENCE();
+}
+RT_DEV Res res_from_parts(const float4& q0, const float4& q1, const float4& q2, const float4& q3, bool& shaded)
+{
+    Res r;
+    r.hit_p = F3(q0.x, q0.y, q0.z);
+    r.ucw = q0.w;
+    r.hit_n = F3(q1.x, q1.y, q1.z);
+    const uint32_t mb = as_uint(q1.w);
+    r.M = (int)(mb & RES_M_MASK);
+    r.vis = (mb & RES_VIS_BIT) != 0u;
+    shaded = (mb & RES_SHADED_BIT) != 0u;
+    r.org_p = F3(q2.x, q2.y, q2.z);
+    r.lum = q2.w;
+    r.org_n = F3(q3.x, q3.y, q3.z);
+    r.w_sum = q3.w;
+    r.rad = F3(0.0f, 0.0f, 0.0f);
+    r.ownv = 0u;
+    return r;
+}
+/* FUSED: halo records live in the exchange lists (HaloFuse, multi-GPU strips); otherwise every record is in in_rec */
+template <int WAVES, bool FUSED>
+__global__ __launch_bounds__(BLOCK) void k_spatial_coop(
+    SceneView S, FrameParams P, HaloFuse F, const float4* __restrict__ g0, const float4* __restrict__ g1, const float4* __restrict__ in_rec,
+    const float4* __restrict__ in_rad, float4* __restrict__ out_rec, float4* __restrict__ out_rad)
+{
+    occupancy_bound<WAVES>();
+    __shared__ __attribute__((aligned(16))) float4 s_img[BLOCK / 64][256];
+    const int lane = threadIdx.x & 63;
+    float4* s_wave = s_img[threadIdx.x >> 6];
+    int x = 0, row = P.lrow0;
+    const bool in_image = tile_pixel<BLOCK>(P, x, row);
+    const int yi = P.H - 1 - row;
+    const size_t li = in_image ? (size_t)x + (size_t)(row - P.lrow0) * P.W : 0; /* out of the image: names record 0, stores nothing */
+    float4 G0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), G1 = G0;
+    if (in_image) { G0 = g0[li]; G1 = g1[li]; }
+    const bool active = in_image && (as_uint(G1.w) & GB_SHADED);
+    const f3 sp = F3(G0.x, G0.y, G0.z), sn = F3(G1.x, G1.y, G1.z);
+    PCG rng = pcg_init(hashPCG4((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame, (uint32_t)(2 + P.pass)), 0);
+    float4 q0, q1, q2, q3;
+    wave_gather_records_at(in_rec, (uint32_t)li, s_wave, lane, q0, q1, q2, q3);
+    bool own_shaded;
+    Res r = res_from_parts(q0, q1, q2, q3, own_shaded);
+    const float4* rad_from = in_rad + li;
+    bool took_other = false;
+    if (P.use_spatial)
+    {
+        const float scale = P.spatial_radius / 1.96f;
+        /* rejection_heuristics' first distance is that of r's origin: the own one until a neighbour's sample is taken, that
+         * neighbour's from then on (res_take_sample copies the origin) - the same expression on the same operands */
+        float d0 = length(r.org_p - P.eye);
+        for (int k = 0; k < P.spatial_count; ++k) /* wave-uniform trip count: every lane takes part in every round's fetch */
+        {
+            bool have = false;
+            uint32_t nidx = (uint32_t)li;
+            const float4* nq = in_rec + 4 * li;
+            const float4* nrad = nullptr;
+            if (active)
+            {
+                const float rv0 = rng.uniformf();
+                const float rv1 = rng.uniformf();
+                /* common/reservoir.hpp:89-95 with portable log/cos/sin */
+                const float radius = sqrtf(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
+                const float phi = 2.0f * kPI * rv1;
+                float sn_phi, cs_phi;
+                pm_sincosf(phi, &sn_phi, &cs_phi);
+                const float gx = radius * cs_phi, gy = radius * sn_phi;
+                const int nx = f2i_sat((float)x + scale * gx);
+                const int ny = f2i_sat((float)yi + scale * gy);
+                const int nrow = P.H - 1 - ny;
+                const int lr = nrow - P.lrow0;
+                have = !(nx < 0 || nx >= P.W || ny < 0 || ny >= P.H) && !(nx == x && ny == yi) && !(lr < 0 || lr >= P.lrows);
+                if (have)
+                {
+                    nidx = (uint32_t)nx + (uint32_t)lr * (uint32_t)P.W;
+                    if (FUSED) nq = halo_record(F, P.W, in_rec, in_rad, (size_t)nidx, nx, nrow, nrad);
+                    else nrad = in_rad + nidx;
+                }
+            }
+            if (FUSED) wave_gather_records(nq, s_wave, lane, q0, q1, q2, q3);
+            else wave_gather_records_at(in_rec, nidx, s_wave, lane, q0, q1, q2, q3);
+            bool n_shaded;
+            Res nr = res_from_parts(q0, q1, q2, q3, n_shaded);
+            if (have && n_shaded) /* not shaded: sky or emissive neighbour (10_restir_di.cu:326-338) */
+            {
+                float p_hat_y = target_unshadowed(sp, sn, nr.hit_p, nr.hit_n, nr.lum);
+                if (P.vis_reuse) p_hat_y *= nr.vis ? 1.0f : 0.0f;
+                /* rejection_heuristics(r.org_p, r.org_n, nr.org_p, nr.org_n, P.eye) (rt_device.h) with d0 carried */
+                const float d1 = length(nr.org_p - P.eye);
+                const float diff = (d1 - d0) * (d1 - d0) / d0;
+                float rw = 1.0f;
+                rw *= pm_expf(-32.0f * diff);
+                rw *= pm_pow8f(fmax_dev(dot(r.org_n, nr.org_n), 0.0f));
+                nr.M = scale_M(nr.M, rw);
+                const float weight = p_hat_y * nr.ucw * (float)nr.M;
+                const float u = rng.uniformf();
+                r.w_sum += weight;
+                r.M += nr.M;
+                if (u < weight / r.w_sum)
+                {
+                    res_take_sample(r, nr);
+                    d0 = d1;
+                    rad_from = nrad;
+                    took_other = true;
+                }
+            }
+        }
+        const float p_hat = target_unshadowed(sp, sn, r.hit_p, r.hit_n, r.lum);
+        r.ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
+    }
+    if (active)
+    {
+        const float4 rq = *rad_from;
+        r.rad = F3(rq.x, rq.y, rq.z);
+        r.ownv = took_other ? 0u : as_uint(rq.w);
+    }
+    else
+        r = res_zero(); /* the reference stores nothing here (:275-287); we keep the shaded bit valid */
+    const uint32_t mbits = ((uint32_t)r.M & RES_M_MASK) | (r.vis ? RES_VIS_BIT : 0u) | (active ? RES_SHADED_BIT : 0u);
+    wave_scatter_records(out_rec, in_image ? (int)li : -1, s_wave, lane, make_float4(r.hit_p.x, r.hit_p.y, r.hit_p.z, r.ucw),
+                         make_float4(r.hit_n.x, r.hit_n.y, r.hit_n.z, as_float(mbits)), make_float4(r.org_p.x, r.org_p.y, r.org_p.z, r.lum),
+                         make_float4(r.org_n.x, r.org_n.y, r.org_n.z, r.w_sum));
+    if (!in_image) return;
+    out_rad[li] = make_float4(r.rad.x, r.rad.y, r.rad.z, as_float(r.ownv));
+    if (FUSED) res_give(F, P.W, li, x, row, r, active);
+}
+
 /* SURVEY.md §8(d) ALGORITHMIC bytes of one spatial_resampling launch, counted with the
  * reference's record sizes (Visibility 16 B, Reservoir 76 B): per pixel 16; per shaded pixel
  * +76 in +76 out; per neighbour that passed the on-screen / not-self tests +16, and +76 more if
@@ -1968,6 +2179,7 @@ __global__ void k_math_eval(int fn, const float* __restrict__ in, int n, float* 
         case 25: r = pm_powf_pos(in[i], 1.0f / 2.2f); break;
         case 26: r = in[2 * (size_t)i] / in[2 * (size_t)i + 1]; break;
         case 27: r = sqrtf(in[i]); break;
+        case 30: r = as_float(f2i_sat(in[i])); break; /* the bits of the int */
         default: break;
     }
     out[i] = r;

@@ -75,9 +75,9 @@ struct rt_ctx
      * pass's occupancy limiter (extra dynamic LDS). Defaults from the sweep in DESIGN.md §5. */
     int tune_tile_mode[5] = {1, 0, 1, 0, 0};
     int tune_spatial_lds = 0;     /* rt_tuning key 4: extra dynamic LDS per unshadowed spatial workgroup (A/B of the old throttle) */
-    int tune_spatial_variant = 0; /* rt_tuning key 8: 0 = k_spatial_gather (default since the xnack- build: 0.169 / 0.176 / 0.178 ms per pass
-                                     against 0.174 / 0.179 / 0.181), 1 = k_spatial_lds (staged shaded-bit window; falls back to 0 where it
-                                     does not apply) */
+    int tune_spatial_variant = 2; /* rt_tuning key 8: 2 = k_spatial_coop (default: four lanes per record, LDS-DMA gathers, transposed
+                                     stores), 0 = k_spatial_gather (one per-lane gather per neighbour), 1 = k_spatial_lds (staged
+                                     shaded-bit window; falls back to 0 where it does not apply) */
     int tune_spatial_waves = -1;  /* rt_tuning key 9: register budget of the unshadowed spatial pass in wavefronts per SIMD: 4, 5, 6, 0 = what the
                                      kernel needs (7), -1 = auto: 4 for the gather kernel (its neighbour window must stay in L2: 0.184 vs 0.202 ms
                                      per pass), none for the LDS-staged kernel (0.181 ms unbounded, 0.188 at 4) — profiles/r02_spatial_variants.json */
@@ -1484,6 +1484,15 @@ static int launch_spatial(rt_ctx* c, int frame, int pass, int in_phys, int out_p
         switch (c->tune_spatial_waves) { case 4: RT_SPL(4); break; case 5: RT_SPL(5); break; case 6: RT_SPL(6); break; default: RT_SPL(0); break; }
 #undef RT_SPL
     }
+    else if (c->tune_spatial_variant == 2)
+    {
+#define RT_SPC2(WV, FU) k_spatial_coop<WV, FU><<<launch_grid(c), BLOCK, (size_t)c->tune_spatial_lds, c->stream>>>(S, P, c->fuse, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys])
+#define RT_SPC(WV) do { if (fused) RT_SPC2(WV, true); else RT_SPC2(WV, false); } while (0)
+        const bool fused = c->fuse.recv[0] || c->fuse.recv[1] || c->fuse.send[0] || c->fuse.send[1];
+        switch (c->tune_spatial_waves < 0 ? RT_SPATIAL_GATHER_AUTO_WAVES : c->tune_spatial_waves) { case 4: RT_SPC(4); break; case 5: RT_SPC(5); break; case 6: RT_SPC(6); break; default: RT_SPC(0); break; }
+#undef RT_SPC2
+#undef RT_SPC
+    }
     else
     {
 #define RT_SPG(WV) k_spatial_gather<WV><<<launch_grid(c), BLOCK, (size_t)c->tune_spatial_lds, c->stream>>>(S, P, c->fuse, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys])
@@ -2524,7 +2533,7 @@ int rt_tuning(rt_ctx* c, int key, int value)
     else if (key == 5 && value >= 0 && value <= 3) c->bvh_builder = value; /* before rt_scene_set */
     else if (key == 6 && value >= 0 && value <= 2) c->pt_wavefront = value;
     else if (key == 7 && value >= 0) c->bvh_bfs_records = value; /* before rt_scene_set */
-    else if (key == 8 && (value == 0 || value == 1)) c->tune_spatial_variant = value;
+    else if (key == 8 && value >= 0 && value <= 2) c->tune_spatial_variant = value;
     else if (key == 9 && (value == 0 || value == -1 || (value >= 4 && value <= 6))) c->tune_spatial_waves = value;
     else if (key == 10 && value >= 1 && value <= 256) c->ploc_radius = value; /* before rt_scene_set */
     else if (key == 11 && (value == 0 || value == 1)) c->tune_defer_vis = value;

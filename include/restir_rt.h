@@ -348,10 +348,12 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
  * for 09_ris, whose per-bounce RIS makes compaction pay; one launch for 07_pt). Same results.
  * key 7 (before rt_scene_set): number of wide-BVH records emitted breadth-first before the
  * collapse switches to depth-first order (record order only; no measurable effect, default 2048).
- * key 8: unshadowed spatial_resampling as 0 (default since the library is built for gfx950:xnack-, where it is the faster
- * one) = dependent record gathers, 1 = LDS-staged variant: the tile's +-87-pixel window of shaded bits staged in LDS,
- * neighbour addresses derived from LDS alone, the record of neighbour k+1 in flight while neighbour k is merged
- * (whole-frame contexts, radius <= 30, <= 5 neighbours; the gather kernel otherwise).
+ * key 8: unshadowed spatial_resampling as 2 (default) = the wavefront fetches the 64 neighbour records of a round together,
+ * four lanes per 64-B record, as LDS-DMA loads that land transposed in LDS, and writes its 64 records the same way (a
+ * quarter of the L1 address slots and L2 write requests of 0); 0 = one dependent per-lane record gather per neighbour;
+ * 1 = LDS-staged variant: the tile's +-87-pixel window of shaded bits staged in LDS, neighbour addresses derived from LDS
+ * alone, the record of neighbour k+1 in flight while neighbour k is merged (whole-frame contexts, radius <= 30, <= 5
+ * neighbours; kernel 0 otherwise). Per pass at 1920x1080: 0.150 / 0.183 / 0.184 ms (2 / 0 / 1).
  * key 9: register budget of the unshadowed spatial pass, in wavefronts per SIMD (4, 5, 6; 0 = unbounded = 7; -1 = auto,
  * default: 6 for the gather kernel, none for the LDS-staged kernel).
  * key 10 (before rt_scene_set): PLOC search radius of builder 2 (places in Morton order, default 16).

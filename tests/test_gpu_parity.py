@@ -95,6 +95,14 @@ def test_portable_math_and_ieee_on_device(api, oracle):
     dev = r.math_eval(26, x)
     host = (a / b).astype(np.float32)
     assert _eq_bits(dev, host), "fp32 division differs from IEEE"
+    # float -> int the way every kernel and the oracle do it (rt_device.h f2i_sat = v_cvt_i32_f32): NaN -> 0, saturating, toward zero
+    x = np.concatenate([(u * 4000 - 2000).astype(np.float32), (u * 1e10 - 5e9).astype(np.float32),
+                        np.float32([np.nan, np.inf, -np.inf, 2147483520.0, 2147483648.0, -2147483648.0, -2147483904.0, 3e9, -3e9, -0.0, 0.99999994, -0.99999994,
+                                    1e-45, -1e-45])])
+    dev = r.math_eval(30, x).view(np.int32)
+    x64 = x.astype(np.float64)
+    host = np.where(np.isnan(x64), 0, np.clip(np.trunc(np.nan_to_num(x64, nan=0.0, posinf=3e9, neginf=-3e9)), -2147483648, 2147483647)).astype(np.int64)
+    assert (dev.astype(np.int64) == host).all(), "float -> int conversion differs"
     r.close()
 
 
@@ -786,14 +794,15 @@ def test_interactive_camera_and_accumulation_reset(api, oracle, scenes):
 @pytest.mark.parametrize("W,H,optkw", [(480, 270, dict()), (333, 190, dict(spatial_resampling_sample_count=3, use_visibility_reuse=0)),
                                        (1920, 1080, dict())])
 def test_lds_staged_spatial_variant_is_bit_identical(api, scenes, W, H, optkw):
-    """rt_tuning key 8 = 1: the unshadowed spatial pass with the tile's shaded-bit window staged in LDS makes the same
+    """rt_tuning key 8 = 1 (the unshadowed spatial pass with the tile's shaded-bit window staged in LDS) and 8 = 2 (the
+    wavefront fetches its 64 neighbour records together, four lanes per record, through LDS) make the same
     decisions as the gather kernel: accumulation, pixels and all three reservoir buffers identical over 3 frames."""
     from cedec_2024_rt_amd.types import bench_options
 
     tris = scenes.make_blocks_restir() if W == 1920 else scenes.make_quad_room()
     eye, at = (scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT) if W == 1920 else ((0.5, 2.5, 6.0), (0.0, 1.5, -1.0))
     rs = []
-    for variant in (0, 1):
+    for variant in (0, 1, 2):
         r = api.Renderer(W, H)
         r.set_scene(tris)
         r.lookat(eye, at)
@@ -804,7 +813,8 @@ def test_lds_staged_spatial_variant_is_bit_identical(api, scenes, W, H, optkw):
         for r in rs:
             r.frame(frame)
         for buf in (api.RT_BUF_ACCUMULATION, api.RT_BUF_PIXELS, api.RT_BUF_RES_0, api.RT_BUF_RES_1, api.RT_BUF_RES_TEMPORAL):
-            assert _eq_bits(rs[0].download(buf), rs[1].download(buf)), (frame, buf)
+            for r in rs[1:]:
+                assert _eq_bits(rs[0].download(buf), r.download(buf)), (frame, buf)
     for r in rs:
         r.close()
 

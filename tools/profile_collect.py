@@ -115,7 +115,7 @@ if scon is not None:
     json.dump(sh, open(os.path.join(dst, f"{tag}_shadowed_pmc.json"), "w"), indent=1)
 
 # spatial kernel HBM traffic, corrected as calibrated in profiles/r01_fetch_calibration.json
-sp = [k for k in fw["FETCH_SIZE"] if k.startswith(("k_spatial_gather", "k_spatial_lds", "k_spatial<false"))]
+sp = [k for k in fw["FETCH_SIZE"] if k.startswith(("k_spatial_coop", "k_spatial_gather", "k_spatial_lds", "k_spatial<false"))]
 if sp:
     k = sp[0]
     W, H = 1920, 1080
@@ -132,7 +132,7 @@ if sp:
     if os.path.exists(bidf):
         bid = open(bidf).read().split()[0]
     vfrac = {kk: round(e["valu_issue_fraction"], 3) for kk, e in out.items()
-             if "valu_issue_fraction" in e and kk.split("<")[0] in ("k_raycast", "k_generate_candidate", "k_resolve", "k_spatial", "k_spatial_gather", "k_spatial_lds")}
+             if "valu_issue_fraction" in e and kk.split("<")[0] in ("k_raycast", "k_generate_candidate", "k_resolve", "k_spatial", "k_spatial_coop", "k_spatial_gather", "k_spatial_lds")}
     json.dump({
         "kernel": k, "round": tag, "build_id": bid, "lib_sha256": sha, "valu_issue_frac": vfrac,
         "workload": "blocks_restir stand-in 1920x1080, bench options",
