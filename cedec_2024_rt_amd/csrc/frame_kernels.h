@@ -297,6 +297,8 @@ RT_DEV bool temporal_merge(const FrameParams& P, int x, int yi, f3 sp, f3 sn, Re
 #ifndef RT_GENERATE_WS_WAVES
 #define RT_GENERATE_WS_WAVES 5
 #endif
+RT_DEV void wave_scatter_records(float4* __restrict__ rec, const int idx, float4* s_wave, const int lane, const float4& q0, const float4& q1,
+                                 const float4& q2, const float4& q3);
 template <bool FUSE_TEMPORAL, bool SHADOWED, bool DEFER = false, bool PIPE = false, bool WS = false>
 __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_WAVES) void k_generate_candidate(
     SceneView S, FrameParams P, const float4* __restrict__ g0, const float4* __restrict__ g1,
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_W
     const uint32_t flags = as_uint(G1.w);
     if (in_image && !(flags & GB_SHADED))
     {
-        res_store(out_rec, out_rad, li, r, false); /* Reservoir{} (:56-70) */
+        if (!LATE) res_store(out_rec, out_rad, li, r, false); /* Reservoir{} (:56-70); LATE: with the wavefront's other records below */
         if (!DEFER && !LATE) return;
     }
     /* DEFER keeps every lane to the end (the queue append is a wave-level operation); so does LATE (every lane of the
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_W
     }
     if (!LATE) res_store(out_rec, out_rad, li, r, true);
     }
-    if (LATE)
+    if constexpr (LATE)
     {
         /* Work-sharing kernel: the merge first, the visibility-reuse ray of :127-131 after it, at ONE call site for the
          * whole wavefront. The ray's answer is observable only if the candidate survived (otherwise the stored bit is
@@ -468,7 +470,14 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_W
          * lanes outside the image walk no ray of their own and take over parts of the others' walks instead. */
         const bool visible = check_visibility_wide<TRACE_BLOCK, true>(S.wide, s_stack, late_sp, late_sn, r.hit_p, late_live, S.bvh.tv, as_int(G0.w));
         if (late_live) { r.vis = visible; r.ownv = ownv_of(visible); }
-        if (in_image && (flags & GB_SHADED)) res_store(out_rec, out_rad, li, r, true);
+        /* the wavefront's 64 records leave together, a quad per record (wave_scatter_records below; the walk's LDS is idle now) */
+        const bool shaded = in_image && (flags & GB_SHADED);
+        const uint32_t mbits = ((uint32_t)r.M & RES_M_MASK) | (r.vis ? RES_VIS_BIT : 0u) | (shaded ? RES_SHADED_BIT : 0u);
+        static_assert(sizeof(s_stack) >= 4096, "the record image needs 64 x 64 B");
+        wave_scatter_records(out_rec, in_image ? (int)li : -1, reinterpret_cast<float4*>(s_stack), (int)(threadIdx.x & 63),
+                             make_float4(r.hit_p.x, r.hit_p.y, r.hit_p.z, r.ucw), make_float4(r.hit_n.x, r.hit_n.y, r.hit_n.z, as_float(mbits)),
+                             make_float4(r.org_p.x, r.org_p.y, r.org_p.z, r.lum), make_float4(r.org_n.x, r.org_n.y, r.org_n.z, r.w_sum));
+        if (in_image) out_rad[li] = make_float4(r.rad.x, r.rad.y, r.rad.z, as_float(r.ownv));
     }
     if (DEFER)
     {
