@@ -43,10 +43,8 @@ if ROOT not in sys.path:
 W, H = 1920, 1080
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HALO = 87
-# relative cost of a storage row for the strip partition: every pixel pays the primary ray and the
-# epilogue, a shaded pixel also RIS + reuse + two shadow rays (kernel times of profiles/r02_a: 0.33 ms
-# over all pixels, 2.0 ms over the shaded ones)
-COST_PIXEL, COST_SHADED = 1, 7
+# strip heights: rounds of "every rank times its own strip alone, the strips are re-cut by measured cost per row" (make_strip)
+BALANCE_ROUNDS = 2
 
 
 def cpu_baseline(tris, eye, center, frames=2):
@@ -289,28 +287,50 @@ def _main():
         return r, build_ms
 
     def make_strip(w, h):
-        """This rank's strip context + native driver. Strip heights are cost-weighted: an equal partition
-        renders the G-buffer once, every rank reports the shaded pixels of its rows, and the strips are cut so
-        that the most expensive one is as cheap as possible (>= 87 rows each)."""
+        """This rank's strip context + native driver. Strip heights are cut by MEASURED cost: the job runs at the pace of
+        its slowest rank, and what a strip costs is far from proportional to its rows or its shaded pixels (fixed work per
+        frame, halo work per boundary; a shaded-pixel model made the slowest strip 7 % slower than equal rows at 4K,
+        profiles/r03_strip_balance.jsonl). So each rank times a few frames of its own strip with the MIRROR transport (same
+        launches and message sizes, no neighbour involved), the times are all-gathered, every rank re-cuts the rows by
+        piecewise-constant cost per row (rt_mg_partition, >= 87 rows each), BALANCE_ROUNDS times; the cut with the lowest
+        maximum is kept. Start-up work, outside the timed region; the strips are in config.strips."""
         uid = [api.mg_unique_id() if rank == 0 and not dev_mirror else None]
         if dev_shm:
             uid = [f"rtmg_{os.getpid()}_{time.time_ns():x}_{w}x{h}" if rank == 0 else None]  # per-run nonce: never a stale segment
         dist.broadcast_object_list(uid, src=0)
         bounds = api.mg_partition(h, world, HALO)
-        r, build_ms = make_renderer(w, h, bounds[rank])
         part = "equal rows"
-        if not os.environ.get("BENCH_EQUAL_STRIPS"):
-            r.raycast()
-            mine = r.row_shaded().astype(np.int64)
-            allc = [None] * world
-            dist.all_gather_object(allc, mine)
-            cost = np.concatenate(allc) * COST_SHADED + w * COST_PIXEL
-            nb = api.mg_partition(h, world, HALO, cost.astype(np.uint32))
-            if nb != bounds:
-                r.close()
-                bounds = nb
-                r, build_ms = make_renderer(w, h, bounds[rank])
-            part = "cost-weighted rows"
+        # ranks that share one GPU (the dev transports) cannot time their strips: equal rows there (BENCH_FORCE_BALANCE runs the
+        # rounds anyway, to exercise this code on a one-GPU box)
+        if not os.environ.get("BENCH_EQUAL_STRIPS") and ((not dev_shm and not dev_mirror) or os.environ.get("BENCH_FORCE_BALANCE")):
+            best = None
+            for it in range(BALANCE_ROUNDS + 1):
+                wd.tick("strip balance round %d" % it, 600)
+                rb, _ = make_renderer(w, h, bounds[rank])
+                mgb = api.MultiGpu(rb, rank, bounds, transport=api.RT_MG_TRANSPORT_MIRROR)
+                for f in range(1, 7):
+                    mgb.frame(f)
+                rb.sync()
+                t0 = time.perf_counter()
+                for f in range(7, 27):
+                    mgb.frame(f)
+                rb.sync()
+                mine = (time.perf_counter() - t0) / 20 * 1e3
+                mgb.close()
+                rb.close()
+                allt = [None] * world
+                dist.all_gather_object(allt, mine)
+                if best is None or max(allt) < best[0]:
+                    best = (max(allt), bounds, it)
+                if it == BALANCE_ROUNDS:
+                    break
+                cost = np.zeros(h)
+                for (a, b), ms in zip(bounds, allt):
+                    cost[a:b] = ms / (b - a)
+                bounds = api.mg_partition(h, world, HALO, np.maximum(1, cost / cost.max() * 60000).astype(np.uint32))
+            bounds = best[1]
+            part = "rows cut by measured cost per strip (round %d of %d: slowest strip alone %.3f ms)" % (best[2], BALANCE_ROUNDS, best[0])
+        r, build_ms = make_renderer(w, h, bounds[rank])
         def python_strips(why):
             """every rank TOGETHER: the round-1 schedule (Python StripFrame over torch.distributed send/recv: same HIP
             kernels, same images, a slower host loop)"""

@@ -14,7 +14,8 @@
  *     finds finished. A frame whose plan is not there (first frame, camera / option / scene change,
  *     non-consecutive frame number) builds it on the spot with one synchronisation ("cold" frame);
  *   - dense halos are sent from and received into the reservoir buffers themselves (no staging);
- *   - RCCL is called directly (ncclSend/ncclRecv grouped per exchange on a communication stream),
+ *   - RCCL is called directly (ncclSend/ncclRecv grouped per exchange; on the main stream whenever that stream would
+ *     only wait for the exchange anyway, see comm_on_main; on a communication stream otherwise),
  *     loaded with dlopen so that librestir_rt.so has no link-time dependency on it;
  *   - cost-weighted strip heights (rt_mg_partition) and the boundary/interior row bands.
  *
@@ -151,6 +152,13 @@ struct rt_mg
     std::vector<int> bounds;
     int transport = RT_MG_TRANSPORT_RCCL;
     bool sparse = true, two_lanes = true;
+    /* RCCL: grouped send / recv on the MAIN stream instead of the communication stream. A cross-stream dependency costs
+     * ~10 us on this GPU (tools/stream_hops.hip: 2.5 us per link on one stream, 13.5 across two), and an exchange on the
+     * communication stream puts two of them on the frame's critical chain (pass -> send, recv -> next pass): 6 per frame.
+     * The main stream has nothing else to do while an exchange is in flight whenever the interior rows run on the second
+     * lane or there are none, so the exchange goes there then (the MIRROR transport, which the compute-side bounds are
+     * measured with, always copied on the main stream). RT_MG_COMM_STREAM=1 in the environment keeps the separate stream. */
+    bool comm_on_main = false, pending_on_main = false;
     bool fuse_halos = true; /* sparse halos packed / unpacked by the spatial passes themselves (rt_halo_fuse_set, r03) */
     std::string err;
 
@@ -465,6 +473,10 @@ int rt_mg_create(rt_ctx* ctx, int rank, int world, const int* bounds, int transp
     m->bounds.assign(bounds, bounds + world + 1);
     m->sparse = !(flags & RT_MG_DENSE);
     m->two_lanes = !(flags & RT_MG_ONE_LANE);
+    {
+        const char* e = getenv("RT_MG_COMM_STREAM");
+        m->comm_on_main = !(e && e[0] == '1');
+    }
     m->fuse_halos = !(flags & RT_MG_SEPARATE_PACK);
     memset(&m->stats, 0, sizeof(m->stats));
     int ra = 0, rb = 0;
@@ -683,17 +695,23 @@ static int post(rt_mg* m, std::vector<Exchange>&& xs)
     }
     if (m->transport == RT_MG_TRANSPORT_RCCL)
     {
-        MG_HIP(m, hipEventRecord(m->ev_packed, ms));
-        MG_HIP(m, hipStreamWaitEvent(m->comm, m->ev_packed, 0));
+        const bool on_main = m->comm_on_main && (m->n_itr == 0 || m->two_lanes); /* one lane with interior rows: they follow the boundary rows on the main stream */
+        hipStream_t cs = on_main ? ms : m->comm;
+        m->pending_on_main = on_main;
+        if (!on_main)
+        {
+            MG_HIP(m, hipEventRecord(m->ev_packed, ms));
+            MG_HIP(m, hipStreamWaitEvent(cs, m->ev_packed, 0));
+        }
         MG_NCCL(m, g_rccl.GroupStart());
         for (auto& x : m->pending_x)
             for (auto& p : x.parts)
             {
-                MG_NCCL(m, g_rccl.Send(p.send, p.send_bytes, ncclUint8, x.peer, m->nccl, m->comm));
-                MG_NCCL(m, g_rccl.Recv(p.recv, p.recv_bytes, ncclUint8, x.peer, m->nccl, m->comm));
+                MG_NCCL(m, g_rccl.Send(p.send, p.send_bytes, ncclUint8, x.peer, m->nccl, cs));
+                MG_NCCL(m, g_rccl.Recv(p.recv, p.recv_bytes, ncclUint8, x.peer, m->nccl, cs));
             }
         MG_NCCL(m, g_rccl.GroupEnd());
-        MG_HIP(m, hipEventRecord(m->ev_arrived, m->comm));
+        if (!on_main) MG_HIP(m, hipEventRecord(m->ev_arrived, cs));
         return RT_OK;
     }
     m->pending_local.clear();
@@ -718,7 +736,7 @@ static int complete(rt_mg* m)
     m->pending = false;
     if (m->transport == RT_MG_TRANSPORT_RCCL)
     {
-        MG_HIP(m, hipStreamWaitEvent(ms, m->ev_arrived, 0));
+        if (!m->pending_on_main) MG_HIP(m, hipStreamWaitEvent(ms, m->ev_arrived, 0));
         return RT_OK;
     }
     if (m->transport == RT_MG_TRANSPORT_SHM)

@@ -1,4 +1,4 @@
-"""What ONE rank of an N-strip frame costs when it never waits for a neighbour: the native strip
+"""What a rank of an N-strip frame costs when it never waits for a neighbour: the native strip
 driver (rt_mg_*, csrc/strip_mg.cpp) with the MIRROR transport (a rank receives the bytes it sent, by a
 device copy), alone on the GPU. Same launches, same pack/unpack work and message sizes as a real
 exchange; only the xGMI hop and the peers' skew are missing. Reported per N and image size:
@@ -7,6 +7,10 @@ exchange; only the xGMI hop and the peers' skew are missing. Reported per N and 
   host_us         host time spent enqueueing one frame (rt_mg_stats.host_ns / frames)
   plan_wait_us    host time waiting for the next frame's halo plan (0 = the plan was ready)
   speedup_bound   single-GPU ms / this rank's ms: the scaling the compute side allows
+
+The N-GPU job runs at the pace of its SLOWEST rank. The table cases time the middle rank of an equal partition (comparable
+with r02 / r03_c); the "all ranks" cases time EVERY rank, for equal rows and for the rows bench.py cuts at start-up
+(measured cost per strip fed back into rt_mg_partition, BALANCE_ROUNDS rounds), and report the maximum.
 
   python tools/strip_overhead.py [--out profiles/r02_strip_overhead.json]
 """
@@ -23,8 +27,8 @@ from cedec_2024_rt_amd import api, scenes  # noqa: E402
 from cedec_2024_rt_amd.types import bench_options  # noqa: E402
 
 
-def measure(W, H, N, flags, tris, frames=40, warm=6, rank=None):
-    bounds = api.mg_partition(H, N)
+def measure(W, H, N, flags, tris, frames=40, warm=6, rank=None, bounds=None):
+    bounds = bounds or api.mg_partition(H, N)
     rank = N // 2 if rank is None else rank
     a, b = bounds[rank]
     r = api.Renderer(W, H, rows=(a, b), halo=87 if N > 1 else 0)
@@ -81,6 +85,27 @@ def main():
                 m["speedup_bound"] = round(single / m["ms_per_frame"], 2)
                 res[f"{W}x{H} N={N} {name}"] = m
                 print(json.dumps({f"{W}x{H} N={N} {name}": m}), flush=True)
+    # every rank, slowest counts: equal rows, then bench.py's start-up balancing
+    import numpy as np
+    for (W, H) in ((1920, 1080), (3840, 2160)):
+        single = res[f"{W}x{H} N=1 single"]["ms_per_frame"]
+        for N in (2, 4, 8):
+            bounds = api.mg_partition(H, N)
+            best = None
+            for it in range(3):
+                t = [measure(W, H, N, 0, tris, frames=24, rank=k, bounds=bounds)["ms_per_frame"] for k in range(N)]
+                row = dict(rows=[b - a for a, b in bounds], ms=t, max_ms=max(t), speedup_bound=round(single / max(t), 2))
+                if it == 0:
+                    res[f"{W}x{H} N={N} all ranks, equal rows"] = row
+                    print(json.dumps({f"{W}x{H} N={N} all ranks, equal rows": row}), flush=True)
+                if best is None or row["max_ms"] < best["max_ms"]:
+                    best = dict(row, round=it)
+                cost = np.zeros(H)
+                for (a, b), ms in zip(bounds, t):
+                    cost[a:b] = ms / (b - a)
+                bounds = api.mg_partition(H, N, 87, np.maximum(1, cost / cost.max() * 60000).astype(np.uint32))
+            res[f"{W}x{H} N={N} all ranks, rows cut by measured cost"] = best
+            print(json.dumps({f"{W}x{H} N={N} all ranks, rows cut by measured cost": best}), flush=True)
     if args.out:
         with open(args.out, "w") as f:
             json.dump(res, f, indent=1)

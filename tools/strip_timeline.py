@@ -33,7 +33,7 @@ for a, b in zip(steady[:-1], steady[1:]):
 n = len(per)
 print("frames %d: period %.1f us, busy (union) %.1f us, idle %.1f us, operations per frame %.1f" % (
     n, sum(per) / n / 1e3, sum(busy) / n / 1e3, (sum(per) - sum(busy)) / n / 1e3, (steady[-1] - steady[0]) / n))
-a, b = steady[-2], steady[-1]
+a, b = steady[len(steady) // 2], steady[len(steady) // 2 + 1]  # a frame from the middle of the steady part: the last ones belong to the draining pipeline
 t0, end = ops[a][0], ops[a][0]
 print("%9s %8s %8s  %-5s %s" % ("start us", "dur us", "gap us", "queue", "operation"))
 for s, e, name, q in ops[a:b]:
