@@ -299,6 +299,11 @@ RT_DEV bool temporal_merge(const FrameParams& P, int x, int yi, f3 sp, f3 sn, Re
 #endif
 RT_DEV void wave_scatter_records(float4* __restrict__ rec, const int idx, float4* s_wave, const int lane, const float4& q0, const float4& q1,
                                  const float4& q2, const float4& q3);
+RT_DEV void wave_gather_records_at(const float4* __restrict__ rec, const uint32_t idx, float4* s_wave, const int lane, float4& q0, float4& q1,
+                                   float4& q2, float4& q3);
+#ifndef RT_RIS_COOP
+#define RT_RIS_COOP 1 /* 0: per-lane light record gathers in the work-sharing generate kernel too (A/B) */
+#endif
 template <bool FUSE_TEMPORAL, bool SHADOWED, bool DEFER = false, bool PIPE = false, bool WS = false>
 __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_WAVES) void k_generate_candidate(
     SceneView S, FrameParams P, const float4* __restrict__ g0, const float4* __restrict__ g1,
@@ -327,15 +332,61 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_W
     }
     /* DEFER keeps every lane to the end (the queue append is a wave-level operation); so does LATE (every lane of the
      * wavefront joins the walk, with or without a ray of its own) */
-    if (in_image && (flags & GB_SHADED))
-    {
+    const bool act = in_image && (flags & GB_SHADED);
     const f3 sp = F3(G0.x, G0.y, G0.z), sn = F3(G1.x, G1.y, G1.z);
-
     PCG rng = pcg_init(hashPCG4((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame, 0u), 0);
     const float fL = (float)(size_t)P.n_lights;
     int sel = -1;
     float sel_bx = 0.0f, sel_by = 0.0f; /* warped barycentrics of the selected candidate */
-    if (PIPE)
+    /* RIS loop of the work-sharing kernel (every lane stays to the end): the wavefront fetches the 64 light records of a round
+     * together, four lanes per 64-B record, through the walk's idle LDS (wave_gather_records_at, as the spatial pass does:
+     * a per-lane gather of a random 64-B record is 4 wave-instructions x 64 cache lines, and the 32 candidates of a pixel
+     * are 80 % of this kernel's 10 200 vector-L1 accesses per wavefront, at one access per cycle and CU). Same draws in the
+     * same order, same arithmetic; lanes without a shaded pixel name light 0 and ignore it. */
+    constexpr bool RIS_COOP = LATE && !PIPE && RT_RIS_COOP && RT_LIGHT_STRIDE == 4;
+    if constexpr (RIS_COOP)
+    {
+        static_assert(sizeof(s_stack) >= 4096, "the record image needs 64 x 64 B");
+        float4* s_img = reinterpret_cast<float4*>(s_stack);
+        const int lane = (int)(threadIdx.x & 63);
+        for (int i = 0; i < P.ris_sample_count; ++i)
+        {
+            float bx = 0.0f, by = 0.0f;
+            uint32_t nth = 0u;
+            if (act)
+            {
+                const float rv0 = rng.uniformf();
+                bx = rng.uniformf();
+                by = rng.uniformf();
+                nth = (uint32_t)(rv0 * fL);
+                if (nth == (uint32_t)P.n_lights) nth = (uint32_t)P.n_lights - 1u;
+            }
+            float4 L0, L1, L2, L3n;
+            wave_gather_records_at(S.lights, nth, s_img, lane, L0, L1, L2, L3n);
+            if (act)
+            {
+                const f3 v0 = F3(L0.x, L0.y, L0.z), v1 = F3(L0.w, L1.x, L1.y), v2 = F3(L1.z, L1.w, L2.x);
+                warp_unit_triangle(bx, by);
+                const f3 lp = (1.0f - bx - by) * v0 + bx * v1 + by * v2;
+                const f3 ln = F3(L3n.x, L3n.y, L3n.z);
+                const float p_hat = target_unshadowed(sp, sn, lp, ln, L2.y); /* unshadowed always (:104) */
+                const float weight = p_hat / L2.z;                          /* 1/L * 1/area (:98-99) */
+                const float u = rng.uniformf();
+                r.w_sum += weight;
+                r.M += 1;
+                if (u < weight / r.w_sum)
+                {
+                    sel = (int)nth; sel_bx = bx; sel_by = by;
+                }
+            }
+        }
+    }
+    if (act)
+    {
+    if (RIS_COOP)
+    {
+    }
+    else if (PIPE)
     {
         /* Software-pipelined form of the loop below (same draws in the same order, same arithmetic): the light record
          * of candidate i+1 is requested before the arithmetic of candidate i, so the L2 gather (four 16-B loads of a

@@ -264,7 +264,7 @@ int rt_create(int device, int width, int height, int row_begin, int row_end, int
      * created lazily, after a host has destroyed and re-created contexts, can land on the queue of the very stream they are
      * meant to run beside (measured: the pipelined stage 0 on the main stream's queue, 0.39 -> 0.51 ms per frame at 1080p
      * in 8 strips, profiles/r03_hw_queue_mapping.txt). Order of importance: main, pipelined stage 0, tail, second lane. */
-    RT_HIP(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    RT_HIP(c, hipStreamCreateWithPriority(&c->own_stream, hipStreamNonBlocking, stream_priority("RT_MAIN_PRIORITY", 0)));
     RT_HIP(c, hipStreamCreateWithPriority(&c->spec_stream, hipStreamNonBlocking, stream_priority("RT_SPEC_PRIORITY", 0)));
     RT_HIP(c, hipStreamCreateWithPriority(&c->tail_stream, hipStreamNonBlocking, stream_priority("RT_TAIL_PRIORITY", 0)));
     /* default priority: with the lowest priority the lane was starved in some exchanges (A/B in DESIGN.md §7) */
