@@ -42,7 +42,7 @@ r.close()
 res = {"single_ms": single}
 equal = api.mg_partition(H, N, 87)
 for name, bounds in (("equal rows", equal),
-                     ("shaded-pixel model 1:7 (bench.py until r03_d)", api.mg_partition(H, N, 87, (shaded * 7 + W).astype(np.uint32))),
+                     ("shaded-pixel model 1:7 (bench.py until r03_e)", api.mg_partition(H, N, 87, (shaded * 7 + W).astype(np.uint32))),
                      ("shaded-pixel model 2:9", api.mg_partition(H, N, 87, (shaded * 9 + 2 * W).astype(np.uint32)))):
     t = measure_all(bounds)
     res[name] = dict(rows=[b - a for a, b in bounds], ms=t, max_ms=max(t), bound=round(single / max(t), 2))
