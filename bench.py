@@ -44,7 +44,7 @@ W, H = 1920, 1080
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HALO = 87
 # strip heights: rounds of "every rank times its own strip alone, the strips are re-cut by measured cost per row" (make_strip)
-BALANCE_ROUNDS = 2
+BALANCE_ROUNDS = 4
 
 
 def cpu_baseline(tris, eye, center, frames=2):
@@ -292,8 +292,8 @@ def _main():
         frame, halo work per boundary; a shaded-pixel model made the slowest strip 7 % slower than equal rows at 4K,
         profiles/r03_strip_balance.jsonl). So each rank times a few frames of its own strip with the MIRROR transport (same
         launches and message sizes, no neighbour involved), the times are all-gathered, every rank re-cuts the rows by
-        piecewise-constant cost per row (rt_mg_partition, >= 87 rows each), BALANCE_ROUNDS times; the cut with the lowest
-        maximum is kept. Start-up work, outside the timed region; the strips are in config.strips."""
+        piecewise-constant cost per row averaged over the rounds so far (rt_mg_partition, >= 87 rows each), BALANCE_ROUNDS
+        times. Start-up work, outside the timed region; the strips are in config.strips."""
         uid = [api.mg_unique_id() if rank == 0 and not dev_mirror else None]
         if dev_shm:
             uid = [f"rtmg_{os.getpid()}_{time.time_ns():x}_{w}x{h}" if rank == 0 else None]  # per-run nonce: never a stale segment
@@ -303,8 +303,8 @@ def _main():
         # ranks that share one GPU (the dev transports) cannot time their strips: equal rows there (BENCH_FORCE_BALANCE runs the
         # rounds anyway, to exercise this code on a one-GPU box)
         if not os.environ.get("BENCH_EQUAL_STRIPS") and ((not dev_shm and not dev_mirror) or os.environ.get("BENCH_FORCE_BALANCE")):
-            best = None
-            for it in range(BALANCE_ROUNDS + 1):
+            est, slowest = [], []
+            for it in range(BALANCE_ROUNDS):
                 wd.tick("strip balance round %d" % it, 600)
                 rb, _ = make_renderer(w, h, bounds[rank])
                 mgb = api.MultiGpu(rb, rank, bounds, transport=api.RT_MG_TRANSPORT_MIRROR)
@@ -312,24 +312,23 @@ def _main():
                     mgb.frame(f)
                 rb.sync()
                 t0 = time.perf_counter()
-                for f in range(7, 27):
+                for f in range(7, 47):
                     mgb.frame(f)
                 rb.sync()
-                mine = (time.perf_counter() - t0) / 20 * 1e3
+                mine = (time.perf_counter() - t0) / 40 * 1e3
                 mgb.close()
                 rb.close()
                 allt = [None] * world
                 dist.all_gather_object(allt, mine)
-                if best is None or max(allt) < best[0]:
-                    best = (max(allt), bounds, it)
-                if it == BALANCE_ROUNDS:
-                    break
+                slowest.append(max(allt))
                 cost = np.zeros(h)
                 for (a, b), ms in zip(bounds, allt):
                     cost[a:b] = ms / (b - a)
+                est.append(cost)
+                cost = np.mean(est, axis=0)  # the estimates of all rounds so far, averaged per row: one round alone is +-1 % noisy
                 bounds = api.mg_partition(h, world, HALO, np.maximum(1, cost / cost.max() * 60000).astype(np.uint32))
-            bounds = best[1]
-            part = "rows cut by measured cost per strip (round %d of %d: slowest strip alone %.3f ms)" % (best[2], BALANCE_ROUNDS, best[0])
+            part = "rows cut by measured cost per strip (%d rounds; slowest strip alone, equal rows -> last measured cut: %.3f -> %.3f ms)" % (
+                BALANCE_ROUNDS, slowest[0], slowest[-1])
         r, build_ms = make_renderer(w, h, bounds[rank])
         def python_strips(why):
             """every rank TOGETHER: the round-1 schedule (Python StripFrame over torch.distributed send/recv: same HIP

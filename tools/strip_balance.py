@@ -41,20 +41,23 @@ shaded = r.row_shaded().astype(np.int64)
 r.close()
 res = {"single_ms": single}
 equal = api.mg_partition(H, N, 87)
-for name, bounds in (("equal rows", equal),
+for name, bounds in (("equal rows", equal),) if os.environ.get("BALANCE_ONLY") else (("equal rows", equal),
                      ("shaded-pixel model 1:7 (bench.py until r03_e)", api.mg_partition(H, N, 87, (shaded * 7 + W).astype(np.uint32))),
                      ("shaded-pixel model 2:9", api.mg_partition(H, N, 87, (shaded * 9 + 2 * W).astype(np.uint32)))):
     t = measure_all(bounds)
     res[name] = dict(rows=[b - a for a, b in bounds], ms=t, max_ms=max(t), bound=round(single / max(t), 2))
     print(json.dumps({name: res[name]}), flush=True)
-# measured costs: piecewise-constant cost per row from each strip's own time, a few rounds
+# measured costs: piecewise-constant cost per row from each strip's own time; the estimates of all rounds so far are averaged per row
 bounds, t = equal, res["equal rows"]["ms"]
-for it in range(3):
+est = []
+for it in range(5):
     cost = np.zeros(H)
     for (a, b), ms in zip(bounds, t):
         cost[a:b] = ms / (b - a)
+    est.append(cost)
+    cost = np.mean(est, axis=0)
     bounds = api.mg_partition(H, N, 87, np.maximum(1, cost / cost.max() * 60000).astype(np.uint32))
-    t = measure_all(bounds)
-    name = f"measured costs, round {it + 1}"
+    t = measure_all(bounds, frames=40)
+    name = f"measured costs (averaged over rounds), round {it + 1}"
     res[name] = dict(rows=[b - a for a, b in bounds], ms=t, max_ms=max(t), bound=round(single / max(t), 2))
     print(json.dumps({name: res[name]}), flush=True)

@@ -10,7 +10,7 @@ exchange; only the xGMI hop and the peers' skew are missing. Reported per N and 
 
 The N-GPU job runs at the pace of its SLOWEST rank. The table cases time the middle rank of an equal partition (comparable
 with r02 / r03_c); the "all ranks" cases time EVERY rank, for equal rows and for the rows bench.py cuts at start-up
-(measured cost per strip fed back into rt_mg_partition, BALANCE_ROUNDS rounds), and report the maximum.
+(measured cost per strip, averaged over the rounds, fed back into rt_mg_partition, 4 rounds), and report the maximum.
 
   python tools/strip_overhead.py [--out profiles/r02_strip_overhead.json]
 """
@@ -91,21 +91,23 @@ def main():
         single = res[f"{W}x{H} N=1 single"]["ms_per_frame"]
         for N in (2, 4, 8):
             bounds = api.mg_partition(H, N)
-            best = None
-            for it in range(3):
-                t = [measure(W, H, N, 0, tris, frames=24, rank=k, bounds=bounds)["ms_per_frame"] for k in range(N)]
+            est = []
+            for it in range(5):  # 4 balance rounds as bench.py does them, then the cut they arrive at
+                t = [measure(W, H, N, 0, tris, frames=40, rank=k, bounds=bounds)["ms_per_frame"] for k in range(N)]
                 row = dict(rows=[b - a for a, b in bounds], ms=t, max_ms=max(t), speedup_bound=round(single / max(t), 2))
                 if it == 0:
                     res[f"{W}x{H} N={N} all ranks, equal rows"] = row
                     print(json.dumps({f"{W}x{H} N={N} all ranks, equal rows": row}), flush=True)
-                if best is None or row["max_ms"] < best["max_ms"]:
-                    best = dict(row, round=it)
+                if it == 4 or N == 2:
+                    res[f"{W}x{H} N={N} all ranks, rows cut by measured cost"] = row
+                    print(json.dumps({f"{W}x{H} N={N} all ranks, rows cut by measured cost": row}), flush=True)
+                    break
                 cost = np.zeros(H)
                 for (a, b), ms in zip(bounds, t):
                     cost[a:b] = ms / (b - a)
+                est.append(cost)
+                cost = np.mean(est, axis=0)
                 bounds = api.mg_partition(H, N, 87, np.maximum(1, cost / cost.max() * 60000).astype(np.uint32))
-            res[f"{W}x{H} N={N} all ranks, rows cut by measured cost"] = best
-            print(json.dumps({f"{W}x{H} N={N} all ranks, rows cut by measured cost": best}), flush=True)
     if args.out:
         with open(args.out, "w") as f:
             json.dump(res, f, indent=1)
