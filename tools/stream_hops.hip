@@ -34,12 +34,48 @@ static double run(int nstreams, int links, int* d, int busy_iters)
     for (auto& e : ev) hipEventDestroy(e);
     return best / links;
 }
+// one stream, `links` tiny kernels, and between consecutive kernels: `recs` hipEventRecord on that stream and `waits`
+// hipStreamWaitEvent on an event of ANOTHER stream that completed long ago: what bookkeeping between two kernels costs
+static double run_marks(int links, int recs, int waits, int* d)
+{
+    hipStream_t s, other;
+    hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    hipStreamCreateWithFlags(&other, hipStreamNonBlocking);
+    std::vector<hipEvent_t> ev(8);
+    for (auto& e : ev) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    hipEvent_t old_ev;
+    hipEventCreateWithFlags(&old_ev, hipEventDisableTiming);
+    tiny<<<1, 64, 0, other>>>(d);
+    hipEventRecord(old_ev, other);
+    hipStreamSynchronize(other);
+    double best = 1e30;
+    for (int rep = 0; rep < 5; ++rep)
+    {
+        hipStreamSynchronize(s);
+        auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < links; ++i)
+        {
+            for (int k = 0; k < waits; ++k) hipStreamWaitEvent(s, old_ev, 0);
+            for (int k = 0; k < recs; ++k) hipEventRecord(ev[k & 7], s);
+            tiny<<<1, 64, 0, s>>>(d);
+        }
+        hipStreamSynchronize(s);
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (us < best) best = us;
+    }
+    hipStreamDestroy(s); hipStreamDestroy(other);
+    for (auto& e : ev) hipEventDestroy(e);
+    hipEventDestroy(old_ev);
+    return best / links;
+}
 int main()
 {
     int* d;
     hipMalloc(&d, 64);
     hipMemset(d, 0, 64);
     const int links = 400;
+    printf("one stream, per kernel: plain %.2f us; + 1 event record %.2f; + 4 records %.2f; + 1 wait on a long-completed event of another stream %.2f; + 4 waits %.2f; + 4 records + 3 waits %.2f\n",
+           run_marks(links, 0, 0, d), run_marks(links, 1, 0, d), run_marks(links, 4, 0, d), run_marks(links, 0, 1, d), run_marks(links, 0, 4, d), run_marks(links, 4, 3, d));
     for (int busy_iters : {0, 20000})
     {
         printf("%s kernels, %d links: one stream %.2f us / link, two streams %.2f, three streams %.2f\n", busy_iters ? "~20 us" : "empty", links,
