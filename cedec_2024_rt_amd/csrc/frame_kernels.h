@@ -301,6 +301,8 @@ RT_DEV void wave_scatter_records(float4* __restrict__ rec, const int idx, float4
                                  const float4& q2, const float4& q3);
 RT_DEV void wave_gather_records_at(const float4* __restrict__ rec, const uint32_t idx, float4* s_wave, const int lane, float4& q0, float4& q1,
                                    float4& q2, float4& q3);
+RT_DEV void wave_gather_records(const float4* q, float4* s_wave, const int lane, float4& q0, float4& q1, float4& q2, float4& q3);
+RT_DEV Res res_from_parts(const float4& q0, const float4& q1, const float4& q2, const float4& q3, bool& shaded);
 #ifndef RT_RIS_COOP
 #define RT_RIS_COOP 1 /* 0: per-lane light record gathers in the work-sharing generate kernel too (A/B) */
 #endif
@@ -779,7 +781,133 @@ RT_DEV void spatial_pixel(const SceneView& S, const FrameParams& P, const HaloFu
 }
 
 /* shadowed target function: a tracing kernel (one-wavefront workgroups, LDS traversal stack) */
-template <bool SHADOWED>
+/* The shadowed pass with the wavefront's record traffic in the cooperative form of k_spatial_coop (four lanes per 64-B record
+ * through the walk's LDS, which is idle outside the batch walk): the five neighbour records are fetched once for the ray
+ * targets and once more for the merge, the 64 results leave a quad per record. Every lane stays to the end (a lane without a
+ * shaded pixel names its own record, holds no ray and helps the others' walks). Same draws, same rays, same arithmetic as
+ * spatial_pixel<true> (the <= 5 neighbour form). rt_tuning key 8 = 0 keeps the per-lane form. */
+template <int TB>
+RT_DEV void spatial_wave_shadowed(const SceneView& S, const FrameParams& P, const HaloFuse& F, uint32_t* s_stack, const float4* __restrict__ g0,
+                                  const float4* __restrict__ g1, const float4* __restrict__ in_rec, const float4* __restrict__ in_rad,
+                                  float4* __restrict__ out_rec, float4* __restrict__ out_rad)
+{
+    float4* s_img = reinterpret_cast<float4*>(s_stack);
+    const int lane = (int)(threadIdx.x & 63);
+    int x = 0, row = P.lrow0;
+    const bool in_image = tile_pixel<TB>(P, x, row);
+    const int yi = P.H - 1 - row;
+    const size_t li = in_image ? (size_t)x + (size_t)(row - P.lrow0) * P.W : 0;
+    float4 G0 = make_float4(0.0f, 0.0f, 0.0f, as_float(-1)), G1 = make_float4(0.0f, 1.0f, 0.0f, 0.0f);
+    if (in_image) { G0 = g0[li]; G1 = g1[li]; }
+    const bool active = in_image && (as_uint(G1.w) & GB_SHADED);
+    const f3 sp = F3(G0.x, G0.y, G0.z), sn = F3(G1.x, G1.y, G1.z);
+    PCG rng = pcg_init(hashPCG4((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame, (uint32_t)(2 + P.pass)), 0);
+    float4 q0, q1, q2, q3;
+    wave_gather_records_at(in_rec, (uint32_t)li, s_img, lane, q0, q1, q2, q3);
+    bool own_shaded;
+    Res r = res_from_parts(q0, q1, q2, q3, own_shaded);
+    const float4* rad_from = in_rad + li;
+
+    const float scale = P.spatial_radius / 1.96f;
+    const float4* prec[5]; /* the neighbour's record (reservoir buffer or received halo list), nullptr = none */
+    const float4* prad[5];
+    float ud[5];
+    f3 tgt[6];
+    uint32_t need = 0u;
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+    {
+        prec[k] = nullptr; prad[k] = nullptr; ud[k] = 0.0f; tgt[k] = F3(0.0f, 0.0f, 0.0f);
+        if (k < P.spatial_count) /* wave-uniform */
+        {
+            const float4* nq = in_rec + 4 * li;
+            const float4* nrad = nullptr;
+            bool have = false;
+            if (active)
+            {
+                const float rv0 = rng.uniformf();
+                const float rv1 = rng.uniformf();
+                const float radius = sqrtf(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
+                const float phi = 2.0f * kPI * rv1;
+                float sn_phi, cs_phi;
+                pm_sincosf(phi, &sn_phi, &cs_phi);
+                const float gx = radius * cs_phi, gy = radius * sn_phi;
+                const int nx = f2i_sat((float)x + scale * gx);
+                const int ny = f2i_sat((float)yi + scale * gy);
+                const int lr = P.H - 1 - ny - P.lrow0;
+                have = !(nx < 0 || nx >= P.W || ny < 0 || ny >= P.H) && !(nx == x && ny == yi) && !(lr < 0 || lr >= P.lrows);
+                if (have) nq = halo_record(F, P.W, in_rec, in_rad, (size_t)nx + (size_t)lr * P.W, nx, P.H - 1 - ny, nrad);
+            }
+            wave_gather_records(nq, s_img, lane, q0, q1, q2, q3);
+            const uint32_t mb = as_uint(q1.w);
+            if (have && (mb & RES_SHADED_BIT))
+            {
+                prec[k] = nq; prad[k] = nrad;
+                ud[k] = rng.uniformf();
+                tgt[k] = F3(q0.x, q0.y, q0.z);
+                const bool moot = (q0.w == 0.0f) || (P.vis_reuse && !(mb & RES_VIS_BIT));
+                if (!moot) need |= 1u << k;
+            }
+        }
+    }
+    tgt[5] = r.hit_p;
+    /* the own sample's ray: walked by the kernel that wrote this record if the flag says so (see rt_device.h) */
+    uint32_t own_flags = 0u;
+    if (active)
+    {
+        own_flags = as_uint(in_rad[li].w);
+        if (!(own_flags & OWNV_KNOWN)) need |= 1u << 5;
+    }
+    uint32_t occl = occluded_batch<6, TB>(S.wide, s_stack, sp, sn, tgt, need, S.bvh.tv, active ? as_int(G0.w) : -1);
+    if ((own_flags & OWNV_KNOWN) && !(own_flags & OWNV_VISIBLE)) occl |= 1u << 5;
+    int sel = 5;
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+    {
+        if (k < P.spatial_count)
+        {
+            wave_gather_records(prec[k] ? prec[k] : in_rec + 4 * li, s_img, lane, q0, q1, q2, q3);
+            if (prec[k])
+            {
+                bool n_shaded;
+                Res nr = res_from_parts(q0, q1, q2, q3, n_shaded);
+                /* evaluate_target_function with the shadow term (common/reservoir.hpp:42-59) */
+                const float V = (occl >> k) & 1u ? 0.0f : 1.0f;
+                float p_hat_y = (1.0f / kPI) * geometry_term(sp, sn, nr.hit_p, nr.hit_n) * V * nr.lum;
+                if (P.vis_reuse) p_hat_y *= nr.vis ? 1.0f : 0.0f;
+                nr.M = scale_M(nr.M, rejection_heuristics(r.org_p, r.org_n, nr.org_p, nr.org_n, P.eye));
+                const float weight = p_hat_y * nr.ucw * (float)nr.M;
+                r.w_sum += weight;
+                r.M += nr.M;
+                if (ud[k] < weight / r.w_sum)
+                {
+                    res_take_sample(r, nr);
+                    rad_from = prad[k];
+                    sel = k;
+                }
+            }
+        }
+    }
+    const float Vf = (occl >> sel) & 1u ? 0.0f : 1.0f;
+    const float p_hat = (1.0f / kPI) * geometry_term(sp, sn, r.hit_p, r.hit_n) * Vf * r.lum;
+    r.ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
+    if (active)
+    {
+        const float4 rq = *rad_from;
+        r.rad = F3(rq.x, rq.y, rq.z);
+        r.ownv = ownv_of(Vf != 0.0f);
+    }
+    else
+        r = res_zero(); /* the reference stores nothing here (:275-287); we keep the shaded bit valid */
+    const uint32_t mbits = ((uint32_t)r.M & RES_M_MASK) | (r.vis ? RES_VIS_BIT : 0u) | (active ? RES_SHADED_BIT : 0u);
+    wave_scatter_records(out_rec, in_image ? (int)li : -1, s_img, lane, make_float4(r.hit_p.x, r.hit_p.y, r.hit_p.z, r.ucw),
+                         make_float4(r.hit_n.x, r.hit_n.y, r.hit_n.z, as_float(mbits)), make_float4(r.org_p.x, r.org_p.y, r.org_p.z, r.lum),
+                         make_float4(r.org_n.x, r.org_n.y, r.org_n.z, r.w_sum));
+    if (!in_image) return;
+    out_rad[li] = make_float4(r.rad.x, r.rad.y, r.rad.z, as_float(r.ownv));
+    res_give(F, P.W, li, x, row, r, active);
+}
+template <bool SHADOWED, bool COOP = false>
 __global__ __launch_bounds__(TRACE_BLOCK, RT_SHSPATIAL_WAVES) void k_spatial(SceneView S, FrameParams P, HaloFuse F, const float4* __restrict__ g0,
                                                     const float4* __restrict__ g1, const float4* __restrict__ in_rec,
                                                     const float4* __restrict__ in_rad, float4* __restrict__ out_rec,
@@ -787,6 +915,12 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_SHSPATIAL_WAVES) void k_spatial(Sce
 {
     static_assert(SHADOWED, "the unshadowed pass is k_spatial_gather / k_spatial_lds");
     __shared__ __attribute__((aligned(16))) uint32_t s_stack[(RT_BATCH_WS ? WIDE_LDS_ROWS : WIDE_LDS_STACK) * TRACE_BLOCK];
+    if constexpr (COOP)
+    {
+        static_assert(sizeof(s_stack) >= 4096, "the record image needs 64 x 64 B");
+        spatial_wave_shadowed<TRACE_BLOCK>(S, P, F, s_stack, g0, g1, in_rec, in_rad, out_rec, out_rad);
+        return;
+    }
     int x, row;
     if (!tile_pixel<TRACE_BLOCK>(P, x, row)) return;
     spatial_pixel<true, TRACE_BLOCK>(S, P, F, s_stack, x, row, g0, g1, in_rec, in_rad, out_rec, out_rad);
