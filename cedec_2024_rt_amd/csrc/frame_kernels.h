@@ -809,19 +809,17 @@ RT_DEV void spatial_wave_shadowed(const SceneView& S, const FrameParams& P, cons
     const float4* rad_from = in_rad + li;
 
     const float scale = P.spatial_radius / 1.96f;
-    const float4* prec[5]; /* the neighbour's record (reservoir buffer or received halo list), nullptr = none */
-    const float4* prad[5];
+    uint32_t pcode[5]; /* where the neighbour's record is (halo_code: reservoir buffer or received halo list), HALO_CODE_NONE = none */
     float ud[5];
     f3 tgt[6];
     uint32_t need = 0u;
 #pragma unroll
     for (int k = 0; k < 5; ++k)
     {
-        prec[k] = nullptr; prad[k] = nullptr; ud[k] = 0.0f; tgt[k] = F3(0.0f, 0.0f, 0.0f);
+        pcode[k] = HALO_CODE_NONE; ud[k] = 0.0f; tgt[k] = F3(0.0f, 0.0f, 0.0f);
         if (k < P.spatial_count) /* wave-uniform */
         {
-            const float4* nq = in_rec + 4 * li;
-            const float4* nrad = nullptr;
+            uint32_t ncode = 4u * (uint32_t)li;
             bool have = false;
             if (active)
             {
@@ -836,13 +834,13 @@ RT_DEV void spatial_wave_shadowed(const SceneView& S, const FrameParams& P, cons
                 const int ny = f2i_sat((float)yi + scale * gy);
                 const int lr = P.H - 1 - ny - P.lrow0;
                 have = !(nx < 0 || nx >= P.W || ny < 0 || ny >= P.H) && !(nx == x && ny == yi) && !(lr < 0 || lr >= P.lrows);
-                if (have) nq = halo_record(F, P.W, in_rec, in_rad, (size_t)nx + (size_t)lr * P.W, nx, P.H - 1 - ny, nrad);
+                if (have) ncode = halo_code(F, P.W, (size_t)nx + (size_t)lr * P.W, nx, P.H - 1 - ny);
             }
-            wave_gather_records(nq, s_img, lane, q0, q1, q2, q3);
+            wave_gather_records(halo_code_record(F, in_rec, ncode), s_img, lane, q0, q1, q2, q3);
             const uint32_t mb = as_uint(q1.w);
             if (have && (mb & RES_SHADED_BIT))
             {
-                prec[k] = nq; prad[k] = nrad;
+                pcode[k] = ncode;
                 ud[k] = rng.uniformf();
                 tgt[k] = F3(q0.x, q0.y, q0.z);
                 const bool moot = (q0.w == 0.0f) || (P.vis_reuse && !(mb & RES_VIS_BIT));
@@ -866,8 +864,8 @@ RT_DEV void spatial_wave_shadowed(const SceneView& S, const FrameParams& P, cons
     {
         if (k < P.spatial_count)
         {
-            wave_gather_records(prec[k] ? prec[k] : in_rec + 4 * li, s_img, lane, q0, q1, q2, q3);
-            if (prec[k])
+            wave_gather_records(halo_code_record(F, in_rec, pcode[k] != HALO_CODE_NONE ? pcode[k] : 4u * (uint32_t)li), s_img, lane, q0, q1, q2, q3);
+            if (pcode[k] != HALO_CODE_NONE)
             {
                 bool n_shaded;
                 Res nr = res_from_parts(q0, q1, q2, q3, n_shaded);
@@ -882,7 +880,7 @@ RT_DEV void spatial_wave_shadowed(const SceneView& S, const FrameParams& P, cons
                 if (ud[k] < weight / r.w_sum)
                 {
                     res_take_sample(r, nr);
-                    rad_from = prad[k];
+                    rad_from = halo_code_radiance(F, in_rec, in_rad, pcode[k]);
                     sel = k;
                 }
             }

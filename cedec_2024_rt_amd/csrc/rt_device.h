@@ -301,6 +301,33 @@ RT_DEV const float4* halo_record(const HaloFuse& F, int W, const float4* __restr
         }
     return q;
 }
+/* the same place as ONE word (a kernel that keeps five of them across a long walk): bits 31..30 = 0 reservoir buffer,
+ * 1 / 2 = received list of side 0 / 1; bits 29..0 = the record's first float4 (buffer: 4 x pixel, list: 5 x entry).
+ * Buffers of up to 2^28 pixels (rt_create refuses more local pixels than that in strips... the whole-frame limit is the same). */
+constexpr uint32_t HALO_CODE_NONE = 0xffffffffu;
+RT_DEV uint32_t halo_code(const HaloFuse& F, int W, size_t pid, int nx, int nrow)
+{
+    uint32_t code = 4u * (uint32_t)pid;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+        if (F.recv[s] && (unsigned)(nrow - F.need_row0[s]) < (unsigned)F.rows)
+        {
+            bool marked;
+            const uint32_t idx = halo_list_index(F.need_bm[s], F.nw, (uint32_t)(nrow - F.need_row0[s]) * (uint32_t)W + (uint32_t)nx, marked);
+            code = ((uint32_t)(s + 1) << 30) | (5u * idx);
+        }
+    return code;
+}
+RT_DEV const float4* halo_code_record(const HaloFuse& F, const float4* __restrict__ in_rec, uint32_t code)
+{
+    const uint32_t sel = code >> 30;
+    const float4* base = sel == 0u ? in_rec : (sel == 1u ? F.recv[0] : F.recv[1]);
+    return base + (code & 0x3fffffffu);
+}
+RT_DEV const float4* halo_code_radiance(const HaloFuse& F, const float4* __restrict__ in_rec, const float4* __restrict__ in_rad, uint32_t code)
+{
+    return (code >> 30) == 0u ? in_rad + ((code & 0x3fffffffu) >> 2) : halo_code_record(F, in_rec, code) + 4;
+}
 /* the send list's copy of the record of pixel (x, row), if a neighbour strip marked it */
 RT_DEV void res_give(const HaloFuse& F, int W, size_t i, int x, int row, const Res& r, bool shaded)
 {
