@@ -164,7 +164,7 @@ def summarise(ops):
 
 KERNELS = [("k_raycast", "k_raycast<false>("), ("k_raycast<WS>", "k_raycast<true>("), ("k_generate_candidate<true,false>", "k_generate_candidate<true, false, false, false, false>("),
            ("k_generate_candidate<true,false,WS>", "k_generate_candidate<true, false, false, false, true>("), ("k_resolve<WS>", "k_resolve<true>("), ("k_resolve_stream", "k_resolve_stream("),
-           ("k_spatial_gather", "k_spatial_gather<6>("), ("k_spatial_coop", "k_spatial_coop<6, false>("), ("k_spatial_coop<fused>", "k_spatial_coop<6, true>("), ("k_halo_mark", "k_halo_mark("), ("k_spatial_lds", "k_spatial_lds("), ("k_resolve", "k_resolve<false>("), ("k_spatial<true>", "k_spatial<true>("),
+           ("k_spatial_gather", "k_spatial_gather<6>("), ("k_spatial_coop", "k_spatial_coop<6, false>("), ("k_spatial_coop<fused>", "k_spatial_coop<6, true>("), ("k_halo_mark", "k_halo_mark("), ("k_spatial_lds", "k_spatial_lds("), ("k_resolve", "k_resolve<false>("), ("k_spatial<true>", "k_spatial<true, true>("), ("k_spatial<true> per-lane records", "k_spatial<true, false>("),
            ("k_temporal<false>", "k_temporal<false>("), ("k_tone_mapping", "k_tone_mapping("),
            ("k_path_trace<9,false>", "k_path_trace<9, false>(")]
 LOOP_KERNELS = {"k_raycast", "k_generate_candidate<true,false>", "k_spatial_gather", "k_spatial_coop", "k_halo_mark", "k_resolve", "k_spatial<true>"}
