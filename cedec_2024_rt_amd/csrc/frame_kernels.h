@@ -1140,9 +1140,12 @@ RT_DEV void wave_gather_records_at(const float4* __restrict__ rec, const uint32_
     uint32_t from[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) from[j] = (uint32_t)__shfl((int)idx, 16 * j + (lane >> 2));
-    const int part = (lane & 3) ^ ((lane >> 4) & 3);
+    const uint32_t part16 = (uint32_t)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+    /* a wave-uniform base + a 32-bit byte offset per lane: one address instruction per load instead of a 64-bit shift and add
+     * (the buffers hold at most 2^26 records: rt_create, rt_scene_set) */
+    const char* base = reinterpret_cast<const char*>(rec);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wave_gather_issue(rec + 4 * (size_t)from[j] + part, s_wave + 64 * j, lane);
+    for (int j = 0; j < 4; ++j) wave_gather_issue(reinterpret_cast<const float4*>(base + (from[j] * 64u + part16)), s_wave + 64 * j, lane);
     wave_gather_finish(s_wave, lane, q0, q1, q2, q3);
 }
 /* the reverse for the 64 records a wavefront writes: every lane puts its record into the image, then in round j lane l
@@ -1160,10 +1163,11 @@ RT_DEV void wave_scatter_records(float4* __restrict__ rec, const int idx, float4
 #pragma unroll
     for (int j = 0; j < 4; ++j) to[j] = __shfl(idx, 16 * j + (lane >> 2));
     RT_WAVE_LDS_FENCE();
-    const int part = (lane & 3) ^ ((lane >> 4) & 3);
+    const uint32_t part16 = (uint32_t)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+    char* base = reinterpret_cast<char*>(rec);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        if (to[j] >= 0) rec[4 * (size_t)to[j] + part] = s_wave[64 * j + lane];
+        if (to[j] >= 0) *reinterpret_cast<float4*>(base + ((uint32_t)to[j] * 64u + part16)) = s_wave[64 * j + lane];
     RT_WAVE_LDS_FENCE();
 }
 RT_DEV Res res_from_parts(const float4& q0, const float4& q1, const float4& q2, const float4& q3, bool& shaded)
@@ -1193,7 +1197,7 @@ __global__ __launch_bounds__(BLOCK) void k_spatial_coop(
     occupancy_bound<WAVES>();
     __shared__ __attribute__((aligned(16))) float4 s_img[BLOCK / 64][256];
     const int lane = threadIdx.x & 63;
-    float4* s_wave = s_img[threadIdx.x >> 6];
+    float4* s_wave = s_img[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))]; /* a scalar: the LDS-DMA base (M0) without per-load lane reads */
     int x = 0, row = P.lrow0;
     const bool in_image = tile_pixel<BLOCK>(P, x, row);
     const int yi = P.H - 1 - row;

@@ -252,6 +252,8 @@ int rt_create(int device, int width, int height, int row_begin, int row_end, int
     c->lrow0 = row_begin - halo < 0 ? 0 : row_begin - halo;
     const int lend = row_end + halo > height ? height : row_end + halo;
     c->lrows = lend - c->lrow0;
+    /* the cooperative record fetches address a reservoir buffer by 32-bit byte offsets (frame_kernels.h, wave_gather_records_at) */
+    if ((size_t)c->lrows * (size_t)width > ((size_t)1 << 26)) { delete c; *out = nullptr; return RT_ERR_UNSUPPORTED; }
     c->opt = default_options();
     memset(&c->rg, 0, sizeof(c->rg));
     RT_HIP(c, hipSetDevice(device));
@@ -922,6 +924,7 @@ int rt_scene_set(rt_ctx* c, const rt_triangle* triangles, uint32_t count)
     for (int i = 0; i < n; ++i)
         if (triangles[i].emissive[0] > 0.0f || triangles[i].emissive[1] > 0.0f || triangles[i].emissive[2] > 0.0f)
             lights.push_back((uint32_t)i);
+    if (lights.size() > ((size_t)1 << 26)) RT_FAIL(c, RT_ERR_UNSUPPORTED, "more than 2^26 emissive triangles (the light table is addressed by 32-bit byte offsets)");
     c->n_lights = (int)lights.size();
     c->bvh_height = 0;
     if (n == 0) { c->has_scene = true; return RT_OK; }
