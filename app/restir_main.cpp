@@ -6,8 +6,14 @@
  *   restir_app [--obj scene.obj | --tris scene.tris] [--size W H] [--frames N]
  *              [--eye x y z] [--lookat x y z] [--temporal 0|1] [--spatial 0|1]
  *              [--shadowed 0|1] [--visreuse 0|1] [--accumulate 0|1] [--by-kernel]
- *              [--example 10|7|8|9] [--ppm out.ppm] [--png out.png] [--pfm out.pfm] [--dump-tris out.tris]
- *              [--ranks N [--mirror | --shm] [--equal-strips]]
+ *              [--example 10|7|8|9|4] [--ppm out.ppm] [--png out.png] [--pfm out.pfm] [--rgba out.raw] [--dump-tris out.tris]
+ *              [--ranks N [--mirror | --shm] [--equal-strips]] [--threads N]
+ *
+ * --example 4: BASELINE config #1 — the `kernelMain` of examples/04_ao/04_ao.cu:31-88 as a host C++ loop over the
+ * image rows (cedec_2024_rt_amd/csrc/host_path.h: brute-force closest hit, 64 ambient-occlusion rays per pixel,
+ * host libm), on --threads host threads (default: all). No GPU call is made: it runs on a machine without one.
+ * Defaults then follow 04_ao.cpp (256x256 is the BASELINE size; camera (8,8,8) -> (0,0,0), common/misc.hpp:217-218);
+ * --rgba writes the W*H RGBA8 bytes in the reference's storage order (what its pixel buffer holds).
  *
  * --ranks N: the multi-GPU frame loop: N processes, forked before anything touches a GPU,
  * rank r on device r, each rendering one row strip through the native strip driver (rt_mg_*: sparse
@@ -43,6 +49,7 @@
 #include <unistd.h>
 
 #include "../include/restir_rt.h"
+#include "../cedec_2024_rt_amd/csrc/host_path.h"
 
 /* RGB8 PNG, top row first, as saveScreenshot writes it (common/misc.hpp:226-245 via stbi_write_png);
  * the deflate stream uses stored blocks only (no compression: no zlib dependency). */
@@ -314,9 +321,9 @@ int main(int argc, char** argv)
     /* camera "blocks_restir.obj 1", 10_restir_di.cpp:188-189 */
     float eye[3] = {-0.579885f, 22.194597f, -6.567105f}, lookat[3] = {5.224952f, 20.847435f, 1.431192f};
     const float up[3] = {0, 1, 0};
-    std::string obj, tris_path, ppm, png, pfm, dump;
-    bool by_kernel = false, mirror = false, shm = false, equal_strips = false;
-    int example = 10, ranks = 1;
+    std::string obj, tris_path, ppm, png, pfm, dump, rgba;
+    bool by_kernel = false, mirror = false, shm = false, equal_strips = false, size_set = false, cam_set = false;
+    int example = 10, ranks = 1, threads = 0;
     rt_options opt;
     memset(&opt, 0, sizeof(opt));
     opt.max_depth = 6; opt.ris_sample_count = 32; opt.rejection_heuristics_threshold = 0.2f;
@@ -329,10 +336,10 @@ int main(int argc, char** argv)
         auto f = [&](int k) { return (float)atof(argv[i + k]); };
         if (a == "--obj") obj = argv[++i];
         else if (a == "--tris") tris_path = argv[++i];
-        else if (a == "--size") { W = atoi(argv[i + 1]); H = atoi(argv[i + 2]); i += 2; }
+        else if (a == "--size") { W = atoi(argv[i + 1]); H = atoi(argv[i + 2]); i += 2; size_set = true; }
         else if (a == "--frames") frames = atoi(argv[++i]);
-        else if (a == "--eye") { eye[0] = f(1); eye[1] = f(2); eye[2] = f(3); i += 3; }
-        else if (a == "--lookat") { lookat[0] = f(1); lookat[1] = f(2); lookat[2] = f(3); i += 3; }
+        else if (a == "--eye") { eye[0] = f(1); eye[1] = f(2); eye[2] = f(3); i += 3; cam_set = true; }
+        else if (a == "--lookat") { lookat[0] = f(1); lookat[1] = f(2); lookat[2] = f(3); i += 3; cam_set = true; }
         else if (a == "--temporal") opt.use_temporal_resampling = (uint8_t)atoi(argv[++i]);
         else if (a == "--spatial") opt.use_spatial_resampling = (uint8_t)atoi(argv[++i]);
         else if (a == "--shadowed") opt.use_shadowed_target_function = (uint8_t)atoi(argv[++i]);
@@ -348,6 +355,8 @@ int main(int argc, char** argv)
         else if (a == "--ppm") ppm = argv[++i];
         else if (a == "--png") png = argv[++i];
         else if (a == "--pfm") pfm = argv[++i];
+        else if (a == "--rgba") rgba = argv[++i];
+        else if (a == "--threads") threads = atoi(argv[++i]);
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     std::vector<rt_triangle> triangles = !obj.empty() ? load_obj(obj) : load_tris(tris_path);
@@ -360,6 +369,50 @@ int main(int argc, char** argv)
         printf("triangles: %zu\n", triangles.size());
         return 0;
     }
+
+    if (example == 4)
+    {
+        /* BASELINE config #1: 04_ao as a host loop (host_path.h); no context, no GPU */
+        if (!size_set) { W = 256; H = 256; }
+        if (!cam_set) { eye[0] = eye[1] = eye[2] = 8.0f; lookat[0] = lookat[1] = lookat[2] = 0.0f; } /* common/misc.hpp:217-218 */
+        if (ranks > 1) { fprintf(stderr, "--example 4 is a host loop: --threads, not --ranks\n"); return 2; }
+        rt_raygen rg;
+        rt_host::raygen_lookat(&rg, eye, lookat, up, 3.14159265358979323846f / 4.0f, W, H); /* 04_ao.cpp:124-135 */
+        std::vector<uint8_t> px((size_t)W * H * 4);
+        const auto t0 = std::chrono::steady_clock::now();
+        rt_host::ao04_image(triangles.data(), (uint32_t)triangles.size(), rg, W, H, threads, px.data());
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        const unsigned hw = std::thread::hardware_concurrency();
+        size_t hit = 0;
+        for (size_t i = 0; i < (size_t)W * H; ++i) hit += px[4 * i] != 32 || px[4 * i + 1] != 32;
+        printf("triangles: %zu\n04_ao %dx%d: %.1f ms on %d host thread(s), %zu of %zu pixels hit\n", triangles.size(), W, H, ms,
+               threads > 0 ? threads : (int)(hw ? hw : 1), hit, (size_t)W * H);
+        if (!rgba.empty())
+        {
+            FILE* f = fopen(rgba.c_str(), "wb");
+            if (!f) { fprintf(stderr, "cannot write %s\n", rgba.c_str()); return 1; }
+            fwrite(px.data(), 1, px.size(), f);
+            fclose(f);
+        }
+        if (!ppm.empty())
+        {
+            FILE* f = fopen(ppm.c_str(), "wb");
+            if (!f) { fprintf(stderr, "cannot write %s\n", ppm.c_str()); return 1; }
+            fprintf(f, "P6\n%d %d\n255\n", W, H);
+            for (int y = H - 1; y >= 0; --y)
+                for (int x = 0; x < W; ++x) fwrite(&px[4 * ((size_t)y * W + x)], 1, 3, f);
+            fclose(f);
+        }
+        if (!png.empty())
+        {
+            std::vector<uint8_t> rgb((size_t)W * H * 3);
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < W; ++x) memcpy(&rgb[3 * ((size_t)y * W + x)], &px[4 * ((size_t)(H - 1 - y) * W + x)], 3);
+            write_png(png.c_str(), W, H, rgb.data());
+        }
+        return 0;
+    }
+    if (example != 10 && example != 7 && example != 8 && example != 9) { fprintf(stderr, "--example 10, 7, 8, 9 or 4\n"); return 2; }
 
     if (ranks > 1)
     {

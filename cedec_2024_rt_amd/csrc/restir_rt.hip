@@ -36,6 +36,7 @@ static_assert(sizeof(rt_raygen) == 36, "RayGenerator layout (common/camera.hpp:5
 static_assert(sizeof(BvhNode) == 64, "BVH node");
 
 #include "frame_kernels.h"
+#include "host_path.h"
 #include "bvh_build_host.h"
 #include "bvh_build_device.h"
 
@@ -982,17 +983,8 @@ int rt_camera_lookat(rt_ctx* c, const float eye[3], const float center[3], const
 {
     RT_CHECK_CTX(c);
     if (!eye || !center || !up) RT_FAIL(c, RT_ERR_ARG, "null camera vector");
-    const f3 e = F3(eye[0], eye[1], eye[2]), ce = F3(center[0], center[1], center[2]), u0 = F3(up[0], up[1], up[2]);
-    const f3 f = normalize(ce - e);
-    const f3 s = normalize(cross(f, u0));
-    const f3 u = cross(s, f);
-    const float tanThetaY = tanf(fovy * 0.5f);
-    const float tanThetaX = tanThetaY / (float)c->H * (float)c->W;
-    const f3 r = s * tanThetaX, uu = u * tanThetaY;
-    c->rg.origin[0] = e.x; c->rg.origin[1] = e.y; c->rg.origin[2] = e.z;
-    c->rg.right[0] = r.x; c->rg.right[1] = r.y; c->rg.right[2] = r.z;
-    c->rg.up[0] = uu.x; c->rg.up[1] = uu.y; c->rg.up[2] = uu.z;
-    c->eye[0] = e.x; c->eye[1] = e.y; c->eye[2] = e.z;
+    rt_host::raygen_lookat(&c->rg, eye, center, up, fovy, c->W, c->H); /* host_path.h: shared with the host-only config #1 */
+    memcpy(c->eye, eye, 12);
     memcpy(c->cam_eye, eye, 12);
     memcpy(c->cam_at, center, 12);
     c->cam_fovy = fovy;

@@ -8,13 +8,19 @@
  * has to be conservative (BVH box tests) may use explicit __builtin_fmaf.
  */
 #pragma once
-#include <hip/hip_runtime.h>
 #include <stdint.h>
-
-#include "portable_math.h"
-
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define RT_DEV __device__ __forceinline__
 #define RT_HD __host__ __device__ __forceinline__
+#else
+/* host-only translation units (app/restir_main.cpp through host_path.h: BASELINE config #1, the 04_ao host loop) compile
+ * the [parity] functions below as plain inline C++ (g++ -ffp-contract=off); the HBM record layouts are device-side only */
+#include <math.h>
+#define RT_HD inline __attribute__((always_inline))
+#endif
+
+#include "portable_math.h"
 
 namespace rt
 {
@@ -174,6 +180,7 @@ RT_HD bool intersect_ray_triangle(float& tOut, float& uOut, float& vOut, f3 ro, 
     return false;
 }
 
+#if defined(__HIPCC__)
 /* --------------------------------------------------------- HBM record layouts
  *
  * G-buffer (written once per frame by raycast, read by every later pass), 32 B / pixel:
@@ -356,5 +363,7 @@ RT_DEV void res_store_give(const HaloFuse& F, int W, float4* __restrict__ rec, f
     res_store(rec, radb, i, r, shaded);
     res_give(F, W, i, x, row, r, shaded);
 }
+
+#endif /* __HIPCC__ */
 
 }  // namespace rt

@@ -24,6 +24,13 @@ def test_config1_04_ao_256x256_on_this_host(oracle, golden_dir):
         oracle.set_math_mode(oracle.MATH_PORTABLE)
 
 
+def test_config1_04_ao_product_host_loop_on_this_host(tmp_path, golden_dir):
+    """the PRODUCT's config #1 (restir_app --example 4, host_path.h) on the GPU box's cores and libm"""
+    from tests import test_app_config1 as t
+
+    t.test_config1_04_ao_product_host_loop(tmp_path, golden_dir)
+
+
 def test_obj_readers_match_tinyobj_fixture_on_this_host(tmp_path):
     from tests import test_scenes as t
 
