@@ -8,7 +8,7 @@
  * intersect_ray_triangle, tri_normal) compiled as plain C++; transcendental functions are the host's libm
  * (cosf / sinf / powf / tanf), which is what the reference's host-compiled kernel calls — this path is compared
  * byte for byte with the reference's own kernel run on the host (tests/golden/ref_ao04_256.npz), not with the GPU.
- * Compile with -ffp-contract=off. Nothing here includes or links anything from oracle/.
+ * Compile with -ffp-contract=off. The test infrastructure (the CPU checker directory) is not used here in any form.
  */
 #pragma once
 #include <atomic>
