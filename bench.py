@@ -404,7 +404,7 @@ def _main():
     info = r.scene_info()
 
     spatial_ms = per_kernel = algo_bytes = pcie_ms = event_median = None
-    verified = mg_stats = None
+    verified = mg_stats = walks = verified_seq = None
     if world == 1:
         # algorithmic bytes of the three spatial launches of one timed frame (RNG replay, untimed): pass k of
         # frame f reads the buffer the previous pass wrote; the count only depends on the shaded bits
@@ -435,6 +435,45 @@ def _main():
             r.frame(frame)
             r.download(api.RT_BUF_PIXELS)
         pcie_ms = (time.perf_counter() - tp) / n_pcie * 1e3
+        # BVH walks really performed: the headline counts the REFERENCE's raytrace() calls; the build
+        # settles some shadow rays with a one-triangle test and skips rays whose answer an earlier kernel of the frame holds
+        # or nobody can observe. Counted by the kernels themselves over 4 more frames (untimed; a few atomics per wavefront).
+        r.walk_stats_enable(True)
+        n_walk = 4
+        for _ in range(n_walk):
+            frame += 1
+            r.frame(frame)
+        ws = r.walk_stats()
+        r.walk_stats_enable(False)
+        # frames are pipelined: stage 0 of the frame after the last one has run too -> per-frame averages over the launches counted
+        n_stage0 = ws["raycast"]["reference_rays"] / float(width * height)
+        per = {k: {kk: (vv / (n_stage0 if k in ("raycast", "generate_candidate") else n_walk)) for kk, vv in c.items()} for k, c in ws.items()}
+        walks = {"per_kernel": {k: {kk: int(round(vv)) for kk, vv in c.items()} for k, c in per.items()},
+                 "reference_rays": int(round(sum(c["reference_rays"] for c in per.values()))),
+                 "walked": int(round(sum(c["walked"] for c in per.values()))),
+                 "settled_by_self_test": int(round(sum(c["self_test"] for c in per.values()))),
+                 "not_evaluated": int(round(sum(c["not_evaluated"] for c in per.values())))}
+        # the timed path against the reference's launch sequence: a second context renders the same frame
+        # numbers one C-ABI call per reference kernel, synchronously (10_restir_di.cpp:270-379); the accumulation buffer and the
+        # temporal history of the last frame must be identical, bit for bit. Outside every timed region.
+        if os.environ.get("BENCH_VERIFY", "1") not in ("", "0"):
+            wd.tick("verification against the kernel sequence", 600)
+            acc_fast = r.download(api.RT_BUF_ACCUMULATION)
+            hist_fast = r.download(api.RT_BUF_RES_TEMPORAL)
+            seq = api.Renderer(width, height, device=local_rank)
+            seq.set_scene(tris)
+            seq.lookat(eye, center)
+            seq.set_options(opt)
+            for f in range(1, frame + 1):
+                seq.frame_by_kernels(f)
+            acc_seq = seq.download(api.RT_BUF_ACCUMULATION)
+            hist_seq = seq.download(api.RT_BUF_RES_TEMPORAL)
+            shaded_mask = hist_seq["M"] > 0
+            verified_seq = bool(np.array_equal(acc_fast.view(np.uint32), acc_seq.view(np.uint32))
+                                and all(np.array_equal(np.ascontiguousarray(hist_fast[f_][shaded_mask]).view(np.uint8),
+                                                       np.ascontiguousarray(hist_seq[f_][shaded_mask]).view(np.uint8))
+                                        for f_ in hist_seq.dtype.names if f_ != "pad"))
+            seq.close()
     else:
         st = mg.stats()
         mine = dict(rank=rank, rows=list(R["bounds"][rank]), host_us_per_frame=round(st["host_ns"] / K / 1e3, 1),
@@ -530,26 +569,41 @@ def _main():
         if world == 1:
             sha = lib_sha256()
             pmc = committed_pmc(sha, api.build_id())
-            ach = algo_bytes / (spatial_ms * 1e-3) / 1e9
+            contract_ach = algo_bytes / (spatial_ms * 1e-3) / 1e9
             traffic = pmc["traffic"]
+            measured_ach = (traffic / (spatial_ms * 1e-3) / 1e9) if traffic else None
             out["roofline"] = {
-                "kernel": "k_spatial (spatial_resampling)",
-                # the contract prices this kernel against HBM (bytes in reference-record sizes / time / 8 TB/s =
-                # `frac`); what really limits it is in `limiter` and `hbm_frac_measured` / `valu_issue_frac`
-                "bound": "hbm", "bound_measured": "valu", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "k_spatial_coop (spatial_resampling)",
+                # r04: `achieved` / `frac` are what the HBM counters of THIS build say the kernel moves per
+                # launch (FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes; tools/profile_round.sh)
+                # over the launch duration measured live here with HIP events; null when no counter pass of this build is
+                # committed (rt_build_id mismatch). The SURVEY 8(d) figure — algorithmic bytes in REFERENCE record sizes
+                # (16 + 76 B per neighbour; the kernel gathers one 64-B record, mostly from L2) / time / peak — is
+                # `contract_achieved` / `contract_frac`; it exceeds what the kernel moves and can pass 1.
+                "bound": "valu" if measured_ach is not None else "hbm", "bound_contract": "hbm",
+                "achieved": measured_ach if measured_ach is not None else contract_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (measured_ach if measured_ach is not None else contract_ach) / HBM_PEAK_GBS,
+                "frac_kind": "HBM counter traffic / launch time / peak" if measured_ach is not None else "CONTRACT figure (no counter pass of this build is committed)",
+                "traffic": traffic,
+                "contract_achieved": contract_ach, "contract_frac": contract_ach / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_launch": algo_bytes, "ms_per_launch": spatial_ms,
-                # the contract fraction counts reference-record bytes (16 + 76 B per neighbour) and can exceed 1: the kernel
-                # gathers 64-B records that mostly hit L2, so its real HBM traffic is lower (hbm_frac_measured) and it is
-                # limited by vector-ALU issue (valu_issue_frac), not by HBM
-                "hbm_frac_measured": (traffic / (spatial_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                "traffic_source": pmc["source"], "limiter": "vector-ALU issue (not HBM; the L1 address-slot limit of r02 went with the four-lanes-per-record fetch)",
-                "valu_issue_frac": pmc["valu"],
+                "traffic_source": pmc["source"],
+                "limiter": "vector-ALU issue and memory latency, not HBM bandwidth (counters: valu_issue_frac_weighted, DESIGN.md section 5.1)",
+                "valu_issue_frac_weighted": pmc["valu"],
             }
             out["lib_sha256"] = sha
             out["build_id"] = api.build_id()
             out["kernel_ms"] = per_kernel
             out["gpu_event_median_ms"] = event_median
+            # SURVEY 8(d)'s frame time = GPU-event median of >= 50 un-overlapped frames; `value` is pipelined throughput
+            out["value_gpu_event_median"] = {"value": total_rays / event_median / 1e3, "unit": "Mray/s", "ms_per_frame": event_median,
+                                             "note": "rays / GPU-event median of frames run back to back on one stream (SURVEY 8d's definition of the frame time)"}
+            if walks is not None:
+                out["bvh_walks_per_frame"] = walks
+                out["Mwalk_per_s"] = walks["walked"] / ms / 1e3
+                out["value_counts"] = "raytrace() calls of the REFERENCE per frame (SURVEY 8d); BVH traversals actually performed: bvh_walks_per_frame / Mwalk_per_s"
+            if verified_seq is not None:
+                out["verified_vs_kernel_sequence"] = verified_seq
             out["pcie_inclusive"] = {"ms_per_frame": pcie_ms, "value": total_rays / pcie_ms / 1e3, "unit": "Mray/s",
                                      "note": "frame + RGBA8 read-back to pageable host memory + sync, as the reference's loop does"}
             if not args.no_cpu_baseline and (width, height) == (W, H):

@@ -32,9 +32,10 @@ EXPORTS = [
     "rt_mg_partition", "rt_mg_bands", "rt_mg_unique_id", "rt_mg_load_error", "rt_mg_hub_create", "rt_mg_hub_destroy", "rt_mg_create",
     "rt_mg_destroy", "rt_mg_last_error", "rt_mg_frame", "rt_mg_frame_begin", "rt_mg_frame_step", "rt_mg_get_stats", "rt_mg_reset_stats",
     "rt_mg_selftest_rccl", "rt_tuning_get", "rt_build_id", "rt_halo_fuse_set", "rt_side_stream", "rt_copy_parts",
+    "rt_walk_stats_enable", "rt_walk_stats",
 ]
 
-RT_MG_TRANSPORT_RCCL, RT_MG_TRANSPORT_LOCAL, RT_MG_TRANSPORT_MIRROR, RT_MG_TRANSPORT_SHM = 0, 1, 2, 3
+RT_MG_TRANSPORT_RCCL, RT_MG_TRANSPORT_LOCAL, RT_MG_TRANSPORT_MIRROR, RT_MG_TRANSPORT_SHM, RT_MG_TRANSPORT_RCCL_SELF = 0, 1, 2, 3, 4
 RT_MG_DENSE, RT_MG_ONE_LANE, RT_MG_SEPARATE_PACK = 1, 2, 4
 
 
@@ -125,6 +126,8 @@ def load_library():
     L.rt_halo_pack.argtypes = [vp, ci, ci, ci, vp]
     L.rt_halo_unpack.argtypes = [vp, ci, ci, ci, vp]
     L.rt_ray_count.argtypes = [vp, vp, vp]
+    L.rt_walk_stats_enable.argtypes = [vp, ci]
+    L.rt_walk_stats.argtypes = [vp, vp]
     L.rt_timing_enable.argtypes = [vp, ci]
     L.rt_timing.argtypes = [vp, vp]
     L.rt_spatial_bytes.argtypes = [vp, ci, ci, ci, vp, vp]
@@ -565,6 +568,18 @@ class Renderer:
         a = C.c_uint64()
         self._ck(self.L.rt_visibility_rays_walked(self.h, C.byref(a)))
         return a.value
+
+    WALK_KERNELS = ("raycast", "generate_candidate", "spatial_resampling", "resolve")
+
+    def walk_stats_enable(self, on=True):
+        self._ck(self.L.rt_walk_stats_enable(self.h, int(bool(on))))
+
+    def walk_stats(self):
+        """per kernel: reference rays / walked through the BVH / settled by the self-occlusion test / not evaluated"""
+        a = np.zeros(16, dtype=np.uint64)
+        self._ck(self.L.rt_walk_stats(self.h, _p(a)))
+        return {k: dict(reference_rays=int(a[4 * i]), walked=int(a[4 * i + 1]), self_test=int(a[4 * i + 2]), not_evaluated=int(a[4 * i + 3]))
+                for i, k in enumerate(self.WALK_KERNELS)}
 
     def row_shaded(self):
         """shaded pixels per owned storage row (uint32)"""

@@ -30,7 +30,42 @@ struct FrameParams
     int accumulate, ris_sample_count, use_temporal, use_spatial, spatial_count, vis_reuse;
     float spatial_radius;
     int tile_mode; /* workgroup -> tile order inside an XCD's band: 0 row-major, 1 column-major */
+    uint32_t ownv_tag; /* own-visibility flags are written / trusted under this tag only (rt_device.h); 0 = never */
+    /* rt_walk_stats (measurement, off = nullptr: one wave-uniform test per kernel): 4 counters per kernel slot
+     * {rays the reference traces here, walked through the BVH, settled by the one-triangle self-occlusion test, not evaluated
+     * (answer known from the own-visibility flags, or unobservable)}; slots WALK_RAYCAST .. WALK_RESOLVE */
+    unsigned long long* stats;
 };
+enum { WALK_RAYCAST = 0, WALK_GENERATE = 1, WALK_SPATIAL = 2, WALK_RESOLVE = 3 };
+/* one ray per lane at most; works under any exec mask (ballots count the active lanes) */
+RT_DEV void count_walk_flags(unsigned long long* __restrict__ st, bool ref, bool walked, bool self, bool skipped)
+{
+    const unsigned long long b0 = __ballot(ref), b1 = __ballot(walked), b2 = __ballot(self), b3 = __ballot(skipped);
+    const unsigned long long act = __ballot(true);
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1)
+    {
+        if (b0) atomicAdd(&st[0], (unsigned long long)__popcll(b0));
+        if (b1) atomicAdd(&st[1], (unsigned long long)__popcll(b1));
+        if (b2) atomicAdd(&st[2], (unsigned long long)__popcll(b2));
+        if (b3) atomicAdd(&st[3], (unsigned long long)__popcll(b3));
+    }
+}
+/* several rays per lane; every lane of the wavefront must be active */
+RT_DEV void count_walk_counts(unsigned long long* __restrict__ st, uint32_t ref, uint32_t walked, uint32_t self, uint32_t skipped)
+{
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        ref += __shfl_down(ref, off); walked += __shfl_down(walked, off);
+        self += __shfl_down(self, off); skipped += __shfl_down(skipped, off);
+    }
+    if ((threadIdx.x & 63) == 0)
+    {
+        if (ref) atomicAdd(&st[0], (unsigned long long)ref);
+        if (walked) atomicAdd(&st[1], (unsigned long long)walked);
+        if (self) atomicAdd(&st[2], (unsigned long long)self);
+        if (skipped) atomicAdd(&st[3], (unsigned long long)skipped);
+    }
+}
 
 struct SceneView
 {
@@ -182,6 +217,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_RAYCAST_WS_WAVES : RT_RAYCAST_
     if (!tile_pixel<TRACE_BLOCK>(P, x, row)) return;
     const int yi = P.H - 1 - row;
     const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
+    if (P.stats) count_walk_flags(P.stats + 4 * WALK_RAYCAST, true, true, false, false); /* every primary ray is walked */
 
     const float u = (float)x / (float)P.W, v = (float)yi / (float)P.H;
     const f3 forward = normalize(cross(P.rg_up, P.rg_right));
@@ -500,14 +536,14 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_W
     }
     if (P.vis_reuse && !DEFER && !LATE) r.vis = V_cur != 0.0f; /* :127-131 */
     /* the ray surface point -> candidate has been walked from this pixel (shadowed target: always; else the visibility-reuse ray) */
-    if (SHADOWED || (P.vis_reuse && !DEFER && !LATE)) r.ownv = ownv_of(V_cur != 0.0f);
+    if (SHADOWED || (P.vis_reuse && !DEFER && !LATE)) r.ownv = ownv_of(P.ownv_tag, V_cur != 0.0f);
 
     if (FUSE_TEMPORAL)
     {
         if (!SHADOWED) load_prev(); /* after the walk: not live across it */
         const bool took_prev = temporal_merge<SHADOWED>(P, x, yi, sp, sn, r, pr, V_cur, V_prev);
         /* the previous frame's sample won: its ray from THIS surface point is known under the shadowed target only */
-        if (took_prev) r.ownv = SHADOWED ? ownv_of(V_prev != 0.0f) : 0u;
+        if (took_prev) r.ownv = SHADOWED ? ownv_of(P.ownv_tag, V_prev != 0.0f) : 0u;
         /* unshadowed: neither the merge decision nor ucw depends on the candidate's visibility; the bit is stored
          * clear here and set by k_candidate_visibility if the ray finds the light unoccluded */
         if (DEFER) need_ray = P.vis_reuse && !took_prev;
@@ -521,8 +557,16 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_W
          * whole wavefront. The ray's answer is observable only if the candidate survived (otherwise the stored bit is
          * the previous sample's, reservoir.hpp:36); lanes whose candidate did not survive, sky / emissive pixels and
          * lanes outside the image walk no ray of their own and take over parts of the others' walks instead. */
+        if (P.stats)
+        {
+            /* the reference walks the visibility-reuse ray of every shaded pixel (:127-131); here: only where the answer is
+             * observable (the candidate survived the merge), less what the own triangle settles */
+            const bool ref_ray = act && P.vis_reuse;
+            const bool self = self_occluded(S.bvh.tv, as_int(G0.w), late_sp + 0.001f * late_sn, r.hit_p - late_sp, late_sn, late_live);
+            count_walk_flags(P.stats + 4 * WALK_GENERATE, ref_ray, late_live && !self, late_live && self, ref_ray && !late_live);
+        }
         const bool visible = check_visibility_wide<TRACE_BLOCK, true>(S.wide, s_stack, late_sp, late_sn, r.hit_p, late_live, S.bvh.tv, as_int(G0.w));
-        if (late_live) { r.vis = visible; r.ownv = ownv_of(visible); }
+        if (late_live) { r.vis = visible; r.ownv = ownv_of(P.ownv_tag, visible); }
         /* the wavefront's 64 records leave together, a quad per record (wave_scatter_records below; the walk's LDS is idle now) */
         const bool shaded = in_image && (flags & GB_SHADED);
         const uint32_t mbits = ((uint32_t)r.M & RES_M_MASK) | (r.vis ? RES_VIS_BIT : 0u) | (shaded ? RES_SHADED_BIT : 0u);
@@ -604,7 +648,7 @@ __global__ __launch_bounds__(BLOCK) void k_temporal(SceneView S, FrameParams P, 
     float V_cur = 1.0f, V_prev = 1.0f;
     if (SHADOWED) temporal_rays(S, s_stack, P, sp, sn, r, pr, true, V_cur, V_prev, as_int(G0.w));
     const bool took_prev = temporal_merge<SHADOWED>(P, x, yi, sp, sn, r, pr, V_cur, V_prev);
-    if (SHADOWED) r.ownv = ownv_of((took_prev ? V_prev : V_cur) != 0.0f);
+    if (SHADOWED) r.ownv = ownv_of(P.ownv_tag, (took_prev ? V_prev : V_cur) != 0.0f);
     else if (took_prev) r.ownv = 0u;
     res_store(rec, radb, li, r, true);
 }
@@ -694,7 +738,7 @@ RT_DEV void spatial_pixel(const SceneView& S, const FrameParams& P, const HaloFu
         }
         tgt[5] = r.hit_p;
         /* the own sample's ray: walked by the kernel that wrote this record if the flag says so (see rt_device.h) */
-        const uint32_t own_flags = as_uint(in_rad[li].w);
+        const uint32_t own_flags = ownv_trusted(P.ownv_tag, as_uint(in_rad[li].w));
         if (!(own_flags & OWNV_KNOWN)) need |= 1u << 5;
         uint32_t occl = occluded_batch<6, TB>(S.wide, s_stack, sp, sn, tgt, need, S.bvh.tv, as_int(G0.w));
         if ((own_flags & OWNV_KNOWN) && !(own_flags & OWNV_VISIBLE)) occl |= 1u << 5;
@@ -725,7 +769,7 @@ RT_DEV void spatial_pixel(const SceneView& S, const FrameParams& P, const HaloFu
         const float Vf = (occl >> sel) & 1u ? 0.0f : 1.0f;
         const float p_hat = (1.0f / kPI) * geometry_term(sp, sn, r.hit_p, r.hit_n) * Vf * r.lum;
         r.ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
-        r.ownv = ownv_of(Vf != 0.0f);
+        r.ownv = ownv_of(P.ownv_tag, Vf != 0.0f);
         took_other = true; /* flags set above */
     }
     else if (P.use_spatial)
@@ -853,8 +897,18 @@ RT_DEV void spatial_wave_shadowed(const SceneView& S, const FrameParams& P, cons
     uint32_t own_flags = 0u;
     if (active)
     {
-        own_flags = as_uint(in_rad[li].w);
+        own_flags = ownv_trusted(P.ownv_tag, as_uint(in_rad[li].w));
         if (!(own_flags & OWNV_KNOWN)) need |= 1u << 5;
+    }
+    if (P.stats)
+    {
+        /* reference: one ray per neighbour that reaches the merge + the final sample's (:346-350, :370-378) */
+        uint32_t n_ref = active ? 1u : 0u;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) n_ref += pcode[k] != HALO_CODE_NONE ? 1u : 0u;
+        const uint32_t self = self_occluded_mask<6>(S.bvh.tv, active ? as_int(G0.w) : -1, sp, sn, tgt, need);
+        const uint32_t n_need = (uint32_t)__popc(need), n_self = (uint32_t)__popc(self);
+        count_walk_counts(P.stats + 4 * WALK_SPATIAL, n_ref, n_need - n_self, n_self, n_ref - n_need);
     }
     uint32_t occl = occluded_batch<6, TB>(S.wide, s_stack, sp, sn, tgt, need, S.bvh.tv, active ? as_int(G0.w) : -1);
     if ((own_flags & OWNV_KNOWN) && !(own_flags & OWNV_VISIBLE)) occl |= 1u << 5;
@@ -893,7 +947,7 @@ RT_DEV void spatial_wave_shadowed(const SceneView& S, const FrameParams& P, cons
     {
         const float4 rq = *rad_from;
         r.rad = F3(rq.x, rq.y, rq.z);
-        r.ownv = ownv_of(Vf != 0.0f);
+        r.ownv = ownv_of(P.ownv_tag, Vf != 0.0f);
     }
     else
         r = res_zero(); /* the reference stores nothing here (:275-287); we keep the shaded bit valid */
@@ -1600,8 +1654,13 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_RESOLVE_WAVES) void k_resolve(Scene
     const float G = geometry_term(sp, sn, hp, hn);
     /* the "fresh shadow ray" of :443-444 repeats the ray an earlier kernel of this frame walked from this pixel to this
      * sample if the record says so (rt_device.h, own-visibility flags): those lanes only help the others' walks */
-    const uint32_t ownv = as_uint(rq.w);
+    const uint32_t ownv = ownv_trusted(P.ownv_tag, as_uint(rq.w));
     const bool known = (ownv & OWNV_KNOWN) != 0u;
+    if (P.stats)
+    {
+        const bool self = self_occluded(S.bvh.tv, tri, sp + 0.001f * sn, hp - sp, sn, !known);
+        count_walk_flags(P.stats + 4 * WALK_RESOLVE, true, !known && !self, !known && self, known);
+    }
     const bool walked = check_visibility_wide<TRACE_BLOCK, WS>(S.wide, s_stack, sp, sn, hp, !known, S.bvh.tv, tri);
     const float V = (known ? (ownv & OWNV_VISIBLE) != 0u : walked) ? 1.0f : 0.0f;
     const f3 radiance = brdf * G * V * F3(rq.x, rq.y, rq.z) * q0.w;

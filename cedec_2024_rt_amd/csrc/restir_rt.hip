@@ -61,7 +61,13 @@ struct rt_ctx
     float4* d_gset[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}}; /* [set]{vis, g0, g1}; d_vis/d_g0/d_g1 = set gcur */
     int gcur = 0, timed_spec_set = -1;
     bool spec_valid = false, spec_timed[2] = {false, false};
+    bool spec_outstanding = false; /* work recorded by ev_spec_done that the main stream has not waited for yet */
     uint64_t spec_epoch = 0;
+    /* tags of the own-visibility flags (rt_device.h): one number per staged frame and per pipelined stage 0; the launches of
+     * a staged frame carry frame_tag (cur_tag while they are enqueued), the per-kernel entry points carry 0 */
+    uint32_t ownv_serial = 0, frame_tag = 0, cur_tag = 0, spec_gen_tag = 0;
+    unsigned long long* d_walk = nullptr; /* rt_walk_stats: 4 kernel slots x 4 counters */
+    bool walk_on = false;
     int tune_ws_primary = 0; /* rt_tuning key 16: primary rays with the work-sharing closest-hit walk (A/B: no gain) */
     int tune_stream = 0; /* rt_tuning key 15: resolve as a stream of pixels through persistent wavefronts (A/B: slower) */
     int n_cus = 256;
@@ -223,7 +229,15 @@ static FrameParams make_params(const rt_ctx* c, int frame, int pass, int kernel 
     P.spatial_count = c->opt.spatial_resampling_sample_count; P.vis_reuse = c->opt.use_visibility_reuse;
     P.spatial_radius = c->opt.spatial_resampling_radius;
     P.tile_mode = c->tune_tile_mode[kernel];
+    P.ownv_tag = c->cur_tag;
+    P.stats = c->walk_on ? c->d_walk : nullptr;
     return P;
+}
+static uint32_t next_ownv_tag(rt_ctx* c)
+{
+    c->ownv_serial = (c->ownv_serial + 1u) & 0x3fffffffu;
+    if (c->ownv_serial == 0u) c->ownv_serial = 1u;
+    return c->ownv_serial;
 }
 static SceneView make_scene(const rt_ctx* c)
 {
@@ -241,9 +255,9 @@ int rt_create(int device, int width, int height, int row_begin, int row_end, int
 {
     if (!out || width <= 0 || height <= 0 || row_begin < 0 || row_end > height || row_begin >= row_end || halo < 0)
         return RT_ERR_ARG;
-    /* five streams of a context want a hardware queue each (see below); effective if this is the process's first HIP call,
-     * harmless otherwise — hosts that initialise HIP earlier export GPU_MAX_HW_QUEUES=8 themselves */
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    /* five streams of a context want a hardware queue each (see below): the HOST exports GPU_MAX_HW_QUEUES=8 before its first
+     * HIP call (the Python package, bench.py and restir_app do). The library itself does not touch the
+     * environment: setenv is not safe beside the host's other threads and has no effect once HIP is initialised. */
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device >= ndev) return RT_ERR_NO_DEVICE;
     rt_ctx* c = new rt_ctx();
@@ -339,6 +353,7 @@ int rt_destroy(rt_ctx* c)
     hipFree(c->d_shaded_bits);
     hipFree(c->d_visq[0]); hipFree(c->d_visq[1]); hipFree(c->d_visq_count);
     if (c->h_visq_count) hipHostFree(c->h_visq_count);
+    hipFree(c->d_walk);
     hipFree(c->d_counter); hipFree(c->d_stage); hipFree(c->d_paths[0]); hipFree(c->d_paths[1]); hipFree(c->d_pt_counters);
     if (c->ev_created) for (auto& e : c->ev) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -1169,6 +1184,17 @@ static int join_tail(rt_ctx* c)
 /* a kernel of the staged frame that WRITES reservoir buffer `phys` (and reads only what the tail reads too): it waits for the
  * tail only if that is the buffer the tail reads */
 static int join_tail_for(rt_ctx* c, int phys) { return (c->tail_pending_main && phys == c->tail_phys) ? join_tail(c) : RT_OK; }
+/* the pipelined stage 0 (spec_stream) may still be running when a call outside the staged frame — or a frame that does not
+ * take its results — starts to write what it reads (the history buffer, the other G-buffer set) or reads what it writes: the
+ * stream about to be used waits for it first (cheap: that work is behind already). ADVICE r03. */
+static int join_spec(rt_ctx* c)
+{
+    if (!c->spec_outstanding) return RT_OK;
+    RT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_spec_done, 0));
+    if (c->stream != c->aux_stream) c->spec_outstanding = false;
+    return RT_OK;
+}
+#define JOIN_SPEC(c) do { const int _js = join_spec(c); if (_js != RT_OK) return _js; } while (0)
 static int trace_grid(const rt_ctx* c)
 {
     const int rows = c->sub0 >= 0 ? c->sub1 - c->sub0 : c->row_end - c->row_begin;
@@ -1188,6 +1214,7 @@ int rt_raycast(rt_ctx* c)
 {
     RT_CHECK_CTX(c);
     JOIN_TAIL(c);
+    JOIN_SPEC(c);
     NEED_SCENE(c);
     if (c->tune_ws_primary) k_raycast<true><<<trace_grid(c), TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_vis, c->d_g0, c->d_g1);
     else k_raycast<false><<<trace_grid(c), TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_vis, c->d_g0, c->d_g1);
@@ -1263,7 +1290,11 @@ static int launch_next_raycast(rt_ctx* c, int frame)
         hipStream_t ms = c->stream;
         float4 *g0 = c->d_g0, *g1 = c->d_g1;
         c->stream = c->spec_stream; c->d_g0 = c->d_gset[o][1]; c->d_g1 = c->d_gset[o][2];
+        const uint32_t tag_now = c->cur_tag;
+        c->spec_gen_tag = next_ownv_tag(c); /* the frame that takes these candidates continues under their tag */
+        c->cur_tag = c->spec_gen_tag;
         rc = launch_generate(c, frame + 1, c->spare, c->fY, c->opt.use_temporal_resampling != 0);
+        c->cur_tag = tag_now;
         c->stream = ms; c->d_g0 = g0; c->d_g1 = g1;
         if (rc == RT_OK)
         {
@@ -1276,6 +1307,7 @@ static int launch_next_raycast(rt_ctx* c, int frame)
     c->sub0 = s0; c->sub1 = s1; c->subb0 = b0; c->subb1 = b1;
     if (rc != RT_OK) return rc;
     RT_HIP(c, hipEventRecord(c->ev_spec_done, c->spec_stream));
+    c->spec_outstanding = true;
     c->spec_valid = true;
     c->spec_epoch = c->epoch;
     return RT_OK;
@@ -1290,6 +1322,7 @@ static int raycast_or_take(rt_ctx* c, bool whole, int frame)
         c->gcur ^= 1;
         c->d_vis = c->d_gset[c->gcur][0]; c->d_g0 = c->d_gset[c->gcur][1]; c->d_g1 = c->d_gset[c->gcur][2];
         RT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_spec_done, 0));
+        c->spec_outstanding = false;
         if (c->spec_gen_valid && use_next_generate(c) && c->spec_gen_frame == frame && c->spec_res_epoch == c->res_epoch &&
             c->spec_gen_hist == c->fX)
         {
@@ -1306,6 +1339,8 @@ static int raycast_or_take(rt_ctx* c, bool whole, int frame)
             else c->spare = r0;
             c->f_in = c->fY; c->f_out = c->fZ;
             c->gen_taken = true;
+            c->frame_tag = c->spec_gen_tag; /* own-visibility flags of the candidates were written under this tag */
+            c->cur_tag = c->frame_tag;
         }
         c->spec_gen_valid = false;
         c->spec_valid = false;
@@ -1377,6 +1412,7 @@ int rt_generate_candidate(rt_ctx* c, int frame, int dst)
 {
     RT_CHECK_CTX(c);
     JOIN_TAIL(c);
+    JOIN_SPEC(c);
     NEED_SCENE(c);
     NEED_RES(c, dst);
     ++c->res_epoch; /* a reservoir buffer changes outside the staged frame: a pipelined stage 0 is stale */
@@ -1388,6 +1424,7 @@ int rt_temporal_resampling(rt_ctx* c, int frame, int prev, int inout)
 {
     RT_CHECK_CTX(c);
     JOIN_TAIL(c);
+    JOIN_SPEC(c);
     NEED_SCENE(c);
     NEED_RES(c, prev);
     NEED_RES(c, inout);
@@ -1409,6 +1446,7 @@ int rt_save_temporal_reservoir(rt_ctx* c, int src, int dst)
 {
     RT_CHECK_CTX(c);
     JOIN_TAIL(c);
+    JOIN_SPEC(c);
     NEED_RES(c, src);
     NEED_RES(c, dst);
     ++c->res_epoch; /* a reservoir buffer changes outside the staged frame: a pipelined stage 0 is stale */
@@ -1508,6 +1546,7 @@ int rt_spatial_resampling(rt_ctx* c, int frame, int pass, int in, int out)
 {
     RT_CHECK_CTX(c);
     JOIN_TAIL(c);
+    JOIN_SPEC(c);
     NEED_SCENE(c);
     NEED_RES(c, in);
     NEED_RES(c, out);
@@ -1659,6 +1698,7 @@ int rt_frame_stage_begin(rt_ctx* c, int frame, int stage, int clear_first)
         c->f_stage = 0;
         c->gen_taken = false;
         c->f_frame = frame;
+        c->frame_tag = next_ownv_tag(c);
         return RT_OK;
     }
     if (stage != c->f_stage) RT_FAIL(c, RT_ERR_STATE, "rt_frame_stage: expected stage %d, got %d", c->f_stage, stage);
@@ -1717,6 +1757,7 @@ static int stage_run_ranges(rt_ctx* c, int frame, int stage, int part, int row0,
     const bool T = c->timing && whole;
     auto mark = [&](int i) { if (T && i <= 8) hipEventRecord(c->ev[i], c->stream); };
     c->sub0 = row0; c->sub1 = row1;
+    c->cur_tag = c->frame_tag; /* launches of the staged frame write / trust own-visibility flags under the frame's tag */
     int rc = RT_OK;
     if (stage == 0)
     {
@@ -1777,6 +1818,7 @@ static int stage_run_ranges(rt_ctx* c, int frame, int stage, int part, int row0,
     }
     c->sub0 = c->sub1 = -1;
     c->subb0 = c->subb1 = 0;
+    c->cur_tag = 0u;
     return rc;
 }
 
@@ -1968,6 +2010,7 @@ int rt_upload(rt_ctx* c, int buf, const void* src, size_t bytes)
 {
     RT_CHECK_CTX(c);
     JOIN_TAIL(c);
+    JOIN_SPEC(c);
     if (!src) RT_FAIL(c, RT_ERR_ARG, "null src");
     const size_t n = local_pixels(c);
     switch (buf)
@@ -2399,6 +2442,33 @@ int rt_ray_count(rt_ctx* c, uint64_t* rays, uint64_t* shaded_pixels)
 
 /* shaded pixels (hit and not emissive: the ones that run RIS, reuse and shadow rays) of each owned
  * storage row of the current G-buffer, row_end - row_begin host counters */
+/* BVH walks the build really performs (include/restir_rt.h) */
+int rt_walk_stats_enable(rt_ctx* c, int on)
+{
+    RT_CHECK_CTX(c);
+    int rc = rt_sync(c);
+    if (rc != RT_OK) return rc;
+    if (on)
+    {
+        if (!c->d_walk) RT_HIP(c, hipMalloc(&c->d_walk, 16 * 8));
+        RT_HIP(c, hipMemset(c->d_walk, 0, 16 * 8));
+    }
+    c->walk_on = on != 0;
+    /* a pipelined stage 0 enqueued before the switch carries the other setting: the next frame runs its own */
+    c->spec_valid = false; c->spec_gen_valid = false;
+    return RT_OK;
+}
+int rt_walk_stats(rt_ctx* c, uint64_t out[16])
+{
+    RT_CHECK_CTX(c);
+    if (!out) return RT_ERR_ARG;
+    if (!c->d_walk) RT_FAIL(c, RT_ERR_STATE, "rt_walk_stats_enable first");
+    int rc = rt_sync(c);
+    if (rc != RT_OK) return rc;
+    RT_HIP(c, hipMemcpy(out, c->d_walk, 16 * 8, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
 int rt_row_shaded(rt_ctx* c, uint32_t* counts)
 {
     RT_CHECK_CTX(c);

@@ -197,13 +197,17 @@ RT_HD bool intersect_ray_triangle(float& tOut, float& uOut, float& vOut, f3 ro, 
  * selected sample. Together they hold every field of the reference's 76-B Reservoir
  * (common/reservoir.hpp:5-38) losslessly for 0 <= M < 2^30.
  *
- * Own-visibility flags (r03; not part of the reference's Reservoir, never downloaded): OWNV_KNOWN = a kernel of THIS frame
- * has already evaluated the shadow ray from THIS pixel's surface point to the sample the record holds, OWNV_VISIBLE =
+ * Own-visibility flags (r03; not part of the reference's Reservoir, never downloaded): OWNV_KNOWN = a kernel of THIS staged
+ * frame has already evaluated the shadow ray from THIS pixel's surface point to the sample the record holds, OWNV_VISIBLE =
  * its answer. The reference traces that same ray again in the next kernel (the own sample's p-hat of the next spatial pass
  * under the shadowed target function, 10_restir_di.cu:370-378; resolve's "fresh" ray, :443-444): same origin, same
- * target, same frame, same scene => same answer, so the kernels that find the flag set skip the walk. Every kernel
- * rewrites the flags with the record (clear whenever it did not evaluate that ray itself), so they can never be stale;
- * uploads and the per-kernel API start from "unknown".
+ * target, same frame, same scene => same answer, so the kernels that find the flag set skip the walk.
+ * r04: the flags carry a TAG (bits 31..2) naming the staged frame they were computed in — one number per rt_frame /
+ * rt_frame_stage sequence and per pipelined stage 0, handed to the kernels in FrameParams::ownv_tag. A reader trusts
+ * OWNV_KNOWN only under its own tag, so a record an EARLIER frame wrote (a frame without spatial passes resolves
+ * reservoir_buffer1, which it did not write; a camera or option change in between) is walked afresh, as the reference
+ * does. Tag 0 = "trust nothing, record nothing": the per-kernel entry points (rt_generate_candidate, rt_spatial_resampling,
+ * rt_resolve, ...), where the caller may change camera, G-buffer or buffers between any two calls. Uploads store 0.
  */
 constexpr uint32_t GB_SHADED = 1u;
 constexpr uint32_t GB_EMISSIVE = 2u;
@@ -215,7 +219,9 @@ constexpr uint32_t OWNV_VISIBLE = 2u;
 #ifndef RT_OWNV
 #define RT_OWNV 1 /* 0: never set the flags (A/B) */
 #endif
-RT_HD uint32_t ownv_of(bool visible) { return RT_OWNV ? (OWNV_KNOWN | (visible ? OWNV_VISIBLE : 0u)) : 0u; }
+RT_HD uint32_t ownv_of(uint32_t tag, bool visible) { return (RT_OWNV && tag) ? ((tag << 2) | OWNV_KNOWN | (visible ? OWNV_VISIBLE : 0u)) : 0u; }
+/* the flags as this launch may use them: 0 unless they were written under this launch's tag */
+RT_HD uint32_t ownv_trusted(uint32_t tag, uint32_t flags) { return (tag != 0u && (flags >> 2) == tag) ? (flags & (OWNV_KNOWN | OWNV_VISIBLE)) : 0u; }
 
 struct Res
 {

@@ -242,6 +242,7 @@ struct rt_mg
         if (_r != ncclSuccess) MG_FAIL(m, RT_ERR_COMM, "%s failed: %s", #call, g_rccl.GetErrorString(_r)); \
     } while (0)
 
+static bool is_rccl(const rt_mg* m) { return m->transport == RT_MG_TRANSPORT_RCCL || m->transport == RT_MG_TRANSPORT_RCCL_SELF; }
 static hipStream_t main_stream(rt_mg* m)
 {
     void* s = nullptr;
@@ -428,8 +429,16 @@ static int wait_event_deadline(rt_mg* m, hipEvent_t ev, const char* what)
 static int rccl_handshake(rt_mg* m)
 {
     if (m->sides.empty()) return RT_OK;
-    int *d = nullptr, h_send[2][4], h_recv[2][4];
+    /* host buffers are PINNED: a device -> pageable-host copy completes synchronously on the host, so a stalled first
+     * exchange would block inside hipMemcpyAsync and never reach the deadline below; on a timeout both the
+     * device and the host buffer are leaked on purpose — the stuck stream may still write them */
+    int* d = nullptr;
+    int (*h)[2][4] = nullptr; /* h[0] = what I send, h[1] = what arrived */
     MG_HIP(m, hipMalloc(&d, 2 * 2 * 16));
+    MG_HIP(m, hipHostMalloc((void**)&h, 2 * sizeof(*h), hipHostMallocDefault));
+    memset(h, 0, 2 * sizeof(*h));
+    int (&h_send)[2][4] = h[0];
+    int (&h_recv)[2][4] = h[1];
     for (size_t i = 0; i < m->sides.size(); ++i)
     {
         const auto& s = m->sides[i];
@@ -449,14 +458,17 @@ static int rccl_handshake(rt_mg* m)
     MG_HIP(m, hipMemcpyAsync(h_recv, d + 8, sizeof(h_recv), hipMemcpyDeviceToHost, m->comm));
     MG_HIP(m, hipEventRecord(m->ev_arrived, m->comm));
     int rc = wait_event_deadline(m, m->ev_arrived, "the RCCL handshake (16-byte grouped send/recv with the neighbours)");
-    if (rc != RT_OK) return rc; /* d is leaked on purpose: the stream may still own it */
+    if (rc != RT_OK) return rc; /* d and h are leaked on purpose: the stream may still own them */
+    int got[2][4];
+    memcpy(got, h_recv, sizeof(got));
     hipFree(d);
+    hipHostFree(h);
     for (size_t i = 0; i < m->sides.size(); ++i)
     {
         const auto& s = m->sides[i];
-        if (h_recv[i][0] != 0x52544d47 || h_recv[i][1] != s.peer || h_recv[i][2] != (s.side == 0 ? m->a : m->b) || h_recv[i][3] != m->halo)
+        if (got[i][0] != 0x52544d47 || got[i][1] != s.peer || got[i][2] != (s.side == 0 ? m->a : m->b) || got[i][3] != m->halo)
             MG_FAIL(m, RT_ERR_COMM, "RCCL handshake: rank %d expected {rank %d, edge row %d, halo %d} from its neighbour, received {magic %08x, rank %d, edge row %d, halo %d}",
-                    m->rank, s.peer, s.side == 0 ? m->a : m->b, m->halo, (unsigned)h_recv[i][0], h_recv[i][1], h_recv[i][2], h_recv[i][3]);
+                    m->rank, s.peer, s.side == 0 ? m->a : m->b, m->halo, (unsigned)got[i][0], got[i][1], got[i][2], got[i][3]);
     }
     return RT_OK;
 }
@@ -582,6 +594,14 @@ int rt_mg_create(rt_ctx* ctx, int rank, int world, const int* bounds, int transp
         close(fd);
         if (m->shm.base == MAP_FAILED) { m->shm.base = nullptr; MG_FAIL(m, RT_ERR_COMM, "mmap of the shared segment failed"); }
     }
+    else if (world > 1 && transport == RT_MG_TRANSPORT_RCCL_SELF)
+    {
+        /* one rank alone with a communicator of its own: the peers of the partition do not exist, every message goes to self */
+        if (!g_rccl.load()) MG_FAIL(m, RT_ERR_COMM, "%s", g_rccl.err.c_str());
+        ncclUniqueId id;
+        MG_NCCL(m, g_rccl.GetUniqueId(&id));
+        MG_NCCL(m, g_rccl.CommInitRank(&m->nccl, 1, id, 0));
+    }
     else if (world > 1 && transport != RT_MG_TRANSPORT_MIRROR) MG_FAIL(m, RT_ERR_ARG, "unknown transport %d", transport);
     return RT_OK;
 }
@@ -693,8 +713,9 @@ static int post(rt_mg* m, std::vector<Exchange>&& xs)
         }
         return RT_OK;
     }
-    if (m->transport == RT_MG_TRANSPORT_RCCL)
+    if (is_rccl(m))
     {
+        const bool self = m->transport == RT_MG_TRANSPORT_RCCL_SELF;
         const bool on_main = m->comm_on_main && (m->n_itr == 0 || m->two_lanes); /* one lane with interior rows: they follow the boundary rows on the main stream */
         hipStream_t cs = on_main ? ms : m->comm;
         m->pending_on_main = on_main;
@@ -707,8 +728,9 @@ static int post(rt_mg* m, std::vector<Exchange>&& xs)
         for (auto& x : m->pending_x)
             for (auto& p : x.parts)
             {
-                MG_NCCL(m, g_rccl.Send(p.send, p.send_bytes, ncclUint8, x.peer, m->nccl, cs));
-                MG_NCCL(m, g_rccl.Recv(p.recv, p.recv_bytes, ncclUint8, x.peer, m->nccl, cs));
+                if (self && p.send_bytes != p.recv_bytes) MG_FAIL(m, RT_ERR_STATE, "RCCL_SELF transport: %zu bytes out, %zu in", p.send_bytes, p.recv_bytes);
+                MG_NCCL(m, g_rccl.Send(p.send, p.send_bytes, ncclUint8, self ? 0 : x.peer, m->nccl, cs));
+                MG_NCCL(m, g_rccl.Recv(p.recv, p.recv_bytes, ncclUint8, self ? 0 : x.peer, m->nccl, cs));
             }
         MG_NCCL(m, g_rccl.GroupEnd());
         if (!on_main) MG_HIP(m, hipEventRecord(m->ev_arrived, cs));
@@ -734,7 +756,7 @@ static int complete(rt_mg* m)
     if (!m->pending) return RT_OK;
     hipStream_t ms = main_stream(m);
     m->pending = false;
-    if (m->transport == RT_MG_TRANSPORT_RCCL)
+    if (is_rccl(m))
     {
         if (!m->pending_on_main) MG_HIP(m, hipStreamWaitEvent(ms, m->ev_arrived, 0));
         return RT_OK;

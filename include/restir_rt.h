@@ -251,7 +251,11 @@ int rt_lane(rt_ctx* ctx, int second);
 typedef struct rt_mg rt_mg;
 enum { RT_MG_TRANSPORT_RCCL = 0, RT_MG_TRANSPORT_LOCAL = 1, RT_MG_TRANSPORT_MIRROR = 2 /* a rank receives what it sent: one rank alone, for overhead measurements (results are not a frame) */,
        RT_MG_TRANSPORT_SHM = 3 /* N processes of one node through a POSIX shared-memory segment (arg = its name, the same string on every
-                                  rank): host-staged and blocking, for exact multi-process runs where RCCL cannot go (N ranks on ONE GPU) */ };
+                                  rank): host-staged and blocking, for exact multi-process runs where RCCL cannot go (N ranks on ONE GPU) */,
+       RT_MG_TRANSPORT_RCCL_SELF = 4 /* MIRROR with the real thing on the chain (r04): one rank alone, a ONE-rank RCCL communicator, every
+                                  exchange = the grouped ncclSend/ncclRecv of the RCCL transport with the true per-side message sizes, on the
+                                  stream the RCCL transport uses, addressed to the rank itself — so overhead measurements on a 1-GPU box
+                                  contain RCCL's launch and copy kernel (no xGMI wire time: bytes / link rate is added separately) */ };
 enum { RT_MG_DENSE = 1 /* whole 87-row bands, sent from the buffers in place */, RT_MG_ONE_LANE = 2 /* no second stream */,
        RT_MG_SEPARATE_PACK = 4 /* sparse halos packed / unpacked by launches of their own (r02) instead of by the spatial passes */ };
 typedef struct
@@ -295,6 +299,20 @@ int rt_ray_count(rt_ctx* ctx, uint64_t* rays, uint64_t* shaded_pixels);
 /* visibility-reuse rays the last rt_frame actually walked (rt_tuning key 11; the reference count of rt_ray_count does
  * not change): candidates that survived the temporal merge */
 int rt_visibility_rays_walked(rt_ctx* ctx, uint64_t* walked);
+/* BVH walks the build really performs, next to the rays the reference traces (r04; common/raytrace.hpp:18-52 is what a
+ * "ray" costs the reference: every raytrace() call is a traversal). While enabled, the frame's default kernels count per
+ * kernel slot k = 0 raycast, 1 generate_candidate(+temporal_resampling), 2 spatial_resampling (shadowed target function; the
+ * unshadowed pass traces nothing), 3 resolve:
+ *   out[4k + 0] rays the reference traces in that kernel,  out[4k + 1] of them walked through the BVH here,
+ *   out[4k + 2] settled by the one-triangle self-occlusion test (the ray starts below its own surface),
+ *   out[4k + 3] not evaluated: the answer is known from the own-visibility flags of an earlier kernel of the frame, or
+ *               cannot be observed (visibility-reuse ray of a candidate that lost the temporal merge, weight-0 neighbours).
+ * Counters accumulate over launches since rt_walk_stats_enable(ctx, 1) (which zeroes them; both calls synchronise). Covered:
+ * k_raycast, the fused work-sharing generate_candidate of rt_frame (unshadowed), k_resolve, the <= 5-neighbour shadowed
+ * spatial pass; other variants (rt_tuning A/B forms, shadowed candidates) leave their slot untouched. Results and timing
+ * of a frame do not depend on it beyond a few atomics per wavefront; bench.py measures with it off. */
+int rt_walk_stats_enable(rt_ctx* ctx, int on);
+int rt_walk_stats(rt_ctx* ctx, uint64_t out[16]);
 /* shaded pixels of each owned storage row (row_end - row_begin counters): the row cost of rt_mg_partition */
 int rt_row_shaded(rt_ctx* ctx, uint32_t* counts);
 /* time spent by the last `rt_frame` per kernel, HIP events on the context's stream.

@@ -1,0 +1,292 @@
+"""Round-4 GPU tests (VERDICT r03 items 1, 2, 4 and ADVICE r03):
+
+* the code path bench.py TIMES — frames enqueued back to back, three frames' work in flight over three streams, four
+  rotating reservoir buffers — against the oracle (not against another setting of the product): 12 frames at 480x270,
+  6 at 1920x1080, and 12 through rt_mg_frame on three LOCAL strips (10_restir_di.cpp:257-383);
+* own-visibility flags are not trusted across frames / camera moves / per-kernel calls (10_restir_di.cu:443-444: the
+  reference always traces the fresh ray);
+* the RCCL_SELF transport (real grouped ncclSend/ncclRecv to self with the true message sizes) moves the same bytes
+  as the MIRROR transport;
+* rt_walk_stats: rays the reference traces = walked + settled by the self test + not evaluated, per kernel.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FOVY = np.float32(np.pi) / np.float32(4)
+
+
+def _eq_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
+
+
+def _res_bad(a, b, mask):
+    bad = []
+    for f in a.dtype.names:
+        if f == "pad":
+            continue
+        x, y = np.ascontiguousarray(a[f][mask]), np.ascontiguousarray(b[f][mask])
+        if not _eq_bits(x, y):
+            bad.append(f)
+    return bad
+
+
+@pytest.fixture(scope="module")
+def api():
+    from cedec_2024_rt_amd import api as _api
+
+    return _api
+
+
+@pytest.fixture(scope="module")
+def scenes():
+    from cedec_2024_rt_amd import scenes as s
+
+    return s
+
+
+def _oracle_frames(oracle, tris, W, H, eye, at, frames, **optkw):
+    oracle.set_math_mode(oracle.MATH_PORTABLE)
+    sc = oracle.Scene(tris, use_bvh=True)
+    rg = oracle.raygen_lookat(eye, at, (0, 1, 0), FOVY, W, H)
+    st = oracle.new_state(W, H)
+    opt = oracle.bench_options(**optkw)
+    eyev = np.asarray(eye, np.float32)
+    for f in range(1, frames + 1):
+        sc.frame(W, H, f, rg, eyev, opt, st, None)
+    shaded = (st["vis"]["index"] >= 0) & ~np.isin(st["vis"]["index"], sc.lights)
+    return st, shaded
+
+
+@pytest.mark.parametrize("W,H,frames,tuning", [
+    (480, 270, 12, {}),            # defaults: pipelined stage 0 (key 14) + tail stream (key 17), as bench.py runs
+    (480, 270, 12, {14: 1}),       # only the next frame's primary rays ahead
+    (1920, 1080, 6, {}),           # the benchmark's own size
+])
+def test_timed_path_back_to_back_frames_vs_oracle(api, oracle, scenes, W, H, frames, tuning):
+    """What bench.py times: blocks_restir, bench options, frames enqueued back to back with NO sync or download in between.
+    The last frame's accumulation, pixels and temporal history == the oracle's (the buffer rotation has a period of several
+    frames; 12 frames cover it more than once)."""
+    from cedec_2024_rt_amd.types import bench_options
+
+    tris = scenes.make_blocks_restir()
+    eye, at = scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT
+    r = api.Renderer(W, H)
+    for k, v in tuning.items():
+        r.tuning(k, v)
+    assert r.tuning_get(14) == tuning.get(14, -1) and r.tuning_get(17) == -1  # the defaults bench.py runs with
+    r.set_scene(tris)
+    r.lookat(eye, at)
+    r.set_options(bench_options())
+    for f in range(1, frames + 1):
+        r.frame(f)  # asynchronous: nothing waits until the downloads below
+    st, shaded = _oracle_frames(oracle, tris, W, H, eye, at, frames)
+    acc = r.download(api.RT_BUF_ACCUMULATION)
+    ref = st["accum"].reshape(acc.shape)
+    nbad = int((acc.view(np.uint32) != ref.view(np.uint32)).any(axis=1).sum())
+    assert nbad == 0, f"frame {frames}: {nbad} pixels differ from the oracle"
+    assert np.array_equal(r.download(api.RT_BUF_PIXELS).reshape(H, W, 4), st["pixels"])
+    bad = _res_bad(r.download(api.RT_BUF_RES_TEMPORAL), st["temporal"], shaded)
+    assert not bad, f"temporal history after frame {frames}: {bad}"
+    r.close()
+
+
+def test_timed_path_three_local_strips_vs_oracle(api, oracle, scenes):
+    """The same through the native strip driver (rt_mg_frame, LOCAL transport, three strips of 480x270): 12 frames enqueued
+    back to back, then every strip's rows against the oracle's frame 12."""
+    from cedec_2024_rt_amd.types import bench_options
+
+    W, H, frames = 480, 270, 12
+    tris = scenes.make_blocks_restir()
+    eye, at = scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT
+    bounds = api.mg_partition(H, 3)
+    ctxs = []
+    for b in bounds:
+        c = api.Renderer(W, H, rows=b, halo=87)
+        c.set_scene(tris)
+        c.lookat(eye, at)
+        c.set_options(bench_options())
+        ctxs.append(c)
+    hub = api.MgHub(3)
+    mgs = [api.MultiGpu(c, k, bounds, transport=api.RT_MG_TRANSPORT_LOCAL, hub=hub) for k, c in enumerate(ctxs)]
+    for f in range(1, frames + 1):
+        api.mg_frame_lockstep(mgs, f)
+    st, shaded = _oracle_frames(oracle, tris, W, H, eye, at, frames)
+    ref = st["accum"].reshape(H, W, 4)
+    hist = st["temporal"].reshape(H, W)
+    sh = shaded.reshape(H, W)
+    for c, (a, b) in zip(ctxs, bounds):
+        acc = c.download(api.RT_BUF_ACCUMULATION).reshape(c.local_rows, W, 4)[a - c.local_row0: b - c.local_row0]
+        assert _eq_bits(acc, ref[a:b]), f"rows {a}:{b}: {int((acc != ref[a:b]).any(axis=2).sum())} pixels differ from the oracle"
+        px = c.download(api.RT_BUF_PIXELS).reshape(c.local_rows, W, 4)[a - c.local_row0: b - c.local_row0]
+        assert np.array_equal(px, st["pixels"][a:b])
+        mine = c.download(api.RT_BUF_RES_TEMPORAL).reshape(c.local_rows, W)[a - c.local_row0: b - c.local_row0]
+        bad = _res_bad(mine.reshape(-1), hist[a:b].reshape(-1), sh[a:b].reshape(-1))
+        assert not bad, f"temporal history of rows {a}:{b}: {bad}"
+    assert mgs[1].stats()["cold_frames"] == 1
+    for m in mgs:
+        m.close()
+    hub.close()
+    for c in ctxs:
+        c.close()
+
+
+@pytest.mark.parametrize("shadowed", [0, 1])
+def test_own_visibility_flags_do_not_outlive_their_frame(api, oracle, scenes, shadowed):
+    """resolve / the shadowed spatial pass skipped the "fresh" shadow ray whenever the record said an
+    earlier kernel had walked it — also when that kernel belonged to an EARLIER frame. (a) three passes, then a camera move
+    and spatial_resampling_passes = 0: the frame resolves reservoir_buffer1, which the previous frames' passes wrote, from
+    new surface points. (b) a staged frame, then a camera move and the per-kernel raycast + resolve on its final buffer.
+    (c) per-kernel generate_candidate, camera move + raycast, per-kernel spatial_resampling + resolve. All == oracle."""
+    from cedec_2024_rt_amd.types import bench_options
+
+    tris = scenes.make_quad_room()
+    W, H = 96, 54
+    eye0, at0 = (0.5, 2.5, 6.0), (0.0, 1.5, -1.0)
+    eye1, at1 = (1.4, 2.1, 5.2), (-0.3, 1.2, -1.0)
+    oracle.set_math_mode(oracle.MATH_PORTABLE)
+    sc = oracle.Scene(tris, use_bvh=True)
+    kw = dict(use_shadowed_target_function=shadowed)
+    rg0 = oracle.raygen_lookat(eye0, at0, (0, 1, 0), FOVY, W, H)
+    rg1 = oracle.raygen_lookat(eye1, at1, (0, 1, 0), FOVY, W, H)
+    e0, e1 = np.asarray(eye0, np.float32), np.asarray(eye1, np.float32)
+
+    # (a) staged frames only
+    r = api.Renderer(W, H)
+    r.set_scene(tris)
+    r.lookat(eye0, at0)
+    r.set_options(bench_options(**kw))
+    st = oracle.new_state(W, H)
+    for f in (1, 2):
+        r.frame(f)
+        sc.frame(W, H, f, rg0, e0, oracle.bench_options(**kw), st, None)
+    r.lookat(eye1, at1)
+    r.set_options(bench_options(spatial_resampling_passes=0, **kw))
+    for f in (3, 4):
+        r.frame(f)
+        sc.frame(W, H, f, rg1, e1, oracle.bench_options(spatial_resampling_passes=0, **kw), st, None)
+        acc = r.download(api.RT_BUF_ACCUMULATION)
+        ref = st["accum"].reshape(acc.shape)
+        assert _eq_bits(acc, ref), f"(a) frame {f}: {int((acc.view(np.uint32) != ref.view(np.uint32)).any(axis=1).sum())} pixels differ"
+    r.close()
+
+    # (b) staged frame, camera move, per-kernel raycast + resolve of the frame's final buffer
+    r = api.Renderer(W, H)
+    r.set_scene(tris)
+    r.lookat(eye0, at0)
+    r.set_options(bench_options(**kw))
+    st = oracle.new_state(W, H)
+    opt = oracle.bench_options(**kw)
+    final = r.frame(1)
+    sc.frame(W, H, 1, rg0, e0, opt, st, None)
+    assert final == api.RT_RES_1
+    r.lookat(eye1, at1)
+    r.raycast()
+    r.resolve(final)
+    sc.raycast(W, H, rg1, st["vis"])
+    sc.resolve(st["accum"], W, H, st["vis"], e1, opt, st["r1"])
+    acc = r.download(api.RT_BUF_ACCUMULATION)
+    ref = st["accum"].reshape(acc.shape)
+    assert _eq_bits(acc, ref), f"(b): {int((acc.view(np.uint32) != ref.view(np.uint32)).any(axis=1).sum())} pixels differ"
+    # and a staged frame right after per-kernel calls is still the oracle's frame
+    r.frame(2)
+    sc.frame(W, H, 2, rg1, e1, opt, st, None)
+    acc = r.download(api.RT_BUF_ACCUMULATION)
+    assert _eq_bits(acc, st["accum"].reshape(acc.shape)), "(b) staged frame after per-kernel calls"
+    r.close()
+
+    # (c) per-kernel calls with a camera move between generate_candidate and the spatial pass
+    r = api.Renderer(W, H)
+    r.set_scene(tris)
+    r.lookat(eye0, at0)
+    r.set_options(bench_options(**kw))
+    st = oracle.new_state(W, H)
+    r.raycast()
+    sc.raycast(W, H, rg0, st["vis"])
+    r.generate_candidate(1, api.RT_RES_0)
+    sc.generate_candidate(W, H, 1, st["vis"], e0, opt, st["r0"])
+    r.lookat(eye1, at1)
+    r.raycast()
+    sc.raycast(W, H, rg1, st["vis"])
+    r.spatial_resampling(1, 0, api.RT_RES_0, api.RT_RES_1)
+    sc.spatial_resampling(W, H, 1, 0, st["vis"], e1, opt, st["r0"], st["r1"])
+    r.resolve(api.RT_RES_1)
+    sc.resolve(st["accum"], W, H, st["vis"], e1, opt, st["r1"])
+    acc = r.download(api.RT_BUF_ACCUMULATION)
+    ref = st["accum"].reshape(acc.shape)
+    assert _eq_bits(acc, ref), f"(c): {int((acc.view(np.uint32) != ref.view(np.uint32)).any(axis=1).sum())} pixels differ"
+    r.close()
+
+
+@pytest.mark.parametrize("N,rank,H,flags", [(3, 1, 300, 0), (2, 0, 270, 0), (3, 1, 600, 0), (3, 1, 300, 1)])
+def test_rccl_self_transport_moves_what_mirror_moves(api, scenes, N, rank, H, flags):
+    """RT_MG_TRANSPORT_RCCL_SELF = the MIRROR transport with the real grouped ncclSend/ncclRecv (to the rank itself, true
+    message sizes, several parts per group) instead of one copy launch: same bytes, so the same (mirror) images."""
+    from cedec_2024_rt_amd.types import bench_options
+
+    W = 160
+    tris = scenes.make_blocks_restir()
+    bounds = api.mg_partition(H, N)
+    out = {}
+    for transport in (api.RT_MG_TRANSPORT_MIRROR, api.RT_MG_TRANSPORT_RCCL_SELF):
+        r = api.Renderer(W, H, rows=bounds[rank], halo=87)
+        r.set_scene(tris)
+        r.lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)
+        r.set_options(bench_options())
+        mg = api.MultiGpu(r, rank, bounds, transport=transport, flags=flags)
+        for f in range(1, 7):
+            mg.frame(f)
+        r.sync()
+        st = mg.stats()
+        out[transport] = (r.download(api.RT_BUF_ACCUMULATION).copy(), r.download(api.RT_BUF_RES_TEMPORAL).copy(), st["bytes_sent"], st["messages"])
+        mg.close()
+        r.close()
+    a, b = out[api.RT_MG_TRANSPORT_MIRROR], out[api.RT_MG_TRANSPORT_RCCL_SELF]
+    assert a[2] == b[2] and a[3] == b[3] and a[2] > 0
+    assert _eq_bits(a[0], b[0]), "accumulation differs between MIRROR and RCCL_SELF"
+    assert _eq_bits(a[1], b[1]), "temporal history differs between MIRROR and RCCL_SELF"
+
+
+@pytest.mark.parametrize("shadowed", [0, 1])
+def test_walk_stats_account_for_every_reference_ray(api, oracle, scenes, shadowed):
+    """rt_walk_stats: per kernel, reference rays = walked + settled by the self-occlusion test + not evaluated; the reference
+    counts are the oracle's (N primary rays, one visibility-reuse and one resolve ray per shaded pixel), and the build
+    walks fewer rays than the reference traces."""
+    from cedec_2024_rt_amd.types import bench_options
+
+    W, H, frames = 480, 270, 3
+    tris = scenes.make_blocks_restir()
+    r = api.Renderer(W, H)
+    r.tuning(14, 0)  # every kernel exactly `frames` times (no stage 0 of a frame that is never rendered)
+    r.set_scene(tris)
+    r.lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)
+    r.set_options(bench_options(use_shadowed_target_function=shadowed))
+    r.frame(1)
+    r.walk_stats_enable(True)
+    for f in range(2, 2 + frames):
+        r.frame(f)
+    ws = r.walk_stats()
+    r.walk_stats_enable(False)
+    rays, n_shaded = r.ray_count()
+    for k, c in ws.items():
+        assert c["reference_rays"] == c["walked"] + c["self_test"] + c["not_evaluated"], (k, c)
+    assert ws["raycast"]["reference_rays"] == W * H * frames == ws["raycast"]["walked"]
+    assert ws["resolve"]["reference_rays"] == n_shaded * frames
+    if not shadowed:
+        assert ws["generate_candidate"]["reference_rays"] == n_shaded * frames
+        assert sum(c["reference_rays"] for c in ws.values()) == rays * frames
+        walked = sum(c["walked"] for c in ws.values())
+        assert W * H * frames < walked < rays * frames
+        assert ws["resolve"]["not_evaluated"] > 0 and ws["resolve"]["self_test"] > 0 and ws["generate_candidate"]["self_test"] > 0
+        assert ws["spatial_resampling"]["reference_rays"] == 0
+    else:
+        assert ws["spatial_resampling"]["reference_rays"] > 3 * n_shaded * frames  # >= 1 ray per shaded pixel and pass
+        assert ws["spatial_resampling"]["walked"] < ws["spatial_resampling"]["reference_rays"]
+        assert ws["resolve"]["not_evaluated"] == n_shaded * frames  # the last pass walked every final sample's ray
+    # the image does not depend on the counting
+    r.frame(2 + frames)
+    acc = r.download(api.RT_BUF_ACCUMULATION)
+    st, _ = _oracle_frames(oracle, tris, W, H, scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT, 2 + frames, use_shadowed_target_function=shadowed)
+    assert _eq_bits(acc, st["accum"].reshape(acc.shape))
+    r.close()

@@ -9,6 +9,11 @@ reads the gfx950 assembly and prints, as Markdown,
     (profiles/r02_valu_rates.json, tools/valu_rates.hip: wall time per wave64 instruction per SIMD at 8 waves/SIMD).
 
   python tools/isa_budget.py > profiles/r03_isa_budget.md        (CPU only: hipcc cross-compiles)
+  python tools/isa_budget.py --class-costs profiles/isa_class_costs.json
+      per kernel, the mean issue cost of the static instructions that fall into the two MIXED buckets of the dynamic
+      class counters (SQ_INSTS_VALU_INT32, and "other" = SQ_INSTS_VALU minus all class counters: moves, selects, f32
+      compares, min / max, div_scale / div_fixup): tools/profile_collect.py prices the dynamic counts with them
+      (valu_issue_frac_weighted).
 
 Classes: F = full rate (v_add/sub/mul/fma/fmac_f32, v_mov, integer add/shift/logic: ~2.5 cycles per wave64
 instruction), C = half rate (min/max/cmp/cndmask/cvt/bfe/perm/alignbit/add3/mul_lo/mad_u64/div_scale/div_fmas/
@@ -78,6 +83,26 @@ def what(op):
     if op.startswith(("v_cmp", "v_cndmask")):
         return "compare / select"
     return "other arithmetic"
+
+
+def bucket(op):
+    """the dynamic class counter a static instruction is (presumably) counted by: SQ_INSTS_VALU_<bucket>, or OTHER"""
+    b = op.replace("_e32", "").replace("_e64", "").replace("_sdwa", "").replace("_dpp", "")
+    if T_OPS.match(b):
+        return "TRANS_F32"
+    if b.startswith("v_cvt_"):
+        return "CVT"
+    if b in ("v_add_f32", "v_sub_f32", "v_subrev_f32"):
+        return "ADD_F32"
+    if b == "v_mul_f32":
+        return "MUL_F32"
+    if b in ("v_fma_f32", "v_fmac_f32", "v_mad_f32", "v_mac_f32", "v_div_fmas_f32"):
+        return "FMA_F32"
+    if b.startswith(("v_mad_u64", "v_mad_i64")) or b.endswith("_b64") or b.endswith("_u64") or b.endswith("_i64"):
+        return "INT64"
+    if re.match(r"^v_(add|sub|subrev|mul_lo|mul_hi|mul|mad|and|or|xor|not|lshl|lshr|ashr|lshlrev|lshrrev|ashrrev|bfe|bfi|add3|alignbit|perm|min|max|med3|add_co|addc_co|sub_co|subb_co|lshl_add|lshl_or|and_or|or3|xad|add_lshl|bcnt|ffbh|ffbl|mbcnt_lo|mbcnt_hi)\w*_(u32|i32|b32|u24|i24|u32_b32)$", b) or b.startswith(("v_cmp_", "v_cmpx_")) and b.endswith(("_u32", "_i32")):
+        return "INT32"
+    return "OTHER"
 
 
 def compile_asm(tmp):
@@ -170,7 +195,36 @@ KERNELS = [("k_raycast", "k_raycast<false>("), ("k_raycast<WS>", "k_raycast<true
 LOOP_KERNELS = {"k_raycast", "k_generate_candidate<true,false>", "k_spatial_gather", "k_spatial_coop", "k_halo_mark", "k_resolve", "k_spatial<true>"}
 
 
+def class_costs(path):
+    """{kernel: {bucket: {static instructions, mean cycles}}} of the frame kernels' static ISA"""
+    with tempfile.TemporaryDirectory() as tmp:
+        asm = compile_asm(tmp)
+    fns = functions(asm)
+    names = demangle(list(fns))
+    out = {"costs_cycles": {"F": round(F_COST, 3), "FMA": round(FMA_COST, 3), "C": round(C_COST, 3), "T": round(T_COST, 3)},
+           "source": "tools/isa_budget.py --class-costs: static gfx950 ISA of each kernel, instruction costs of profiles/r02_valu_rates.json"}
+    for label, needle in KERNELS:
+        cand = [m for m, d in names.items() if needle in d.replace("void ", "")]
+        if not cand:
+            continue
+        agg = collections.defaultdict(lambda: [0, 0.0])
+        for op, n in histogram(fns[cand[0]]).items():
+            if not op.startswith("v_"):
+                continue
+            _, cost = classify(op)
+            a = agg[bucket(op)]
+            a[0] += n
+            a[1] += n * cost
+        short = needle.rstrip("(")
+        out[short] = {b: {"static": n, "mean_cycles": round(c / n, 3)} for b, (n, c) in sorted(agg.items())}
+    json.dump(out, open(path, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--class-costs":
+        class_costs(sys.argv[2])
+        return
     with tempfile.TemporaryDirectory() as tmp:
         asm = compile_asm(tmp)
         res = resources(tmp)

@@ -60,7 +60,53 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     fw[c] = {k: dict(launches=v[c]["launches"], mean_KB=v[c]["mean"]) for k, v in counters("pmc_" + c).items() if c in v}
 json.dump(fw, open(os.path.join(dst, f"{tag}_pmc_fetch_write.json"), "w"), indent=1)
 
+# class-weighted vector-issue utilisation (r01-r03 priced every instruction at 4 cycles, which put
+# k_raycast above 1): dynamic class counts (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32, _INT32, _INT64, _CVT) x the issue
+# costs MEASURED on this chip (profiles/r02_valu_rates.json: full rate 2.4 / fma 2.8 / half rate 4.2 / transcendental 8.2
+# cycles per wave64 instruction per SIMD); the two mixed buckets (INT32; "other" = total - classes: moves, selects, f32
+# compares, min / max) at the mean cost of the kernel's own static instructions of that bucket
+# (profiles/isa_class_costs.json, tools/isa_budget.py --class-costs); clock = GRBM_GUI_ACTIVE / kernel time.
+CLS = {"ADD_F32": "F", "MUL_F32": "F", "FMA_F32": "FMA", "TRANS_F32": "T", "CVT": "C", "INT64": "C"}
+try:
+    ISA = json.load(open(os.path.join(dst, "isa_class_costs.json")))
+except Exception:
+    ISA = {"costs_cycles": {"F": 2.384, "FMA": 2.765, "C": 4.209, "T": 8.152}}
+
+
+def weighted_valu(kernel, e, ms):
+    """adds valu_issue_frac_weighted (and its ingredients) to the counter dict e of one kernel"""
+    total = e.get("SQ_INSTS_VALU")
+    if not total or not ms or e.get("SQ_INSTS_VALU_INT32") is None:
+        return
+    cost = ISA["costs_cycles"]
+    own = None
+    for k, v in ISA.items():
+        if isinstance(v, dict) and "OTHER" in v and (k == kernel or k.split("<")[0] == kernel.split("<")[0]):
+            own = v
+            if k == kernel:
+                break
+    c_int = own["INT32"]["mean_cycles"] if own and "INT32" in own else 3.3
+    c_oth = own["OTHER"]["mean_cycles"] if own else 3.55
+    cyc, classes = 0.0, 0.0
+    for name, cl in CLS.items():
+        n = e.get("SQ_INSTS_VALU_" + name, 0.0) or 0.0
+        cyc += n * cost[cl]
+        classes += n
+    n_int = e.get("SQ_INSTS_VALU_INT32", 0.0) or 0.0
+    other = max(total - classes - n_int, 0.0)
+    cyc += n_int * c_int + other * c_oth
+    ghz = 2.4
+    if e.get("GRBM_GUI_ACTIVE"):
+        ghz = e["GRBM_GUI_ACTIVE"] / (ms * 1e6)  # busy cycles of the launch / its duration
+    e["valu_cycles_per_inst_weighted"] = cyc / total
+    e["clock_GHz_from_GRBM_GUI_ACTIVE"] = ghz
+    e["valu_other_bucket_share"] = other / total
+    e["valu_issue_frac_weighted"] = cyc / 1024.0 / (ms * 1e6 * ghz)
+
+
 valu = counters("pmc_valu")
+for k, cs in counters("pmc_class").items():
+    valu.setdefault(k, {}).update({c: v for c, v in cs.items() if c not in valu.get(k, {})})
 mix = counters("pmc_mix")
 stall = counters("pmc_stall")
 for k, cs in stall.items():
@@ -75,10 +121,14 @@ for k, cs in valu.items():
         ms = stats_avg_ms[k]
         # 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD (16 lanes) for 4 cycles
         e["avg_ms_kernel_trace"] = ms
-        e["valu_issue_ms_at_2p4GHz"] = e["SQ_INSTS_VALU"] * 4 / 1024 / 2.4e6
-        e["valu_issue_fraction"] = e["valu_issue_ms_at_2p4GHz"] / ms
+        e["valu_issue_frac_4cycle_convention_r01_r03"] = e["SQ_INSTS_VALU"] * 4 / 1024 / 2.4e6 / ms
+        weighted_valu(k, e, ms)
         if e.get("SQ_WAVES"):
             e["valu_insts_per_wave"] = e["SQ_INSTS_VALU"] / e["SQ_WAVES"]
+        if e.get("SQ_WAVE_CYCLES"):
+            for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+                if e.get(c) is not None:
+                    e[c + "_share_of_wave_cycles"] = e[c] / e["SQ_WAVE_CYCLES"]
     out[k] = e
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc_valu.json"), "w"), indent=1)
 
@@ -97,7 +147,7 @@ if scon is not None:
             f.write(f'"{k}",{len(v)},{sum(v)},{sum(v)/len(v):.1f},{min(v)},{max(v)},{100.0*sum(v)/stot:.3f}\n')
     s_avg = {k: sum(v) / len(v) * 1e-6 for k, v in srows.items()}
     sh = {}
-    for path in ("sh_pmc_FETCH_SIZE", "sh_pmc_WRITE_SIZE", "sh_pmc_valu", "sh_pmc_stall"):
+    for path in ("sh_pmc_FETCH_SIZE", "sh_pmc_WRITE_SIZE", "sh_pmc_valu", "sh_pmc_class", "sh_pmc_stall"):
         for k, cs in counters(path).items():
             if k.startswith("k_") and "bvh" not in k:
                 sh.setdefault(k, {}).update({c: v["mean"] for c, v in cs.items()})
@@ -105,7 +155,8 @@ if scon is not None:
         if k in s_avg:
             e["avg_ms_kernel_trace"] = s_avg[k]
             if e.get("SQ_INSTS_VALU"):
-                e["valu_issue_fraction"] = e["SQ_INSTS_VALU"] * 4 / 1024 / 2.4e6 / s_avg[k]
+                e["valu_issue_frac_4cycle_convention_r01_r03"] = e["SQ_INSTS_VALU"] * 4 / 1024 / 2.4e6 / s_avg[k]
+                weighted_valu(k, e, s_avg[k])
                 if e.get("SQ_WAVES"):
                     e["valu_insts_per_wave"] = e["SQ_INSTS_VALU"] / e["SQ_WAVES"]
             if e.get("SQ_WAVE_CYCLES"):
@@ -131,10 +182,11 @@ if sp:
     bidf = os.path.join(src, "lib.build_id")
     if os.path.exists(bidf):
         bid = open(bidf).read().split()[0]
-    vfrac = {kk: round(e["valu_issue_fraction"], 3) for kk, e in out.items()
-             if "valu_issue_fraction" in e and kk.split("<")[0] in ("k_raycast", "k_generate_candidate", "k_resolve", "k_spatial", "k_spatial_coop", "k_spatial_gather", "k_spatial_lds")}
+    vfrac = {kk: round(e["valu_issue_frac_weighted"], 3) for kk, e in out.items()
+             if "valu_issue_frac_weighted" in e and kk.split("<")[0] in ("k_raycast", "k_generate_candidate", "k_resolve", "k_spatial", "k_spatial_coop", "k_spatial_gather", "k_spatial_lds")}
     json.dump({
         "kernel": k, "round": tag, "build_id": bid, "lib_sha256": sha, "valu_issue_frac": vfrac,
+        "valu_issue_frac_definition": "class-weighted: dynamic class counters x measured issue costs / (1024 SIMDs x kernel time x measured clock); tools/profile_collect.py",
         "workload": "blocks_restir stand-in 1920x1080, bench options",
         "FETCH_SIZE_KB_per_launch": fetch / 1024, "WRITE_SIZE_KB_per_launch": write / 1024,
         "read_bytes_corrected": corrected, "streamed_read_bytes_known": streamed,

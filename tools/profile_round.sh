@@ -7,7 +7,9 @@ TAG=${1:-rXX}
 export TMPDIR=/tmp
 OUT=gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
-timeout 300 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+# BENCH_VERIFY=0 in the profiled runs below: the kernel-sequence verification context would add its launches to the traces
+timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+export BENCH_VERIFY=0
 # per-kernel profiles are of frames whose kernels run back to back on one stream (RT_TUNING=14=0: without the pipelined stage 0
 # the kernels of consecutive frames do not overlap, so a kernel's duration and counters are its own; the bench line records
 # rt_tuning_env). The headline bench.json above is the default (pipelined) run.
@@ -17,6 +19,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c -d $OUT/pmc_$c -o pmc -- python3 bench.py --no-cpu-baseline --steps 16 --warmup 2 > $OUT/pmc_$c.log 2>&1
 done
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_valu -o pmc -- python3 bench.py --no-cpu-baseline --steps 16 --warmup 2 > $OUT/pmc_valu.log 2>&1
+# dynamic instruction classes (priced with the measured per-class issue costs: valu_issue_frac_weighted)
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT -d $OUT/pmc_class -o pmc -- python3 bench.py --no-cpu-baseline --steps 16 --warmup 2 > $OUT/pmc_class.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU -d $OUT/pmc_mix -o pmc -- python3 bench.py --no-cpu-baseline --steps 16 --warmup 2 > $OUT/pmc_mix.log 2>&1
 # where a wavefront's cycles go (quad-cycles; WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES, MI355X_MICROARCH.md PMC slots)
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS -d $OUT/pmc_stall -o pmc -- python3 bench.py --no-cpu-baseline --steps 16 --warmup 2 > $OUT/pmc_stall.log 2>&1
@@ -36,8 +40,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c -d $OUT/sh_pmc_$c -o pmc -- python3 tools/shadowed_frames.py 12 > $OUT/sh_pmc_$c.log 2>&1
 done
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/sh_pmc_valu -o pmc -- python3 tools/shadowed_frames.py 12 > $OUT/sh_pmc_valu.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT -d $OUT/sh_pmc_class -o pmc -- python3 tools/shadowed_frames.py 12 > $OUT/sh_pmc_class.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS -d $OUT/sh_pmc_stall -o pmc -- python3 tools/shadowed_frames.py 12 > $OUT/sh_pmc_stall.log 2>&1
-unset RT_TUNING
+unset RT_TUNING BENCH_VERIFY
 sha256sum cedec_2024_rt_amd/librestir_rt.so > $OUT/lib.sha256
 python3 -c "from cedec_2024_rt_amd import api; print(api.build_id())" > $OUT/lib.build_id
 # summarise on the box (the raw rocprofv3 databases are too large to travel back) and keep the summaries only

@@ -27,7 +27,11 @@ from cedec_2024_rt_amd import api, scenes  # noqa: E402
 from cedec_2024_rt_amd.types import bench_options  # noqa: E402
 
 
-def measure(W, H, N, flags, tris, frames=40, warm=6, rank=None, bounds=None):
+TRANSPORTS = {"mirror": api.RT_MG_TRANSPORT_MIRROR, "rccl_self": api.RT_MG_TRANSPORT_RCCL_SELF}
+XGMI_GBS = 153.0  # one xGMI link, one direction (MI355X_MICROARCH.md): a strip talks to each neighbour over a link of its own
+
+
+def measure(W, H, N, flags, tris, frames=40, warm=6, rank=None, bounds=None, transport="mirror"):
     bounds = bounds or api.mg_partition(H, N)
     rank = N // 2 if rank is None else rank
     a, b = bounds[rank]
@@ -35,7 +39,7 @@ def measure(W, H, N, flags, tris, frames=40, warm=6, rank=None, bounds=None):
     r.set_scene(tris)
     r.lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)
     r.set_options(bench_options())
-    mg = api.MultiGpu(r, rank, bounds, transport=api.RT_MG_TRANSPORT_MIRROR, flags=flags)
+    mg = api.MultiGpu(r, rank, bounds, transport=TRANSPORTS[transport], flags=flags)
     f = 0
     for _ in range(warm):
         f += 1
@@ -53,7 +57,11 @@ def measure(W, H, N, flags, tris, frames=40, warm=6, rank=None, bounds=None):
     out = dict(rows=b - a, ms_per_frame=round(wall / frames * 1e3, 4), gpu_event_ms_per_frame=round(st["gpu_ns_per_frame"] / 1e6, 4), host_us=round(st["host_ns"] / frames / 1e3, 1),
                host_loop_us=round(t_host / frames * 1e6, 1), plan_wait_us=round(st["plan_wait_ns"] / frames / 1e3, 1),
                cold_frames=st["cold_frames"], MB_sent_per_frame=round(st["bytes_sent"] / frames / 1e6, 3),
-               messages_per_frame=st["messages"] / frames)
+               messages_per_frame=st["messages"] / frames, transport=transport)
+    # what neither transport contains: the wire. Bytes per frame and SIDE over one xGMI link, summed over the frame's exchanges
+    # (3 on the chain; the two sides travel on different links at the same time) - a stated addend, not part of ms_per_frame
+    sides = (1 if rank in (0, N - 1) else 2) if N > 1 else 0
+    out["xgmi_wire_us_per_frame"] = round(st["bytes_sent"] / frames / max(sides, 1) / (XGMI_GBS * 1e9) * 1e6, 1) if sides else 0.0
     mg.close()
     r.close()
     return out
@@ -63,23 +71,40 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     ap.add_argument("--churn", type=int, default=0, help="create and destroy this many strip contexts + drivers first (stream -> hardware queue mapping after a host has re-created its contexts, as bench.py does for cost-weighted strips)")
-    ap.add_argument("--only", default=None, help="WxH:N:sparse|dense|onelane|separate, e.g. 3840x2160:8:sparse (for a kernel trace of one case)")
+    ap.add_argument("--only", default=None, help="WxH:N:sparse|dense|onelane|separate[:rank], e.g. 3840x2160:8:sparse (for a kernel trace of one case)")
+    ap.add_argument("--transport", default="mirror", choices=sorted(TRANSPORTS), help="mirror: one copy launch per exchange; rccl_self: the real grouped ncclSend/ncclRecv (to self)")
+    ap.add_argument("--quick", action="store_true", help="N = 8 only, both sizes, every rank with equal rows (no balance rounds)")
     args = ap.parse_args()
     tris = scenes.make_blocks_restir()
     res = {}
     for _ in range(args.churn):
         measure(1920, 1080, 8, 0, tris, frames=3, warm=1)
+    T = args.transport
     if args.only:
-        wh, n, mode = args.only.split(":")
+        parts = args.only.split(":")
+        wh, n, mode = parts[:3]
         w, h = (int(v) for v in wh.split("x"))
         flags = {"sparse": 0, "dense": api.RT_MG_DENSE, "onelane": api.RT_MG_ONE_LANE, "separate": api.RT_MG_SEPARATE_PACK}[mode]
-        print(json.dumps({args.only: measure(w, h, int(n), flags, tris)}), flush=True)
+        print(json.dumps({args.only: measure(w, h, int(n), flags, tris, transport=T, rank=int(parts[3]) if len(parts) > 3 else None)}), flush=True)
+        return
+    if args.quick:
+        for (W, H) in ((1920, 1080), (3840, 2160)):
+            single = measure(W, H, 1, 0, tris, transport=T)["ms_per_frame"]
+            bounds = api.mg_partition(H, 8)
+            rows = [measure(W, H, 8, 0, tris, rank=k, bounds=bounds, transport=T) for k in range(8)]
+            t = [m["ms_per_frame"] for m in rows]
+            row = dict(transport=T, single_ms=single, ms=t, max_ms=max(t), speedup_bound=round(single / max(t), 2),
+                       xgmi_wire_us_per_frame=max(m["xgmi_wire_us_per_frame"] for m in rows), MB_sent_per_frame=max(m["MB_sent_per_frame"] for m in rows))
+            res[f"{W}x{H} N=8 all ranks, equal rows"] = row
+            print(json.dumps({f"{W}x{H} N=8 all ranks, equal rows": row}), flush=True)
+        if args.out:
+            json.dump(res, open(args.out, "w"), indent=1)
         return
     for (W, H) in ((1920, 1080), (3840, 2160)):
         single = None
         for N in (1, 2, 4, 8):
             for name, flags in (("sparse", 0), ("dense", api.RT_MG_DENSE), ("sparse, one lane", api.RT_MG_ONE_LANE)) if N > 1 else (("single", 0),):
-                m = measure(W, H, N, flags, tris)
+                m = measure(W, H, N, flags, tris, transport=T)
                 if N == 1:
                     single = m["ms_per_frame"]
                 m["speedup_bound"] = round(single / m["ms_per_frame"], 2)
@@ -96,8 +121,8 @@ def main():
                 # reported rows (equal rows, the final cut): the lower of two runs per rank - a rank's time here is one process on a
                 # shared box, its noise (clock dips, a neighbour's job) only ever adds; the balance rounds in between use one run
                 reps = 2 if (it == 0 or it == 4 or N == 2) else 1
-                t = [min(measure(W, H, N, 0, tris, frames=40, rank=k, bounds=bounds)["ms_per_frame"] for _ in range(reps)) for k in range(N)]
-                row = dict(rows=[b - a for a, b in bounds], ms=t, max_ms=max(t), speedup_bound=round(single / max(t), 2))
+                t = [min(measure(W, H, N, 0, tris, frames=40, rank=k, bounds=bounds, transport=T)["ms_per_frame"] for _ in range(reps)) for k in range(N)]
+                row = dict(transport=T, rows=[b - a for a, b in bounds], ms=t, max_ms=max(t), speedup_bound=round(single / max(t), 2))
                 if it == 0:
                     res[f"{W}x{H} N={N} all ranks, equal rows"] = row
                     print(json.dumps({f"{W}x{H} N={N} all ranks, equal rows": row}), flush=True)
