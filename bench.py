@@ -300,9 +300,26 @@ def _main():
         dist.broadcast_object_list(uid, src=0)
         bounds = api.mg_partition(h, world, HALO)
         part = "equal rows"
+        # the cut tools/strip_overhead.py arrived at for this (size, N, scene) — measured once, committed (profiles/strip_cuts.json):
+        # no start-up rounds (4 x (context + BVH build + 46 frames) per rank before the run). BENCH_REBALANCE=1
+        # measures anyway.
+        cached = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "strip_cuts.json")) as f:
+                cached = json.load(f).get(f"{w}x{h}:{world}:{scenes.scene_sha256(tris)[:16]}")
+        except Exception:
+            cached = None
+        if cached and not os.environ.get("BENCH_REBALANCE") and not os.environ.get("BENCH_EQUAL_STRIPS"):
+            e = cached["bounds"]
+            if len(e) == world + 1 and e[0] == 0 and e[-1] == h and all(e[i + 1] - e[i] >= HALO for i in range(world)):
+                bounds = [(int(e[i]), int(e[i + 1])) for i in range(world)]
+                part = "rows cut by measured cost per strip (cached: profiles/strip_cuts.json, slowest strip alone %.3f -> %.3f ms)" % (
+                    cached.get("equal_rows_max_ms", 0.0), cached.get("max_ms", 0.0))
+            else:
+                cached = None
         # ranks that share one GPU (the dev transports) cannot time their strips: equal rows there (BENCH_FORCE_BALANCE runs the
         # rounds anyway, to exercise this code on a one-GPU box)
-        if not os.environ.get("BENCH_EQUAL_STRIPS") and ((not dev_shm and not dev_mirror) or os.environ.get("BENCH_FORCE_BALANCE")):
+        if not cached and not os.environ.get("BENCH_EQUAL_STRIPS") and ((not dev_shm and not dev_mirror) or os.environ.get("BENCH_FORCE_BALANCE")):
             est, slowest = [], []
             for it in range(BALANCE_ROUNDS):
                 wd.tick("strip balance round %d" % it, 600)

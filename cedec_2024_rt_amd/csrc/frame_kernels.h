@@ -1349,6 +1349,187 @@ __global__ __launch_bounds__(BLOCK) void k_spatial_coop(
     if (FUSED) res_give(F, P.W, li, x, row, r, active);
 }
 
+/* Software-pipelined form of k_spatial_coop (rt_tuning key 8 = 3, r04). k_spatial_coop's neighbour loop is
+ * draw -> fetch -> s_waitcnt vmcnt(0) -> merge, five times in series: 55 % of its wave cycles wait for memory with nothing in
+ * flight during a merge. What serialises it is the reference's RNG protocol (the merge draw of neighbour k is consumed only if
+ * that neighbour is shaded, so neighbour k+1's address waits for record k). As in k_spatial_lds, the tile's +-87-pixel window
+ * of shaded bits (5 KB) is staged in LDS, so ALL draws and neighbour addresses are known before the first record arrives; the
+ * records are then fetched four lanes per 64-B record as in k_spatial_coop, but into registers (4 x dwordx4 per lane), so that
+ * the fetch of neighbour k+1 is in flight while neighbour k is transposed through the wavefront's 4 KB LDS image and merged.
+ * Same draws in the same order, same arithmetic, same results. Whole-frame contexts, radius <= 30, <= 5 neighbours. */
+RT_DEV void wave_stage_issue(const float4* __restrict__ rec, const uint32_t idx, const int lane, float4& s0, float4& s1, float4& s2, float4& s3)
+{
+    const uint32_t f0 = (uint32_t)__shfl((int)idx, (lane >> 2)), f1 = (uint32_t)__shfl((int)idx, 16 + (lane >> 2)),
+                   f2 = (uint32_t)__shfl((int)idx, 32 + (lane >> 2)), f3 = (uint32_t)__shfl((int)idx, 48 + (lane >> 2));
+    const uint32_t part16 = (uint32_t)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+    const char* base = reinterpret_cast<const char*>(rec);
+    s0 = *reinterpret_cast<const float4*>(base + (f0 * 64u + part16));
+    s1 = *reinterpret_cast<const float4*>(base + (f1 * 64u + part16));
+    s2 = *reinterpret_cast<const float4*>(base + (f2 * 64u + part16));
+    s3 = *reinterpret_cast<const float4*>(base + (f3 * 64u + part16));
+}
+/* the staged parts -> the wavefront's image -> every lane's own record */
+RT_DEV void wave_stage_take(float4* s_wave, const int lane, const float4& s0, const float4& s1, const float4& s2, const float4& s3, float4& q0,
+                            float4& q1, float4& q2, float4& q3)
+{
+    s_wave[lane] = s0;
+    s_wave[64 + lane] = s1;
+    s_wave[128 + lane] = s2;
+    s_wave[192 + lane] = s3;
+    RT_WAVE_LDS_FENCE();
+    const int rot = (lane >> 2) & 3;
+    q0 = s_wave[4 * lane + (0 ^ rot)];
+    q1 = s_wave[4 * lane + (1 ^ rot)];
+    q2 = s_wave[4 * lane + (2 ^ rot)];
+    q3 = s_wave[4 * lane + (3 ^ rot)];
+    RT_WAVE_LDS_FENCE(); /* the next round overwrites the image */
+}
+template <int WAVES>
+__global__ __launch_bounds__(BLOCK) void k_spatial_pipe(
+    FrameParams P, const uint32_t* __restrict__ bits, const float4* __restrict__ g0, const float4* __restrict__ g1, const float4* __restrict__ in_rec,
+    const float4* __restrict__ in_rad, float4* __restrict__ out_rec, float4* __restrict__ out_rad)
+{
+    occupancy_bound<WAVES>();
+    __shared__ uint32_t s_bits[SPL_ROWS * SPL_WORDS];
+    __shared__ __attribute__((aligned(16))) float4 s_img[BLOCK / 64][256];
+    const int lane = threadIdx.x & 63;
+    float4* s_wave = s_img[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+    int x = 0, row = P.row0;
+    const bool in_image = tile_pixel<BLOCK>(P, x, row);
+    /* the tile origin, from any thread's own (x, row) — see k_spatial_lds */
+#if RT_WAVE_8X8 && RT_TILE_W == 32
+    const int in_tile_row = (threadIdx.x >> 3) & 7;
+#else
+    const int in_tile_row = threadIdx.x >> TILE_W_LOG2;
+#endif
+    const int tx0 = x & ~(TILE_W - 1), trow0 = row - in_tile_row;
+    const int words = (P.W + 31) / 32, tw0 = (tx0 >> 5) - 3;
+    const size_t li = in_image ? (size_t)x + (size_t)(row - P.lrow0) * P.W : 0;
+    /* the own record's fetch first: it travels while the window is staged and the draws are made */
+    float4 s0, s1, s2, s3;
+    wave_stage_issue(in_rec, (uint32_t)li, lane, s0, s1, s2, s3);
+    float4 G0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), G1 = G0;
+    /* radiance side record of the sample the reservoir holds: the own one now, a neighbour's when its sample is taken (the
+     * request then travels behind the remaining merges instead of in front of the stores) */
+    float4 rq = G0;
+    if (in_image) { G0 = g0[li]; G1 = g1[li]; rq = in_rad[li]; }
+    for (int i = threadIdx.x; i < SPL_ROWS * SPL_WORDS; i += BLOCK)
+    {
+        const int r = i / SPL_WORDS, w = i - r * SPL_WORDS;
+        const int grow = trow0 - SPL_HALO + r, gw = tw0 + w;
+        const int lr = grow - P.lrow0;
+        s_bits[i] = (lr >= 0 && lr < P.lrows && gw >= 0 && gw < words) ? bits[(size_t)lr * words + gw] : 0u;
+    }
+    __syncthreads();
+    const int yi = P.H - 1 - row;
+    const bool active = in_image && (as_uint(G1.w) & GB_SHADED);
+    const f3 sp = F3(G0.x, G0.y, G0.z), sn = F3(G1.x, G1.y, G1.z);
+    /* 1. every draw and every neighbour address of the pass from the RNG and the staged bits (10_restir_di.cu:305-340); the
+     * own record is taken and neighbour 0's fetch issued as soon as neighbour 0 is known, so that it travels behind the
+     * draws of neighbours 1..4 */
+    uint32_t nidx[5];
+    float ud[5];
+    uint32_t take = 0u; /* bit k: neighbour k reaches the merge */
+    const int count = P.use_spatial ? P.spatial_count : 0;
+    PCG rng = pcg_init(hashPCG4((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame, (uint32_t)(2 + P.pass)), 0);
+    const float scale = P.spatial_radius / 1.96f;
+    float4 q0, q1, q2, q3;
+    Res r = res_zero();
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+    {
+        nidx[k] = (uint32_t)li; ud[k] = 0.0f;
+        if (k < count && active)
+        {
+            const float rv0 = rng.uniformf();
+            const float rv1 = rng.uniformf();
+            const float radius = sqrtf(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
+            const float phi = 2.0f * kPI * rv1;
+            float sn_phi, cs_phi;
+            pm_sincosf(phi, &sn_phi, &cs_phi);
+            const float gx = radius * cs_phi, gy = radius * sn_phi;
+            const int nx = f2i_sat((float)x + scale * gx);
+            const int ny = f2i_sat((float)yi + scale * gy);
+            const int nrow = P.H - 1 - ny, lr = nrow - P.lrow0;
+            const bool okn = !(nx < 0 || nx >= P.W || ny < 0 || ny >= P.H) && !(nx == x && ny == yi) && !(lr < 0 || lr >= P.lrows);
+            if (okn)
+            {
+                /* |offset| <= 86.43 px for radius <= 30: inside the staged window */
+                const int wr = nrow - (trow0 - SPL_HALO), ww = (nx >> 5) - tw0;
+                const uint32_t word = s_bits[wr * SPL_WORDS + ww];
+                if (word & (1u << (nx & 31)))
+                {
+                    nidx[k] = (uint32_t)nx + (uint32_t)lr * (uint32_t)P.W;
+                    ud[k] = rng.uniformf();
+                    take |= 1u << k;
+                }
+            }
+        }
+        if (k == 0)
+        {
+            /* 2a. the own record (requested before the window was staged) */
+            wave_stage_take(s_wave, lane, s0, s1, s2, s3, q0, q1, q2, q3);
+            bool own_shaded;
+            r = res_from_parts(q0, q1, q2, q3, own_shaded);
+            if (count > 0) wave_stage_issue(in_rec, nidx[0], lane, s0, s1, s2, s3);
+        }
+    }
+    /* 2. the merge chain of :340-371 with the next neighbour's record in flight */
+    bool took_other = false;
+    float d0 = length(r.org_p - P.eye);
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+    {
+        if (k < count) /* wave-uniform */
+        {
+            wave_stage_take(s_wave, lane, s0, s1, s2, s3, q0, q1, q2, q3);
+            if (k + 1 < count) wave_stage_issue(in_rec, nidx[k + 1 < 5 ? k + 1 : 4], lane, s0, s1, s2, s3);
+            if (take & (1u << k))
+            {
+                bool n_shaded;
+                Res nr = res_from_parts(q0, q1, q2, q3, n_shaded);
+                float p_hat_y = target_unshadowed(sp, sn, nr.hit_p, nr.hit_n, nr.lum);
+                if (P.vis_reuse) p_hat_y *= nr.vis ? 1.0f : 0.0f;
+                /* rejection_heuristics(r.org_p, r.org_n, nr.org_p, nr.org_n, P.eye) (rt_device.h) with d0 carried */
+                const float d1 = length(nr.org_p - P.eye);
+                const float diff = (d1 - d0) * (d1 - d0) / d0;
+                float rw = 1.0f;
+                rw *= pm_expf(-32.0f * diff);
+                rw *= pm_pow8f(fmax_dev(dot(r.org_n, nr.org_n), 0.0f));
+                nr.M = scale_M(nr.M, rw);
+                const float weight = p_hat_y * nr.ucw * (float)nr.M;
+                r.w_sum += weight;
+                r.M += nr.M;
+                if (ud[k] < weight / r.w_sum)
+                {
+                    res_take_sample(r, nr);
+                    d0 = d1;
+                    rq = in_rad[nidx[k]];
+                    took_other = true;
+                }
+            }
+        }
+    }
+    if (count > 0)
+    {
+        const float p_hat = target_unshadowed(sp, sn, r.hit_p, r.hit_n, r.lum);
+        r.ucw = p_hat > 0.0f ? r.w_sum / ((float)r.M * p_hat) : 0.0f;
+    }
+    if (active)
+    {
+        r.rad = F3(rq.x, rq.y, rq.z);
+        r.ownv = took_other ? 0u : as_uint(rq.w);
+    }
+    else
+        r = res_zero(); /* the reference stores nothing here (:275-287); we keep the shaded bit valid */
+    const uint32_t mbits = ((uint32_t)r.M & RES_M_MASK) | (r.vis ? RES_VIS_BIT : 0u) | (active ? RES_SHADED_BIT : 0u);
+    wave_scatter_records(out_rec, in_image ? (int)li : -1, s_wave, lane, make_float4(r.hit_p.x, r.hit_p.y, r.hit_p.z, r.ucw),
+                         make_float4(r.hit_n.x, r.hit_n.y, r.hit_n.z, as_float(mbits)), make_float4(r.org_p.x, r.org_p.y, r.org_p.z, r.lum),
+                         make_float4(r.org_n.x, r.org_n.y, r.org_n.z, r.w_sum));
+    if (!in_image) return;
+    out_rad[li] = make_float4(r.rad.x, r.rad.y, r.rad.z, as_float(r.ownv));
+}
+
 /* SURVEY.md §8(d) ALGORITHMIC bytes of one spatial_resampling launch, counted with the
  * reference's record sizes (Visibility 16 B, Reservoir 76 B): per pixel 16; per shaded pixel
  * +76 in +76 out; per neighbour that passed the on-screen / not-self tests +16, and +76 more if
@@ -1501,44 +1682,70 @@ __global__ __launch_bounds__(BLOCK) void k_halo_mark(FrameParams P, const float4
         }
     }
 }
-RT_DEV void halo_scan_one(uint32_t* __restrict__ bitmap, int nw, uint32_t* s_sum)
+/* Exclusive prefix of the per-word popcounts of one bitmap + the total into word 0, CHUNKED over many small workgroups (r04):
+ * workgroup `chunk` owns words [chunk * HALO_SCAN_CHUNK, +HALO_SCAN_CHUNK); it first sums the popcounts of everything in front
+ * of its chunk itself (<= nw words spread over 256 threads: a few KB of L2-resident reads), then scans its own words. No
+ * inter-workgroup dependence, no 1024-thread workgroup: r01-r03 scanned a bitmap with ONE 1024-thread workgroup, which on a
+ * busy GPU waits for 16 free wave slots on one CU (26 -> 280 us at 4K in 8 strips, profiles/r04_strip_timelines.txt). */
+constexpr int HALO_SCAN_CHUNK = 1024, HALO_SCAN_THREADS = 256;
+RT_DEV uint32_t block_sum_256(uint32_t v, uint32_t* s_part)
 {
-    const int t = threadIdx.x, T = blockDim.x;
-    const int per = (nw + T - 1) / T;
-    const int w0 = t * per, w1 = min(nw, w0 + per);
-    uint32_t local = 0;
-    for (int w = w0; w < w1; ++w) local += (uint32_t)__popc(bitmap[1 + w]);
-    s_sum[t] = local;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
     __syncthreads();
-    for (int off = 1; off < T; off <<= 1)
-    {
-        const uint32_t v = t >= off ? s_sum[t - off] : 0u;
-        __syncthreads();
-        s_sum[t] += v;
-        __syncthreads();
-    }
-    uint32_t run = s_sum[t] - local;
-    for (int w = w0; w < w1; ++w)
-    {
-        bitmap[1 + nw + w] = run;
-        run += (uint32_t)__popc(bitmap[1 + w]);
-    }
-    if (t == T - 1) bitmap[0] = s_sum[t];
+    const uint32_t t = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    __syncthreads();
+    return t;
 }
-/* one workgroup per bitmap: exclusive prefix of the per-word popcounts, total into word 0 */
-__global__ void k_halo_scan(uint32_t* __restrict__ bitmaps, int nw, size_t words_per_bitmap)
+RT_DEV void halo_scan_chunk(uint32_t* __restrict__ bitmap, int nw, int chunk, uint32_t* s_part)
 {
-    __shared__ uint32_t s_sum[1024];
-    uint32_t* bitmap = bitmaps + (size_t)blockIdx.x * words_per_bitmap; /* one workgroup per bitmap */
-    halo_scan_one(bitmap, nw, s_sum);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int w_begin = chunk * HALO_SCAN_CHUNK;
+    if (w_begin >= nw) return; /* wave-uniform: whole workgroups beyond the bitmap */
+    /* 1. what lies in front of this chunk */
+    uint32_t before = 0;
+    for (int w = t; w < w_begin; w += HALO_SCAN_THREADS) before += (uint32_t)__popc(bitmap[1 + w]);
+    const uint32_t base = block_sum_256(before, s_part);
+    /* 2. this chunk: four consecutive words per thread */
+    const int w0 = w_begin + 4 * t;
+    uint32_t c[4], mine = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+        c[k] = (w0 + k < nw) ? (uint32_t)__popc(bitmap[1 + w0 + k]) : 0u;
+        mine += c[k];
+    }
+    uint32_t incl = mine; /* inclusive scan over the wavefront */
+    for (int off = 1; off < 64; off <<= 1)
+    {
+        const uint32_t o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) s_part[wave] = incl;
+    __syncthreads();
+    uint32_t wave_base = 0;
+    for (int k = 0; k < wave; ++k) wave_base += s_part[k];
+    const uint32_t chunk_total = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    uint32_t run = base + wave_base + incl - mine;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (w0 + k < nw) { bitmap[1 + nw + w0 + k] = run; run += c[k]; }
+    if (t == 0 && w_begin + HALO_SCAN_CHUNK >= nw) bitmap[0] = base + chunk_total; /* the last chunk knows the total */
 }
-/* the bitmaps of both sides in one launch: blockIdx.y = side, blockIdx.x = pass */
-__global__ void k_halo_scan_sides(HaloRegions R)
+static inline int halo_scan_chunks(int nw) { return (nw + HALO_SCAN_CHUNK - 1) / HALO_SCAN_CHUNK; }
+/* blockIdx.x = chunk, blockIdx.y = bitmap */
+__global__ __launch_bounds__(HALO_SCAN_THREADS) void k_halo_scan(uint32_t* __restrict__ bitmaps, int nw, size_t words_per_bitmap)
 {
-    __shared__ uint32_t s_sum[1024];
-    const int sd = blockIdx.y;
+    __shared__ uint32_t s_part[4];
+    halo_scan_chunk(bitmaps + (size_t)blockIdx.y * words_per_bitmap, nw, (int)blockIdx.x, s_part);
+}
+/* the bitmaps of both sides in one launch: blockIdx.x = chunk, blockIdx.y = pass, blockIdx.z = side */
+__global__ __launch_bounds__(HALO_SCAN_THREADS) void k_halo_scan_sides(HaloRegions R)
+{
+    __shared__ uint32_t s_part[4];
+    const int sd = blockIdx.z;
     if (R.rows[sd] <= 0) return;
-    halo_scan_one(R.bitmaps[sd] + (size_t)blockIdx.x * R.words[sd], (int)((R.words[sd] - 1) / 2), s_sum);
+    halo_scan_chunk(R.bitmaps[sd] + (size_t)blockIdx.y * R.words[sd], (int)((R.words[sd] - 1) / 2), (int)blockIdx.x, s_part);
 }
 
 /* PACK: marked records of rows [row0, row0+rows) -> dense list (64 B record + 16 B radiance each);
@@ -2151,6 +2358,19 @@ __global__ void k_res_from_ref(int n, const uint32_t* __restrict__ in, const flo
     r.lum = luminance(r.rad);
     const bool shaded = (as_uint(g1[i].w) & GB_SHADED) != 0u;
     res_store(rec, radb, (size_t)i, r, shaded);
+}
+
+/* The "sky / emissive neighbour" test of spatial_resampling (10_restir_di.cu:326-338) reads the CURRENT Visibility buffer; the
+ * record keeps that bit (RES_SHADED_BIT) as of the G-buffer it was written under. The per-kernel entry point
+ * rt_spatial_resampling re-derives the bits of its input buffer when the G-buffer has changed since (a camera move or a
+ * visibility upload between generate_candidate and the pass); the staged frame never needs it. */
+__global__ void k_refresh_shaded(int n, const float4* __restrict__ g1, float4* __restrict__ rec)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t* w = reinterpret_cast<uint32_t*>(rec) + 16 * (size_t)i + 7; /* q1.w = M | vis << 31 | shaded << 30 */
+    const uint32_t v = *w, want = (v & ~RES_SHADED_BIT) | ((as_uint(g1[i].w) & GB_SHADED) ? RES_SHADED_BIT : 0u);
+    if (v != want) *w = want;
 }
 
 /* ------------------------------------------------------------- scene tables */

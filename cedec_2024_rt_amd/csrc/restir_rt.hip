@@ -66,6 +66,8 @@ struct rt_ctx
     /* tags of the own-visibility flags (rt_device.h): one number per staged frame and per pipelined stage 0; the launches of
      * a staged frame carry frame_tag (cur_tag while they are enqueued), the per-kernel entry points carry 0 */
     uint32_t ownv_serial = 0, frame_tag = 0, cur_tag = 0, spec_gen_tag = 0;
+    /* which G-buffer a reservoir buffer's shaded bits belong to (k_refresh_shaded): gbuf_serial counts G-buffer writes */
+    uint64_t gbuf_serial = 0, rec_gserial[4] = {0, 0, 0, 0};
     unsigned long long* d_walk = nullptr; /* rt_walk_stats: 4 kernel slots x 4 counters */
     bool walk_on = false;
     int tune_ws_primary = 0; /* rt_tuning key 16: primary rays with the work-sharing closest-hit walk (A/B: no gain) */
@@ -1220,6 +1222,7 @@ int rt_raycast(rt_ctx* c)
     else k_raycast<false><<<trace_grid(c), TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_vis, c->d_g0, c->d_g1);
     RT_HIP(c, hipGetLastError());
     c->has_gbuffer = true;
+    ++c->gbuf_serial;
     c->shaded_bits_stale = true;
     /* halo rows of the G-buffer keep the neighbours' shaded flags: they stay valid until the camera,
      * the scene or the options change (halo_flags_epoch), which is when the neighbours' G-buffers change */
@@ -1345,6 +1348,8 @@ static int raycast_or_take(rt_ctx* c, bool whole, int frame)
         c->spec_gen_valid = false;
         c->spec_valid = false;
         c->has_gbuffer = true;
+        ++c->gbuf_serial;
+        if (c->gen_taken) c->rec_gserial[c->fY] = c->gbuf_serial; /* the candidates were made from this G-buffer set */
         c->shaded_bits_stale = true;
         if (c->spec_timed[c->gcur]) c->timed_spec_set = c->gcur;
         return RT_OK;
@@ -1362,6 +1367,7 @@ static int launch_generate(rt_ctx* c, int frame, int dst_phys, int prev_phys, bo
     const FrameParams P = make_params(c, frame, 0, K_GENERATE);
     const bool sh = c->opt.use_shadowed_target_function;
     float4 *orec = c->d_rec[dst_phys], *orad = c->d_rad[dst_phys];
+    c->rec_gserial[dst_phys] = c->gbuf_serial;
     const float4 *prec = fuse ? c->d_rec[prev_phys] : nullptr, *prad = fuse ? c->d_rad[prev_phys] : nullptr;
     const int g = trace_grid(c);
     if (fuse && !sh && c->tune_defer_vis)
@@ -1454,6 +1460,7 @@ int rt_save_temporal_reservoir(rt_ctx* c, int src, int dst)
     const size_t off = (size_t)(c->row_begin - c->lrow0) * c->W;
     const size_t n = (size_t)(c->row_end - c->row_begin) * c->W;
     const int ps = c->res_map[src], pd = c->res_map[dst];
+    c->rec_gserial[pd] = c->rec_gserial[ps];
     RT_HIP(c, hipMemcpyAsync(c->d_rec[pd] + 4 * off, c->d_rec[ps] + 4 * off, n * 64, hipMemcpyDeviceToDevice, c->stream));
     RT_HIP(c, hipMemcpyAsync(c->d_rad[pd] + off, c->d_rad[ps] + off, n * 16, hipMemcpyDeviceToDevice, c->stream));
     return RT_OK;
@@ -1475,7 +1482,7 @@ static int halo_rows_needed(const rt_options& o)
  * it adds the bitmap launch to every frame */
 static bool use_lds_spatial(const rt_ctx* c)
 {
-    return c->tune_spatial_variant == 1 && c->opt.use_spatial_resampling && !c->opt.use_shadowed_target_function &&
+    return (c->tune_spatial_variant == 1 || c->tune_spatial_variant == 3) && c->opt.use_spatial_resampling && !c->opt.use_shadowed_target_function &&
            halo_rows_needed(c->opt) <= SPL_HALO && c->opt.spatial_resampling_sample_count <= 5 &&
            c->row_begin == 0 && c->row_end == c->H;
 }
@@ -1497,6 +1504,9 @@ static int refresh_shaded_bits(rt_ctx* c)
 #ifndef RT_SPATIAL_GATHER_AUTO_WAVES
 #define RT_SPATIAL_GATHER_AUTO_WAVES 6
 #endif
+#ifndef RT_SPATIAL_PIPE_AUTO_WAVES
+#define RT_SPATIAL_PIPE_AUTO_WAVES 5 /* 16 more registers in flight than k_spatial_coop (the staged record parts) */
+#endif
 static int launch_spatial(rt_ctx* c, int frame, int pass, int in_phys, int out_phys)
 {
     const int need = halo_rows_needed(c->opt);
@@ -1507,6 +1517,7 @@ static int launch_spatial(rt_ctx* c, int frame, int pass, int in_phys, int out_p
     const SceneView S = make_scene(c);
     const FrameParams P = make_params(c, frame, pass, K_SPATIAL);
     const bool lds_variant = use_lds_spatial(c);
+    c->rec_gserial[out_phys] = c->gbuf_serial;
     if (c->opt.use_shadowed_target_function)
     {
         /* the cooperative record traffic of key 8 = 2 applies to the <= 5 neighbour form (spatial_wave_shadowed) */
@@ -1514,6 +1525,15 @@ static int launch_spatial(rt_ctx* c, int frame, int pass, int in_phys, int out_p
             k_spatial<true, true><<<trace_grid(c), TRACE_BLOCK, (size_t)(RT_SHADOWED_SPATIAL_LDS), c->stream>>>(S, P, c->fuse, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys]);
         else
             k_spatial<true, false><<<trace_grid(c), TRACE_BLOCK, (size_t)(RT_SHADOWED_SPATIAL_LDS), c->stream>>>(S, P, c->fuse, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys]);
+    }
+    else if (lds_variant && c->tune_spatial_variant == 3)
+    {
+        /* software-pipelined cooperative kernel (r04): staged shaded bits + the next neighbour's record in flight */
+        const int rc = refresh_shaded_bits(c);
+        if (rc != RT_OK) return rc;
+#define RT_SPP(WV) k_spatial_pipe<WV><<<launch_grid(c), BLOCK, (size_t)c->tune_spatial_lds, c->stream>>>(P, c->d_shaded_bits, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys])
+        switch (c->tune_spatial_waves < 0 ? RT_SPATIAL_PIPE_AUTO_WAVES : c->tune_spatial_waves) { case 4: RT_SPP(4); break; case 5: RT_SPP(5); break; case 6: RT_SPP(6); break; default: RT_SPP(0); break; }
+#undef RT_SPP
     }
     else if (lds_variant)
     {
@@ -1523,7 +1543,7 @@ static int launch_spatial(rt_ctx* c, int frame, int pass, int in_phys, int out_p
         switch (c->tune_spatial_waves) { case 4: RT_SPL(4); break; case 5: RT_SPL(5); break; case 6: RT_SPL(6); break; default: RT_SPL(0); break; }
 #undef RT_SPL
     }
-    else if (c->tune_spatial_variant == 2)
+    else if (c->tune_spatial_variant == 2 || c->tune_spatial_variant == 3) /* 3 where the pipelined kernel does not apply (strips, radius > 30, > 5 neighbours) */
     {
 #define RT_SPC2(WV, FU) k_spatial_coop<WV, FU><<<launch_grid(c), BLOCK, (size_t)c->tune_spatial_lds, c->stream>>>(S, P, c->fuse, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys])
 #define RT_SPC(WV) do { if (fused) RT_SPC2(WV, true); else RT_SPC2(WV, false); } while (0)
@@ -1554,6 +1574,14 @@ int rt_spatial_resampling(rt_ctx* c, int frame, int pass, int in, int out)
     if (in == out) RT_FAIL(c, RT_ERR_ARG, "in and out must differ");
     c->last_frame = frame;
     c->fuse = HaloFuse{};
+    if (c->rec_gserial[c->res_map[in]] != c->gbuf_serial)
+    {
+        /* the G-buffer changed since `in` was written: its neighbour test must see the current shaded flags (frame_kernels.h) */
+        const int n = (int)local_pixels(c);
+        k_refresh_shaded<<<(n + 255) / 256, 256, 0, c->stream>>>(n, c->d_g1, c->d_rec[c->res_map[in]]);
+        RT_HIP(c, hipGetLastError());
+        c->rec_gserial[c->res_map[in]] = c->gbuf_serial;
+    }
     return launch_spatial(c, frame, pass, c->res_map[in], c->res_map[out]);
 }
 
@@ -1878,6 +1906,7 @@ int rt_frame_stage_end(rt_ctx* c, int stage)
          * reference's save_temporal_reservoir makes (10_restir_di.cpp:314-321) */
         const size_t n = local_pixels(c);
         { const int jr = join_tail_for(c, X); if (jr != RT_OK) return jr; }
+        c->rec_gserial[X] = c->rec_gserial[Y];
         RT_HIP(c, hipMemcpyAsync(c->d_rec[X], c->d_rec[Y], n * 64, hipMemcpyDeviceToDevice, c->stream));
         RT_HIP(c, hipMemcpyAsync(c->d_rad[X], c->d_rad[Y], n * 16, hipMemcpyDeviceToDevice, c->stream));
     }
@@ -2025,6 +2054,7 @@ int rt_upload(rt_ctx* c, int buf, const void* src, size_t bytes)
             k_gbuffer_from_vis<<<tile_grid(c->W, c->lrows), BLOCK, 0, c->stream>>>(make_scene(c), P, c->d_vis, c->d_g0, c->d_g1);
             RT_HIP(c, hipGetLastError());
             c->has_gbuffer = true;
+            ++c->gbuf_serial;
             c->shaded_bits_stale = true;
             ++c->epoch;
             break;
@@ -2041,6 +2071,7 @@ int rt_upload(rt_ctx* c, int buf, const void* src, size_t bytes)
             if (!c->has_gbuffer) RT_FAIL(c, RT_ERR_STATE, "upload RT_BUF_VISIBILITY (or rt_raycast) before reservoirs");
             ++c->res_epoch;
             const int phys = c->res_map[buf - RT_BUF_RES_0];
+            c->rec_gserial[phys] = c->gbuf_serial;
             /* the record keeps M in 30 bits: refuse what it cannot hold rather than truncate */
             for (size_t i = 0; i < n; ++i)
             {
@@ -2189,7 +2220,10 @@ int rt_halo_mark_sides(rt_ctx* c, int frame, int pass, int n_pass, void* bitmaps
     c->sub0 = c->sub1 = -1; c->subb0 = c->subb1 = 0;
     k_halo_mark<<<grid, BLOCK, 0, c->stream>>>(P, c->d_g1, R, pass, n_pass);
     RT_HIP(c, hipGetLastError());
-    k_halo_scan_sides<<<dim3(n_pass, 2), 1024, 0, c->stream>>>(R);
+    {
+        const size_t wmax = R.words[0] > R.words[1] ? R.words[0] : R.words[1];
+        k_halo_scan_sides<<<dim3(halo_scan_chunks((int)((wmax - 1) / 2)), n_pass, 2), HALO_SCAN_THREADS, 0, c->stream>>>(R);
+    }
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }
@@ -2206,7 +2240,7 @@ int rt_halo_scan(rt_ctx* c, int n_rows, int count, void* device_bitmaps)
     RT_CHECK_CTX(c);
     if (count <= 0) return RT_OK;
     const size_t words = rt_halo_bitmap_words(c, n_rows);
-    k_halo_scan<<<count, 1024, 0, c->stream>>>((uint32_t*)device_bitmaps, (int)((words - 1) / 2), words);
+    k_halo_scan<<<dim3(halo_scan_chunks((int)((words - 1) / 2)), count), HALO_SCAN_THREADS, 0, c->stream>>>((uint32_t*)device_bitmaps, (int)((words - 1) / 2), words);
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }
@@ -2604,7 +2638,7 @@ int rt_tuning(rt_ctx* c, int key, int value)
     else if (key == 5 && value >= 0 && value <= 3) c->bvh_builder = value; /* before rt_scene_set */
     else if (key == 6 && value >= 0 && value <= 2) c->pt_wavefront = value;
     else if (key == 7 && value >= 0) c->bvh_bfs_records = value; /* before rt_scene_set */
-    else if (key == 8 && value >= 0 && value <= 2) c->tune_spatial_variant = value;
+    else if (key == 8 && value >= 0 && value <= 3) { c->tune_spatial_variant = value; c->shaded_bits_stale = true; }
     else if (key == 9 && (value == 0 || value == -1 || (value >= 4 && value <= 6))) c->tune_spatial_waves = value;
     else if (key == 10 && value >= 1 && value <= 256) c->ploc_radius = value; /* before rt_scene_set */
     else if (key == 11 && (value == 0 || value == 1)) c->tune_defer_vis = value;

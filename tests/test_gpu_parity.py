@@ -802,7 +802,7 @@ def test_lds_staged_spatial_variant_is_bit_identical(api, scenes, W, H, optkw):
     tris = scenes.make_blocks_restir() if W == 1920 else scenes.make_quad_room()
     eye, at = (scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT) if W == 1920 else ((0.5, 2.5, 6.0), (0.0, 1.5, -1.0))
     rs = []
-    for variant in (0, 1, 2):
+    for variant in (0, 1, 2, 3):  # 3 (r04): the cooperative fetch software-pipelined over the staged shaded-bit window
         r = api.Renderer(W, H)
         r.set_scene(tris)
         r.lookat(eye, at)

@@ -97,7 +97,9 @@ def weighted_valu(kernel, e, ms):
     cyc += n_int * c_int + other * c_oth
     ghz = 2.4
     if e.get("GRBM_GUI_ACTIVE"):
-        ghz = e["GRBM_GUI_ACTIVE"] / (ms * 1e6)  # busy cycles of the launch / its duration
+        g = e["GRBM_GUI_ACTIVE"] / 8.0 / (ms * 1e6)  # busy cycles of the launch (the counter sums the 8 XCDs) / its duration
+        if 1.5 < g < 3.2:
+            ghz = g
     e["valu_cycles_per_inst_weighted"] = cyc / total
     e["clock_GHz_from_GRBM_GUI_ACTIVE"] = ghz
     e["valu_other_bucket_share"] = other / total

@@ -17,11 +17,14 @@ W, H = 1920, 1080
 tris = scenes.make_blocks_restir()
 only = sys.argv[1] if len(sys.argv) > 1 else None
 out = {}
-CASES = [("gather", 0, 0, -1), ("lds", 0, 1, -1), ("coop", 0, 2, -1)]
-if not only:
+CASES = [("gather", 0, 0, -1), ("lds", 0, 1, -1), ("coop", 0, 2, -1), ("pipe", 0, 3, -1)]
+if only == "r04":
+    only = None
+    CASES = [("coop w6", 0, 2, 6), ("coop w5", 0, 2, 5)] + [("pipe w%d" % w, 0, 3, w) for w in (0, 6, 5, 4)]
+elif not only:
     CASES = [("gather w%d" % w, 0, 0, w) for w in (0, 6, 5, 4)] + [("gather w5 +lds32k", 32768, 0, 5), ("gather w0 +lds32k", 32768, 0, 0)] + \
             [("lds w%d" % w, 0, 1, w) for w in (0, 6, 5, 4)] + [("lds w0 +lds32k", 32768, 1, 0)] + \
-            [("coop w%d" % w, 0, 2, w) for w in (0, 6, 5, 4)]
+            [("coop w%d" % w, 0, 2, w) for w in (0, 6, 5, 4)] + [("pipe w%d" % w, 0, 3, w) for w in (0, 6, 5, 4)]
 for name, key4, key8, key9 in CASES:
     if only and only != name:
         continue

@@ -1,37 +1,42 @@
-"""What a rank of an N-strip frame costs when it never waits for a neighbour: the native strip
-driver (rt_mg_*, csrc/strip_mg.cpp) with the MIRROR transport (a rank receives the bytes it sent, by a
-device copy), alone on the GPU. Same launches, same pack/unpack work and message sizes as a real
-exchange; only the xGMI hop and the peers' skew are missing. Reported per N and image size:
+"""What a rank of an N-strip frame costs when it never waits for a neighbour: the native strip driver (rt_mg_*,
+csrc/strip_mg.cpp) with one rank ALONE on the GPU, its neighbours replaced by a transport that hands it back what it sent:
 
-  ms_per_frame    wall time per frame of the rank in a steady loop (GPU-bound)
-  host_us         host time spent enqueueing one frame (rt_mg_stats.host_ns / frames)
-  plan_wait_us    host time waiting for the next frame's halo plan (0 = the plan was ready)
-  speedup_bound   single-GPU ms / this rank's ms: the scaling the compute side allows
+  --transport mirror      one copy launch per exchange (rt_copy_parts): the compute side only (r02 / r03 tables)
+  --transport rccl_self   the real grouped ncclSend/ncclRecv of the RCCL transport, true message sizes, to the rank itself on
+                          a one-rank communicator (r04): RCCL's launch + copy kernel are on the chain; the xGMI wire is not
+                          (xgmi_wire_us_per_frame = bytes per frame and side / 153 GB/s: a stated addend)
 
-The N-GPU job runs at the pace of its SLOWEST rank. The table cases time the middle rank of an equal partition (comparable
-with r02 / r03_c); the "all ranks" cases time EVERY rank, for equal rows and for the rows bench.py cuts at start-up
-(measured cost per strip, averaged over the rounds, fed back into rt_mg_partition, 4 rounds), and report the maximum.
+Same launches, same pack/unpack work and message sizes as a real exchange; the peers' skew is missing. Every measurement
+runs in a PROCESS OF ITS OWN (HIP maps streams onto hardware queues by creation history: a process that has created and
+destroyed contexts before measures something else — 1.55 instead of 1.07 ms at 4K with RCCL's own streams in the mix,
+profiles/r04_strip_notes.txt). The N-GPU job runs at the pace of its SLOWEST rank: every rank is timed (lower of two runs),
+for equal rows and for rows re-cut by measured cost per strip (4 rounds, as bench.py's start-up does); the final cuts are
+written to profiles/strip_cuts.json, which bench.py uses instead of re-measuring.
 
-  python tools/strip_overhead.py [--out profiles/r02_strip_overhead.json]
+  python tools/strip_overhead.py --transport rccl_self --out profiles/r04_strip_overhead_rccl_self.json [--sizes 1920x1080] [--ns 8]
+  python tools/strip_overhead.py --only 3840x2160:8:sparse[:rank] --transport mirror      (one case, this process: for rocprofv3)
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from cedec_2024_rt_amd import api, scenes  # noqa: E402
-from cedec_2024_rt_amd.types import bench_options  # noqa: E402
-
-
-TRANSPORTS = {"mirror": api.RT_MG_TRANSPORT_MIRROR, "rccl_self": api.RT_MG_TRANSPORT_RCCL_SELF}
 XGMI_GBS = 153.0  # one xGMI link, one direction (MI355X_MICROARCH.md): a strip talks to each neighbour over a link of its own
+FLAGS = {"sparse": 0, "dense": 1, "onelane": 2, "separate": 4}
+CUTS = os.path.join(ROOT, "profiles", "strip_cuts.json")
 
 
 def measure(W, H, N, flags, tris, frames=40, warm=6, rank=None, bounds=None, transport="mirror"):
+    """one rank, in THIS process"""
+    from cedec_2024_rt_amd import api, scenes
+    from cedec_2024_rt_amd.types import bench_options
+
+    T = {"mirror": api.RT_MG_TRANSPORT_MIRROR, "rccl_self": api.RT_MG_TRANSPORT_RCCL_SELF}[transport]
     bounds = bounds or api.mg_partition(H, N)
     rank = N // 2 if rank is None else rank
     a, b = bounds[rank]
@@ -39,7 +44,7 @@ def measure(W, H, N, flags, tris, frames=40, warm=6, rank=None, bounds=None, tra
     r.set_scene(tris)
     r.lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)
     r.set_options(bench_options())
-    mg = api.MultiGpu(r, rank, bounds, transport=TRANSPORTS[transport], flags=flags)
+    mg = api.MultiGpu(r, rank, bounds, transport=T, flags=flags)
     f = 0
     for _ in range(warm):
         f += 1
@@ -58,8 +63,6 @@ def measure(W, H, N, flags, tris, frames=40, warm=6, rank=None, bounds=None, tra
                host_loop_us=round(t_host / frames * 1e6, 1), plan_wait_us=round(st["plan_wait_ns"] / frames / 1e3, 1),
                cold_frames=st["cold_frames"], MB_sent_per_frame=round(st["bytes_sent"] / frames / 1e6, 3),
                messages_per_frame=st["messages"] / frames, transport=transport)
-    # what neither transport contains: the wire. Bytes per frame and SIDE over one xGMI link, summed over the frame's exchanges
-    # (3 on the chain; the two sides travel on different links at the same time) - a stated addend, not part of ms_per_frame
     sides = (1 if rank in (0, N - 1) else 2) if N > 1 else 0
     out["xgmi_wire_us_per_frame"] = round(st["bytes_sent"] / frames / max(sides, 1) / (XGMI_GBS * 1e9) * 1e6, 1) if sides else 0.0
     mg.close()
@@ -67,68 +70,79 @@ def measure(W, H, N, flags, tris, frames=40, warm=6, rank=None, bounds=None, tra
     return out
 
 
+def fresh(W, H, N, mode, rank, bounds, transport):
+    """the same in a process of its own; returns the measurement dict"""
+    cmd = [sys.executable, os.path.abspath(__file__), "--only", f"{W}x{H}:{N}:{mode}:{rank}", "--transport", transport]
+    if bounds is not None:
+        cmd += ["--bounds", ",".join(str(v) for v in [bounds[0][0]] + [e for _, e in bounds])]
+    for attempt in range(2):
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        for line in p.stdout.splitlines():
+            if line.startswith("{"):
+                return list(json.loads(line).values())[0]
+    raise RuntimeError(f"measurement failed: {' '.join(cmd)}\n{p.stderr[-2000:]}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
-    ap.add_argument("--churn", type=int, default=0, help="create and destroy this many strip contexts + drivers first (stream -> hardware queue mapping after a host has re-created its contexts, as bench.py does for cost-weighted strips)")
-    ap.add_argument("--only", default=None, help="WxH:N:sparse|dense|onelane|separate[:rank], e.g. 3840x2160:8:sparse (for a kernel trace of one case)")
-    ap.add_argument("--transport", default="mirror", choices=sorted(TRANSPORTS), help="mirror: one copy launch per exchange; rccl_self: the real grouped ncclSend/ncclRecv (to self)")
-    ap.add_argument("--quick", action="store_true", help="N = 8 only, both sizes, every rank with equal rows (no balance rounds)")
+    ap.add_argument("--only", default=None, help="WxH:N:sparse|dense|onelane|separate[:rank] — one case in this process")
+    ap.add_argument("--bounds", default=None, help="strip edges for --only: 0,a,b,...,H")
+    ap.add_argument("--transport", default="mirror", choices=("mirror", "rccl_self"))
+    ap.add_argument("--sizes", default="1920x1080,3840x2160")
+    ap.add_argument("--ns", default="2,4,8")
+    ap.add_argument("--rounds", type=int, default=4, help="balance rounds for N = 8 (0: equal rows only)")
     args = ap.parse_args()
-    tris = scenes.make_blocks_restir()
-    res = {}
-    for _ in range(args.churn):
-        measure(1920, 1080, 8, 0, tris, frames=3, warm=1)
     T = args.transport
     if args.only:
+        from cedec_2024_rt_amd import scenes
+
         parts = args.only.split(":")
-        wh, n, mode = parts[:3]
-        w, h = (int(v) for v in wh.split("x"))
-        flags = {"sparse": 0, "dense": api.RT_MG_DENSE, "onelane": api.RT_MG_ONE_LANE, "separate": api.RT_MG_SEPARATE_PACK}[mode]
-        print(json.dumps({args.only: measure(w, h, int(n), flags, tris, transport=T, rank=int(parts[3]) if len(parts) > 3 else None)}), flush=True)
+        w, h = (int(v) for v in parts[0].split("x"))
+        n = int(parts[1])
+        bounds = None
+        if args.bounds:
+            e = [int(v) for v in args.bounds.split(",")]
+            bounds = [(e[i], e[i + 1]) for i in range(len(e) - 1)]
+        m = measure(w, h, n, FLAGS[parts[2]], scenes.make_blocks_restir(), transport=T, rank=int(parts[3]) if len(parts) > 3 else None, bounds=bounds)
+        print(json.dumps({args.only: m}), flush=True)
         return
-    if args.quick:
-        for (W, H) in ((1920, 1080), (3840, 2160)):
-            single = measure(W, H, 1, 0, tris, transport=T)["ms_per_frame"]
-            bounds = api.mg_partition(H, 8)
-            rows = [measure(W, H, 8, 0, tris, rank=k, bounds=bounds, transport=T) for k in range(8)]
-            t = [m["ms_per_frame"] for m in rows]
-            row = dict(transport=T, single_ms=single, ms=t, max_ms=max(t), speedup_bound=round(single / max(t), 2),
-                       xgmi_wire_us_per_frame=max(m["xgmi_wire_us_per_frame"] for m in rows), MB_sent_per_frame=max(m["MB_sent_per_frame"] for m in rows))
-            res[f"{W}x{H} N=8 all ranks, equal rows"] = row
-            print(json.dumps({f"{W}x{H} N=8 all ranks, equal rows": row}), flush=True)
-        if args.out:
-            json.dump(res, open(args.out, "w"), indent=1)
-        return
-    for (W, H) in ((1920, 1080), (3840, 2160)):
-        single = None
-        for N in (1, 2, 4, 8):
-            for name, flags in (("sparse", 0), ("dense", api.RT_MG_DENSE), ("sparse, one lane", api.RT_MG_ONE_LANE)) if N > 1 else (("single", 0),):
-                m = measure(W, H, N, flags, tris, transport=T)
-                if N == 1:
-                    single = m["ms_per_frame"]
-                m["speedup_bound"] = round(single / m["ms_per_frame"], 2)
-                res[f"{W}x{H} N={N} {name}"] = m
-                print(json.dumps({f"{W}x{H} N={N} {name}": m}), flush=True)
-    # every rank, slowest counts: equal rows, then bench.py's start-up balancing
+
     import numpy as np
-    for (W, H) in ((1920, 1080), (3840, 2160)):
-        single = res[f"{W}x{H} N=1 single"]["ms_per_frame"]
-        for N in (2, 4, 8):
+
+    from cedec_2024_rt_amd import api, scenes
+
+    res = {"transport": T, "note": "one rank alone on the GPU, a process per measurement, lower of two runs per rank where two were made; "
+                                   "speedup_bound = single-context frame of the same run / slowest rank"}
+    cuts = {}
+    if os.path.exists(CUTS):
+        cuts = json.load(open(CUTS))
+    sha = scenes.scene_sha256(scenes.make_blocks_restir())[:16]
+    for wh in args.sizes.split(","):
+        W, H = (int(v) for v in wh.split("x"))
+        single = min(fresh(W, H, 1, "sparse", 0, None, T)["ms_per_frame"] for _ in range(2))
+        res[f"{W}x{H} N=1 single"] = dict(ms_per_frame=single)
+        print(json.dumps({f"{W}x{H} N=1": single}), flush=True)
+        for N in (int(v) for v in args.ns.split(",")):
             bounds = api.mg_partition(H, N)
             est = []
-            for it in range(5):  # 4 balance rounds as bench.py does them, then the cut they arrive at
-                # reported rows (equal rows, the final cut): the lower of two runs per rank - a rank's time here is one process on a
-                # shared box, its noise (clock dips, a neighbour's job) only ever adds; the balance rounds in between use one run
-                reps = 2 if (it == 0 or it == 4 or N == 2) else 1
-                t = [min(measure(W, H, N, 0, tris, frames=40, rank=k, bounds=bounds, transport=T)["ms_per_frame"] for _ in range(reps)) for k in range(N)]
-                row = dict(transport=T, rows=[b - a for a, b in bounds], ms=t, max_ms=max(t), speedup_bound=round(single / max(t), 2))
-                if it == 0:
-                    res[f"{W}x{H} N={N} all ranks, equal rows"] = row
-                    print(json.dumps({f"{W}x{H} N={N} all ranks, equal rows": row}), flush=True)
-                if it == 4 or N == 2:
-                    res[f"{W}x{H} N={N} all ranks, rows cut by measured cost"] = row
-                    print(json.dumps({f"{W}x{H} N={N} all ranks, rows cut by measured cost": row}), flush=True)
+            rounds = args.rounds if N == 8 else 0
+            for it in range(rounds + 1):
+                final = it == rounds
+                reps = 2 if (it == 0 or final) else 1
+                runs = [[fresh(W, H, N, "sparse", k, bounds, T) for _ in range(reps)] for k in range(N)]
+                t = [min(m["ms_per_frame"] for m in rk) for rk in runs]
+                row = dict(rows=[b - a for a, b in bounds], ms=t, max_ms=max(t), speedup_bound=round(single / max(t), 2),
+                           MB_sent_per_frame=max(rk[0]["MB_sent_per_frame"] for rk in runs),
+                           xgmi_wire_us_per_frame=max(rk[0]["xgmi_wire_us_per_frame"] for rk in runs),
+                           host_us=max(rk[0]["host_us"] for rk in runs))
+                name = "equal rows" if it == 0 else ("rows cut by measured cost" if final else f"balance round {it}")
+                res[f"{W}x{H} N={N} all ranks, {name}"] = row
+                print(json.dumps({f"{W}x{H} N={N} all ranks, {name}": row}), flush=True)
+                if final:
+                    if rounds:
+                        cuts[f"{W}x{H}:{N}:{sha}"] = dict(bounds=[bounds[0][0]] + [e for _, e in bounds], transport=T, max_ms=max(t),
+                                                          equal_rows_max_ms=res[f"{W}x{H} N={N} all ranks, equal rows"]["max_ms"])
                     break
                 cost = np.zeros(H)
                 for (a, b), ms in zip(bounds, t):
@@ -139,6 +153,9 @@ def main():
     if args.out:
         with open(args.out, "w") as f:
             json.dump(res, f, indent=1)
+    if cuts:
+        with open(CUTS, "w") as f:
+            json.dump(cuts, f, indent=1)
 
 
 if __name__ == "__main__":
