@@ -1,4 +1,5 @@
-"""Timings of BASELINE.json configs #1-#3 and #4 at 4K (results table of BASELINE.md / DESIGN.md)."""
+"""Timings of BASELINE.json configs #1-#3 and #4 at 4K (results table of BASELINE.md / DESIGN.md).
+  python tools/config_table.py > profiles/rNN_config_table.json"""
 import sys, os, json, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,7 +1,8 @@
 """How long is the slowest wavefront? Per-ray BVH steps and per-wavefront passes (inner + leaf) of the frame's
 shadow rays and primary rays at 1920x1080: mean, percentiles and maximum. A launch that fits the GPU in one round
 (a strip of a multi-GPU frame) lasts as long as its slowest wavefront, so the tail of this distribution — not
-the mean — bounds strong scaling."""
+the mean — bounds strong scaling.
+  python tools/wave_tail.py > profiles/rNN_wave_tail.txt"""
 import os
 import sys
 
