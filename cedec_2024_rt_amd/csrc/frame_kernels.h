@@ -259,6 +259,14 @@ RT_DEV float target_function(const SceneView& S, uint32_t* s_stack, f3 op, f3 on
     return target_unshadowed(op, on, hp, hn, lum);
 }
 
+/* weight = p_hat / pdf (10_restir_di.cu:98-105) with the pdf's refined reciprocal from the light table (k_light_table) */
+RT_DEV float div_pdf(float p_hat, float pdf, float r1)
+{
+#if RT_FAST_DIV
+    if (r1 == r1 && div_num_ok(p_hat)) return div_by(p_hat, pdf, r1);
+#endif
+    return p_hat / pdf;
+}
 RT_DEV void res_take_sample(Res& r, const Res& o)
 {
     r.hit_p = o.hit_p; r.hit_n = o.hit_n; r.org_p = o.org_p; r.org_n = o.org_n;
@@ -408,7 +416,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_W
                 const f3 lp = (1.0f - bx - by) * v0 + bx * v1 + by * v2;
                 const f3 ln = F3(L3n.x, L3n.y, L3n.z);
                 const float p_hat = target_unshadowed(sp, sn, lp, ln, L2.y); /* unshadowed always (:104) */
-                const float weight = p_hat / L2.z;                          /* 1/L * 1/area (:98-99) */
+                const float weight = div_pdf(p_hat, L2.z, L3n.w);           /* 1/L * 1/area (:98-99) */
                 const float u = rng.uniformf();
                 r.w_sum += weight;
                 r.M += 1;
@@ -460,7 +468,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_W
             const f3 lp = (1.0f - bx - by) * v0 + bx * v1 + by * v2;
             const f3 ln = F3(C3.x, C3.y, C3.z);
             const float p_hat = target_unshadowed(sp, sn, lp, ln, C2.y);
-            const float weight = p_hat / C2.z;
+            const float weight = div_pdf(p_hat, C2.z, C3.w);
             r.w_sum += weight;
             r.M += 1;
             if (u < weight / r.w_sum)
@@ -494,7 +502,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_W
         const float lum = L2.y;
         const float light_pdf = L2.z; /* 1/L * 1/area (:98-99) */
         const float p_hat = target_unshadowed(sp, sn, lp, ln, lum); /* unshadowed always (:104) */
-        const float weight = p_hat / light_pdf;
+        const float weight = div_pdf(p_hat, light_pdf, L3n.w);
         const float u = rng.uniformf();
         /* common/reservoir.hpp:22-29 */
         r.w_sum += weight;
@@ -709,7 +717,7 @@ RT_DEV void spatial_pixel(const SceneView& S, const FrameParams& P, const HaloFu
             {
                 const float rv0 = rng.uniformf();
                 const float rv1 = rng.uniformf();
-                const float radius = sqrtf(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
+                const float radius = sqrt_guarded(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
                 const float phi = 2.0f * kPI * rv1;
                 float sn_phi, cs_phi;
                 pm_sincosf(phi, &sn_phi, &cs_phi);
@@ -780,7 +788,7 @@ RT_DEV void spatial_pixel(const SceneView& S, const FrameParams& P, const HaloFu
             const float rv0 = rng.uniformf();
             const float rv1 = rng.uniformf();
             /* common/reservoir.hpp:89-95 with portable log/cos/sin */
-            const float radius = sqrtf(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
+            const float radius = sqrt_guarded(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
             const float phi = 2.0f * kPI * rv1;
             float sn_phi, cs_phi;
             pm_sincosf(phi, &sn_phi, &cs_phi);
@@ -869,7 +877,7 @@ RT_DEV void spatial_wave_shadowed(const SceneView& S, const FrameParams& P, cons
             {
                 const float rv0 = rng.uniformf();
                 const float rv1 = rng.uniformf();
-                const float radius = sqrtf(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
+                const float radius = sqrt_guarded(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
                 const float phi = 2.0f * kPI * rv1;
                 float sn_phi, cs_phi;
                 pm_sincosf(phi, &sn_phi, &cs_phi);
@@ -1082,7 +1090,7 @@ __global__ __launch_bounds__(BLOCK) void k_spatial_lds(
             {
                 const float rv0 = rng.uniformf();
                 const float rv1 = rng.uniformf();
-                const float radius = sqrtf(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
+                const float radius = sqrt_guarded(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
                 const float phi = 2.0f * kPI * rv1;
                 float sn_phi, cs_phi;
                 pm_sincosf(phi, &sn_phi, &cs_phi);
@@ -1284,7 +1292,7 @@ __global__ __launch_bounds__(BLOCK) void k_spatial_coop(
                 const float rv0 = rng.uniformf();
                 const float rv1 = rng.uniformf();
                 /* common/reservoir.hpp:89-95 with portable log/cos/sin */
-                const float radius = sqrtf(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
+                const float radius = sqrt_guarded(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
                 const float phi = 2.0f * kPI * rv1;
                 float sn_phi, cs_phi;
                 pm_sincosf(phi, &sn_phi, &cs_phi);
@@ -1443,7 +1451,7 @@ __global__ __launch_bounds__(BLOCK) void k_spatial_pipe(
         {
             const float rv0 = rng.uniformf();
             const float rv1 = rng.uniformf();
-            const float radius = sqrtf(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
+            const float radius = sqrt_guarded(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
             const float phi = 2.0f * kPI * rv1;
             float sn_phi, cs_phi;
             pm_sincosf(phi, &sn_phi, &cs_phi);
@@ -1558,7 +1566,7 @@ __global__ __launch_bounds__(BLOCK) void k_spatial_bytes(FrameParams P, const fl
                 {
                     const float rv0 = rng.uniformf();
                     const float rv1 = rng.uniformf();
-                    const float radius = sqrtf(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
+                    const float radius = sqrt_guarded(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
                     const float phi = 2.0f * kPI * rv1;
                     float sn_phi, cs_phi;
                     pm_sincosf(phi, &sn_phi, &cs_phi);
@@ -1659,7 +1667,7 @@ __global__ __launch_bounds__(BLOCK) void k_halo_mark(FrameParams P, const float4
         {
             const float rv0 = rng.uniformf();
             const float rv1 = rng.uniformf();
-            const float radius = sqrtf(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
+            const float radius = sqrt_guarded(fmax_dev(-2.0f * pm_logf(rv0), 0.0f));
             const float phi = 2.0f * kPI * rv1;
             float sn_phi, cs_phi;
             pm_sincosf(phi, &sn_phi, &cs_phi);
@@ -2394,7 +2402,8 @@ __global__ void k_light_table(int n_lights, const uint32_t* __restrict__ light_i
     L[2] = make_float4(v2.z, luminance(ke), pdf, as_float(ti));
 #if RT_LIGHT_STRIDE == 4
     const f3 nn = tri_normal(v0, v1, v2);
-    L[3] = make_float4(nn.x, nn.y, nn.z, 0.0f);
+    /* .w: the refined reciprocal of the pdf for div_by (rt_device.h), NaN if the pdf is outside the range it is exact for */
+    L[3] = make_float4(nn.x, nn.y, nn.z, div_den_ok(pdf) ? rcp_refined(pdf) : as_float(0x7fc00000u));
 #endif
     light_ke[i] = make_float4(ke.x, ke.y, ke.z, 0.0f);
 }
@@ -2655,6 +2664,30 @@ __global__ void k_math_eval(int fn, const float* __restrict__ in, int n, float* 
         case 26: r = in[2 * (size_t)i] / in[2 * (size_t)i + 1]; break;
         case 27: r = sqrtf(in[i]); break;
         case 30: r = as_float(f2i_sat(in[i])); break; /* the bits of the int */
+        /* guarded divisions / square root against the compiler's (rt_device.h): the XOR of the two results' bits */
+        case 31:
+        {
+            const float* q = in + 12 * (size_t)i;
+            const f3 p0 = F3(q[0], q[1], q[2]), n0 = F3(q[3], q[4], q[5]), p1 = F3(q[6], q[7], q[8]), n1 = F3(q[9], q[10], q[11]);
+            r = as_float(as_uint(geometry_term(p0, n0, p1, n1)) ^ as_uint(geometry_term_plain(p0, n0, p1, n1)));
+            break;
+        }
+        case 32: /* was the fast path of geometry_term taken? (coverage of the test's inputs) */
+        {
+            const float* q = in + 12 * (size_t)i;
+            const f3 v = F3(q[6], q[7], q[8]) - F3(q[0], q[1], q[2]);
+            r = (div_den_ok(dot(v, v)) && __builtin_fminf(__builtin_fminf(fabsf(v.x), fabsf(v.y)), fabsf(v.z)) >= kDivNumLo) ? 1.0f : 0.0f;
+            break;
+        }
+        case 33: /* n / d through the refined reciprocal wherever the range tests admit it */
+        {
+            const float n = in[2 * (size_t)i], d = in[2 * (size_t)i + 1];
+            const bool ok = div_den_ok(fabsf(d)) && div_num_ok(fabsf(n));
+            r = ok ? as_float(as_uint(div_by(n, d, rcp_refined(d))) ^ as_uint(n / d)) : as_float(0xffffffffu);
+            break;
+        }
+        case 34: r = div_den_ok(in[i]) ? as_float(as_uint(sqrt_in_range(in[i])) ^ as_uint(sqrtf(in[i]))) : as_float(0xffffffffu); break;
+        case 35: r = div_pdf(in[2 * (size_t)i], in[2 * (size_t)i + 1], div_den_ok(in[2 * (size_t)i + 1]) ? rcp_refined(in[2 * (size_t)i + 1]) : as_float(0x7fc00000u)); break;
         default: break;
     }
     out[i] = r;

@@ -44,7 +44,8 @@ RT_HD f3 cross(f3 a, f3 b)
     return F3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 RT_HD float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-RT_HD float length(f3 a) { return sqrtf(dot(a, a)); }
+RT_HD float sqrt_guarded(float x); /* sqrtf, through sqrt_in_range on the device where the argument admits it (below) */
+RT_HD float length(f3 a) { return sqrt_guarded(dot(a, a)); }
 RT_HD f3 normalize(f3 a) { return a / length(a); }
 RT_HD f3 mix(f3 a, f3 b, float t) { return a + (b - a) * t; }
 RT_HD float luminance(f3 a) { return dot(a, F3(0.1762044f, 0.8129847f, 0.0108109f)); }
@@ -108,8 +109,98 @@ RT_HD void warp_unit_triangle(float& x, float& y)
     if (y > x) { x *= 0.5f; y -= x; }
     else { y *= 0.5f; x -= y; }
 }
+/* ---- IEEE binary32 division without its scaling and fix-up steps (device only, r04) ----------------------------------
+ * hipcc expands `n / d` (no fast-math, fp32 denormals on) into the 11-instruction sequence
+ *     ds = v_div_scale(d, d, n); ns = v_div_scale(n, d, n); r0 = v_rcp(ds); e0 = fma(-ds, r0, 1); r1 = fma(e0, r0, r0);
+ *     q0 = ns * r1; e1 = fma(-ds, q0, ns); q1 = fma(e1, r1, q0); e2 = fma(-ds, q1, ns); q = v_div_fmas(e2, r1, q1);
+ *     result = v_div_fixup(q, d, n)
+ * v_div_scale returns its first operand UNCHANGED and clears VCC (so v_div_fmas is a plain fma) unless the denominator is
+ * denormal or >= 2^126, the quotient would be denormal or overflow (exponent difference >= 96 or <= -126), the numerator
+ * is below 2^-103, or an operand is 0 / inf / NaN; v_div_fixup returns q unchanged (with the sign of n / d, which q has)
+ * unless an operand is 0 / inf / NaN or the quotient under- / overflows (CDNA3 ISA guide, V_DIV_SCALE_F32 /
+ * V_DIV_FMAS_F32 / V_DIV_FIXUP_F32). So for
+ *     2^-40 <= |d| <= 2^40   and   2^-79 <= |n| < 2^56        (exponent difference within [-119, 95])
+ * the same result comes from r1 = rcp_refined(d) (3 instructions, once per DENOMINATOR) and div_by(n, d, r1)
+ * (5 instructions per numerator) — literally the operations above with ds = d, ns = n. The kernels use it where several
+ * numerators share a denominator (normalize: 18 instead of 33 instructions) or the denominator's r1 can be stored
+ * (the light table's pdf), behind range tests on the operands' bits; anything outside (zeros, denormals, NaN, huge or
+ * tiny values) takes the compiler's division. Checked on the device against `/` over random and edge operands
+ * (tests/test_gpu_round4.py::test_guarded_division_is_ieee). RT_FAST_DIV=0 compiles the plain divisions everywhere (A/B). */
+#ifndef RT_FAST_DIV
+#define RT_FAST_DIV 1
+#endif
+#if defined(__HIPCC__)
+/* (the host pass of hipcc parses device functions too: the two hardware instructions are named for the device pass only) */
+#if defined(__HIP_DEVICE_COMPILE__)
+RT_DEV float hw_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+RT_DEV float hw_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+#else
+RT_DEV float hw_rcp(float x) { return 1.0f / x; }
+RT_DEV float hw_sqrt(float x) { return sqrtf(x); }
+#endif
+RT_DEV float rcp_refined(float d)
+{
+    const float r0 = hw_rcp(d);
+    const float e0 = __builtin_fmaf(-d, r0, 1.0f);
+    return __builtin_fmaf(e0, r0, r0);
+}
+RT_DEV float div_by(float n, float d, float r1)
+{
+    const float q0 = n * r1;
+    const float e1 = __builtin_fmaf(-d, q0, n);
+    const float q1 = __builtin_fmaf(e1, r1, q0);
+    const float e2 = __builtin_fmaf(-d, q1, n);
+    return __builtin_fmaf(e2, r1, q1);
+}
+/* d >= 0 (a sum of squares, a pdf, a weight sum): 2^-40 <= d <= 2^40; zero, negative, inf and NaN bits fall outside */
+RT_DEV bool div_den_ok(float d) { return (pm_f2u(d) - 0x2b800000u) <= (0x53800000u - 0x2b800000u); }
+/* n >= 0: 2^-79 <= n <= 2^55 (zero takes the compiler's division: rare, and its sign rules are v_div_fixup's) */
+RT_DEV bool div_num_ok(float n) { return (pm_f2u(n) - 0x18000000u) <= (0x5b000000u - 0x18000000u); }
+constexpr float kDivNumLo = 1.6543612251060553e-24f; /* 2^-79 */
+/* sqrtf the same way: hipcc's expansion is scale-up of arguments below 2^-96, v_sqrt_f32, a +-1 ulp correction from two
+ * fma residuals, scale-down, and a v_cmp_class fix-up for 0 / inf (15 instructions); for 2^-40 <= x <= 2^40 the scaling
+ * and the fix-up are identities and the 9 instructions in between give the same bits */
+RT_DEV float sqrt_in_range(float x)
+{
+    const float s = hw_sqrt(x);
+    const float dn = pm_u2f(pm_f2u(s) - 1u), up = pm_u2f(pm_f2u(s) + 1u);
+    const float e_dn = __builtin_fmaf(-dn, s, x), e_up = __builtin_fmaf(-up, s, x);
+    float r = (0.0f >= e_dn) ? dn : s;
+    r = (0.0f < e_up) ? up : r;
+    return r;
+}
+#endif
+
+RT_HD float sqrt_guarded(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && RT_FAST_DIV
+    if (div_den_ok(x)) return sqrt_in_range(x);
+#endif
+    return sqrtf(x);
+}
+
 /* common/core.hpp:287-295 [parity] */
 RT_HD float geometry_term(f3 p0, f3 n0, f3 p1, f3 n1)
+{
+    f3 v = p1 - p0;
+    const float sqr_dist = dot(v, v);
+#if defined(__HIP_DEVICE_COMPILE__) && RT_FAST_DIV
+    /* normalize = three divisions by |v| = sqrt(sqr_dist): one refined reciprocal for the three; then / sqr_dist */
+    if (div_den_ok(sqr_dist) && __builtin_fminf(__builtin_fminf(fabsf(v.x), fabsf(v.y)), fabsf(v.z)) >= kDivNumLo)
+    {
+        const float len = sqrt_in_range(sqr_dist); /* in [2^-20, 2^20]; |v.i| <= len (1 + 2^-22) */
+        const float rl = rcp_refined(len);
+        v = F3(div_by(v.x, len, rl), div_by(v.y, len, rl), div_by(v.z, len, rl));
+        const float num = fabsf(dot(v, n0)) * fabsf(dot(-v, n1));
+        if (div_num_ok(num)) return div_by(num, sqr_dist, rcp_refined(sqr_dist));
+        return num / sqr_dist;
+    }
+#endif
+    v = normalize(v);
+    return fabsf(dot(v, n0)) * fabsf(dot(-v, n1)) / sqr_dist;
+}
+/* the same with the compiler's divisions and square root only (device self-check of the guarded forms: k_math_eval) */
+RT_HD float geometry_term_plain(f3 p0, f3 n0, f3 p1, f3 n1)
 {
     f3 v = p1 - p0;
     const float sqr_dist = dot(v, v);

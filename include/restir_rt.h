@@ -419,8 +419,9 @@ int rt_tuning_get(rt_ctx* ctx, int key, int* value);
  * every clean rebuild of the same sources, so counter profiles (profiles/spatial_pmc_latest.json) can be matched to the
  * library that is benchmarked. "unknown" if the library was built without the Makefile. */
 const char* rt_build_id(void);
-/* elementwise device evaluation of the portable math / IEEE div & sqrt (parity tests);
- * fn ids as in tests/test_portable_math.py */
+/* elementwise device evaluation of the portable math / IEEE div & sqrt (parity tests); fn ids as in
+ * tests/test_portable_math.py; 31..35 (r04): the guarded shared-reciprocal divisions and square root of rt_device.h against
+ * the compiler's (31 / 32: 12 floats per item = p0, n0, p1, n1; 33 / 35: 2 floats per item; results are XORs of bit patterns) */
 int rt_math_eval(rt_ctx* ctx, int fn, const float* in, uint32_t n, float* out);
 
 #ifdef __cplusplus

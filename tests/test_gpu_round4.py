@@ -290,3 +290,82 @@ def test_walk_stats_account_for_every_reference_ray(api, oracle, scenes, shadowe
     st, _ = _oracle_frames(oracle, tris, W, H, scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT, 2 + frames, use_shadowed_target_function=shadowed)
     assert _eq_bits(acc, st["accum"].reshape(acc.shape))
     r.close()
+
+
+def _log_uniform(rng, n, e_lo, e_hi, signed=False):
+    """float32 values with exponents uniform in [e_lo, e_hi) and random mantissas (every binade equally likely)"""
+    e = rng.integers(e_lo + 127, e_hi + 127, size=n, dtype=np.uint32)
+    m = rng.integers(0, 1 << 23, size=n, dtype=np.uint32)
+    # a quarter of the mantissas at the extremes: all zeros, all ones, one bit
+    k = n // 4
+    m[:k // 3] = 0
+    m[k // 3: 2 * k // 3] = (1 << 23) - 1
+    m[2 * k // 3: k] = 1 << rng.integers(0, 23, size=k - 2 * k // 3, dtype=np.uint32)
+    bits = (e << 23) | m
+    if signed:
+        bits |= rng.integers(0, 2, size=n, dtype=np.uint32) << 31
+    return bits.view(np.float32)
+
+
+def test_guarded_division_is_ieee(api):
+    """rt_device.h (r04): inside their operand ranges the shared-reciprocal division (div_by after rcp_refined), the stored-
+    reciprocal division by a light's pdf (div_pdf) and sqrt_in_range are the compiler's IEEE division / square root bit for bit —
+    they ARE its instruction sequence minus the scaling and fix-up steps, which are identities there — and outside the ranges
+    the kernels take the compiler's form. Device self-check: XOR of the two results' bits over random operands (every binade,
+    extreme mantissas, both signs, range borders), and the fused forms as the kernels call them (geometry_term)."""
+    r = api.Renderer(8, 8)
+    rng = np.random.default_rng(404)
+    none = np.uint32(0xFFFFFFFF)
+    # n / d through the refined reciprocal
+    covered = 0
+    for batch in range(6):
+        n = 4_000_000
+        num = _log_uniform(rng, n, -95, 70, signed=True)
+        den = _log_uniform(rng, n, -50, 50, signed=True)
+        if batch == 0:  # the borders of the ranges and neighbours
+            edge_d = np.float32([2.0 ** -40, 2.0 ** 40, np.nextafter(np.float32(2.0 ** -40), np.float32(1)), np.nextafter(np.float32(2.0 ** 40), np.float32(0))])
+            edge_n = np.float32([2.0 ** -79, 2.0 ** 55, np.nextafter(np.float32(2.0 ** -79), np.float32(1)), np.nextafter(np.float32(2.0 ** 55), np.float32(0)), 1.0, 3.0])
+            g = np.array(np.meshgrid(edge_n, edge_d)).reshape(2, -1)
+            num[: g.shape[1]], den[: g.shape[1]] = g[0], g[1]
+        x = np.stack([num, den], axis=1).astype(np.float32)
+        out = r.math_eval(33, x).view(np.uint32)
+        took = out != none
+        covered += int(took.sum())
+        bad = took & (out != 0)
+        assert not bad.any(), f"div_by differs from IEEE division for {int(bad.sum())} operand pairs, e.g. {x[bad][:3]}"
+    assert covered > 6_000_000, covered
+    # square root
+    x = np.concatenate([_log_uniform(rng, 8_000_000, -45, 45), (np.arange(1, 200001, dtype=np.float32) ** 2), np.float32([2.0 ** -40, 2.0 ** 40, 1.0, 2.0, 4.0])])
+    out = r.math_eval(34, x).view(np.uint32)
+    took = out != none
+    assert took.sum() > 6_000_000 and not (took & (out != 0)).any(), "sqrt_in_range differs from sqrtf"
+    # p_hat / pdf with the light table's stored reciprocal == IEEE (numpy) for every operand, in range or not
+    ph = np.concatenate([_log_uniform(rng, 3_000_000, -126, 100), np.float32([0.0, 1e-45, 1e-38, 3.4e38])])
+    pdf = np.concatenate([_log_uniform(rng, 3_000_000, -60, 60), np.float32([1.0, 1e-3, 1e3, 2.0 ** -41])])
+    with np.errstate(all="ignore"):
+        want = (ph / pdf).astype(np.float32)
+    got = r.math_eval(35, np.stack([ph, pdf], axis=1).astype(np.float32))
+    assert _eq_bits(got, want), f"div_pdf: {(got.view(np.uint32) != want.view(np.uint32)).sum()} differ"
+    # geometry_term as the kernels call it: random point pairs, and pairs built to leave the fast range
+    n = 3_000_000
+    p0 = (rng.random((n, 3), dtype=np.float32) * 60 - 30).astype(np.float32)
+    p1 = (rng.random((n, 3), dtype=np.float32) * 60 - 30).astype(np.float32)
+    k = n // 10
+    p1[:k, 0] = p0[:k, 0]                                   # a zero component (axis-aligned geometry)
+    p1[k:2 * k] = p0[k:2 * k] + (rng.random((k, 3), dtype=np.float32) * np.float32(1e-4)).astype(np.float32)   # nearly the same point
+    p1[2 * k:3 * k] = p0[2 * k:3 * k]                       # the same point: 0 / 0
+    p1[3 * k:4 * k, 1] = (p0[3 * k:4 * k, 1] + np.float32(1e-30)).astype(np.float32)
+    p0[4 * k:5 * k] *= np.float32(1e18)                     # far outside
+    p1[5 * k:6 * k] = (p0[5 * k:6 * k] + _log_uniform(rng, 3 * k, -100, 10, signed=True).reshape(k, 3)).astype(np.float32)
+    nrm = rng.normal(size=(2, n, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=2, keepdims=True)
+    nrm[0, : n // 7] = np.float32([0, 1, 0])
+    x = np.concatenate([p0, nrm[0], p1, nrm[1]], axis=1).astype(np.float32)
+    out = r.math_eval(31, x).view(np.uint32)
+    fast = r.math_eval(32, x)
+    # NaN results (0 / 0) may differ in payload only if both are NaN: compare as "same bits or both NaN"
+    plain_nan = ~np.isfinite(p0).all(axis=1) | (p0 == p1).all(axis=1)
+    bad = (out != 0) & ~plain_nan
+    assert not bad.any(), f"geometry_term: {int(bad.sum())} of {n} differ from the compiler's divisions, e.g. {x[bad][:2]}"
+    assert 0.3 < float(fast.mean()) < 0.95, float(fast.mean())   # both paths are exercised
+    r.close()
