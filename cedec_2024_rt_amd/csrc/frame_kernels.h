@@ -1622,10 +1622,70 @@ struct HaloRegions
     uint32_t* bitmaps[2];
     int quick; /* 1 = rows far from the regions test their draws against a radius bound first (rt_tuning key 18) */
 };
-__global__ __launch_bounds__(BLOCK) void k_halo_mark(FrameParams P, const float4* __restrict__ g1, HaloRegions R, int pass0, int n_pass)
+/* WINDOW (r04): the marks of a workgroup's 32x8 tile go into an LDS bitmap of the tile's +-87-pixel window first (one per
+ * pass: 182 rows x 7 words, the window of k_spatial_lds) and only its non-zero words reach the global bitmaps, one atomicOr
+ * per word and workgroup. The direct form issues one global atomic per marked neighbour — ~1.2 M per frame of a 1080p strip,
+ * many to the same word, at ~140 ns per same-address atomic (measured in the BVH builder): the kernel took 84 us
+ * for a 135-row strip and 310 us for a 270-row 4K strip with ~12 us of arithmetic, a fifth of the strip's frame
+ * (profiles/r04_strip_timelines.txt). Needs W % 32 == 0 (window words = bitmap words), a reach <= 87 px and <= 3 passes per
+ * launch; the host falls back to the direct form otherwise. Same marks (the tests compare both with the replay). */
+constexpr int MARK_MAX_PASSES = 3;
+template <bool WINDOW>
+RT_DEV void halo_mark_pixel(const FrameParams& P, const float4* __restrict__ g1, const HaloRegions& R, int pass0, int n_pass, bool in_image, int x,
+                            int row, int trow0, int tw0, uint32_t* s_win, const uint32_t* s_bits);
+/* `bits` (WINDOW): shaded bit per pixel of all local rows (k_shaded_bitmap), staged for the tile's window: the replay's
+ * "is the neighbour shaded" test — which decides whether the merge draw is consumed — reads LDS instead of gathering 4 bytes
+ * of a 16-byte G-buffer record per neighbour (15 dependent 64-cache-line gathers per pixel were what the kernel waited for) */
+template <bool WINDOW>
+__global__ __launch_bounds__(BLOCK) void k_halo_mark(FrameParams P, const float4* __restrict__ g1, const uint32_t* __restrict__ bits, HaloRegions R, int pass0,
+                                                      int n_pass)
 {
-    int x, row;
-    if (!tile_pixel(P, x, row)) return;
+    __shared__ uint32_t s_win[WINDOW ? MARK_MAX_PASSES * SPL_ROWS * SPL_WORDS : 1];
+    __shared__ uint32_t s_bits[WINDOW ? SPL_ROWS * SPL_WORDS : 1];
+    int x = 0, row = P.row0;
+    const bool in_image = tile_pixel(P, x, row);
+#if RT_WAVE_8X8 && RT_TILE_W == 32
+    const int in_tile_row = (threadIdx.x >> 3) & 7;
+#else
+    const int in_tile_row = threadIdx.x >> TILE_W_LOG2;
+#endif
+    const int trow0 = row - in_tile_row, tw0 = ((x & ~(TILE_W - 1)) >> 5) - 3; /* the tile's origin, from any thread (k_spatial_lds) */
+    if (WINDOW)
+    {
+        for (int i = threadIdx.x; i < n_pass * SPL_ROWS * SPL_WORDS; i += BLOCK) s_win[i] = 0u;
+        const int words = P.W >> 5;
+        for (int i = threadIdx.x; i < SPL_ROWS * SPL_WORDS; i += BLOCK)
+        {
+            const int r = i / SPL_WORDS, w = i - r * SPL_WORDS;
+            const int lr = trow0 - SPL_HALO + r - P.lrow0, gw = tw0 + w;
+            s_bits[i] = (lr >= 0 && lr < P.lrows && gw >= 0 && gw < words) ? bits[(size_t)lr * words + gw] : 0u;
+        }
+        __syncthreads();
+    }
+    halo_mark_pixel<WINDOW>(P, g1, R, pass0, n_pass, in_image, x, row, trow0, tw0, s_win, s_bits);
+    if (WINDOW)
+    {
+        __syncthreads();
+        const int words_per_row = P.W >> 5;
+        for (int i = threadIdx.x; i < n_pass * SPL_ROWS * SPL_WORDS; i += BLOCK)
+        {
+            const uint32_t w = s_win[i];
+            if (!w) continue;
+            const int pi = i / (SPL_ROWS * SPL_WORDS), rem = i - pi * (SPL_ROWS * SPL_WORDS);
+            const int r = rem / SPL_WORDS, ww = rem - r * SPL_WORDS;
+            const int nrow = trow0 - SPL_HALO + r, gw = tw0 + ww;
+#pragma unroll
+            for (int sd = 0; sd < 2; ++sd)
+                if (nrow >= R.row0[sd] && nrow < R.row0[sd] + R.rows[sd])
+                    atomicOr(&R.bitmaps[sd][(size_t)pi * R.words[sd] + 1 + (size_t)(nrow - R.row0[sd]) * words_per_row + gw], w);
+        }
+    }
+}
+template <bool WINDOW>
+RT_DEV void halo_mark_pixel(const FrameParams& P, const float4* __restrict__ g1, const HaloRegions& R, int pass0, int n_pass, bool in_image, int x,
+                            int row, int trow0, int tw0, uint32_t* s_win, const uint32_t* s_bits)
+{
+    if (!in_image) return;
     const int yi = P.H - 1 - row;
     const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
     if (!(as_uint(g1[li].w) & GB_SHADED) || !P.use_spatial) return;
@@ -1678,14 +1738,26 @@ __global__ __launch_bounds__(BLOCK) void k_halo_mark(FrameParams P, const float4
             const int nrow = P.H - 1 - ny;
             const int lr = nrow - P.lrow0;
             if (lr < 0 || lr >= P.lrows) continue;
+            if (WINDOW)
+            {
+                /* every row of the window, region or not: the flush keeps the region rows */
+                atomicOr(&s_win[(pi * SPL_ROWS + (nrow - (trow0 - SPL_HALO))) * SPL_WORDS + ((nx >> 5) - tw0)], 1u << (nx & 31));
+            }
+            else
+            {
 #pragma unroll
-            for (int sd = 0; sd < 2; ++sd)
-                if (nrow >= R.row0[sd] && nrow < R.row0[sd] + R.rows[sd])
-                {
-                    const uint32_t bit = (uint32_t)(nrow - R.row0[sd]) * (uint32_t)P.W + (uint32_t)nx;
-                    atomicOr(&R.bitmaps[sd][(size_t)pi * R.words[sd] + 1 + (bit >> 5)], 1u << (bit & 31u));
-                }
-            if (!(as_uint(g1[(size_t)nx + (size_t)lr * P.W].w) & GB_SHADED)) continue;
+                for (int sd = 0; sd < 2; ++sd)
+                    if (nrow >= R.row0[sd] && nrow < R.row0[sd] + R.rows[sd])
+                    {
+                        const uint32_t bit = (uint32_t)(nrow - R.row0[sd]) * (uint32_t)P.W + (uint32_t)nx;
+                        atomicOr(&R.bitmaps[sd][(size_t)pi * R.words[sd] + 1 + (bit >> 5)], 1u << (bit & 31u));
+                    }
+            }
+            if (WINDOW)
+            {
+                if (!(s_bits[(nrow - (trow0 - SPL_HALO)) * SPL_WORDS + ((nx >> 5) - tw0)] & (1u << (nx & 31)))) continue;
+            }
+            else if (!(as_uint(g1[(size_t)nx + (size_t)lr * P.W].w) & GB_SHADED)) continue;
             rng.uniformf();
         }
     }

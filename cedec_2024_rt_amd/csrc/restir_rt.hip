@@ -91,6 +91,7 @@ struct rt_ctx
                                      kernel needs (7), -1 = auto: 4 for the gather kernel (its neighbour window must stay in L2: 0.184 vs 0.202 ms
                                      per pass), none for the LDS-staged kernel (0.181 ms unbounded, 0.188 at 4) — profiles/r02_spatial_variants.json */
     uint32_t* d_shaded_bits = nullptr;
+    uint32_t* d_mark_bits = nullptr; /* rt_halo_mark (key 19): shaded bits of all local rows, rebuilt per mark */
     bool shaded_bits_stale = true;
     /* deferred visibility-reuse rays of the fused candidate kernel (frame_kernels.h, DEFER): one queue per lane
      * (main / second stream), its counter, and the last count that reached the host (sizes the next launch) */
@@ -146,6 +147,7 @@ struct rt_ctx
     int tail_phys = -1; /* reservoir buffer the tail in flight reads (the frame's final one) */
     int tune_tail = -1; /* -1 auto = on, 0 never, 1 always */
     int tune_mark_quick = 1; /* rt_tuning key 18: quick reject in k_halo_mark */
+    int tune_mark_window = 1; /* rt_tuning key 19 (r04): k_halo_mark collects a workgroup's marks in LDS first */
     HaloFuse fuse = {};        /* rt_halo_fuse_set: halo lists read / written by the running stage's spatial pass itself */
     int spare = 3;             /* physical buffer not named by res_map */
     bool spec_gen_valid = false, gen_taken = false;
@@ -352,7 +354,7 @@ int rt_destroy(rt_ctx* c)
     for (auto& gs : c->d_gset) for (auto& p : gs) hipFree(p);
     hipFree(c->d_accum); hipFree(c->d_pixels);
     for (int k = 0; k < 4; ++k) { hipFree(c->d_rec[k]); hipFree(c->d_rad[k]); }
-    hipFree(c->d_shaded_bits);
+    hipFree(c->d_shaded_bits); hipFree(c->d_mark_bits);
     hipFree(c->d_visq[0]); hipFree(c->d_visq[1]); hipFree(c->d_visq_count);
     if (c->h_visq_count) hipHostFree(c->h_visq_count);
     hipFree(c->d_walk);
@@ -2218,7 +2220,19 @@ int rt_halo_mark_sides(rt_ctx* c, int frame, int pass, int n_pass, void* bitmaps
     const FrameParams P = make_params(c, frame, pass, K_OTHER);
     const int grid = launch_grid(c);
     c->sub0 = c->sub1 = -1; c->subb0 = c->subb1 = 0;
-    k_halo_mark<<<grid, BLOCK, 0, c->stream>>>(P, c->d_g1, R, pass, n_pass);
+    /* marks collected per workgroup in an LDS window, one global atomic per non-zero word (frame_kernels.h) where it applies */
+    const bool window = c->tune_mark_window && (c->W % 32) == 0 && n_pass <= MARK_MAX_PASSES && halo_rows_needed(c->opt) <= SPL_HALO;
+    if (window)
+    {
+        /* the shaded bit of every local pixel (own rows + the neighbours' flags in the halo rows), rebuilt in front of every
+         * mark on the marking stream: ~3 us, and no staleness to track across the two G-buffer sets of the pipelined stage 0 */
+        const int words = c->W / 32;
+        if (!c->d_mark_bits) RT_HIP(c, hipMalloc(&c->d_mark_bits, (size_t)c->lrows * words * 4));
+        k_shaded_bitmap<<<dim3((c->W + 255) / 256, c->lrows), 256, 0, c->stream>>>(c->W, c->lrows, c->d_g1, c->d_mark_bits);
+        RT_HIP(c, hipGetLastError());
+        k_halo_mark<true><<<grid, BLOCK, 0, c->stream>>>(P, c->d_g1, c->d_mark_bits, R, pass, n_pass);
+    }
+    else k_halo_mark<false><<<grid, BLOCK, 0, c->stream>>>(P, c->d_g1, nullptr, R, pass, n_pass);
     RT_HIP(c, hipGetLastError());
     {
         const size_t wmax = R.words[0] > R.words[1] ? R.words[0] : R.words[1];
@@ -2649,6 +2663,7 @@ int rt_tuning(rt_ctx* c, int key, int value)
     else if (key == 14 && value >= -1 && value <= 2) { c->tune_spec = value; if (!use_next_raycast(c)) c->spec_valid = false; if (!use_next_generate(c)) c->spec_gen_valid = false; }
     else if (key == 17 && value >= -1 && value <= 1) c->tune_tail = value;
     else if (key == 18 && (value == 0 || value == 1)) c->tune_mark_quick = value;
+    else if (key == 19 && (value == 0 || value == 1)) c->tune_mark_window = value;
     else RT_FAIL(c, RT_ERR_ARG, "bad tuning key/value %d/%d", key, value);
     return RT_OK;
 }
@@ -2674,6 +2689,7 @@ int rt_tuning_get(rt_ctx* c, int key, int* value)
         case 16: *value = c->tune_ws_primary; break;
         case 17: *value = c->tune_tail; break;
         case 18: *value = c->tune_mark_quick; break;
+        case 19: *value = c->tune_mark_window; break;
         default: RT_FAIL(c, RT_ERR_ARG, "bad tuning key %d", key);
     }
     return RT_OK;

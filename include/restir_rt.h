@@ -410,7 +410,15 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
  * 0 = never. Off while rt_timing is enabled. Same results.
  * key 18 (r03): 1 (default) = rt_halo_mark lets rows more than 40 rows from a neighbour's region test the pass's first draws
  * against a bound on the neighbour distance (radius = sqrt(-2 log rv0) <= the rows to go) before replaying log / sqrt / sincos
- * for every neighbour: nine passes in ten are skipped there. 0 = full replay everywhere. Same marks (tested bit for bit). */
+ * for every neighbour: nine passes in ten are skipped there. 0 = full replay everywhere. Same marks (tested bit for bit).
+ * key 8 = 3 (r04): the cooperative spatial kernel software-pipelined over the staged shaded-bit window (all draws and neighbour
+ * addresses first, the record of neighbour k+1 in flight while neighbour k is merged; whole-frame contexts, radius <= 30, <= 5
+ * neighbours, else kernel 2). Evaluated and left off: 0.152 against 0.1435 ms per pass at 1920x1080 (5 instead of 6 wavefronts
+ * per SIMD for the 16 staged registers, a barrier for the window). Same results.
+ * key 19 (r04): 1 (default) = rt_halo_mark collects the marks of a workgroup's tile in an LDS bitmap of its +-87-pixel window
+ * and sends only the non-zero words to the global bitmaps (image widths that are multiples of 32, reach <= 87 px, <= 3 passes
+ * per call; the direct form otherwise): the direct form's one global atomicOr per marked neighbour, many to one word, made the
+ * kernel 84 us for a 135-row strip at 1920 px and 310 us for a 270-row strip at 3840 px. 0 = direct. Same marks. */
 int rt_tuning(rt_ctx* ctx, int key, int value);
 /* the value a key holds now (measurement records name the builder / variants that were really used) */
 int rt_tuning_get(rt_ctx* ctx, int key, int* value);

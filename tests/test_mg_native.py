@@ -269,7 +269,7 @@ def test_native_strips_option_change_and_irregular_bounds():
 
 @pytest.mark.gpu
 def test_halo_mark_quick_reject_marks_the_same_records():
-    """rt_tuning key 18: the quick reject of k_halo_mark (rows far from a neighbour's region test the pass's first draws
+    """rt_tuning keys 18 and 19: the quick reject of k_halo_mark (rows far from a neighbour's region test the pass's first draws
     against a bound on the neighbour distance before replaying log / sqrt / sincos) marks exactly the records of the full
     replay: need-bitmaps, counts and prefix words of both sides, three passes, four frames, a 270-row strip of the
     benchmark frame and a 135-row one (bands that meet)."""
@@ -307,15 +307,17 @@ def test_halo_mark_quick_reject_marks_the_same_records():
         marked = 0
         for frame in (1, 2, 3, 4):
             got = []
-            for quick in (0, 1):
+            for quick, window in ((0, 0), (1, 0), (0, 1), (1, 1)):  # key 19 (r04): marks collected in an LDS window per workgroup
                 mid.tuning(18, quick)
+                mid.tuning(19, window)
                 bm = torch.full((2, 3 * words), -1, dtype=torch.int32, device="cuda")
                 torch.cuda.synchronize()  # torch fills on its own stream; the context marks on its non-blocking stream
                 rc = L.rt_halo_mark_sides(mid.h, frame, 0, 3, C.c_void_p(bm[0].data_ptr()), C.c_void_p(bm[1].data_ptr()))
                 assert rc == 0, mid.last_error() if hasattr(mid, "last_error") else rc
                 mid.sync()
                 got.append(bm.cpu().numpy().copy())
-            assert np.array_equal(got[0], got[1]), f"{n} strips, frame {frame}: {(got[0] != got[1]).sum()} words differ"
+            for k in (1, 2, 3):
+                assert np.array_equal(got[0], got[k]), f"{n} strips, frame {frame}, variant {k}: {(got[0] != got[k]).sum()} words differ"
             marked += int(got[0][0, 0]) + int(got[0][1, 0])
         assert marked > 10000, marked
         for c in ctxs:
