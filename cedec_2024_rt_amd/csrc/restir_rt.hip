@@ -70,7 +70,8 @@ struct rt_ctx
     uint64_t gbuf_serial = 0, rec_gserial[4] = {0, 0, 0, 0};
     unsigned long long* d_walk = nullptr; /* rt_walk_stats: 4 kernel slots x 4 counters */
     bool walk_on = false;
-    int tune_ws_primary = 0; /* rt_tuning key 16: primary rays with the work-sharing closest-hit walk (A/B: no gain) */
+    int tune_ws_primary = -1; /* rt_tuning key 16: primary rays with the work-sharing closest-hit walk: -1 auto (r04) = launches of at
+                                 most about one generation of wavefronts (a 135-row strip: -1.5 % of its frame; whole frames +2 %), 0 never, 1 always */
     int tune_stream = 0; /* rt_tuning key 15: resolve as a stream of pixels through persistent wavefronts (A/B: slower) */
     int n_cus = 256;
     int tune_spec = -1; /* rt_tuning key 14: -1 auto = strip contexts: primary rays AND candidates of the next frame, 0 never,
@@ -82,7 +83,9 @@ struct rt_ctx
     int n_tris = 0, n_lights = 0, bvh_height = 0, n_refs = 0;
     /* rt_tuning: tile order per kernel {raycast, generate, spatial, resolve, other} and the spatial
      * pass's occupancy limiter (extra dynamic LDS). Defaults from the sweep in DESIGN.md §5. */
-    int tune_tile_mode[5] = {1, 0, 1, 0, 0};
+    int tune_tile_mode[5] = {-1, 0, -1, 0, 0}; /* -1 = auto: column-major for whole-frame contexts, row-major for strips (r04: a strip's
+                                                  band of an XCD is a few tile rows; row-major is 6 % of a 135-row strip's frame and 3 % of a
+                                                  270-row one's, profiles/r04_strip_tile_modes.txt; whole frames lose 4 % with it) */
     int tune_spatial_lds = 0;     /* rt_tuning key 4: extra dynamic LDS per unshadowed spatial workgroup (A/B of the old throttle) */
     int tune_spatial_variant = 2; /* rt_tuning key 8: 2 = k_spatial_coop (default: four lanes per record, LDS-DMA gathers, transposed
                                      stores), 0 = k_spatial_gather (one per-lane gather per neighbour), 1 = k_spatial_lds (staged
@@ -232,7 +235,14 @@ static FrameParams make_params(const rt_ctx* c, int frame, int pass, int kernel 
     P.use_temporal = c->opt.use_temporal_resampling; P.use_spatial = c->opt.use_spatial_resampling;
     P.spatial_count = c->opt.spatial_resampling_sample_count; P.vis_reuse = c->opt.use_visibility_reuse;
     P.spatial_radius = c->opt.spatial_resampling_radius;
-    P.tile_mode = c->tune_tile_mode[kernel];
+    {
+        /* auto (r04, profiles/r04_strip_tile_modes.txt): whole frames column-major; strips trace their primary rays row-major, and
+         * run the spatial pass row-major too when they are short (a 135-row strip: -6 % of its frame; a 270-row strip keeps
+         * column-major: its neighbour window would not stay in the XCD's L2 otherwise) */
+        const bool whole = c->row_begin == 0 && c->row_end == c->H;
+        const int autom = whole ? 1 : (kernel == K_SPATIAL && c->row_end - c->row_begin >= 200 ? 1 : 0);
+        P.tile_mode = c->tune_tile_mode[kernel] >= 0 ? c->tune_tile_mode[kernel] : autom;
+    }
     P.ownv_tag = c->cur_tag;
     P.stats = c->walk_on ? c->d_walk : nullptr;
     return P;
@@ -1159,6 +1169,10 @@ static int launch_grid(const rt_ctx* c)
 #define RT_WS_AUTO_WAVES 12288
 #endif
 static bool use_ws(const rt_ctx* c, int grid) { return c->tune_ws < 0 ? grid <= RT_WS_AUTO_WAVES : c->tune_ws != 0; }
+#ifndef RT_WS_PRIMARY_AUTO_WAVES
+#define RT_WS_PRIMARY_AUTO_WAVES 8192
+#endif
+static bool use_ws_primary(const rt_ctx* c, int grid) { return c->tune_ws_primary < 0 ? grid <= RT_WS_PRIMARY_AUTO_WAVES : c->tune_ws_primary != 0; }
 /* grid of the tracing kernels: TRACE_BLOCK threads on TileShape<TRACE_BLOCK> tiles */
 /* priority of a side stream: 0 = default, +1 = lowest, -1 = highest (the range HIP reports), overridable for A/B runs */
 static int stream_priority(const char* env, int dflt)
@@ -1220,7 +1234,7 @@ int rt_raycast(rt_ctx* c)
     JOIN_TAIL(c);
     JOIN_SPEC(c);
     NEED_SCENE(c);
-    if (c->tune_ws_primary) k_raycast<true><<<trace_grid(c), TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_vis, c->d_g0, c->d_g1);
+    if (use_ws_primary(c, trace_grid(c))) k_raycast<true><<<trace_grid(c), TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_vis, c->d_g0, c->d_g1);
     else k_raycast<false><<<trace_grid(c), TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_vis, c->d_g0, c->d_g1);
     RT_HIP(c, hipGetLastError());
     c->has_gbuffer = true;
@@ -1274,7 +1288,7 @@ static int launch_next_raycast(rt_ctx* c, int frame)
     const int s0 = c->sub0, s1 = c->sub1, b0 = c->subb0, b1 = c->subb1;
     c->sub0 = c->sub1 = -1; c->subb0 = c->subb1 = 0; /* all owned rows */
     if (c->timing) hipEventRecord(c->ev_spec_t[o][0], c->spec_stream);
-    if (c->tune_ws_primary) k_raycast<true><<<trace_grid(c), TRACE_BLOCK, 0, c->spec_stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_gset[o][0], c->d_gset[o][1], c->d_gset[o][2]);
+    if (use_ws_primary(c, trace_grid(c))) k_raycast<true><<<trace_grid(c), TRACE_BLOCK, 0, c->spec_stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_gset[o][0], c->d_gset[o][1], c->d_gset[o][2]);
     else k_raycast<false><<<trace_grid(c), TRACE_BLOCK, 0, c->spec_stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_gset[o][0], c->d_gset[o][1], c->d_gset[o][2]);
     RT_HIP(c, hipGetLastError());
     if (c->timing) hipEventRecord(c->ev_spec_t[o][1], c->spec_stream);
@@ -2647,7 +2661,7 @@ int rt_bvh_config(rt_ctx* c, float split_factor)
 int rt_tuning(rt_ctx* c, int key, int value)
 {
     RT_CHECK_CTX(c);
-    if (key >= 0 && key <= 3 && (value == 0 || value == 1)) c->tune_tile_mode[key] = value;
+    if (key >= 0 && key <= 3 && (value == 0 || value == 1 || value == -1)) c->tune_tile_mode[key] = value;
     else if (key == 4 && value >= 0 && value <= 160 * 1024) c->tune_spatial_lds = value;
     else if (key == 5 && value >= 0 && value <= 3) c->bvh_builder = value; /* before rt_scene_set */
     else if (key == 6 && value >= 0 && value <= 2) c->pt_wavefront = value;
@@ -2659,7 +2673,7 @@ int rt_tuning(rt_ctx* c, int key, int value)
     else if (key == 12 && (value == 0 || value == 1)) c->tune_ris_pipe = value;
     else if (key == 13 && value >= -1 && value <= 1) c->tune_ws = value;
     else if (key == 15 && (value == 0 || value == 1)) c->tune_stream = value;
-    else if (key == 16 && (value == 0 || value == 1)) c->tune_ws_primary = value;
+    else if (key == 16 && value >= -1 && value <= 1) c->tune_ws_primary = value;
     else if (key == 14 && value >= -1 && value <= 2) { c->tune_spec = value; if (!use_next_raycast(c)) c->spec_valid = false; if (!use_next_generate(c)) c->spec_gen_valid = false; }
     else if (key == 17 && value >= -1 && value <= 1) c->tune_tail = value;
     else if (key == 18 && (value == 0 || value == 1)) c->tune_mark_quick = value;

@@ -351,7 +351,9 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
 /* performance knobs; results never depend on them. keys 0..3: workgroup->tile order inside an XCD
  * band for raycast / generate_candidate / spatial_resampling / resolve (0 row-major, 1 column-major);
  * key 4: extra LDS bytes per unshadowed spatial_resampling workgroup (round 1's occupancy throttle, kept for
- * A/B runs; the kernel carries an explicit register budget instead, key 9: 6 wavefronts per SIMD by default). Defaults: {1,0,1,0}, 0.
+ * A/B runs; the kernel carries an explicit register budget instead, key 9: 6 wavefronts per SIMD by default). Defaults: {-1,0,-1,0}, 0;
+ * -1 (r04) = auto: column-major for whole-frame contexts, row-major for strip contexts (an XCD's band of a strip is a few tile
+ * rows: row-major is 6 % of a 135-row strip's frame, 3 % of a 270-row strip's; whole frames lose 4 % with it).
  * key 5 (before rt_scene_set): builder (default 3). 0 = device LBVH (Morton codes + Karras) with host pre-split and host
  * collapse (round 1), 1 = host binned SAH (the reference requests HIPRT's high-quality build,
  * common/loader.hpp:98-99), 2 = on the device: pre-split, Morton sort, PLOC hierarchy, wide collapse; only the boxes
@@ -399,7 +401,7 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
  * left off (default 0): same instruction count as the work-sharing kernel but 0.48 against 0.36 ms — a wavefront
  * holding rays of several tiles and ages sends 1.5x the requests to L2 and misses 2.6x as often, see DESIGN.md
  * section 5.2 and profiles/r02_stream_resolve_ab.txt. Same results.
- * key 16: 1 = primary rays with the work-sharing CLOSEST-hit walk (csrc/bvh.h closest_ws: pieces of a ray walked by
+ * key 16: -1 (default, r04) = for launches of at most about one generation of wavefronts (strips), 0 = never, 1 = primary rays with the work-sharing CLOSEST-hit walk (csrc/bvh.h closest_ws: pieces of a ray walked by
  * several lanes, merged by a 64-bit LDS min on (t, index)). Evaluated and left off (default 0): raycast 0.311 -> 0.318 ms
  * at 1080p, 0.997 -> 1.029 at 4K — primary rays of an 8x8 tile are coherent (31.8 passes per wavefront for 23.1 steps
  * per ray) and the walk needs 88 registers instead of 70. Same results.
