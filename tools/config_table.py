@@ -6,19 +6,17 @@ sys.path.insert(0, ROOT)
 import numpy as np
 from cedec_2024_rt_amd import api, scenes
 from cedec_2024_rt_amd.types import bench_options, default_options
-from oracle import binding as ob
+import re, subprocess
 
 g = np.load(os.path.join(ROOT, "tests", "golden", "scenes.npz"))
 out = {}
-# config #1: 04_ao cornellbox1 256x256 on the host (oracle = CPU restatement of examples/04_ao/04_ao.cu)
-ob.set_math_mode(ob.MATH_LIBM)
-sc = ob.Scene(g["cornellbox1"], use_bvh=False)
-rg = ob.raygen_lookat(scenes.DEFAULT_EYE, scenes.DEFAULT_LOOKAT, (0, 1, 0), np.float32(np.pi) / np.float32(4), 256, 256)
-sc.ao_04(32, 32, ob.raygen_lookat(scenes.DEFAULT_EYE, scenes.DEFAULT_LOOKAT, (0, 1, 0), np.float32(np.pi) / np.float32(4), 32, 32))
-t0 = time.perf_counter(); px = sc.ao_04(256, 256, rg); dt = time.perf_counter() - t0
-hit = int((px[..., 0] != 32).sum()); rays = 256 * 256 + 64 * hit
-out["config1_04_ao_cpu"] = dict(ms=dt * 1e3, rays=rays, mray_s=rays / dt / 1e6, threads=ob.max_threads(), brute_force_tris=36)
-ob.set_math_mode(ob.MATH_PORTABLE)
+# config #1: 04_ao cornellbox1 256x256 as the product's host loop (restir_app --example 4, csrc/host_path.h; no GPU call)
+p = subprocess.run([os.path.join(ROOT, "app", "restir_app"), "--example", "4", "--obj", os.path.join(ROOT, "tests", "golden", "assets", "cornellbox1.obj")],
+                   capture_output=True, text=True)
+m = re.search(r"04_ao 256x256: ([0-9.]+) ms on (\d+) host thread\(s\), (\d+) of", p.stdout)
+ms1, threads, hit = float(m.group(1)), int(m.group(2)), int(m.group(3))
+rays = 256 * 256 + 64 * hit
+out["config1_04_ao_host_loop"] = dict(ms=ms1, rays=rays, mray_s=rays / ms1 / 1e3, threads=threads, brute_force_tris=36)
 
 def timed(fn, n):
     fn(); r.sync()
@@ -71,5 +69,15 @@ def f4k():
 for _ in range(3): f4k()
 ms = timed(f4k, 20); rays, shaded = r.ray_count()
 out["config4_at_4k_1gpu"] = dict(ms_per_frame=ms, rays=rays, mray_s=rays / ms / 1e3)
+r.close()
+# README key 3 (use_shadowed_target_function) on the benchmark frame: frames pipelined as bench.py runs them
+r = api.Renderer(1920, 1080); r.set_scene(tris); r.lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)
+r.set_options(bench_options(use_shadowed_target_function=1))
+fr = [0]
+def fsh():
+    fr[0] += 1; r.frame(fr[0])
+for _ in range(3): fsh()
+ms = timed(fsh, 20); rays, shaded = r.ray_count()
+out["config4_shadowed_target_1080p"] = dict(ms_per_frame=ms, reference_rays=rays, mray_s_reference_rays=rays / ms / 1e3)
 r.close()
 print(json.dumps(out, indent=1))
