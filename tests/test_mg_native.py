@@ -405,3 +405,24 @@ def test_multi_process_host_app_shm_equals_single_process(tmp_path):
     assert "3 ranks:" in out and out.count("cold frame") == 3, out
     a, b = open(one, "rb").read(), open(many, "rb").read()
     assert len(a) == len(b) and a == b
+
+
+def test_cached_strip_cuts_are_valid_partitions():
+    """profiles/strip_cuts.json (written by tools/strip_overhead.py, read by bench.py instead of start-up balance rounds): every
+    entry is a partition of the image rows into N strips of at least the 87-row halo, keyed by size, N and the scene's hash."""
+    import json
+    import re
+
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "strip_cuts.json")
+    if not os.path.exists(p):
+        pytest.skip("no cached cuts committed")
+    cuts = json.load(open(p))
+    assert cuts
+    for key, c in cuts.items():
+        m = re.fullmatch(r"(\d+)x(\d+):(\d+):([0-9a-f]{16})", key)
+        assert m, key
+        H, n = int(m.group(2)), int(m.group(3))
+        e = c["bounds"]
+        assert len(e) == n + 1 and e[0] == 0 and e[-1] == H, key
+        assert all(e[i + 1] - e[i] >= 87 for i in range(n)), key
+        assert c["max_ms"] <= c["equal_rows_max_ms"] * 1.05, key  # a cut that is worse than equal rows should not be cached
