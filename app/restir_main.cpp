@@ -7,7 +7,7 @@
  *              [--eye x y z] [--lookat x y z] [--temporal 0|1] [--spatial 0|1]
  *              [--shadowed 0|1] [--visreuse 0|1] [--accumulate 0|1] [--by-kernel]
  *              [--example 10|7|8|9|4] [--ppm out.ppm] [--png out.png] [--pfm out.pfm] [--rgba out.raw] [--dump-tris out.tris]
- *              [--ranks N [--mirror | --shm] [--equal-strips]] [--threads N]
+ *              [--ranks N [--mirror | --shm] [--bounds 0,a,b,...,H | --cost-strips]] [--threads N]
  *
  * --example 4: BASELINE config #1 — the `kernelMain` of examples/04_ao/04_ao.cu:31-88 as a host C++ loop over the
  * image rows (cedec_2024_rt_amd/csrc/host_path.h: brute-force closest hit, 64 ambient-occlusion rays per pixel,
@@ -17,8 +17,9 @@
  *
  * --ranks N: the multi-GPU frame loop: N processes, forked before anything touches a GPU,
  * rank r on device r, each rendering one row strip through the native strip driver (rt_mg_*: sparse
- * reservoir halos over RCCL send/recv with rank +-1). Strip heights are cost-weighted from the shaded
- * pixels per row unless --equal-strips. --pfm then receives every rank's rows (one file, written in
+ * reservoir halos over RCCL send/recv with rank +-1). Strip heights: equal rows by default; --bounds gives the
+ * edges explicitly (e.g. a cut measured by tools/strip_overhead.py, profiles/strip_cuts.json); --cost-strips weights
+ * rows by their shaded pixels (round 2's model; measured worse than equal rows at 3840x2160, docs/MEASUREMENT_LOG_r01_r03.md). --pfm then receives every rank's rows (one file, written in
  * place). --mirror: all ranks on device 0 with the MIRROR transport (1-GPU boxes; timing/launch smoke
  * run, the image is not a frame). --shm: all ranks on device 0 with the host-staged shared-memory transport
  * (exact image, slow).
@@ -214,8 +215,9 @@ static void shared_barrier(Shared* sh, int which, int ranks)
         usleep(200);
     }
 }
-static int rank_main(int rank, int ranks, bool mirror, bool shm, bool equal_strips, Shared* sh, const std::vector<rt_triangle>& triangles, int W,
-                     int H, int frames, const float* eye, const float* lookat, const rt_options& opt, const std::string& pfm)
+static int rank_main(int rank, int ranks, bool mirror, bool shm, bool equal_strips, const std::vector<int>& given_bounds, Shared* sh,
+                     const std::vector<rt_triangle>& triangles, int W, int H, int frames, const float* eye, const float* lookat, const rt_options& opt,
+                     const std::string& pfm)
 {
     const float up[3] = {0, 1, 0};
     const int halo = 87, device = (mirror || shm) ? 0 : rank;
@@ -229,6 +231,13 @@ static int rank_main(int rank, int ranks, bool mirror, bool shm, bool equal_stri
     while (!sh->uid_ready.load()) usleep(200);
     std::vector<int> bounds((size_t)ranks + 1);
     if (rt_mg_partition(H, ranks, halo, nullptr, bounds.data()) != RT_OK) { fprintf(stderr, "%d rows cannot be cut into %d strips of >= %d rows\n", H, ranks, halo); return 1; }
+    if (!given_bounds.empty())
+    {
+        bool ok = (int)given_bounds.size() == ranks + 1 && given_bounds.front() == 0 && given_bounds.back() == H;
+        for (int r = 0; ok && r < ranks; ++r) ok = given_bounds[(size_t)r + 1] - given_bounds[(size_t)r] >= halo;
+        if (!ok) { fprintf(stderr, "--bounds: %d + 1 edges from 0 to %d, strips of >= %d rows\n", ranks, H, halo); return 1; }
+        bounds = given_bounds;
+    }
     rt_ctx* ctx = nullptr;
     auto make_ctx = [&]() -> int {
         int rc = rt_create(device, W, H, bounds[(size_t)rank], bounds[(size_t)rank + 1], halo, &ctx);
@@ -240,7 +249,7 @@ static int rank_main(int rank, int ranks, bool mirror, bool shm, bool equal_stri
     };
     int rc = make_ctx();
     if (rc != RT_OK) die(ctx, "strip context", rc);
-    if (!equal_strips)
+    if (!equal_strips && given_bounds.empty())
     {
         /* cost-weighted heights: shaded pixels per row from one raycast of the equal partition */
         CK(rt_raycast(ctx));
@@ -322,7 +331,8 @@ int main(int argc, char** argv)
     float eye[3] = {-0.579885f, 22.194597f, -6.567105f}, lookat[3] = {5.224952f, 20.847435f, 1.431192f};
     const float up[3] = {0, 1, 0};
     std::string obj, tris_path, ppm, png, pfm, dump, rgba;
-    bool by_kernel = false, mirror = false, shm = false, equal_strips = false, size_set = false, cam_set = false;
+    bool by_kernel = false, mirror = false, shm = false, equal_strips = true, size_set = false, cam_set = false;
+    std::vector<int> given_bounds;
     int example = 10, ranks = 1, threads = 0;
     rt_options opt;
     memset(&opt, 0, sizeof(opt));
@@ -351,6 +361,13 @@ int main(int argc, char** argv)
         else if (a == "--mirror") mirror = true;
         else if (a == "--shm") shm = true;
         else if (a == "--equal-strips") equal_strips = true;
+        else if (a == "--cost-strips") equal_strips = false;
+        else if (a == "--bounds")
+        {
+            std::stringstream ss(argv[++i]);
+            std::string tok;
+            while (std::getline(ss, tok, ',')) given_bounds.push_back(atoi(tok.c_str()));
+        }
         else if (a == "--dump-tris") dump = argv[++i]; /* write the loaded triangle array and exit (no GPU needed) */
         else if (a == "--ppm") ppm = argv[++i];
         else if (a == "--png") png = argv[++i];
@@ -436,7 +453,7 @@ int main(int argc, char** argv)
             const pid_t pid = fork();
             if (pid == 0)
             {
-                const int code = rank_main(r, ranks, mirror, shm, equal_strips, sh, triangles, W, H, frames, eye, lookat, opt, pfm);
+                const int code = rank_main(r, ranks, mirror, shm, equal_strips, given_bounds, sh, triangles, W, H, frames, eye, lookat, opt, pfm);
                 fflush(stdout);
                 fflush(stderr);
                 _exit(code); /* no atexit handlers of the parent's image in a forked child */

@@ -401,10 +401,15 @@ def test_multi_process_host_app_shm_equals_single_process(tmp_path):
     common = ["--tris", tpath, "--size", "160", "330", "--frames", "5", "--eye", "0.5", "2.5", "6.0", "--lookat", "0.0", "1.5", "-1.0"]
     one, many = str(tmp_path / "one.pfm"), str(tmp_path / "many.pfm")
     subprocess.check_call([app] + common + ["--pfm", one], stdout=subprocess.DEVNULL, timeout=120)
-    out = subprocess.check_output([app] + common + ["--pfm", many, "--ranks", "3", "--shm"], timeout=300).decode()
-    assert "3 ranks:" in out and out.count("cold frame") == 3, out
-    a, b = open(one, "rb").read(), open(many, "rb").read()
-    assert len(a) == len(b) and a == b
+    a = open(one, "rb").read()
+    # cost-weighted heights (round 2's shaded-pixel model), explicit irregular bounds (a measured cut), equal rows (the default)
+    for extra in (["--cost-strips"], ["--bounds", "0,95,230,330"], []):
+        out = subprocess.check_output([app] + common + ["--pfm", many, "--ranks", "3", "--shm"] + extra, timeout=300).decode()
+        assert "3 ranks:" in out and out.count("cold frame") == 3, out
+        if extra[:1] == ["--bounds"]:
+            assert "rows [0,95)" in out and "rows [95,230)" in out and "rows [230,330)" in out, out
+        b = open(many, "rb").read()
+        assert len(a) == len(b) and a == b, extra
 
 
 def test_cached_strip_cuts_are_valid_partitions():
