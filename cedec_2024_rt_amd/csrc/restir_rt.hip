@@ -2391,6 +2391,7 @@ int rt_copy_parts(rt_ctx* c, int n, const void* const* src, void* const* dst, co
     }
     if (largest == 0) return RT_OK;
     const size_t want = (largest / 16 + 255) / 256;
+    /* up to 2048 workgroups per part: fewer, fatter ones (8 / 32) were slower on a busy GPU, profiles/r04_strip_interior_late.txt */
     const unsigned gx = (unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
     k_copy_parts<<<dim3(gx, (unsigned)n), 256, 0, c->stream>>>(P);
     RT_HIP(c, hipGetLastError());

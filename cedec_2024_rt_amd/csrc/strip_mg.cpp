@@ -159,6 +159,7 @@ struct rt_mg
      * lane or there are none, so the exchange goes there then (the MIRROR transport, which the compute-side bounds are
      * measured with, always copied on the main stream). RT_MG_COMM_STREAM=1 in the environment keeps the separate stream. */
     bool comm_on_main = false, pending_on_main = false;
+    bool interior_late = false; /* RT_MG_INTERIOR_LATE=1 */
     bool fuse_halos = true; /* sparse halos packed / unpacked by the spatial passes themselves (rt_halo_fuse_set, r03) */
     std::string err;
 
@@ -490,6 +491,10 @@ int rt_mg_create(rt_ctx* ctx, int rank, int world, const int* bounds, int transp
         m->comm_on_main = !(e && e[0] == '1');
     }
     m->fuse_halos = !(flags & RT_MG_SEPARATE_PACK);
+    {
+        const char* e = getenv("RT_MG_INTERIOR_LATE");
+        m->interior_late = e && e[0] == '1';
+    }
     memset(&m->stats, 0, sizeof(m->stats));
     int ra = 0, rb = 0;
     MG_RT(m, rt_geometry(ctx, &m->W, &m->H, &ra, &rb, &m->halo));
@@ -1162,8 +1167,17 @@ static int frame_step(rt_mg* m, int* more)
             const int s = m->stage; /* spatial pass s - 1 */
             const bool lanes = m->two_lanes && exchanges && m->n_itr > 0;
             MG_RT(m, rt_frame_stage_begin(m->ctx, m->frame, s, 0));
-            if (lanes) { rc = run_rows(m, s, 0, m->itr, m->n_itr, true); if (rc != RT_OK) return rc; }
+            /* interior rows on the second lane: beside the exchange in flight (default: on real links they hide the wire), or —
+             * RT_MG_INTERIOR_LATE=1 — only once the exchange has completed: its kernel then does not queue for wavefront slots
+             * behind them (A/B on the stand-in transports, profiles/r04_strip_interior_late.txt) */
+            if (lanes && !m->interior_late) { rc = run_rows(m, s, 0, m->itr, m->n_itr, true); if (rc != RT_OK) return rc; }
             if (exchanges) { rc = finish_halo(m); if (rc != RT_OK) return rc; }
+            if (lanes && m->interior_late)
+            {
+                MG_RT(m, rt_frame_stage_fork(m->ctx)); /* the lane starts behind the completed exchange */
+                rc = run_rows(m, s, 0, m->itr, m->n_itr, true);
+                if (rc != RT_OK) return rc;
+            }
             if (exchanges && m->use_sparse && m->fuse_halos)
             {
                 /* this pass gathers its halo records from the lists that just arrived and fills the lists of the next
