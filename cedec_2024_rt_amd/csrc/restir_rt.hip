@@ -1537,7 +1537,7 @@ static int launch_spatial(rt_ctx* c, int frame, int pass, int in_phys, int out_p
     if (c->opt.use_shadowed_target_function)
     {
         /* the cooperative record traffic of key 8 = 2 applies to the <= 5 neighbour form (spatial_wave_shadowed) */
-        if (c->tune_spatial_variant == 2 && c->opt.use_spatial_resampling && c->opt.spatial_resampling_sample_count <= 5)
+        if (c->tune_spatial_variant >= 2 && c->opt.use_spatial_resampling && c->opt.spatial_resampling_sample_count <= 5)
             k_spatial<true, true><<<trace_grid(c), TRACE_BLOCK, (size_t)(RT_SHADOWED_SPATIAL_LDS), c->stream>>>(S, P, c->fuse, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys]);
         else
             k_spatial<true, false><<<trace_grid(c), TRACE_BLOCK, (size_t)(RT_SHADOWED_SPATIAL_LDS), c->stream>>>(S, P, c->fuse, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys]);

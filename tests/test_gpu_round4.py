@@ -256,8 +256,12 @@ def test_walk_stats_account_for_every_reference_ray(api, oracle, scenes, shadowe
     """rt_walk_stats: per kernel, reference rays = walked + settled by the self-occlusion test + not evaluated; the reference
     counts are the oracle's (N primary rays, one visibility-reuse and one resolve ray per shaded pixel), and the build
     walks fewer rays than the reference traces."""
+    import os
+
     from cedec_2024_rt_amd.types import bench_options
 
+    if os.environ.get("RT_TUNING"):
+        pytest.skip("the counters cover the default kernels; RT_TUNING selects A/B forms")
     W, H, frames = 480, 270, 3
     tris = scenes.make_blocks_restir()
     r = api.Renderer(W, H)
