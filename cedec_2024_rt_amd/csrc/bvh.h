@@ -204,6 +204,11 @@ constexpr int WIDE_LDS_STACK = RT_WIDE_LDS_STACK;
 #endif
 constexpr int WIDE_OVF_STACK = RT_WIDE_TOTAL_STACK - RT_WIDE_LDS_STACK; /* total 64 >= 3 * wide height + 1 (checked at build) */
 constexpr uint32_t WIDE_LEAF_BIT = 0x80000000u;
+#ifndef RT_WIDE_STRIDE
+#define RT_WIDE_STRIDE 3 /* float4 per wide record in HBM: 3 = packed 48 B, 4 = 64-B slots (a record never straddles a line) */
+#endif
+constexpr int WIDE_STRIDE = RT_WIDE_STRIDE;
+static_assert(WIDE_STRIDE == 3 || WIDE_STRIDE == 4, "wide record stride");
 #ifndef WIDE_ANY_SORTED
 #define WIDE_ANY_SORTED 0 /* any-hit rays: visit children nearest-first (1) or in slot order (0) */
 #endif
@@ -288,7 +293,7 @@ RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3
             if (has_pend)
             {
                 if (STATS) stats[1]++;
-                const float4* g = bvh.rec + 3 * (size_t)(pend & ~WIDE_LEAF_BIT);
+                const float4* g = bvh.rec + WIDE_STRIDE * (size_t)(pend & ~WIDE_LEAF_BIT);
                 const float4 t0 = g[0], t1 = g[1], t2 = g[2];
                 pend = pend2; pend2 = NONE;
                 const f3 v0 = F3(t0.x, t0.y, t0.z), v1 = F3(t0.w, t1.x, t1.y), v2 = F3(t1.z, t1.w, t2.x);
@@ -309,7 +314,7 @@ RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3
         if (has_inner)
         {
             if (STATS) stats[0]++;
-            const float4* g = bvh.rec + 3 * (size_t)cur;
+            const float4* g = bvh.rec + WIDE_STRIDE * (size_t)cur;
             const float4 q0 = g[0], q1f = g[1], q2f = g[2];
             const uint32_t e = as_uint(q0.w);
             const uint32_t base = as_uint(q1f.x), meta = as_uint(q1f.y);
@@ -579,7 +584,7 @@ RT_DEV bool occluded_ws(const WideView& bvh, uint32_t* __restrict__ lds_generic,
             if (has_pend)
             {
                 if (stats) stats[3] += 1u; /* triangle tests by this lane */
-                const float4* g = bvh.rec + 3 * (size_t)(pend & ~WIDE_LEAF_BIT);
+                const float4* g = bvh.rec + WIDE_STRIDE * (size_t)(pend & ~WIDE_LEAF_BIT);
                 const float4 t0 = g[0], t1 = g[1], t2 = g[2];
                 pend = pend2; pend2 = NONE;
                 const f3 v0 = F3(t0.x, t0.y, t0.z), v1 = F3(t0.w, t1.x, t1.y), v2 = F3(t1.z, t1.w, t2.x);
@@ -595,7 +600,7 @@ RT_DEV bool occluded_ws(const WideView& bvh, uint32_t* __restrict__ lds_generic,
         if (has_inner)
         {
             if (stats) stats[1] += 0x10000u;
-            const float4* g = bvh.rec + 3 * (size_t)cur;
+            const float4* g = bvh.rec + WIDE_STRIDE * (size_t)cur;
             const float4 q0 = g[0], q1f = g[1], q2f = g[2];
             const uint32_t e = as_uint(q0.w);
             const uint32_t cbase = as_uint(q1f.x), meta = as_uint(q1f.y);
@@ -756,7 +761,7 @@ RT_DEV bool closest_ws(const WideView& bvh, const float4* __restrict__ tv, uint3
         {
             if (has_pend)
             {
-                const float4* g = bvh.rec + 3 * (size_t)(pend & ~WIDE_LEAF_BIT);
+                const float4* g = bvh.rec + WIDE_STRIDE * (size_t)(pend & ~WIDE_LEAF_BIT);
                 const float4 t0 = g[0], t1 = g[1], t2 = g[2];
                 pend = pend2; pend2 = NONE;
                 const f3 v0 = F3(t0.x, t0.y, t0.z), v1 = F3(t0.w, t1.x, t1.y), v2 = F3(t1.z, t1.w, t2.x);
@@ -774,7 +779,7 @@ RT_DEV bool closest_ws(const WideView& bvh, const float4* __restrict__ tv, uint3
         }
         if (has_inner)
         {
-            const float4* g = bvh.rec + 3 * (size_t)cur;
+            const float4* g = bvh.rec + WIDE_STRIDE * (size_t)cur;
             const float4 q0 = g[0], q1f = g[1], q2f = g[2];
             const uint32_t e = as_uint(q0.w);
             const uint32_t cbase = as_uint(q1f.x), meta = as_uint(q1f.y);
@@ -1004,7 +1009,7 @@ RT_DEV void occluded_stream(const WideView& bvh, uint32_t* __restrict__ lds_gene
         {
             if (has_pend)
             {
-                const float4* g = bvh.rec + 3 * (size_t)(pend & ~WIDE_LEAF_BIT);
+                const float4* g = bvh.rec + WIDE_STRIDE * (size_t)(pend & ~WIDE_LEAF_BIT);
                 const float4 t0 = g[0], t1 = g[1], t2 = g[2];
                 pend = pend2; pend2 = NONE;
                 const f3 v0 = F3(t0.x, t0.y, t0.z), v1 = F3(t0.w, t1.x, t1.y), v2 = F3(t1.z, t1.w, t2.x);
@@ -1019,7 +1024,7 @@ RT_DEV void occluded_stream(const WideView& bvh, uint32_t* __restrict__ lds_gene
         }
         if (has_inner)
         {
-            const float4* g = bvh.rec + 3 * (size_t)cur;
+            const float4* g = bvh.rec + WIDE_STRIDE * (size_t)cur;
             const float4 q0 = g[0], q1f = g[1], q2f = g[2];
             const uint32_t e = as_uint(q0.w);
             const uint32_t cbase = as_uint(q1f.x), meta = as_uint(q1f.y);
@@ -1228,7 +1233,7 @@ RT_DEV uint32_t occluded_batch_plain(const WideView& bvh, uint32_t* __restrict__
         {
             if (has_pend)
             {
-                const float4* g = bvh.rec + 3 * (size_t)(pend & ~WIDE_LEAF_BIT);
+                const float4* g = bvh.rec + WIDE_STRIDE * (size_t)(pend & ~WIDE_LEAF_BIT);
                 const float4 t0 = g[0], t1 = g[1], t2 = g[2];
                 pend = pend2; pend2 = NONE;
                 const f3 v0 = F3(t0.x, t0.y, t0.z), v1 = F3(t0.w, t1.x, t1.y), v2 = F3(t1.z, t1.w, t2.x);
@@ -1243,7 +1248,7 @@ RT_DEV uint32_t occluded_batch_plain(const WideView& bvh, uint32_t* __restrict__
         }
         if (has_inner)
         {
-            const float4* g = bvh.rec + 3 * (size_t)cur;
+            const float4* g = bvh.rec + WIDE_STRIDE * (size_t)cur;
             const float4 q0 = g[0], q1f = g[1], q2f = g[2];
             const uint32_t e = as_uint(q0.w);
             const uint32_t base = as_uint(q1f.x), meta = as_uint(q1f.y);
@@ -1420,7 +1425,7 @@ RT_DEV uint32_t occluded_batch_ws(const WideView& bvh, uint32_t* __restrict__ ld
         {
             if (has_pend)
             {
-                const float4* g = bvh.rec + 3 * (size_t)(pend & ~WIDE_LEAF_BIT);
+                const float4* g = bvh.rec + WIDE_STRIDE * (size_t)(pend & ~WIDE_LEAF_BIT);
                 const float4 t0 = g[0], t1 = g[1], t2 = g[2];
                 pend = pend2; pend2 = NONE;
                 const f3 v0 = F3(t0.x, t0.y, t0.z), v1 = F3(t0.w, t1.x, t1.y), v2 = F3(t1.z, t1.w, t2.x);
@@ -1435,7 +1440,7 @@ RT_DEV uint32_t occluded_batch_ws(const WideView& bvh, uint32_t* __restrict__ ld
         }
         if (has_inner)
         {
-            const float4* g = bvh.rec + 3 * (size_t)cur;
+            const float4* g = bvh.rec + WIDE_STRIDE * (size_t)cur;
             const float4 q0 = g[0], q1f = g[1], q2f = g[2];
             const uint32_t e = as_uint(q0.w);
             const uint32_t cbase = as_uint(q1f.x), meta = as_uint(q1f.y);

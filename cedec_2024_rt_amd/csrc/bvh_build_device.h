@@ -835,7 +835,7 @@ __global__ void k_collapse_init(CollapseState* st, CollapseItem* q0)
  * (ascending box area) and conservative quantisation as bvh_build_host.h::collapse_wide. */
 __global__ void k_collapse_level(const BvhNode* __restrict__ bin, const float* __restrict__ tris /* 15 floats */, int level,
                                  CollapseState* __restrict__ st, const CollapseItem* __restrict__ in, CollapseItem* __restrict__ out,
-                                 uint32_t* __restrict__ recs /* 12 words per record */)
+                                 uint32_t* __restrict__ recs /* 12 words per record, 4 * WIDE_STRIDE apart */)
 {
     const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned int n_in = st->count[level & 1];
@@ -919,13 +919,13 @@ __global__ void k_collapse_level(const BvhNode* __restrict__ bin, const float* _
             meta |= 2u << (8 * k);
             const int ti = ~ch[k].bin;
             const float* tv = tris + 15 * (size_t)ti;
-            uint32_t* Lr = recs + 12 * (size_t)(base + (unsigned int)k);
+            uint32_t* Lr = recs + 4 * WIDE_STRIDE * (size_t)(base + (unsigned int)k);
             for (int i = 0; i < 9; ++i) Lr[i] = __float_as_uint(tv[i]);
             Lr[9] = (uint32_t)ti;
             Lr[10] = Lr[11] = 0u;
         }
     }
-    uint32_t* R = recs + 12 * (size_t)wk.out;
+    uint32_t* R = recs + 4 * WIDE_STRIDE * (size_t)wk.out;
     R[0] = __float_as_uint(lo[0]); R[1] = __float_as_uint(lo[1]); R[2] = __float_as_uint(lo[2]);
     R[3] = ebits[0] | (ebits[1] << 8) | (ebits[2] << 16);
     R[4] = base; R[5] = meta; R[6] = q[0]; R[7] = q[1];

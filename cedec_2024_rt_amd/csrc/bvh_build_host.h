@@ -115,9 +115,9 @@ static void split_refs(const rt_triangle* tris, int n, float L, float pad, std::
 /* ---- collapse the binary tree (LBVH or SAH) into the 4-wide quantised structure of bvh.h (host) ---- */
 struct WideRec
 {
-    uint32_t w[12];
-}; /* 48 B */
-static_assert(sizeof(WideRec) == 48, "wide record");
+    uint32_t w[4 * WIDE_STRIDE]; /* 12 words used */
+}; /* 48 B (64 with RT_WIDE_STRIDE = 4) */
+static_assert(sizeof(WideRec) == 16 * WIDE_STRIDE, "wide record");
 
 static inline float box_area6(const float* lo, const float* hi)
 {

@@ -345,8 +345,12 @@ RT_DEV void wave_scatter_records(float4* __restrict__ rec, const int idx, float4
                                  const float4& q2, const float4& q3);
 RT_DEV void wave_gather_records_at(const float4* __restrict__ rec, const uint32_t idx, float4* s_wave, const int lane, float4& q0, float4& q1,
                                    float4& q2, float4& q3);
+RT_DEV void wave_gather_request_at(const float4* __restrict__ rec, const uint32_t idx, float4* s_wave, const int lane);
+RT_DEV void wave_gather_finish(float4* s_wave, const int lane, float4& q0, float4& q1, float4& q2, float4& q3);
 RT_DEV void wave_gather_records(const float4* q, float4* s_wave, const int lane, float4& q0, float4& q1, float4& q2, float4& q3);
-RT_DEV Res res_from_parts(const float4& q0, const float4& q1, const float4& q2, const float4& q3, bool& shaded);
+#ifndef RT_RIS_PIPE
+#define RT_RIS_PIPE 1 /* 0: request the light record of candidate i after its draws and wait for it (A/B) */
+#endif
 #ifndef RT_RIS_COOP
 #define RT_RIS_COOP 1 /* 0: per-lane light record gathers in the work-sharing generate kernel too (A/B) */
 #endif
@@ -395,6 +399,50 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_W
         static_assert(sizeof(s_stack) >= 4096, "the record image needs 64 x 64 B");
         float4* s_img = reinterpret_cast<float4*>(s_stack);
         const int lane = (int)(threadIdx.x & 63);
+#if RT_RIS_PIPE
+        /* the four draws of a candidate do not depend on the reservoir: candidate i + 1 is drawn and its light record
+         * requested before candidate i's arithmetic, which then runs with the fetch in flight (the record of candidate i
+         * is in registers by then: one 4-KB image per wavefront is enough). Same draws in the same order. */
+        float bx_n = 0.0f, by_n = 0.0f, u_n = 0.0f;
+        uint32_t nth_n = 0u;
+        auto draw_and_request = [&]() {
+            if (act)
+            {
+                const float rv0 = rng.uniformf();
+                bx_n = rng.uniformf();
+                by_n = rng.uniformf();
+                u_n = rng.uniformf();
+                nth_n = (uint32_t)(rv0 * fL);
+                if (nth_n == (uint32_t)P.n_lights) nth_n = (uint32_t)P.n_lights - 1u;
+            }
+            wave_gather_request_at(S.lights, nth_n, s_img, lane);
+        };
+        if (P.ris_sample_count > 0) draw_and_request();
+        for (int i = 0; i < P.ris_sample_count; ++i)
+        {
+            float4 L0, L1, L2, L3n;
+            wave_gather_finish(s_img, lane, L0, L1, L2, L3n);
+            float bx = bx_n, by = by_n;
+            const float u = u_n;
+            const uint32_t nth = nth_n;
+            if (i + 1 < P.ris_sample_count) draw_and_request();
+            if (act)
+            {
+                const f3 v0 = F3(L0.x, L0.y, L0.z), v1 = F3(L0.w, L1.x, L1.y), v2 = F3(L1.z, L1.w, L2.x);
+                warp_unit_triangle(bx, by);
+                const f3 lp = (1.0f - bx - by) * v0 + bx * v1 + by * v2;
+                const f3 ln = F3(L3n.x, L3n.y, L3n.z);
+                const float p_hat = target_unshadowed(sp, sn, lp, ln, L2.y); /* unshadowed always (:104) */
+                const float weight = div_pdf(p_hat, L2.z, L3n.w);           /* 1/L * 1/area (:98-99) */
+                r.w_sum += weight;
+                r.M += 1;
+                if (u < weight / r.w_sum)
+                {
+                    sel = (int)nth; sel_bx = bx; sel_by = by;
+                }
+            }
+        }
+#else
         for (int i = 0; i < P.ris_sample_count; ++i)
         {
             float bx = 0.0f, by = 0.0f;
@@ -426,6 +474,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_W
                 }
             }
         }
+#endif
     }
     if (act)
     {
@@ -582,7 +631,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_W
         wave_scatter_records(out_rec, in_image ? (int)li : -1, reinterpret_cast<float4*>(s_stack), (int)(threadIdx.x & 63),
                              make_float4(r.hit_p.x, r.hit_p.y, r.hit_p.z, r.ucw), make_float4(r.hit_n.x, r.hit_n.y, r.hit_n.z, as_float(mbits)),
                              make_float4(r.org_p.x, r.org_p.y, r.org_p.z, r.lum), make_float4(r.org_n.x, r.org_n.y, r.org_n.z, r.w_sum));
-        if (in_image) out_rad[li] = make_float4(r.rad.x, r.rad.y, r.rad.z, as_float(r.ownv));
+        if (in_image) store_stream<2>(out_rad + li, make_float4(r.rad.x, r.rad.y, r.rad.z, as_float(r.ownv)));
     }
     if (DEFER)
     {
@@ -964,7 +1013,7 @@ RT_DEV void spatial_wave_shadowed(const SceneView& S, const FrameParams& P, cons
                          make_float4(r.hit_n.x, r.hit_n.y, r.hit_n.z, as_float(mbits)), make_float4(r.org_p.x, r.org_p.y, r.org_p.z, r.lum),
                          make_float4(r.org_n.x, r.org_n.y, r.org_n.z, r.w_sum));
     if (!in_image) return;
-    out_rad[li] = make_float4(r.rad.x, r.rad.y, r.rad.z, as_float(r.ownv));
+    store_stream<2>(out_rad + li, make_float4(r.rad.x, r.rad.y, r.rad.z, as_float(r.ownv)));
     res_give(F, P.W, li, x, row, r, active);
 }
 template <bool SHADOWED, bool COOP = false>
@@ -1196,8 +1245,9 @@ RT_DEV void wave_gather_records(const float4* q, float4* s_wave, const int lane,
     for (int j = 0; j < 4; ++j) wave_gather_issue(p[j] + part, s_wave + 64 * j, lane);
     wave_gather_finish(s_wave, lane, q0, q1, q2, q3);
 }
-RT_DEV void wave_gather_records_at(const float4* __restrict__ rec, const uint32_t idx, float4* s_wave, const int lane, float4& q0, float4& q1,
-                                   float4& q2, float4& q3)
+/* the request half of wave_gather_records_at: the wavefront's 64 records are on their way into the image when this returns
+ * (wave_gather_finish collects them); the image must not be in use */
+RT_DEV void wave_gather_request_at(const float4* __restrict__ rec, const uint32_t idx, float4* s_wave, const int lane)
 {
     uint32_t from[4];
 #pragma unroll
@@ -1208,6 +1258,11 @@ RT_DEV void wave_gather_records_at(const float4* __restrict__ rec, const uint32_
     const char* base = reinterpret_cast<const char*>(rec);
 #pragma unroll
     for (int j = 0; j < 4; ++j) wave_gather_issue(reinterpret_cast<const float4*>(base + (from[j] * 64u + part16)), s_wave + 64 * j, lane);
+}
+RT_DEV void wave_gather_records_at(const float4* __restrict__ rec, const uint32_t idx, float4* s_wave, const int lane, float4& q0, float4& q1,
+                                   float4& q2, float4& q3)
+{
+    wave_gather_request_at(rec, idx, s_wave, lane);
     wave_gather_finish(s_wave, lane, q0, q1, q2, q3);
 }
 /* the reverse for the 64 records a wavefront writes: every lane puts its record into the image, then in round j lane l
@@ -1229,26 +1284,8 @@ RT_DEV void wave_scatter_records(float4* __restrict__ rec, const int idx, float4
     char* base = reinterpret_cast<char*>(rec);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        if (to[j] >= 0) *reinterpret_cast<float4*>(base + ((uint32_t)to[j] * 64u + part16)) = s_wave[64 * j + lane];
+        if (to[j] >= 0) store_stream<1>(reinterpret_cast<float4*>(base + ((uint32_t)to[j] * 64u + part16)), s_wave[64 * j + lane]);
     RT_WAVE_LDS_FENCE();
-}
-RT_DEV Res res_from_parts(const float4& q0, const float4& q1, const float4& q2, const float4& q3, bool& shaded)
-{
-    Res r;
-    r.hit_p = F3(q0.x, q0.y, q0.z);
-    r.ucw = q0.w;
-    r.hit_n = F3(q1.x, q1.y, q1.z);
-    const uint32_t mb = as_uint(q1.w);
-    r.M = (int)(mb & RES_M_MASK);
-    r.vis = (mb & RES_VIS_BIT) != 0u;
-    shaded = (mb & RES_SHADED_BIT) != 0u;
-    r.org_p = F3(q2.x, q2.y, q2.z);
-    r.lum = q2.w;
-    r.org_n = F3(q3.x, q3.y, q3.z);
-    r.w_sum = q3.w;
-    r.rad = F3(0.0f, 0.0f, 0.0f);
-    r.ownv = 0u;
-    return r;
 }
 /* FUSED: halo records live in the exchange lists (HaloFuse, multi-GPU strips); otherwise every record is in in_rec */
 template <int WAVES, bool FUSED>
@@ -1353,7 +1390,7 @@ __global__ __launch_bounds__(BLOCK) void k_spatial_coop(
                          make_float4(r.hit_n.x, r.hit_n.y, r.hit_n.z, as_float(mbits)), make_float4(r.org_p.x, r.org_p.y, r.org_p.z, r.lum),
                          make_float4(r.org_n.x, r.org_n.y, r.org_n.z, r.w_sum));
     if (!in_image) return;
-    out_rad[li] = make_float4(r.rad.x, r.rad.y, r.rad.z, as_float(r.ownv));
+    store_stream<2>(out_rad + li, make_float4(r.rad.x, r.rad.y, r.rad.z, as_float(r.ownv)));
     if (FUSED) res_give(F, P.W, li, x, row, r, active);
 }
 
@@ -1535,7 +1572,7 @@ __global__ __launch_bounds__(BLOCK) void k_spatial_pipe(
                          make_float4(r.hit_n.x, r.hit_n.y, r.hit_n.z, as_float(mbits)), make_float4(r.org_p.x, r.org_p.y, r.org_p.z, r.lum),
                          make_float4(r.org_n.x, r.org_n.y, r.org_n.z, r.w_sum));
     if (!in_image) return;
-    out_rad[li] = make_float4(r.rad.x, r.rad.y, r.rad.z, as_float(r.ownv));
+    store_stream<2>(out_rad + li, make_float4(r.rad.x, r.rad.y, r.rad.z, as_float(r.ownv)));
 }
 
 /* SURVEY.md §8(d) ALGORITHMIC bytes of one spatial_resampling launch, counted with the
@@ -2632,7 +2669,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_queue(WideView wide, const floa
         /* no `continue` for idle lanes: they must fall through to the loop header together with
          * the working lanes (a spinning divergent path would starve the others) */
         bool done = false;
-        const float4* r = wide.rec + 3 * (size_t)(cur & ~WIDE_LEAF_BIT);
+        const float4* r = wide.rec + WIDE_STRIDE * (size_t)(cur & ~WIDE_LEAF_BIT);
         if (cur == IDLE) {}
         else if (cur & WIDE_LEAF_BIT)
         {

@@ -726,7 +726,7 @@ static int build_bvh_device(rt_ctx* c, int n_tris)
     BD_HIP(hipGetLastError());
     /* 5. wide collapse, level by level */
     const size_t rec_cap = (size_t)n * 2 + 8;
-    BD_HIP(hipMalloc(&c->d_wide, rec_cap * 48));
+    BD_HIP(hipMalloc(&c->d_wide, rec_cap * 16 * WIDE_STRIDE));
     CollapseItem* d_q[2] = {(CollapseItem*)dalloc((size_t)n * sizeof(CollapseItem)), (CollapseItem*)dalloc((size_t)n * sizeof(CollapseItem))};
     BD_PTR(d_q[0]); BD_PTR(d_q[1]);
     CollapseState* d_cs = (CollapseState*)dalloc(sizeof(CollapseState)); BD_PTR(d_cs);

@@ -63,6 +63,9 @@ RT_HD float fmax_dev(float a, float b) { return (a != a) ? b : ((b != b) ? a : (
 
 /* ------------------------------------------------------------------ RNG */
 /* common/rng.hpp:8-58 [parity, integer] */
+#ifndef RT_PCG_SERIAL
+#define RT_PCG_SERIAL 1
+#endif
 struct PCG
 {
     uint64_t state, inc;
@@ -70,6 +73,11 @@ struct PCG
     {
         const uint64_t old = state;
         state = old * 6364136223846793005ULL + inc;
+#if RT_PCG_SERIAL && defined(__HIP_DEVICE_COMPILE__)
+        /* hipcc otherwise folds two steps into A^2 s + (A + 1) c beside the single step the output needs: a shorter dependency
+         * chain for 10 multiply-class instructions per two draws instead of 8; the kernels are bound by issue, not by the chain */
+        asm("" : "+v"(state));
+#endif
         const uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
         const uint32_t rot = (uint32_t)(old >> 59u);
         return (xorshifted >> rot) | (xorshifted << ((0u - rot) & 31u));
@@ -333,22 +341,29 @@ RT_HD Res res_zero()
     return r;
 }
 
+/* stores of records no launch reads again before the next one (RT_NT_STORE bit 0: the records' cooperative scatter, bit 1: the
+ * radiance side records and res_store): non-temporal = streaming hint for the L2 */
+#ifndef RT_NT_STORE
+#define RT_NT_STORE 3
+#endif
+typedef float rt_v4f __attribute__((ext_vector_type(4)));
+template <int BIT>
+RT_DEV void store_stream(float4* p, const float4& v)
+{
+    if (RT_NT_STORE & BIT) __builtin_nontemporal_store(rt_v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<rt_v4f*>(p));
+    else *p = v;
+}
 RT_DEV void res_store(float4* __restrict__ rec, float4* __restrict__ radb, size_t i, const Res& r, bool shaded)
 {
     const uint32_t mbits = ((uint32_t)r.M & RES_M_MASK) | (r.vis ? RES_VIS_BIT : 0u) | (shaded ? RES_SHADED_BIT : 0u);
-    rec[4 * i + 0] = make_float4(r.hit_p.x, r.hit_p.y, r.hit_p.z, r.ucw);
-    rec[4 * i + 1] = make_float4(r.hit_n.x, r.hit_n.y, r.hit_n.z, as_float(mbits));
-    rec[4 * i + 2] = make_float4(r.org_p.x, r.org_p.y, r.org_p.z, r.lum);
-    rec[4 * i + 3] = make_float4(r.org_n.x, r.org_n.y, r.org_n.z, r.w_sum);
-    radb[i] = make_float4(r.rad.x, r.rad.y, r.rad.z, as_float(r.ownv));
+    store_stream<2>(rec + 4 * i + 0, make_float4(r.hit_p.x, r.hit_p.y, r.hit_p.z, r.ucw));
+    store_stream<2>(rec + 4 * i + 1, make_float4(r.hit_n.x, r.hit_n.y, r.hit_n.z, as_float(mbits)));
+    store_stream<2>(rec + 4 * i + 2, make_float4(r.org_p.x, r.org_p.y, r.org_p.z, r.lum));
+    store_stream<2>(rec + 4 * i + 3, make_float4(r.org_n.x, r.org_n.y, r.org_n.z, r.w_sum));
+    store_stream<2>(radb + i, make_float4(r.rad.x, r.rad.y, r.rad.z, as_float(r.ownv)));
 }
-/* loads everything except radiance; q = the record's four float4 (in a reservoir buffer or in a halo list) */
-RT_DEV Res res_load_at(const float4* __restrict__ q, bool& shaded)
+RT_DEV Res res_from_parts(const float4& q0, const float4& q1, const float4& q2, const float4& q3, bool& shaded)
 {
-    const float4 q0 = q[0];
-    const float4 q1 = q[1];
-    const float4 q2 = q[2];
-    const float4 q3 = q[3];
     Res r;
     r.hit_p = F3(q0.x, q0.y, q0.z);
     r.ucw = q0.w;
@@ -364,6 +379,15 @@ RT_DEV Res res_load_at(const float4* __restrict__ q, bool& shaded)
     r.rad = F3(0.0f, 0.0f, 0.0f);
     r.ownv = 0u;
     return r;
+}
+/* loads everything except radiance; q = the record's four float4 (in a reservoir buffer or in a halo list) */
+RT_DEV Res res_load_at(const float4* __restrict__ q, bool& shaded)
+{
+    const float4 q0 = q[0];
+    const float4 q1 = q[1];
+    const float4 q2 = q[2];
+    const float4 q3 = q[3];
+    return res_from_parts(q0, q1, q2, q3, shaded);
 }
 RT_DEV Res res_load(const float4* __restrict__ rec, size_t i, bool& shaded) { return res_load_at(rec + 4 * i, shaded); }
 
