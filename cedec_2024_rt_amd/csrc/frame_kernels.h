@@ -341,6 +341,7 @@ RT_DEV bool temporal_merge(const FrameParams& P, int x, int yi, f3 sp, f3 sn, Re
 #ifndef RT_GENERATE_WS_WAVES
 #define RT_GENERATE_WS_WAVES 5
 #endif
+template <bool STREAM = true>
 RT_DEV void wave_scatter_records(float4* __restrict__ rec, const int idx, float4* s_wave, const int lane, const float4& q0, const float4& q1,
                                  const float4& q2, const float4& q3);
 RT_DEV void wave_gather_records_at(const float4* __restrict__ rec, const uint32_t idx, float4* s_wave, const int lane, float4& q0, float4& q1,
@@ -350,6 +351,9 @@ RT_DEV void wave_gather_finish(float4* s_wave, const int lane, float4& q0, float
 RT_DEV void wave_gather_records(const float4* q, float4* s_wave, const int lane, float4& q0, float4& q1, float4& q2, float4& q3);
 #ifndef RT_RIS_PIPE
 #define RT_RIS_PIPE 1 /* 0: request the light record of candidate i after its draws and wait for it (A/B) */
+#endif
+#ifndef RT_SHADOWED_RIS_COOP
+#define RT_SHADOWED_RIS_COOP 1 /* 0: the shadowed-target generate kernel gathers its light records per lane (A/B) */
 #endif
 #ifndef RT_RIS_COOP
 #define RT_RIS_COOP 1 /* 0: per-lane light record gathers in the work-sharing generate kernel too (A/B) */
@@ -362,10 +366,12 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_W
 {
     static_assert(!DEFER || (FUSE_TEMPORAL && !SHADOWED), "deferred visibility: fused unshadowed kernel only");
     constexpr bool LATE = WS && FUSE_TEMPORAL && !SHADOWED && !DEFER; /* the visibility-reuse ray after the temporal merge */
+    /* shadowed target: every lane stays through the RIS loop, so that the wavefront can fetch its light records together */
+    constexpr bool STAY = SHADOWED && !DEFER && !PIPE && RT_SHADOWED_RIS_COOP && RT_RIS_COOP && RT_LIGHT_STRIDE == 4;
     __shared__ __attribute__((aligned(16))) uint32_t s_stack[DEFER ? 4 : ((WS || (SHADOWED && RT_BATCH_WS)) ? WIDE_LDS_ROWS : WIDE_LDS_STACK) * TRACE_BLOCK];
     int x = 0, row = P.row0;
     const bool in_image = tile_pixel<TRACE_BLOCK>(P, x, row);
-    if (!DEFER && !LATE && !in_image) return;
+    if (!DEFER && !LATE && !STAY && !in_image) return;
     const int yi = P.H - 1 - row;
     const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
     bool need_ray = false; /* DEFER: this lane's candidate survived and needs its visibility walked */
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_W
     if (in_image && !(flags & GB_SHADED))
     {
         if (!LATE) res_store(out_rec, out_rad, li, r, false); /* Reservoir{} (:56-70); LATE: with the wavefront's other records below */
-        if (!DEFER && !LATE) return;
+        if (!DEFER && !LATE && !STAY) return;
     }
     /* DEFER keeps every lane to the end (the queue append is a wave-level operation); so does LATE (every lane of the
      * wavefront joins the walk, with or without a ray of its own) */
@@ -393,7 +399,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_W
      * a per-lane gather of a random 64-B record is 4 wave-instructions x 64 cache lines, and the 32 candidates of a pixel
      * are 80 % of this kernel's 10 200 vector-L1 accesses per wavefront, at one access per cycle and CU). Same draws in the
      * same order, same arithmetic; lanes without a shaded pixel name light 0 and ignore it. */
-    constexpr bool RIS_COOP = LATE && !PIPE && RT_RIS_COOP && RT_LIGHT_STRIDE == 4;
+    constexpr bool RIS_COOP = (LATE && !PIPE && RT_RIS_COOP && RT_LIGHT_STRIDE == 4) || STAY;
     if constexpr (RIS_COOP)
     {
         static_assert(sizeof(s_stack) >= 4096, "the record image needs 64 x 64 B");
@@ -408,10 +414,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_W
         auto draw_and_request = [&]() {
             if (act)
             {
-                const float rv0 = rng.uniformf();
-                bx_n = rng.uniformf();
-                by_n = rng.uniformf();
-                u_n = rng.uniformf();
+                const float rv0 = rng.uniformf_chained();
+                bx_n = rng.uniformf_chained();
+                by_n = rng.uniformf_chained();
+                u_n = rng.uniformf_chained();
                 nth_n = (uint32_t)(rv0 * fL);
                 if (nth_n == (uint32_t)P.n_lights) nth_n = (uint32_t)P.n_lights - 1u;
             }
@@ -1009,11 +1015,11 @@ RT_DEV void spatial_wave_shadowed(const SceneView& S, const FrameParams& P, cons
     else
         r = res_zero(); /* the reference stores nothing here (:275-287); we keep the shaded bit valid */
     const uint32_t mbits = ((uint32_t)r.M & RES_M_MASK) | (r.vis ? RES_VIS_BIT : 0u) | (active ? RES_SHADED_BIT : 0u);
-    wave_scatter_records(out_rec, in_image ? (int)li : -1, s_img, lane, make_float4(r.hit_p.x, r.hit_p.y, r.hit_p.z, r.ucw),
+    wave_scatter_records<false>(out_rec, in_image ? (int)li : -1, s_img, lane, make_float4(r.hit_p.x, r.hit_p.y, r.hit_p.z, r.ucw),
                          make_float4(r.hit_n.x, r.hit_n.y, r.hit_n.z, as_float(mbits)), make_float4(r.org_p.x, r.org_p.y, r.org_p.z, r.lum),
                          make_float4(r.org_n.x, r.org_n.y, r.org_n.z, r.w_sum));
     if (!in_image) return;
-    store_stream<2>(out_rad + li, make_float4(r.rad.x, r.rad.y, r.rad.z, as_float(r.ownv)));
+    store_stream<0>(out_rad + li, make_float4(r.rad.x, r.rad.y, r.rad.z, as_float(r.ownv)));
     res_give(F, P.W, li, x, row, r, active);
 }
 template <bool SHADOWED, bool COOP = false>
@@ -1268,6 +1274,7 @@ RT_DEV void wave_gather_records_at(const float4* __restrict__ rec, const uint32_
 /* the reverse for the 64 records a wavefront writes: every lane puts its record into the image, then in round j lane l
  * stores one 16-B part of the record of lane 16 j + l / 4: a quad writes one whole 64-B segment (64 write requests per
  * wavefront reach L2 instead of 256 partial ones). idx = the record's index in rec, < 0: this lane stores nothing. */
+template <bool STREAM>
 RT_DEV void wave_scatter_records(float4* __restrict__ rec, const int idx, float4* s_wave, const int lane, const float4& q0, const float4& q1,
                                  const float4& q2, const float4& q3)
 {
@@ -1284,7 +1291,7 @@ RT_DEV void wave_scatter_records(float4* __restrict__ rec, const int idx, float4
     char* base = reinterpret_cast<char*>(rec);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        if (to[j] >= 0) store_stream<1>(reinterpret_cast<float4*>(base + ((uint32_t)to[j] * 64u + part16)), s_wave[64 * j + lane]);
+        if (to[j] >= 0) store_stream<STREAM ? 1 : 0>(reinterpret_cast<float4*>(base + ((uint32_t)to[j] * 64u + part16)), s_wave[64 * j + lane]);
     RT_WAVE_LDS_FENCE();
 }
 /* FUSED: halo records live in the exchange lists (HaloFuse, multi-GPU strips); otherwise every record is in in_rec */

@@ -64,29 +64,33 @@ RT_HD float fmax_dev(float a, float b) { return (a != a) ? b : ((b != b) ? a : (
 /* ------------------------------------------------------------------ RNG */
 /* common/rng.hpp:8-58 [parity, integer] */
 #ifndef RT_PCG_SERIAL
-#define RT_PCG_SERIAL 1
+#define RT_PCG_SERIAL 2 /* 2: every draw takes one LCG step, 1: only the marked loops (uniformf_chained), 0: none */
 #endif
 struct PCG
 {
     uint64_t state, inc;
+    /* CHAINED (device): hipcc otherwise folds two steps into A^2 s + (A + 1) c beside the single step the output needs - a
+     * shorter dependency chain for 10 multiply-class instructions per two draws instead of 8; the kernels are bound by vector
+     * issue, not by that chain (RIS loop of generate_candidate -1.2 %, shadowed frame -0.7 %). */
+    template <bool CHAINED = false>
     RT_HD uint32_t uniform()
     {
         const uint64_t old = state;
         state = old * 6364136223846793005ULL + inc;
-#if RT_PCG_SERIAL && defined(__HIP_DEVICE_COMPILE__)
-        /* hipcc otherwise folds two steps into A^2 s + (A + 1) c beside the single step the output needs: a shorter dependency
-         * chain for 10 multiply-class instructions per two draws instead of 8; the kernels are bound by issue, not by the chain */
-        asm("" : "+v"(state));
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (RT_PCG_SERIAL == 2 || (RT_PCG_SERIAL == 1 && CHAINED)) asm("" : "+v"(state));
 #endif
         const uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
         const uint32_t rot = (uint32_t)(old >> 59u);
         return (xorshifted >> rot) | (xorshifted << ((0u - rot) & 31u));
     }
+    template <bool CHAINED = false>
     RT_HD float uniformf()
     {
-        const uint32_t bits = (uniform() >> 9) | 0x3f800000u;
+        const uint32_t bits = (uniform<CHAINED>() >> 9) | 0x3f800000u;
         return pm_u2f(bits) - 1.0f;
     }
+    RT_HD float uniformf_chained() { return uniformf<true>(); }
 };
 RT_HD PCG pcg_init(uint64_t seed, uint64_t sequence)
 {
@@ -341,8 +345,10 @@ RT_HD Res res_zero()
     return r;
 }
 
-/* stores of records no launch reads again before the next one (RT_NT_STORE bit 0: the records' cooperative scatter, bit 1: the
- * radiance side records and res_store): non-temporal = streaming hint for the L2 */
+/* Stores of the unshadowed frame's reservoir records (RT_NT_STORE bit 0: the wavefront's cooperative scatter, bit 1: the radiance
+ * side records beside it) are non-temporal: 166 MB per launch that the launch does not read again would otherwise push the
+ * records the gathers want out of the L2 (spatial pass -5 %, frame -1.5 %; loads with the hint: slower everywhere). Not in the
+ * shadowed-target kernels (a 1.5-ms pass finds the previous pass's records in the 256-MB MALL: +1.2 % with the hint). */
 #ifndef RT_NT_STORE
 #define RT_NT_STORE 3
 #endif
@@ -356,11 +362,11 @@ RT_DEV void store_stream(float4* p, const float4& v)
 RT_DEV void res_store(float4* __restrict__ rec, float4* __restrict__ radb, size_t i, const Res& r, bool shaded)
 {
     const uint32_t mbits = ((uint32_t)r.M & RES_M_MASK) | (r.vis ? RES_VIS_BIT : 0u) | (shaded ? RES_SHADED_BIT : 0u);
-    store_stream<2>(rec + 4 * i + 0, make_float4(r.hit_p.x, r.hit_p.y, r.hit_p.z, r.ucw));
-    store_stream<2>(rec + 4 * i + 1, make_float4(r.hit_n.x, r.hit_n.y, r.hit_n.z, as_float(mbits)));
-    store_stream<2>(rec + 4 * i + 2, make_float4(r.org_p.x, r.org_p.y, r.org_p.z, r.lum));
-    store_stream<2>(rec + 4 * i + 3, make_float4(r.org_n.x, r.org_n.y, r.org_n.z, r.w_sum));
-    store_stream<2>(radb + i, make_float4(r.rad.x, r.rad.y, r.rad.z, as_float(r.ownv)));
+    rec[4 * i + 0] = make_float4(r.hit_p.x, r.hit_p.y, r.hit_p.z, r.ucw);
+    rec[4 * i + 1] = make_float4(r.hit_n.x, r.hit_n.y, r.hit_n.z, as_float(mbits));
+    rec[4 * i + 2] = make_float4(r.org_p.x, r.org_p.y, r.org_p.z, r.lum);
+    rec[4 * i + 3] = make_float4(r.org_n.x, r.org_n.y, r.org_n.z, r.w_sum);
+    radb[i] = make_float4(r.rad.x, r.rad.y, r.rad.z, as_float(r.ownv));
 }
 RT_DEV Res res_from_parts(const float4& q0, const float4& q1, const float4& q2, const float4& q3, bool& shaded)
 {
