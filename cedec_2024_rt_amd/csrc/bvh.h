@@ -195,9 +195,14 @@ struct WideView
     int n_tris;
     int n_rec;
 };
+/* 14 entries (r04; 24 before): with the registers the kernels need without the SLP vectoriser (61 - 80), LDS is what limits
+ * the wavefronts per CU, and the work-sharing kernels' 14 + 2 rows are exactly the 4-KB record image of the cooperative
+ * fetches. 24 -> 22..14: generate -4 %, resolve -6 % (one more wavefront per SIMD); 14 vs 16..20: raycast -2 %. Deeper
+ * walks continue in scratch (results identical: test_deep_stack). */
 #ifndef RT_WIDE_LDS_STACK
-#define RT_WIDE_LDS_STACK 24
+#define RT_WIDE_LDS_STACK 14
 #endif
+static_assert(RT_WIDE_LDS_STACK >= 14, "the work-sharing kernels stage 64 x 64-B records in their stack rows");
 constexpr int WIDE_LDS_STACK = RT_WIDE_LDS_STACK;
 #ifndef RT_WIDE_TOTAL_STACK
 #define RT_WIDE_TOTAL_STACK 64

@@ -341,6 +341,9 @@ RT_DEV bool temporal_merge(const FrameParams& P, int x, int yi, f3 sp, f3 sn, Re
 #ifndef RT_GENERATE_WS_WAVES
 #define RT_GENERATE_WS_WAVES 5
 #endif
+#ifndef RT_GENERATE_SH_WAVES
+#define RT_GENERATE_SH_WAVES RT_TRACE_WAVES /* the shadowed-target kernel (110 VGPRs) */
+#endif
 template <bool STREAM = true>
 RT_DEV void wave_scatter_records(float4* __restrict__ rec, const int idx, float4* s_wave, const int lane, const float4& q0, const float4& q1,
                                  const float4& q2, const float4& q3);
@@ -359,7 +362,7 @@ RT_DEV void wave_gather_records(const float4* q, float4* s_wave, const int lane,
 #define RT_RIS_COOP 1 /* 0: per-lane light record gathers in the work-sharing generate kernel too (A/B) */
 #endif
 template <bool FUSE_TEMPORAL, bool SHADOWED, bool DEFER = false, bool PIPE = false, bool WS = false>
-__global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : RT_TRACE_WAVES) void k_generate_candidate(
+__global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : (SHADOWED ? RT_GENERATE_SH_WAVES : RT_TRACE_WAVES)) void k_generate_candidate(
     SceneView S, FrameParams P, const float4* __restrict__ g0, const float4* __restrict__ g1,
     const float4* __restrict__ prev_rec, const float4* __restrict__ prev_rad, float4* __restrict__ out_rec,
     float4* __restrict__ out_rad, uint32_t* __restrict__ vis_queue = nullptr, unsigned int* __restrict__ vis_count = nullptr)
@@ -723,7 +726,8 @@ __global__ __launch_bounds__(BLOCK) void k_temporal(SceneView S, FrameParams P, 
  * shaded bit kept inside the record; radiance (side record) is fetched once, for the sample
  * that survived. */
 #ifndef RT_SHSPATIAL_WAVES
-#define RT_SHSPATIAL_WAVES 4 /* <= 128 VGPRs: 4 wavefronts per SIMD instead of 3 (shadowed frame 10.0 -> 9.2 ms; 5 and 6 spill: 14.5, 11.8 ms) */
+#define RT_SHSPATIAL_WAVES 7 /* register budget in wavefronts per SIMD. r02: 4 (<= 128 VGPRs; 5 and 6 spilled badly). r04, without the SLP
+                                * vectoriser the kernel needs 112: shadowed frame 5.34 (4) / 4.93 (5) / 4.72 (6) / 4.66 (7) / 4.90 ms (8) */
 #endif
 /* one pixel of the pass (x, row already resolved by the caller's tile mapping) */
 template <bool SHADOWED, int TB>
@@ -1954,7 +1958,7 @@ __global__ void k_halo_flags(float4* __restrict__ g1, size_t off, int n_pix, uin
 /* register budget in wavefronts per SIMD. r01 (one lane, one ray): 6 (86 -> 80 VGPRs) was 3 % faster than none.
  * r02, with the work-sharing walk: 5 (96 VGPRs) is 3 % faster than 6 and equal to 4 (profiles/r02_ws_register_budgets.txt) */
 #ifndef RT_RESOLVE_WAVES
-#define RT_RESOLVE_WAVES 5
+#define RT_RESOLVE_WAVES 8 /* r04: 64 VGPRs without a spill once the SLP vectoriser is off: 0.257 (5) / 0.248 (7) / 0.240 ms (8) */
 #endif
 template <bool WS>
 __global__ __launch_bounds__(TRACE_BLOCK, RT_RESOLVE_WAVES) void k_resolve(SceneView S, FrameParams P, const float4* __restrict__ g0,
