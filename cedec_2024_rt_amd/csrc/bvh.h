@@ -209,6 +209,9 @@ constexpr int WIDE_LDS_STACK = RT_WIDE_LDS_STACK;
 #endif
 constexpr int WIDE_OVF_STACK = RT_WIDE_TOTAL_STACK - RT_WIDE_LDS_STACK; /* total 64 >= 3 * wide height + 1 (checked at build) */
 constexpr uint32_t WIDE_LEAF_BIT = 0x80000000u;
+/* slab test margin: [tn, tf] is accepted iff max(tn, tmin) <= min(tf, best) * PAD. PAD >= (1 + 4e-7) / (1 - 4e-7), the margins
+ * r01-r03 put on both ends (tn * (1 - 4e-7) <= tf * (1 + 4e-7)): whatever that test kept this one keeps (tmin, best >= 0) */
+constexpr float WIDE_SLAB_PAD = 1.0f + 0x1p-20f;
 #ifndef RT_WIDE_STRIDE
 #define RT_WIDE_STRIDE 3 /* float4 per wide record in HBM: 3 = packed 48 B, 4 = 64-B slots (a record never straddles a line) */
 #endif
@@ -343,8 +346,9 @@ RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3
                                  __builtin_fmaf(wide_byte(nz, k), Bz, Az));
                 float tf = fminf(fminf(__builtin_fmaf(wide_byte(fx, k), Bx, Ax), __builtin_fmaf(wide_byte(fy, k), By, Ay)),
                                  __builtin_fmaf(wide_byte(fz, k), Bz, Az));
-                tn = fmaxf(tn * (1.0f - 4e-7f), tmin);
-                tf = fminf(tf * (1.0f + 4e-7f), best);
+                /* conservative: rounding may leave tn a few 1e-7 too large and tf too small; one factor on the far side covers both */
+                tn = fmaxf(tn, tmin);
+                tf = fminf(tf, best) * WIDE_SLAB_PAD;
                 const bool h = (m != 0u) && (tn <= tf);
                 td[k] = h ? tn : 3.0e38f;
                 ce[k] = (base + (uint32_t)k) | (m == 2u ? WIDE_LEAF_BIT : 0u);
@@ -627,8 +631,9 @@ RT_DEV bool occluded_ws(const WideView& bvh, uint32_t* __restrict__ lds_generic,
                                  __builtin_fmaf(wide_byte(nz, k), Bz, Az));
                 float tf = fminf(fminf(__builtin_fmaf(wide_byte(fx, k), Bx, Ax), __builtin_fmaf(wide_byte(fy, k), By, Ay)),
                                  __builtin_fmaf(wide_byte(fz, k), Bz, Az));
-                tn = fmaxf(tn * (1.0f - 4e-7f), tmin);
-                tf = fminf(tf * (1.0f + 4e-7f), tmax);
+                /* conservative: rounding may leave tn a few 1e-7 too large and tf too small; one factor on the far side covers both */
+                tn = fmaxf(tn, tmin);
+                tf = fminf(tf, tmax) * WIDE_SLAB_PAD;
                 h[k] = (m != 0u) && (tn <= tf);
                 ce[k] = (cbase + (uint32_t)k) | (m == 2u ? WIDE_LEAF_BIT : 0u);
             }
@@ -807,8 +812,9 @@ RT_DEV bool closest_ws(const WideView& bvh, const float4* __restrict__ tv, uint3
                                  __builtin_fmaf(wide_byte(nz, k), Bz, Az));
                 float tf = fminf(fminf(__builtin_fmaf(wide_byte(fx, k), Bx, Ax), __builtin_fmaf(wide_byte(fy, k), By, Ay)),
                                  __builtin_fmaf(wide_byte(fz, k), Bz, Az));
-                tn = fmaxf(tn * (1.0f - 4e-7f), tmin);
-                tf = fminf(tf * (1.0f + 4e-7f), best);
+                /* conservative: rounding may leave tn a few 1e-7 too large and tf too small; one factor on the far side covers both */
+                tn = fmaxf(tn, tmin);
+                tf = fminf(tf, best) * WIDE_SLAB_PAD;
                 const bool h = (m != 0u) && (tn <= tf);
                 td[k] = h ? tn : 3.0e38f;
                 ce[k] = (cbase + (uint32_t)k) | (m == 2u ? WIDE_LEAF_BIT : 0u);
@@ -1051,8 +1057,9 @@ RT_DEV void occluded_stream(const WideView& bvh, uint32_t* __restrict__ lds_gene
                                  __builtin_fmaf(wide_byte(nz, k), Bz, Az));
                 float tf = fminf(fminf(__builtin_fmaf(wide_byte(fx, k), Bx, Ax), __builtin_fmaf(wide_byte(fy, k), By, Ay)),
                                  __builtin_fmaf(wide_byte(fz, k), Bz, Az));
-                tn = fmaxf(tn * (1.0f - 4e-7f), tmin);
-                tf = fminf(tf * (1.0f + 4e-7f), tmax);
+                /* conservative: rounding may leave tn a few 1e-7 too large and tf too small; one factor on the far side covers both */
+                tn = fmaxf(tn, tmin);
+                tf = fminf(tf, tmax) * WIDE_SLAB_PAD;
                 h[k] = (m != 0u) && (tn <= tf);
                 ce[k] = (cbase + (uint32_t)k) | (m == 2u ? WIDE_LEAF_BIT : 0u);
             }
@@ -1275,8 +1282,9 @@ RT_DEV uint32_t occluded_batch_plain(const WideView& bvh, uint32_t* __restrict__
                                  __builtin_fmaf(wide_byte(nz, k), Bz, Az));
                 float tf = fminf(fminf(__builtin_fmaf(wide_byte(fx, k), Bx, Ax), __builtin_fmaf(wide_byte(fy, k), By, Ay)),
                                  __builtin_fmaf(wide_byte(fz, k), Bz, Az));
-                tn = fmaxf(tn * (1.0f - 4e-7f), tmin);
-                tf = fminf(tf * (1.0f + 4e-7f), tmax);
+                /* conservative: rounding may leave tn a few 1e-7 too large and tf too small; one factor on the far side covers both */
+                tn = fmaxf(tn, tmin);
+                tf = fminf(tf, tmax) * WIDE_SLAB_PAD;
                 h[k] = (m != 0u) && (tn <= tf);
                 ce[k] = (base + (uint32_t)k) | (m == 2u ? WIDE_LEAF_BIT : 0u);
             }
@@ -1467,8 +1475,9 @@ RT_DEV uint32_t occluded_batch_ws(const WideView& bvh, uint32_t* __restrict__ ld
                                  __builtin_fmaf(wide_byte(nz, k), Bz, Az));
                 float tf = fminf(fminf(__builtin_fmaf(wide_byte(fx, k), Bx, Ax), __builtin_fmaf(wide_byte(fy, k), By, Ay)),
                                  __builtin_fmaf(wide_byte(fz, k), Bz, Az));
-                tn = fmaxf(tn * (1.0f - 4e-7f), tmin);
-                tf = fminf(tf * (1.0f + 4e-7f), tmax);
+                /* conservative: rounding may leave tn a few 1e-7 too large and tf too small; one factor on the far side covers both */
+                tn = fmaxf(tn, tmin);
+                tf = fminf(tf, tmax) * WIDE_SLAB_PAD;
                 h[k] = (m != 0u) && (tn <= tf);
                 ce[k] = (cbase + (uint32_t)k) | (m == 2u ? WIDE_LEAF_BIT : 0u);
             }

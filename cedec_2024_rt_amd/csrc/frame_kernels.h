@@ -82,6 +82,7 @@ struct SceneView
 #ifndef RT_LIGHT_STRIDE
 #define RT_LIGHT_STRIDE 4 /* float4 per light record: 3 = normal recomputed per candidate, 4 = normal stored (A/B: 4 is 3 % faster in the fused kernel) */
 #endif
+static_assert(RT_LIGHT_STRIDE == 4, "the 48-B light record (normal recomputed per candidate) is no longer maintained: kernels read the 4th float4");
 constexpr int TILE_W = RT_TILE_W, TILE_H = 256 / RT_TILE_W, BLOCK = 256;
 constexpr int TILE_W_LOG2 = RT_TILE_W == 32 ? 5 : (RT_TILE_W == 16 ? 4 : 3);
 #ifndef RT_TRACE_WAVES
@@ -2725,8 +2726,9 @@ __global__ __launch_bounds__(BLOCK) void k_trace_queue(WideView wide, const floa
                 const float z0 = __builtin_fmaf(wide_byte(lz, k), Bz, Az), z1 = __builtin_fmaf(wide_byte(hz, k), Bz, Az);
                 float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
                 float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-                tn = fmaxf(tn * (1.0f - 4e-7f), tmin);
-                tf = fminf(tf * (1.0f + 4e-7f), best);
+                /* conservative: rounding may leave tn a few 1e-7 too large and tf too small; one factor on the far side covers both */
+                tn = fmaxf(tn, tmin);
+                tf = fminf(tf, best) * WIDE_SLAB_PAD;
                 const bool h = (m != 0u) && (tn <= tf);
                 td[k] = h ? tn : 3.0e38f;
                 ce[k] = (base + (uint32_t)k) | (m == 2u ? WIDE_LEAF_BIT : 0u);
