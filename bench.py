@@ -4,6 +4,10 @@
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both forms work for N > 1. Called plainly (no RANK / WORLD_SIZE in the environment) with --gpus N > 1, this process starts
+N FRESH child processes of itself — one per GPU, rendezvous on 127.0.0.1 — BEFORE it makes any GPU call, relays rank 0's
+single JSON line and exits non-zero with a `"value": null` line if any child fails (launch_ranks below). It never re-execs.
+
 A step = one frame = the timed region of the reference (examples/10_restir_di/10_restir_di.cpp:
 254-383): raycast, generate_candidate(+temporal_resampling), 3 x spatial_resampling, resolve,
 tone_mapping on the synthetic `blocks_restir` stand-in scene at 1920x1080, 1 spp, benchmark
@@ -148,11 +152,7 @@ class Watchdog:
         sys.stderr.write(msg + "\n")
         sys.stderr.flush()
         if self.rank == 0:
-            line = {"metric": "Mray/s", "value": None, "unit": "Mray/s", "n_gpus": self.world, "steps": self.args.steps,
-                    "warmup": self.args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong",
-                    "vs_baseline": None, "dtype": "f32", "data": "synthetic", "error": msg,
-                    "config": {"workload": "10_restir_di blocks_restir stand-in ReSTIR DI (run aborted)"}}
-            os.write(self.json_fd, (json.dumps(line) + "\n").encode())
+            os.write(self.json_fd, (json.dumps(null_line(self.args, self.world, msg)) + "\n").encode())
         os._exit(3)
 
 
@@ -173,6 +173,97 @@ class _PythonStrips:
 
     def close(self):
         pass
+
+
+NULL_LINE = {"metric": "Mray/s", "value": None, "unit": "Mray/s", "ms_per_step": None, "higher_is_better": True, "scaling": "strong",
+             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+             "config": {"workload": "10_restir_di blocks_restir stand-in ReSTIR DI (run aborted)"}}
+
+
+def null_line(args, world, msg):
+    return dict(NULL_LINE, n_gpus=world, steps=args.steps, warmup=args.warmup, error=msg)
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: this process — which has made NO GPU call and has not
+    even imported torch — starts N children of this script, one per GPU (RANK = LOCAL_RANK = 0..N-1, WORLD_SIZE = N, rendezvous
+    on 127.0.0.1 at a free port), exactly the environment torch.distributed.run would give them. Rank 0's stdout is read here
+    and its ONE JSON line is relayed; the other ranks' stdout goes to stderr. If a child exits non-zero the others get
+    BENCH_CHILD_GRACE_S seconds to finish by themselves (every rank has the progress watchdog; rank 0 prints the diagnostic
+    line), then the ones THIS process started are terminated by PID. Exit code: 0 only if every child returned 0 and the
+    line carries a value."""
+    import socket
+    import subprocess
+    import threading
+
+    n = args.gpus
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), BENCH_LAUNCHED_BY_PARENT="1")
+    me = os.path.abspath(__file__)
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")
+        procs.append(subprocess.Popen([sys.executable, me] + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                      stderr=None, cwd=os.getcwd()))
+    lines = []
+
+    def pump():
+        for raw in procs[0].stdout:
+            lines.append(raw.decode(errors="replace").rstrip("\n"))
+
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    limit = float(os.environ.get("BENCH_LAUNCH_TIMEOUT_S", "3000"))
+    grace = float(os.environ.get("BENCH_CHILD_GRACE_S", "90"))
+    t0 = time.monotonic()
+    first_bad = None
+    why = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        if all(rc is not None for rc in rcs):
+            break
+        now = time.monotonic()
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad and first_bad is None:
+            first_bad = now
+            why = "rank %d exited with code %d" % bad[0]
+        if (first_bad is not None and now - first_bad > grace) or now - t0 > limit:
+            why = why or "no result after %.0f s" % limit
+            for p in procs:  # exactly the processes started above, by PID
+                if p.poll() is None:
+                    p.terminate()
+            time.sleep(3.0)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    for p in procs:
+        p.wait()
+    th.join(timeout=10.0)
+    rcs = [p.returncode for p in procs]
+    out = None
+    for ln in lines:
+        try:
+            d = json.loads(ln)
+        except Exception:
+            sys.stderr.write(ln + "\n")
+            continue
+        if isinstance(d, dict) and "metric" in d:
+            out = d
+    ok = all(rc == 0 for rc in rcs) and out is not None and out.get("value") is not None
+    if out is None or (not ok and out.get("value") is not None):
+        out = null_line(args, n, why or "child return codes %s, no JSON line from rank 0" % rcs)
+    if not ok:
+        out.setdefault("error", why or "child return codes %s" % rcs)
+        out["child_return_codes"] = rcs
+    out["launched_by"] = "bench.py itself: %d fresh child processes, started before any GPU call" % n
+    sys.stdout.write(json.dumps(out) + "\n")
+    sys.stdout.flush()
+    raise SystemExit(0 if ok else 1)
 
 
 def main():
@@ -199,6 +290,8 @@ def _main():
     ap.add_argument("--width", type=int, default=W)
     ap.add_argument("--height", type=int, default=H)
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args, sys.argv[1:])  # does not return
 
     # the contract is ONE JSON line on stdout: libraries that print banners to fd 1 (RCCL's version block,
     # gloo's connection messages) are sent to stderr for the duration of the run
@@ -218,11 +311,19 @@ def _main():
     wd = Watchdog(json_fd, rank, world, args)
     frame_limit = float(os.environ.get("BENCH_WATCHDOG_S", "60"))  # seconds without a completed step
     stall_at = tuple(int(v) for v in os.environ["BENCH_TEST_STALL"].split(":")) if os.environ.get("BENCH_TEST_STALL") else None
+    def die(msg):
+        """a start-up condition no rank can recover from: rank 0 still prints the ONE JSON line (value null), exit code 2"""
+        wd.stop()
+        sys.stderr.write("bench.py: " + msg + "\n")
+        if rank == 0:
+            os.write(json_fd, (json.dumps(null_line(args, world, msg)) + "\n").encode())
+        raise SystemExit(2)
+
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        die(f"--gpus {args.gpus} but WORLD_SIZE={world}: start `python bench.py --gpus N` plainly (it launches its own ranks) or under "
+            "torch.distributed.run with --nproc-per-node N")
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+        die("bench.py needs a GPU: the HIP path has no CPU fallback")
     # development aid for 1-GPU boxes (RCCL refuses two ranks on one device): BENCH_DEV_MIRROR=1 runs the N ranks on
     # GPU 0 with the MIRROR transport (every rank receives what it sent) and a gloo control plane. It exercises this
     # script's N > 1 branch and the native driver's launch sequence; its images and timings are NOT a multi-GPU result.
@@ -234,6 +335,9 @@ def _main():
         dev_mirror = True  # same control plane (gloo) and device placement
     if dev_mirror:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        die(f"rank {rank} wants GPU {local_rank} and this node shows {torch.cuda.device_count()} (BENCH_DEV_SHM=1 / BENCH_DEV_MIRROR=1 run "
+            "the N ranks on GPU 0 as a protocol check)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if dev_mirror else dev
@@ -383,20 +487,14 @@ def _main():
                 part += ", FALLBACK: Python StripFrame over torch.distributed (native RCCL driver failed to initialise)"
         return r, mg, bounds, build_ms, part
 
-    def run(w, h, steps, warm):
-        """warm-up + timed region on the current N GPUs; returns the rank-0 summary pieces"""
-        if world == 1:
-            r, build_ms = make_renderer(w, h)
-            step, mg, bounds, part = r.frame, None, [(0, h)], "single GPU"
-        else:
-            r, mg, bounds, build_ms, part = make_strip(w, h)
-            step = mg.frame
-        frame = 0
+    def timed(r, mg, step, frame, w, h, steps, warm):
+        """`warm` untimed frames, then EXACTLY `steps` frames between barrier + synchronize on both sides; max over ranks"""
         for _ in range(warm):
             frame += 1
             wd.tick(f"{w}x{h} warm-up frame {frame}", frame_limit)
             step(frame)
         wd.tick(f"{w}x{h} synchronise after the warm-up", frame_limit)
+        r.sync()
         torch.cuda.synchronize()
         rays = reduce_sum(r.ray_count()[0])
         if mg is not None:
@@ -410,15 +508,41 @@ def _main():
                 time.sleep(1e6)
             step(frame)
         wd.tick(f"{w}x{h} barrier at the end of the timed region")
+        r.sync()  # the context's own streams (non-blocking streams are not covered by the null-stream synchronize)
         barrier()
         dt = reduce_max(time.perf_counter() - t0)
         wd.tick(f"{w}x{h} after the timed region", 600)
+        return frame, rays, dt
+
+    def run(w, h, steps, warm, pipelined=True):
+        """warm-up + timed region on the current N GPUs; returns the rank-0 summary pieces. pipelined=False (one GPU): the frames
+        run back to back on ONE stream, every kernel of frame f before any kernel of frame f+1 — the reference's timed region
+        (10_restir_di.cpp:254-383) repeated, SURVEY 8(d)'s frame time; pipelined=True: stage 0 of frame f+1 beside the passes of
+        frame f (rt_tuning 14, 17 at their defaults)."""
+        if world == 1:
+            r, build_ms = make_renderer(w, h)
+            if not pipelined:
+                r.tuning(14, 0)
+                r.tuning(17, 0)
+            step, mg, bounds, part = r.frame, None, [(0, h)], "single GPU"
+        else:
+            r, mg, bounds, build_ms, part = make_strip(w, h)
+            step = mg.frame
+        frame, rays, dt = timed(r, mg, step, 0, w, h, steps, warm)
         return dict(r=r, mg=mg, frame=frame, rays=rays, dt=dt, bounds=bounds, build_ms=build_ms, part=part, builder=r.bvh_builder())
 
     wd.tick("scene + context set-up", 600)
-    R = run(width, height, K, Wm)
+    # N = 1: the headline is SURVEY 8(d)'s frame — the reference's timed region, frames back to back (VERDICT r04 item 6); the
+    # throughput of pipelined frames is measured right after it on the same context and reported as `value_pipelined`.
+    # N > 1: the native strip driver's frame loop (always pipelined: its look-ahead is what hides the halo exchanges).
+    R = run(width, height, K, Wm, pipelined=(world > 1))
     r, mg, frame, total_rays, elapsed = R["r"], R["mg"], R["frame"], R["rays"], R["dt"]
     info = r.scene_info()
+    pipelined_dt = None
+    if world == 1:
+        r.tuning(14, -1)
+        r.tuning(17, -1)
+        frame, _, pipelined_dt = timed(r, None, r.frame, frame, width, height, K, Wm)
 
     spatial_ms = per_kernel = algo_bytes = pcie_ms = event_median = None
     verified = mg_stats = walks = verified_seq = None
@@ -529,8 +653,9 @@ def _main():
     # latency floor that bounds strong scaling of the 2.3 ms 1080p frame).
     also_4k = None
     if (width, height) == (W, H) and not os.environ.get("BENCH_NO_4K"):
-        R4 = run(3840, 2160, 10, 3)
+        R4 = run(3840, 2160, 10, 3, pipelined=(world > 1))
         also_4k = {"workload": "same scene and options at 3840x2160 (the frame of BASELINE config #5)", "steps": 10, "warmup": 3,
+                   "frames": "pipelined (native strip driver)" if world > 1 else "back to back on one stream, as the headline",
                    "ms_per_step": R4["dt"] / 10 * 1e3, "value": R4["rays"] * 10 / R4["dt"] / 1e6, "unit": "Mray/s",
                    "rays_per_frame": R4["rays"], "strips": [list(b) for b in R4["bounds"]] if world > 1 else None}
         if R4["mg"] is not None:
@@ -558,9 +683,11 @@ def _main():
                 # temporal merge: they depend on frame f only through the history frame f's stage 0 wrote) runs on a second
                 # stream beside the spatial passes and resolve of frame f (rt_tuning key 14; the sync at the end of the
                 # timed region waits for it). kernel_ms / gpu_event_median_ms below are of frames run back to back on one stream.
-                "frame_pipeline": "stage 0 (raycast, generate_candidate + temporal) of frame f+1 beside the spatial passes and resolve of frame f"
-                                  + ("; resolve + tone mapping of frame f beside the first halo exchange of frame f+1; halo records read from / "
-                                     "written to the exchange lists by the spatial passes" if world > 1 else ""),
+                "frame_pipeline": ("stage 0 (raycast, generate_candidate + temporal) of frame f+1 beside the spatial passes and resolve of frame f"
+                                   "; resolve + tone mapping of frame f beside the first halo exchange of frame f+1; halo records read from / "
+                                   "written to the exchange lists by the spatial passes") if world > 1 else
+                                  "none in `value`: every kernel of frame f before any kernel of frame f+1, one stream (rt_tuning 14 = 0, 17 = 0); "
+                                  "`value_pipelined` overlaps stage 0 of frame f+1 with the passes and resolve of frame f",
                 "parallelism": (f"row strips x{world}, {R['part']}, sparse 87-row halos over "
                                 + ("torch.distributed send/recv (Python schedule" + (", gloo on ONE GPU: not a scaling number)" if dev_mirror else ")")
                                    if "FALLBACK" in R["part"] else
@@ -577,6 +704,8 @@ def _main():
         elif dev_mirror:
             out["dev_mirror"] = "N ranks on ONE GPU with the MIRROR transport: script/driver smoke run, not a multi-GPU measurement"
         if world > 1:
+            out["value_definition"] = ("throughput of the native strip driver's pipelined frames; the N = 1 line's `value` is un-pipelined "
+                                       "frames (SURVEY 8d) and its `value_pipelined` is the figure this one is comparable with")
             out["config"]["strips"] = [list(b) for b in R["bounds"]]
             out["strip_driver"] = mg_stats
             if verified is not None:
@@ -612,9 +741,14 @@ def _main():
             out["build_id"] = api.build_id()
             out["kernel_ms"] = per_kernel
             out["gpu_event_median_ms"] = event_median
-            # SURVEY 8(d)'s frame time = GPU-event median of >= 50 un-overlapped frames; `value` is pipelined throughput
+            # SURVEY 8(d)'s frame time = GPU-event median of >= 50 un-overlapped frames
             out["value_gpu_event_median"] = {"value": total_rays / event_median / 1e3, "unit": "Mray/s", "ms_per_frame": event_median,
-                                             "note": "rays / GPU-event median of frames run back to back on one stream (SURVEY 8d's definition of the frame time)"}
+                                             "note": "rays / GPU-event median of frames run back to back on one stream with per-kernel events (SURVEY 8d's "
+                                                     "definition of the frame time); `value` is the same frames without the events, wall clock over K frames"}
+            out["value_pipelined"] = {"value": total_rays * K / pipelined_dt / 1e6, "unit": "Mray/s", "ms_per_step": pipelined_dt / K * 1e3,
+                                      "steps": K, "warmup": Wm,
+                                      "note": "throughput of pipelined frames (stage 0 of frame f+1 beside the passes of frame f; every kernel still runs "
+                                              "once per frame): the headline of rounds 1-4, and what the N > 1 lines are comparable with"}
             if walks is not None:
                 out["bvh_walks_per_frame"] = walks
                 out["Mwalk_per_s"] = walks["walked"] / ms / 1e3

@@ -1955,6 +1955,25 @@ __global__ void k_halo_flags(float4* __restrict__ g1, size_t off, int n_pix, uin
 }
 
 /* -------------------------------------------------------------------- resolve */
+RT_DEV float aces(float x)
+{
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    return (x * (a * x + b)) / (x * (c * x + d) + e);
+}
+RT_DEV uint32_t to_u8(float v)
+{
+    const float c = fminf(fmax_dev(v, 0.0f), 255.0f);
+    return (uint32_t)(int)c;
+}
+/* common/kernels/common.cu:30-74 for one pixel (display only; powf = portable exp(y*log(x))) */
+RT_DEV uint32_t tone_map_rgba8(float4 a)
+{
+    const float gamma = 1.0f / 2.2f;
+    const float r = pm_powf_pos(aces(a.x / a.w * 1.0f), gamma);
+    const float g = pm_powf_pos(aces(a.y / a.w * 1.0f), gamma);
+    const float b = pm_powf_pos(aces(a.z / a.w * 1.0f), gamma);
+    return to_u8(r * 255.0f) | (to_u8(g * 255.0f) << 8) | (to_u8(b * 255.0f) << 16) | 0xff000000u;
+}
 /* examples/10_restir_di/10_restir_di.cu:390-459 */
 /* register budget in wavefronts per SIMD. r01 (one lane, one ray): 6 (86 -> 80 VGPRs) was 3 % faster than none.
  * r02, with the work-sharing walk: 5 (96 VGPRs) is 3 % faster than 6 and equal to 4 (profiles/r02_ws_register_budgets.txt) */
@@ -1965,8 +1984,13 @@ template <bool WS>
 __global__ __launch_bounds__(TRACE_BLOCK, RT_RESOLVE_WAVES) void k_resolve(SceneView S, FrameParams P, const float4* __restrict__ g0,
                                                     const float4* __restrict__ g1,
                                                     const float4* __restrict__ rec,
-                                                    const float4* __restrict__ radb, float4* __restrict__ accum)
+                                                    const float4* __restrict__ radb, float4* __restrict__ accum,
+                                                    uint32_t* __restrict__ pixels)
 {
+    /* `pixels` (rt_frame's tail, r05): tone_mapping (common/kernels/common.cu:30-74) reads only the pixel's own accumulation
+     * value, the one this thread has just written — the staged frame maps it here instead of launching k_tone_mapping over the
+     * buffer again (one launch and a 16-B read per pixel less). NULL for the per-kernel entry point rt_resolve: the reference's
+     * resolve (10_restir_di.cu:390-459) does not touch the pixel buffer. */
     __shared__ __attribute__((aligned(16))) uint32_t s_stack[(WS ? WIDE_LDS_ROWS : WIDE_LDS_STACK) * TRACE_BLOCK];
     int x, row;
     if (!tile_pixel<TRACE_BLOCK>(P, x, row)) return;
@@ -1974,11 +1998,18 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_RESOLVE_WAVES) void k_resolve(Scene
     const float4 G0 = g0[li], G1 = g1[li];
     const int tri = as_int(G0.w);
     const uint32_t flags = as_uint(G1.w);
-    if (tri < 0) { accum[li] = make_float4(0.0f, 0.0f, 0.0f, 1.0f); return; }
+    if (tri < 0)
+    {
+        /* :414-417 stores {0,0,0,1} whatever `accumulate` says */
+        accum[li] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+        if (pixels) pixels[li] = tone_map_rgba8(make_float4(0.0f, 0.0f, 0.0f, 1.0f));
+        return;
+    }
     if (flags & GB_EMISSIVE)
     {
         const float4 ke = S.trimat[2 * (size_t)tri + 1];
         accum[li] = make_float4(ke.x, ke.y, ke.z, 1.0f);
+        if (pixels) pixels[li] = tone_map_rgba8(make_float4(ke.x, ke.y, ke.z, 1.0f));
         return;
     }
     const f3 sp = F3(G0.x, G0.y, G0.z), sn = F3(G1.x, G1.y, G1.z);
@@ -2000,12 +2031,14 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_RESOLVE_WAVES) void k_resolve(Scene
     const bool walked = check_visibility_wide<TRACE_BLOCK, WS>(S.wide, s_stack, sp, sn, hp, !known, S.bvh.tv, tri);
     const float V = (known ? (ownv & OWNV_VISIBLE) != 0u : walked) ? 1.0f : 0.0f;
     const f3 radiance = brdf * G * V * F3(rq.x, rq.y, rq.z) * q0.w;
+    float4 o = make_float4(radiance.x, radiance.y, radiance.z, 1.0f);
     if (P.accumulate)
     {
         const float4 a = accum[li];
-        accum[li] = make_float4(a.x + radiance.x, a.y + radiance.y, a.z + radiance.z, a.w + 1.0f);
+        o = make_float4(a.x + radiance.x, a.y + radiance.y, a.z + radiance.z, a.w + 1.0f);
     }
-    else { accum[li] = make_float4(radiance.x, radiance.y, radiance.z, 1.0f); }
+    accum[li] = o;
+    if (pixels) pixels[li] = tone_map_rgba8(o);
 }
 
 
@@ -2424,29 +2457,14 @@ __global__ __launch_bounds__(BLOCK) void k_clear(FrameParams P, float4* __restri
     if (!tile_pixel(P, x, row)) return;
     accum[(size_t)x + (size_t)(row - P.lrow0) * P.W] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
-RT_DEV float aces(float x)
-{
-    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
-    return (x * (a * x + b)) / (x * (c * x + d) + e);
-}
-RT_DEV uint32_t to_u8(float v)
-{
-    const float c = fminf(fmax_dev(v, 0.0f), 255.0f);
-    return (uint32_t)(int)c;
-}
-/* common/kernels/common.cu:30-74 (display only; powf = portable exp(y*log(x))) */
+/* common/kernels/common.cu:30-74 */
 __global__ __launch_bounds__(BLOCK) void k_tone_mapping(FrameParams P, const float4* __restrict__ accum,
                                                          uint32_t* __restrict__ pixels)
 {
     int x, row;
     if (!tile_pixel(P, x, row)) return;
     const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
-    const float4 a = accum[li];
-    const float gamma = 1.0f / 2.2f;
-    const float r = pm_powf_pos(aces(a.x / a.w * 1.0f), gamma);
-    const float g = pm_powf_pos(aces(a.y / a.w * 1.0f), gamma);
-    const float b = pm_powf_pos(aces(a.z / a.w * 1.0f), gamma);
-    pixels[li] = to_u8(r * 255.0f) | (to_u8(g * 255.0f) << 8) | (to_u8(b * 255.0f) << 16) | 0xff000000u;
+    pixels[li] = tone_map_rgba8(accum[li]);
 }
 
 /* ------------------------------------------------ layout conversion (upload/download) */

@@ -151,6 +151,7 @@ struct rt_ctx
     int tune_tail = -1; /* -1 auto = on, 0 never, 1 always */
     int tune_mark_quick = 1; /* rt_tuning key 18: quick reject in k_halo_mark */
     int tune_mark_window = 1; /* rt_tuning key 19 (r04): k_halo_mark collects a workgroup's marks in LDS first */
+    int tune_fuse_tonemap = 1; /* rt_tuning key 20 (r05): the staged frame's resolve kernel tone-maps its own pixel */
     HaloFuse fuse = {};        /* rt_halo_fuse_set: halo lists read / written by the running stage's spatial pass itself */
     int spare = 3;             /* physical buffer not named by res_map */
     bool spec_gen_valid = false, gen_taken = false;
@@ -1601,7 +1602,8 @@ int rt_spatial_resampling(rt_ctx* c, int frame, int pass, int in, int out)
     return launch_spatial(c, frame, pass, c->res_map[in], c->res_map[out]);
 }
 
-static int launch_resolve(rt_ctx* c, int phys)
+/* pixels: the staged frame maps each pixel in the resolve kernel itself (rt_tuning key 20, default on); NULL = resolve alone */
+static int launch_resolve(rt_ctx* c, int phys, uint32_t* pixels = nullptr)
 {
     const int g = trace_grid(c);
     if (c->tune_stream)
@@ -1611,8 +1613,8 @@ static int launch_resolve(rt_ctx* c, int phys)
         const int wgs = g < resident ? g : resident;
         k_resolve_stream<<<wgs, TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RESOLVE), c->d_g0, c->d_g1, c->d_rec[phys], c->d_rad[phys], c->d_accum, g);
     }
-    else if (use_ws(c, g)) k_resolve<true><<<g, TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RESOLVE), c->d_g0, c->d_g1, c->d_rec[phys], c->d_rad[phys], c->d_accum);
-    else k_resolve<false><<<g, TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RESOLVE), c->d_g0, c->d_g1, c->d_rec[phys], c->d_rad[phys], c->d_accum);
+    else if (use_ws(c, g)) k_resolve<true><<<g, TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RESOLVE), c->d_g0, c->d_g1, c->d_rec[phys], c->d_rad[phys], c->d_accum, pixels);
+    else k_resolve<false><<<g, TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RESOLVE), c->d_g0, c->d_g1, c->d_rec[phys], c->d_rad[phys], c->d_accum, pixels);
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }
@@ -1845,9 +1847,12 @@ static int stage_run_ranges(rt_ctx* c, int frame, int stage, int part, int row0,
             c->stream = c->tail_stream;
         }
         else rc = join_tail(c);
-        if (rc == RT_OK) rc = launch_resolve(c, final_phys);
+        /* tone_mapping reads the pixel's own accumulation value only (common/kernels/common.cu:30-74): k_resolve maps what it
+         * has just written (r05; not the persistent-wavefront A/B form, which has no such parameter) */
+        const bool fuse_tm = c->tune_fuse_tonemap != 0 && !c->tune_stream;
+        if (rc == RT_OK) rc = launch_resolve(c, final_phys, fuse_tm ? (uint32_t*)c->d_pixels : nullptr);
         mark(7);
-        if (rc == RT_OK) rc = launch_tone_mapping(c);
+        if (rc == RT_OK && !fuse_tm) rc = launch_tone_mapping(c);
         mark(8);
         if (tail)
         {
@@ -2679,6 +2684,7 @@ int rt_tuning(rt_ctx* c, int key, int value)
     else if (key == 17 && value >= -1 && value <= 1) c->tune_tail = value;
     else if (key == 18 && (value == 0 || value == 1)) c->tune_mark_quick = value;
     else if (key == 19 && (value == 0 || value == 1)) c->tune_mark_window = value;
+    else if (key == 20 && (value == 0 || value == 1)) c->tune_fuse_tonemap = value;
     else RT_FAIL(c, RT_ERR_ARG, "bad tuning key/value %d/%d", key, value);
     return RT_OK;
 }
@@ -2705,6 +2711,7 @@ int rt_tuning_get(rt_ctx* c, int key, int* value)
         case 17: *value = c->tune_tail; break;
         case 18: *value = c->tune_mark_quick; break;
         case 19: *value = c->tune_mark_window; break;
+        case 20: *value = c->tune_fuse_tonemap; break;
         default: RT_FAIL(c, RT_ERR_ARG, "bad tuning key %d", key);
     }
     return RT_OK;

@@ -420,7 +420,11 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
  * key 19 (r04): 1 (default) = rt_halo_mark collects the marks of a workgroup's tile in an LDS bitmap of its +-87-pixel window
  * and sends only the non-zero words to the global bitmaps (image widths that are multiples of 32, reach <= 87 px, <= 3 passes
  * per call; the direct form otherwise): the direct form's one global atomicOr per marked neighbour, many to one word, made the
- * kernel 84 us for a 135-row strip at 1920 px and 310 us for a 270-row strip at 3840 px. 0 = direct. Same marks. */
+ * kernel 84 us for a 135-row strip at 1920 px and 310 us for a 270-row strip at 3840 px. 0 = direct. Same marks.
+ * key 20 (r05): 1 (default) = the resolve kernel of rt_frame / rt_frame_stage tone-maps the pixel it has just accumulated
+ * (tone_mapping reads nothing but the pixel's own accumulation value, common/kernels/common.cu:30-74): no k_tone_mapping
+ * launch, no second read of the accumulation buffer. 0 = two launches as the reference. rt_resolve / rt_tone_mapping, the
+ * per-kernel entry points, are always the reference's two kernels. Same pixels. */
 int rt_tuning(rt_ctx* ctx, int key, int value);
 /* the value a key holds now (measurement records name the builder / variants that were really used) */
 int rt_tuning_get(rt_ctx* ctx, int key, int* value);
