@@ -417,8 +417,11 @@ def _main():
             e = cached["bounds"]
             if len(e) == world + 1 and e[0] == 0 and e[-1] == h and all(e[i + 1] - e[i] >= HALO for i in range(world)):
                 bounds = [(int(e[i]), int(e[i + 1])) for i in range(world)]
-                part = "rows cut by measured cost per strip (cached: profiles/strip_cuts.json, slowest strip alone %.3f -> %.3f ms)" % (
-                    cached.get("equal_rows_max_ms", 0.0), cached.get("max_ms", 0.0))
+                # the cut is a load-balance heuristic measured with one library build: it stays usable with another, but never silently
+                same = cached.get("build_id") == api.build_id()
+                part = "rows cut by measured cost per strip (cached: profiles/strip_cuts.json, slowest strip alone %.3f -> %.3f ms, measured with %s)" % (
+                    cached.get("equal_rows_max_ms", 0.0), cached.get("max_ms", 0.0),
+                    "this library build" if same else "ANOTHER library build %s: BENCH_REBALANCE=1 re-measures" % cached.get("build_id", "(unrecorded)"))
             else:
                 cached = None
         # ranks that share one GPU (the dev transports) cannot time their strips: equal rows there (BENCH_FORCE_BALANCE runs the

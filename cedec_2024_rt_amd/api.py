@@ -32,10 +32,10 @@ EXPORTS = [
     "rt_mg_partition", "rt_mg_bands", "rt_mg_unique_id", "rt_mg_load_error", "rt_mg_hub_create", "rt_mg_hub_destroy", "rt_mg_create",
     "rt_mg_destroy", "rt_mg_last_error", "rt_mg_frame", "rt_mg_frame_begin", "rt_mg_frame_step", "rt_mg_get_stats", "rt_mg_reset_stats",
     "rt_mg_selftest_rccl", "rt_tuning_get", "rt_build_id", "rt_halo_fuse_set", "rt_side_stream", "rt_copy_parts",
-    "rt_walk_stats_enable", "rt_walk_stats",
+    "rt_walk_stats_enable", "rt_walk_stats", "rt_wire_delay",
 ]
 
-RT_MG_TRANSPORT_RCCL, RT_MG_TRANSPORT_LOCAL, RT_MG_TRANSPORT_MIRROR, RT_MG_TRANSPORT_SHM, RT_MG_TRANSPORT_RCCL_SELF = 0, 1, 2, 3, 4
+RT_MG_TRANSPORT_RCCL, RT_MG_TRANSPORT_LOCAL, RT_MG_TRANSPORT_MIRROR, RT_MG_TRANSPORT_SHM, RT_MG_TRANSPORT_RCCL_SELF, RT_MG_TRANSPORT_WIRE_MODEL = 0, 1, 2, 3, 4, 5
 RT_MG_DENSE, RT_MG_ONE_LANE, RT_MG_SEPARATE_PACK = 1, 2, 4
 
 
@@ -234,7 +234,7 @@ class MgHub:
 
 
 class _MgStats(C.Structure):
-    _fields_ = [(n, C.c_ulonglong) for n in ("frames", "cold_frames", "host_ns", "plan_wait_ns", "bytes_sent", "messages", "records_sent", "gpu_ns_per_frame")]
+    _fields_ = [(n, C.c_ulonglong) for n in ("frames", "cold_frames", "host_ns", "plan_wait_ns", "bytes_sent", "messages", "records_sent", "gpu_ns_per_frame", "wire_ns")]
 
 
 class MultiGpu:

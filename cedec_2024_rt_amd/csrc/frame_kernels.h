@@ -1830,6 +1830,7 @@ RT_DEV void halo_scan_chunk(uint32_t* __restrict__ bitmap, int nw, int chunk, ui
 {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int w_begin = chunk * HALO_SCAN_CHUNK;
+    if (nw <= 0) { if (chunk == 0 && t == 0) bitmap[0] = 0u; return; } /* an empty region: count 0 */
     if (w_begin >= nw) return; /* wave-uniform: whole workgroups beyond the bitmap */
     /* 1. what lies in front of this chunk */
     uint32_t before = 0;
@@ -1861,7 +1862,7 @@ RT_DEV void halo_scan_chunk(uint32_t* __restrict__ bitmap, int nw, int chunk, ui
         if (w0 + k < nw) { bitmap[1 + nw + w0 + k] = run; run += c[k]; }
     if (t == 0 && w_begin + HALO_SCAN_CHUNK >= nw) bitmap[0] = base + chunk_total; /* the last chunk knows the total */
 }
-static inline int halo_scan_chunks(int nw) { return (nw + HALO_SCAN_CHUNK - 1) / HALO_SCAN_CHUNK; }
+static inline int halo_scan_chunks(int nw) { const int n = (nw + HALO_SCAN_CHUNK - 1) / HALO_SCAN_CHUNK; return n > 0 ? n : 1; } /* never a grid of 0 */
 /* blockIdx.x = chunk, blockIdx.y = bitmap */
 __global__ __launch_bounds__(HALO_SCAN_THREADS) void k_halo_scan(uint32_t* __restrict__ bitmaps, int nw, size_t words_per_bitmap)
 {
@@ -1942,6 +1943,17 @@ __global__ void k_copy_parts(CopyParts P)
     }
     else
         for (size_t i = tid; i < n; i += stride) d[i] = s[i];
+}
+
+/* WIRE_MODEL transport of the strip driver (r05): the time an xGMI link would take, as a DEPENDENT delay on the stream the
+ * exchange runs on — no host sleep, no host involvement. k_wire_stamp notes the GPU's wall clock when the stream reaches it
+ * (= the moment the send's data is ready); k_wire_wait, enqueued behind the exchange's RCCL kernel, lets the stream go on no
+ * earlier than `ticks` after that stamp. One wavefront, sleeping between its clock reads: it takes no slots worth naming. */
+__global__ void k_wire_stamp(unsigned long long* __restrict__ slot) { *slot = wall_clock64(); }
+__global__ void k_wire_wait(const unsigned long long* __restrict__ slot, unsigned long long ticks)
+{
+    const unsigned long long t0 = *slot;
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
 }
 
 /* shaded flags of rows as bytes (halo rows of the G-buffer only ever hold these flags) */

@@ -57,17 +57,22 @@ struct rt_ctx
      * if nothing it depends on changed meanwhile (epoch: camera, scene, options); otherwise frame f+1 traces its
      * primary rays as usual. rt_tuning key 14. */
     hipStream_t spec_stream = nullptr;
-    hipEvent_t ev_spec_go = nullptr, ev_spec_done = nullptr, ev_spec_t[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-    float4* d_gset[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}}; /* [set]{vis, g0, g1}; d_vis/d_g0/d_g1 = set gcur */
+    hipEvent_t ev_spec_go = nullptr, ev_spec_done = nullptr, ev_spec_t[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    /* r05: THREE G-buffer sets (frame f reads set f mod 3): the pipelined stage 0 of frame f+1 overwrites the set of frame f-2,
+     * whose last reader — resolve(f-2) — is two tails back, not the set resolve(f-1) may still be reading (with two sets every
+     * look-ahead raycast waited for the previous frame's resolve: the one edge that made a strip's frame a dependency chain
+     * instead of three streams of independent work, profiles/r05_strip_timelines.txt) */
+    static constexpr int NGSET = 3;
+    float4* d_gset[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}}; /* [set]{vis, g0, g1}; d_vis/d_g0/d_g1 = set gcur */
     int gcur = 0, timed_spec_set = -1;
-    bool spec_valid = false, spec_timed[2] = {false, false};
+    bool spec_valid = false, spec_timed[3] = {false, false, false};
     bool spec_outstanding = false; /* work recorded by ev_spec_done that the main stream has not waited for yet */
     uint64_t spec_epoch = 0;
     /* tags of the own-visibility flags (rt_device.h): one number per staged frame and per pipelined stage 0; the launches of
      * a staged frame carry frame_tag (cur_tag while they are enqueued), the per-kernel entry points carry 0 */
     uint32_t ownv_serial = 0, frame_tag = 0, cur_tag = 0, spec_gen_tag = 0;
     /* which G-buffer a reservoir buffer's shaded bits belong to (k_refresh_shaded): gbuf_serial counts G-buffer writes */
-    uint64_t gbuf_serial = 0, rec_gserial[4] = {0, 0, 0, 0};
+    uint64_t gbuf_serial = 0, rec_gserial[5] = {0, 0, 0, 0, 0};
     unsigned long long* d_walk = nullptr; /* rt_walk_stats: 4 kernel slots x 4 counters */
     bool walk_on = false;
     int tune_ws_primary = -1; /* rt_tuning key 16: primary rays with the work-sharing closest-hit walk: -1 auto (r04) = launches of at
@@ -129,8 +134,10 @@ struct rt_ctx
     uint32_t* d_pixels = nullptr;
     /* three reservoir buffers carry the reference's names (res_map); a fourth, allocated when the pipelined stage 0 is
      * first used, receives the NEXT frame's candidates while this frame's passes still read the other three */
-    float4* d_rec[4] = {nullptr, nullptr, nullptr, nullptr};
-    float4* d_rad[4] = {nullptr, nullptr, nullptr, nullptr};
+    /* r05: and a fifth. The buffer the previous frame's resolve reads ("quarantine") is not handed to the look-ahead candidates
+     * until one more frame has passed: they get the buffer that left the roles a frame earlier (last reader: two tails back). */
+    float4* d_rec[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    float4* d_rad[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int res_map[3] = {0, 1, 2};
     /* Pipelined stage 0 (rt_tuning key 14 = 2, r03): frame f+1's generate_candidate(+temporal_resampling) depends on frame
      * f only through the temporal history, and the reference saves that history right after temporal_resampling, BEFORE
@@ -146,14 +153,27 @@ struct rt_ctx
      * G-buffer set, spare reservoir buffer), and every call outside the staged frame (join_tail). */
     hipStream_t tail_stream = nullptr;
     hipEvent_t ev_tail_go = nullptr, ev_tail = nullptr;
-    bool tail_pending_main = false, tail_pending_spec = false;
+    /* ev_resolved[0] = behind the latest staged frame's resolve (+ tone mapping) on whatever stream it ran, [1] = the one before:
+     * what the pipelined stage 0 waits for before it overwrites the G-buffer set and the reservoir buffer of two frames ago */
+    hipEvent_t ev_resolved[2] = {nullptr, nullptr};
+    int n_resolved = 0;
+    bool resolve_on_tail = false;
+    bool tail_pending_main = false;
     int tail_phys = -1; /* reservoir buffer the tail in flight reads (the frame's final one) */
     int tune_tail = -1; /* -1 auto = on, 0 never, 1 always */
     int tune_mark_quick = 1; /* rt_tuning key 18: quick reject in k_halo_mark */
     int tune_mark_window = 1; /* rt_tuning key 19 (r04): k_halo_mark collects a workgroup's marks in LDS first */
+    unsigned long long* d_wire = nullptr; /* rt_wire_delay: GPU clock stamps */
+    int wall_khz = 100000;
+    int tune_spec_free = -1; /* rt_tuning key 22 (r05): the look-ahead stage 0 free of the main stream and of the latest resolve: -1 auto = strips */
+    int tune_mark_cache = 1; /* rt_tuning key 21 (r05): the shaded-bit rows of the halo marks are built once per epoch */
+    uint64_t mark_bits_epoch = 0, gbuf_epoch = 0; /* epoch d_mark_bits was built under (0: not cached) / the current G-buffer was traced under */
+    hipEvent_t ev_mark_bits = nullptr;
+    bool mark_bits_event_valid = false, mark_bits_rebuilt = false;
     int tune_fuse_tonemap = 1; /* rt_tuning key 20 (r05): the staged frame's resolve kernel tone-maps its own pixel */
     HaloFuse fuse = {};        /* rt_halo_fuse_set: halo lists read / written by the running stage's spatial pass itself */
-    int spare = 3;             /* physical buffer not named by res_map */
+    int spare = 3;             /* physical buffer not named by res_map: the look-ahead candidates' */
+    int quarantine = 4;        /* the buffer that left the roles at the last take (the previous frame's final one, or a free one) */
     bool spec_gen_valid = false, gen_taken = false;
     int spec_gen_frame = 0, spec_gen_hist = -1;
     uint64_t res_epoch = 1, spec_res_epoch = 0;
@@ -306,8 +326,10 @@ int rt_create(int device, int width, int height, int row_begin, int row_end, int
     for (auto& es : c->ev_spec_t) for (auto& e : es) RT_HIP(c, hipEventCreate(&e));
     RT_HIP(c, hipEventCreateWithFlags(&c->ev_tail_go, hipEventDisableTiming));
     RT_HIP(c, hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
+    for (auto& e : c->ev_resolved) RT_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     RT_HIP(c, hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming));
     RT_HIP(c, hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming));
+    RT_HIP(c, hipEventCreateWithFlags(&c->ev_mark_bits, hipEventDisableTiming));
     c->stream = c->own_stream;
     const size_t n = local_pixels(c);
     RT_HIP(c, hipMalloc(&c->d_vis, n * 16));
@@ -353,10 +375,12 @@ int rt_destroy(rt_ctx* c)
     if (c->tail_stream) { hipStreamSynchronize(c->tail_stream); hipStreamDestroy(c->tail_stream); }
     if (c->ev_tail_go) hipEventDestroy(c->ev_tail_go);
     if (c->ev_tail) hipEventDestroy(c->ev_tail);
+    for (auto& e : c->ev_resolved) if (e) hipEventDestroy(e);
     c->spec_valid = false;
     if (c->aux_stream) { hipStreamSynchronize(c->aux_stream); hipStreamDestroy(c->aux_stream); }
     if (c->ev_stage) hipEventDestroy(c->ev_stage);
     if (c->ev_aux) hipEventDestroy(c->ev_aux);
+    if (c->ev_mark_bits) hipEventDestroy(c->ev_mark_bits);
     free_scene(c);
     if (c->spec_stream) { hipStreamSynchronize(c->spec_stream); hipStreamDestroy(c->spec_stream); }
     if (c->ev_spec_go) hipEventDestroy(c->ev_spec_go);
@@ -364,11 +388,11 @@ int rt_destroy(rt_ctx* c)
     for (auto& es : c->ev_spec_t) for (auto& e : es) if (e) hipEventDestroy(e);
     for (auto& gs : c->d_gset) for (auto& p : gs) hipFree(p);
     hipFree(c->d_accum); hipFree(c->d_pixels);
-    for (int k = 0; k < 4; ++k) { hipFree(c->d_rec[k]); hipFree(c->d_rad[k]); }
+    for (int k = 0; k < 5; ++k) { hipFree(c->d_rec[k]); hipFree(c->d_rad[k]); }
     hipFree(c->d_shaded_bits); hipFree(c->d_mark_bits);
     hipFree(c->d_visq[0]); hipFree(c->d_visq[1]); hipFree(c->d_visq_count);
     if (c->h_visq_count) hipHostFree(c->h_visq_count);
-    hipFree(c->d_walk);
+    hipFree(c->d_walk); hipFree(c->d_wire);
     hipFree(c->d_counter); hipFree(c->d_stage); hipFree(c->d_paths[0]); hipFree(c->d_paths[1]); hipFree(c->d_pt_counters);
     if (c->ev_created) for (auto& e : c->ev) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -398,7 +422,7 @@ int rt_sync(rt_ctx* c)
     RT_HIP(c, hipStreamSynchronize(c->stream));
     if (c->spec_stream) RT_HIP(c, hipStreamSynchronize(c->spec_stream)); /* the next frame's raycast is work of this call too */
     if (c->tail_stream) RT_HIP(c, hipStreamSynchronize(c->tail_stream));
-    c->tail_pending_main = false; c->tail_pending_spec = false;
+    c->tail_pending_main = false;
     return RT_OK;
 }
 
@@ -1240,6 +1264,7 @@ int rt_raycast(rt_ctx* c)
     RT_HIP(c, hipGetLastError());
     c->has_gbuffer = true;
     ++c->gbuf_serial;
+    c->gbuf_epoch = c->epoch;
     c->shaded_bits_stale = true;
     /* halo rows of the G-buffer keep the neighbours' shaded flags: they stay valid until the camera,
      * the scene or the options change (halo_flags_epoch), which is when the neighbours' G-buffers change */
@@ -1263,6 +1288,10 @@ static bool use_next_generate(const rt_ctx* c)
     if (!use_next_raycast(c) || c->timing || c->tune_defer_vis) return false;
     return c->tune_spec < 0 || c->tune_spec == 2;
 }
+/* r05, rt_tuning key 22. auto: strips — their kernels are launches of one to three generations of wavefronts and what fills the GPU
+ * is running several of them side by side (rank 4 of 8: 1080p 0.306 -> 0.287 ms, 4K 0.889 -> 0.870, profiles/r05_spec_free_ab.txt);
+ * a whole frame's kernels fill the GPU alone and only take slots from each other (pipelined 1080p frame 1.277 -> 1.296 ms) */
+static bool spec_free(const rt_ctx* c) { return c->tune_spec_free < 0 ? (c->row_begin != 0 || c->row_end != c->H) : c->tune_spec_free != 0; }
 static int launch_generate(rt_ctx* c, int frame, int dst_phys, int prev_phys, bool fuse);
 /* the next frame's primary rays, behind everything enqueued on the main stream so far, on the stream of their own */
 static int launch_next_raycast(rt_ctx* c, int frame)
@@ -1270,22 +1299,30 @@ static int launch_next_raycast(rt_ctx* c, int frame)
     c->spec_gen_valid = false;
     if (!use_next_raycast(c)) { c->spec_valid = false; return RT_OK; }
     const size_t n = local_pixels(c);
-    if (!c->d_gset[c->gcur ^ 1][0])
+    const int o = (c->gcur + 1) % rt_ctx::NGSET;
+    bool fresh_set = false;
+    if (!c->d_gset[o][0])
     {
-        const int o = c->gcur ^ 1;
         for (int k = 0; k < 3; ++k) RT_HIP(c, hipMalloc(&c->d_gset[o][k], n * 16));
-        /* halo rows of g1 hold the neighbours' shaded flags (rt_halo_flags_unpack keeps both sets current from here on) */
+        /* halo rows of g1 hold the neighbours' shaded flags (rt_halo_flags_unpack keeps every set current from here on) */
         for (int k = 0; k < 3; ++k) RT_HIP(c, hipMemcpyAsync(c->d_gset[o][k], c->d_gset[c->gcur][k], n * 16, hipMemcpyDeviceToDevice, c->stream));
+        fresh_set = true;
     }
-    const int o = c->gcur ^ 1;
-    RT_HIP(c, hipEventRecord(c->ev_spec_go, c->stream));
-    RT_HIP(c, hipStreamWaitEvent(c->spec_stream, c->ev_spec_go, 0));
-    if (c->tail_pending_spec)
+    /* What this stage 0 needs from the main stream. If the current frame's stage 0 ran there (a cold frame, the first frames,
+     * per-kernel timing), its candidates are the history read below: behind everything enqueued on the main stream so far. If the
+     * current frame TOOK its stage 0 from this very stream (steady state), nothing: the history was written here, and the set /
+     * buffer overwritten below were last read two resolves ago (r05) — the look-ahead runs on, beside whatever the main and the
+     * tail stream are doing. (r04 waited here for the main stream, i.e. for the previous frame's passes, and for the previous
+     * frame's resolve: raycast(f+2) could not start before resolve(f) had ended.) */
+    if (!c->gen_taken || fresh_set || !spec_free(c))
     {
-        /* the G-buffer set and the spare reservoir buffer written below are what the previous frame's resolve reads */
-        RT_HIP(c, hipStreamWaitEvent(c->spec_stream, c->ev_tail, 0));
-        c->tail_pending_spec = false;
+        RT_HIP(c, hipEventRecord(c->ev_spec_go, c->stream));
+        RT_HIP(c, hipStreamWaitEvent(c->spec_stream, c->ev_spec_go, 0));
     }
+    /* the G-buffer set and the spare reservoir buffer written below: last read by the resolve before the latest one (the set of
+     * frame f-2; the buffer that left the roles when frame f-1 was taken) — or earlier */
+    if (c->n_resolved >= 2 || (c->n_resolved >= 1 && !spec_free(c)))
+        RT_HIP(c, hipStreamWaitEvent(c->spec_stream, c->ev_resolved[(spec_free(c) && c->n_resolved >= 2) ? 1 : 0], 0));
     const int s0 = c->sub0, s1 = c->sub1, b0 = c->subb0, b1 = c->subb1;
     c->sub0 = c->sub1 = -1; c->subb0 = c->subb1 = 0; /* all owned rows */
     if (c->timing) hipEventRecord(c->ev_spec_t[o][0], c->spec_stream);
@@ -1300,12 +1337,12 @@ static int launch_next_raycast(rt_ctx* c, int frame)
         /* candidates (+ temporal merge) of frame + 1: G-buffer = the set just traced, history = the buffer this frame's
          * stage 0 wrote (c->fY), output = the spare buffer; all owned rows, on the same stream behind the raycast */
         const size_t npx = local_pixels(c);
-        if (!c->d_rec[3])
+        if (!c->d_rec[c->spare])
         {
-            RT_HIP(c, hipMalloc(&c->d_rec[3], npx * 64));
-            RT_HIP(c, hipMalloc(&c->d_rad[3], npx * 16));
-            RT_HIP(c, hipMemsetAsync(c->d_rec[3], 0, npx * 64, c->spec_stream));
-            RT_HIP(c, hipMemsetAsync(c->d_rad[3], 0, npx * 16, c->spec_stream));
+            RT_HIP(c, hipMalloc(&c->d_rec[c->spare], npx * 64));
+            RT_HIP(c, hipMalloc(&c->d_rad[c->spare], npx * 16));
+            RT_HIP(c, hipMemsetAsync(c->d_rec[c->spare], 0, npx * 64, c->spec_stream));
+            RT_HIP(c, hipMemsetAsync(c->d_rad[c->spare], 0, npx * 16, c->spec_stream));
         }
         hipStream_t ms = c->stream;
         float4 *g0 = c->d_g0, *g1 = c->d_g1;
@@ -1339,7 +1376,7 @@ static int raycast_or_take(rt_ctx* c, bool whole, int frame)
     c->gen_taken = false;
     if (whole && use_next_raycast(c) && c->spec_valid && c->spec_epoch == c->epoch)
     {
-        c->gcur ^= 1;
+        c->gcur = (c->gcur + 1) % rt_ctx::NGSET;
         c->d_vis = c->d_gset[c->gcur][0]; c->d_g0 = c->d_gset[c->gcur][1]; c->d_g1 = c->d_gset[c->gcur][2];
         RT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_spec_done, 0));
         c->spec_outstanding = false;
@@ -1355,8 +1392,12 @@ static int raycast_or_take(rt_ctx* c, bool whole, int frame)
             const int r0 = c->fY, r1 = c->fZ;
             const int prev_final = c->res_map[c->f_final == RT_RES_1 ? RT_RES_1 : RT_RES_0];
             c->fY = c->spare;
-            if (c->opt.spatial_resampling_passes >= 1 && prev_final == r1) { c->fZ = r0; c->spare = r1; }
-            else c->spare = r0;
+            int freed = r0;
+            if (c->opt.spatial_resampling_passes >= 1 && prev_final == r1) { c->fZ = r0; freed = r1; }
+            /* r05: the freed buffer (the previous frame's final one, or one nobody reads) waits a frame in quarantine; the look-ahead
+             * candidates of the NEXT frame go to the buffer freed a frame earlier. RT_TUNING 22 = 0: the freed one at once (r04). */
+            if (spec_free(c)) { c->spare = c->quarantine; c->quarantine = freed; }
+            else c->spare = freed;
             c->f_in = c->fY; c->f_out = c->fZ;
             c->gen_taken = true;
             c->frame_tag = c->spec_gen_tag; /* own-visibility flags of the candidates were written under this tag */
@@ -1366,6 +1407,7 @@ static int raycast_or_take(rt_ctx* c, bool whole, int frame)
         c->spec_valid = false;
         c->has_gbuffer = true;
         ++c->gbuf_serial;
+        c->gbuf_epoch = c->spec_epoch; /* == c->epoch (checked above) */
         if (c->gen_taken) c->rec_gserial[c->fY] = c->gbuf_serial; /* the candidates were made from this G-buffer set */
         c->shaded_bits_stale = true;
         if (c->spec_timed[c->gcur]) c->timed_spec_set = c->gcur;
@@ -1594,8 +1636,13 @@ int rt_spatial_resampling(rt_ctx* c, int frame, int pass, int in, int out)
     if (c->rec_gserial[c->res_map[in]] != c->gbuf_serial)
     {
         /* the G-buffer changed since `in` was written: its neighbour test must see the current shaded flags (frame_kernels.h) */
-        const int n = (int)local_pixels(c);
-        k_refresh_shaded<<<(n + 255) / 256, 256, 0, c->stream>>>(n, c->d_g1, c->d_rec[c->res_map[in]]);
+        /* own rows always; a strip's halo rows only where the neighbour's flags in g1 are of the current epoch (rt_halo_flags_unpack
+         * after the last camera / scene / option change): stale flags must not rewrite the bits of the neighbour's records */
+        const int first_row = (c->row_begin > c->lrow0 && c->halo_flags_epoch[0] != c->epoch) ? c->row_begin : c->lrow0;
+        const int last_row = (c->lrow0 + c->lrows > c->row_end && c->halo_flags_epoch[1] != c->epoch) ? c->row_end : c->lrow0 + c->lrows;
+        const size_t off = (size_t)(first_row - c->lrow0) * c->W;
+        const int n = (last_row - first_row) * c->W;
+        k_refresh_shaded<<<(n + 255) / 256, 256, 0, c->stream>>>(n, c->d_g1 + off, c->d_rec[c->res_map[in]] + 4 * off);
         RT_HIP(c, hipGetLastError());
         c->rec_gserial[c->res_map[in]] = c->gbuf_serial;
     }
@@ -1860,10 +1907,11 @@ static int stage_run_ranges(rt_ctx* c, int frame, int stage, int part, int row0,
             if (rc == RT_OK)
             {
                 RT_HIP(c, hipEventRecord(c->ev_tail, c->tail_stream));
-                c->tail_pending_main = true; c->tail_pending_spec = true;
+                c->tail_pending_main = true;
                 c->tail_phys = final_phys;
             }
         }
+        c->resolve_on_tail = tail;
     }
     c->sub0 = c->sub1 = -1;
     c->subb0 = c->subb1 = 0;
@@ -1920,6 +1968,14 @@ int rt_frame_stage_end(rt_ctx* c, int stage)
     c->fuse = HaloFuse{};
     if (stage == 0) { const int rc = launch_next_raycast(c, c->f_frame); if (rc != RT_OK) return rc; }
     if (stage <= passes) { c->f_stage = stage + 1; return RT_OK; }
+    {
+        /* behind this frame's resolve (all its parts: the second lane has been joined above), on the stream it ran on: the
+         * look-ahead stage 0 waits for the one before the latest */
+        std::swap(c->ev_resolved[0], c->ev_resolved[1]);
+        RT_HIP(c, hipEventRecord(c->ev_resolved[0], c->resolve_on_tail ? c->tail_stream : c->stream));
+        if (c->n_resolved < 2) ++c->n_resolved;
+        c->resolve_on_tail = false;
+    }
     const int X = c->fX, Y = c->fY, Z = c->fZ;
     if (passes < 2)
     {
@@ -2124,7 +2180,7 @@ static int halo_range(rt_ctx* c, int row0, int n_rows)
  * rt_frame_stage_input reported */
 static int halo_phys(rt_ctx* c, int res)
 {
-    if (res >= RT_RES_PHYS && res < RT_RES_PHYS + 4 && c->d_rec[res - RT_RES_PHYS]) return res - RT_RES_PHYS;
+    if (res >= RT_RES_PHYS && res < RT_RES_PHYS + 5 && c->d_rec[res - RT_RES_PHYS]) return res - RT_RES_PHYS;
     if (res >= 0 && res <= 2) return c->res_map[res];
     return -1;
 }
@@ -2189,11 +2245,12 @@ int rt_halo_flags_unpack(rt_ctx* c, int row0, int n_rows, const void* device_src
     if (rc != RT_OK) return rc;
     if (row0 < c->row_end && row0 + n_rows > c->row_begin) RT_FAIL(c, RT_ERR_ARG, "flags may only be unpacked into halo rows");
     const int n = n_rows * c->W;
-    for (int set = 0; set < 2; ++set)
+    for (int set = 0; set < rt_ctx::NGSET; ++set)
         if (c->d_gset[set][2])
             k_halo_flags<false><<<(n + 255) / 256, 256, 0, c->stream>>>(c->d_gset[set][2], (size_t)(row0 - c->lrow0) * c->W, n, (uint8_t*)const_cast<void*>(device_src));
     RT_HIP(c, hipGetLastError());
     c->shaded_bits_stale = true; /* the LDS-staged spatial pass reads these rows' bits too */
+    c->mark_bits_epoch = 0;      /* and the halo marks' cached rows */
     if (row0 == c->lrow0 && row0 + n_rows == c->row_begin) c->halo_flags_epoch[0] = c->epoch;
     if (row0 == c->row_end && row0 + n_rows == c->lrow0 + c->lrows) c->halo_flags_epoch[1] = c->epoch;
     return RT_OK;
@@ -2247,12 +2304,32 @@ int rt_halo_mark_sides(rt_ctx* c, int frame, int pass, int n_pass, void* bitmaps
          * mark on the marking stream: ~3 us, and no staleness to track across the two G-buffer sets of the pipelined stage 0 */
         const int words = c->W / 32;
         if (!c->d_mark_bits) RT_HIP(c, hipMalloc(&c->d_mark_bits, (size_t)c->lrows * words * 4));
-        k_shaded_bitmap<<<dim3((c->W + 255) / 256, c->lrows), 256, 0, c->stream>>>(c->W, c->lrows, c->d_g1, c->d_mark_bits);
-        RT_HIP(c, hipGetLastError());
+        /* r05: the bits are a function of the camera, the scene and the options (own rows: what raycast writes, the same in both
+         * G-buffer sets; halo rows: the neighbours' flags, unpacked once per epoch), not of the frame: built once per epoch
+         * from a G-buffer traced under it and kept (r04 rebuilt them in front of every mark: 13 us alone, 84 us beside a 4K
+         * strip's raycast). A G-buffer of another epoch (marks before the first raycast after a change) is not cached.
+         * Ordering: a mark that finds the cache valid may run on another stream than the mark that built it — ev_mark_bits. */
+        const bool cacheable = c->gbuf_epoch == c->epoch;
+        if (!(cacheable && c->mark_bits_epoch == c->epoch) || !c->tune_mark_cache)
+        {
+            if (c->mark_bits_event_valid) RT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_mark_bits, 0)); /* earlier readers / writer */
+            k_shaded_bitmap<<<dim3((c->W + 255) / 256, c->lrows), 256, 0, c->stream>>>(c->W, c->lrows, c->d_g1, c->d_mark_bits);
+            RT_HIP(c, hipGetLastError());
+            c->mark_bits_epoch = cacheable ? c->epoch : 0;
+            c->mark_bits_rebuilt = true;
+        }
+        else RT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_mark_bits, 0)); /* the build (and every mark since) is in front of this one */
         k_halo_mark<true><<<grid, BLOCK, 0, c->stream>>>(P, c->d_g1, c->d_mark_bits, R, pass, n_pass);
     }
     else k_halo_mark<false><<<grid, BLOCK, 0, c->stream>>>(P, c->d_g1, nullptr, R, pass, n_pass);
     RT_HIP(c, hipGetLastError());
+    if (window)
+    {
+        /* whoever rebuilds the bits next (another stream, another epoch) waits for this reader; whoever reads them next waits for
+         * the build in front of it */
+        RT_HIP(c, hipEventRecord(c->ev_mark_bits, c->stream));
+        c->mark_bits_event_valid = true;
+    }
     {
         const size_t wmax = R.words[0] > R.words[1] ? R.words[0] : R.words[1];
         k_halo_scan_sides<<<dim3(halo_scan_chunks((int)((wmax - 1) / 2)), n_pass, 2), HALO_SCAN_THREADS, 0, c->stream>>>(R);
@@ -2399,6 +2476,25 @@ int rt_copy_parts(rt_ctx* c, int n, const void* const* src, void* const* dst, co
     /* up to 2048 workgroups per part: fewer, fatter ones (8 / 32) were slower on a busy GPU, profiles/r04_strip_interior_late.txt */
     const unsigned gx = (unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
     k_copy_parts<<<dim3(gx, (unsigned)n), 256, 0, c->stream>>>(P);
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+/* WIRE_MODEL (strip_mg.cpp): phase 0 = stamp the GPU clock on the current stream (in front of an exchange), phase 1 = hold
+ * the current stream until `ns` nanoseconds after that stamp (behind the exchange). slot: 0..7 (one per exchange in flight). */
+int rt_wire_delay(rt_ctx* c, int phase, int slot, unsigned long long ns)
+{
+    RT_CHECK_CTX(c);
+    if (slot < 0 || slot > 7 || (phase != 0 && phase != 1)) RT_FAIL(c, RT_ERR_ARG, "rt_wire_delay: phase 0 / 1, slot 0..7");
+    if (!c->d_wire)
+    {
+        RT_HIP(c, hipMalloc(&c->d_wire, 8 * sizeof(unsigned long long)));
+        RT_HIP(c, hipMemset(c->d_wire, 0, 8 * sizeof(unsigned long long)));
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0) khz = 100000; /* 100 MHz */
+        c->wall_khz = khz;
+    }
+    if (phase == 0) k_wire_stamp<<<1, 1, 0, c->stream>>>(c->d_wire + slot);
+    else k_wire_wait<<<1, 64, 0, c->stream>>>(c->d_wire + slot, (unsigned long long)((double)ns * (double)c->wall_khz * 1e-6));
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }
@@ -2685,6 +2781,8 @@ int rt_tuning(rt_ctx* c, int key, int value)
     else if (key == 18 && (value == 0 || value == 1)) c->tune_mark_quick = value;
     else if (key == 19 && (value == 0 || value == 1)) c->tune_mark_window = value;
     else if (key == 20 && (value == 0 || value == 1)) c->tune_fuse_tonemap = value;
+    else if (key == 21 && (value == 0 || value == 1)) { c->tune_mark_cache = value; c->mark_bits_epoch = 0; }
+    else if (key == 22 && value >= -1 && value <= 1) { c->tune_spec_free = value; c->spec_valid = false; c->spec_gen_valid = false; }
     else RT_FAIL(c, RT_ERR_ARG, "bad tuning key/value %d/%d", key, value);
     return RT_OK;
 }
@@ -2712,6 +2810,8 @@ int rt_tuning_get(rt_ctx* c, int key, int* value)
         case 18: *value = c->tune_mark_quick; break;
         case 19: *value = c->tune_mark_window; break;
         case 20: *value = c->tune_fuse_tonemap; break;
+        case 21: *value = c->tune_mark_cache; break;
+        case 22: *value = c->tune_spec_free; break;
         default: RT_FAIL(c, RT_ERR_ARG, "bad tuning key %d", key);
     }
     return RT_OK;

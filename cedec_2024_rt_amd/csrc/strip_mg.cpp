@@ -138,8 +138,11 @@ struct LocalHub
 };
 }  // namespace
 
+enum { HP_N_ = 7 };
+struct HostProfile { bool on = false; unsigned long long ns[HP_N_] = {}, calls[HP_N_] = {}; };
 struct rt_mg
 {
+    HostProfile hp;
     /* Halo plans live in three slots (slot = frame mod 3): while frame f runs with plan f, plan f+1 (marked during frame
      * f-1) rides on frame f's first halo message, and plan f+2 is being marked on the prep stream. Marking two frames
      * ahead (r03) takes the mark kernel off the critical path: since the next frame's stage 0 runs beside this frame's
@@ -160,6 +163,10 @@ struct rt_mg
      * measured with, always copied on the main stream). RT_MG_COMM_STREAM=1 in the environment keeps the separate stream. */
     bool comm_on_main = false, pending_on_main = false;
     bool interior_late = false; /* RT_MG_INTERIOR_LATE=1 */
+    double wire_gbs = 153.0, wire_lat_us = 5.0; /* WIRE_MODEL: one xGMI link per neighbour (bytes per ns = GB/s), fixed latency */
+    int wire_slot = 0;
+    unsigned long long stats_wire_ns = 0; /* modelled wire time of all exchanges since rt_mg_reset_stats */
+    bool counts_on_comm = false; /* RT_MG_COUNTS_ON_COMM=1 (A/B) */
     bool fuse_halos = true; /* sparse halos packed / unpacked by the spatial passes themselves (rt_halo_fuse_set, r03) */
     std::string err;
 
@@ -216,6 +223,19 @@ struct rt_mg
     rt_mg_stats stats;
 };
 
+/* RT_MG_HOST_PROFILE=1: where the host time of rt_mg_frame_step goes, printed by rt_mg_destroy (stderr). Scoped timers around the
+ * driver's calls into the C-ABI, HIP and RCCL; what is left is the driver's own bookkeeping. */
+enum { HP_STAGE = 0, HP_LAUNCH, HP_RCCL, HP_MARK, HP_PACK, HP_EVENT, HP_COUNTS, HP_N };
+static_assert(HP_N == HP_N_, "HostProfile size");
+static const char* const HP_NAME[HP_N] = {"rt_frame_stage_begin/_end/_fork", "rt_frame_stage_run_* (kernel launches)", "RCCL group (send/recv)", "rt_halo_mark_sides (memset + 2-3 launches)",
+                                          "pack / unpack / fuse_set / wire delay", "hipEventRecord / hipStreamWaitEvent", "counts copy + plan bookkeeping"};
+struct HpScope
+{
+    HostProfile* p; int k; std::chrono::steady_clock::time_point t0;
+    HpScope(HostProfile* p_, int k_) : p(p_ && p_->on ? p_ : nullptr), k(k_) { if (p) t0 = std::chrono::steady_clock::now(); }
+    ~HpScope() { if (p) { p->ns[k] += (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); p->calls[k] += 1; } }
+};
+#define HP(m, k) HpScope _hp(&(m)->hp, (k))
 #define MG_FAIL(m, code, ...)                     \
     do                                            \
     {                                             \
@@ -243,7 +263,8 @@ struct rt_mg
         if (_r != ncclSuccess) MG_FAIL(m, RT_ERR_COMM, "%s failed: %s", #call, g_rccl.GetErrorString(_r)); \
     } while (0)
 
-static bool is_rccl(const rt_mg* m) { return m->transport == RT_MG_TRANSPORT_RCCL || m->transport == RT_MG_TRANSPORT_RCCL_SELF; }
+static bool is_self(const rt_mg* m) { return m->transport == RT_MG_TRANSPORT_RCCL_SELF || m->transport == RT_MG_TRANSPORT_WIRE_MODEL; }
+static bool is_rccl(const rt_mg* m) { return m->transport == RT_MG_TRANSPORT_RCCL || is_self(m); }
 static hipStream_t main_stream(rt_mg* m)
 {
     void* s = nullptr;
@@ -457,7 +478,7 @@ static int rccl_handshake(rt_mg* m)
     }
     MG_NCCL(m, g_rccl.GroupEnd());
     MG_HIP(m, hipMemcpyAsync(h_recv, d + 8, sizeof(h_recv), hipMemcpyDeviceToHost, m->comm));
-    MG_HIP(m, hipEventRecord(m->ev_arrived, m->comm));
+    { HP(m, HP_EVENT); MG_HIP(m, hipEventRecord(m->ev_arrived, m->comm)); }
     int rc = wait_event_deadline(m, m->ev_arrived, "the RCCL handshake (16-byte grouped send/recv with the neighbours)");
     if (rc != RT_OK) return rc; /* d and h are leaked on purpose: the stream may still own them */
     int got[2][4];
@@ -491,11 +512,13 @@ int rt_mg_create(rt_ctx* ctx, int rank, int world, const int* bounds, int transp
         m->comm_on_main = !(e && e[0] == '1');
     }
     m->fuse_halos = !(flags & RT_MG_SEPARATE_PACK);
+    { const char* e = getenv("RT_MG_COUNTS_ON_COMM"); m->counts_on_comm = e && e[0] == '1'; }
     {
         const char* e = getenv("RT_MG_INTERIOR_LATE");
         m->interior_late = e && e[0] == '1';
     }
     memset(&m->stats, 0, sizeof(m->stats));
+    { const char* e = getenv("RT_MG_HOST_PROFILE"); m->hp.on = e && e[0] == '1'; }
     int ra = 0, rb = 0;
     MG_RT(m, rt_geometry(ctx, &m->W, &m->H, &ra, &rb, &m->halo));
     m->a = bounds[rank]; m->b = bounds[rank + 1];
@@ -599,8 +622,15 @@ int rt_mg_create(rt_ctx* ctx, int rank, int world, const int* bounds, int transp
         close(fd);
         if (m->shm.base == MAP_FAILED) { m->shm.base = nullptr; MG_FAIL(m, RT_ERR_COMM, "mmap of the shared segment failed"); }
     }
-    else if (world > 1 && transport == RT_MG_TRANSPORT_RCCL_SELF)
+    else if (world > 1 && (transport == RT_MG_TRANSPORT_RCCL_SELF || transport == RT_MG_TRANSPORT_WIRE_MODEL))
     {
+        if (transport == RT_MG_TRANSPORT_WIRE_MODEL)
+        {
+            const char* g = getenv("RT_MG_WIRE_GBS");
+            const char* l = getenv("RT_MG_WIRE_LAT_US");
+            if (g && atof(g) > 0.0) m->wire_gbs = atof(g);
+            if (l && atof(l) >= 0.0) m->wire_lat_us = atof(l);
+        }
         /* one rank alone with a communicator of its own: the peers of the partition do not exist, every message goes to self */
         if (!g_rccl.load()) MG_FAIL(m, RT_ERR_COMM, "%s", g_rccl.err.c_str());
         ncclUniqueId id;
@@ -614,6 +644,17 @@ int rt_mg_create(rt_ctx* ctx, int rank, int world, const int* bounds, int transp
 int rt_mg_destroy(rt_mg* m)
 {
     if (!m) return RT_ERR_ARG;
+    if (m->hp.on && m->stats.frames)
+    {
+        unsigned long long sum = 0;
+        for (int k = 0; k < HP_N; ++k) sum += m->hp.ns[k];
+        fprintf(stderr, "rt_mg host profile, rank %d: %llu frames since the last reset, %.1f us per frame in rt_mg_frame_step\n", m->rank, m->stats.frames,
+                (double)m->stats.host_ns / (double)m->stats.frames / 1e3);
+        for (int k = 0; k < HP_N; ++k)
+            fprintf(stderr, "  %-46s %7.1f us per frame, %5.1f calls per frame\n", HP_NAME[k], (double)m->hp.ns[k] / (double)m->stats.frames / 1e3,
+                    (double)m->hp.calls[k] / (double)m->stats.frames);
+        fprintf(stderr, "  %-46s %7.1f us per frame\n", "the driver's own bookkeeping (rest)", ((double)m->stats.host_ns - (double)sum) / (double)m->stats.frames / 1e3);
+    }
     if (m->ctx) rt_sync(m->ctx);
     if (m->comm) hipStreamSynchronize(m->comm);
     if (m->prep) hipStreamSynchronize(m->prep);
@@ -662,6 +703,7 @@ int rt_mg_get_stats(rt_mg* m, rt_mg_stats* out)
         if (hipEventSynchronize(m->ev_t1) == hipSuccess && hipEventElapsedTime(&ms, m->ev_t0, m->ev_t1) == hipSuccess)
             m->stats.gpu_ns_per_frame = (unsigned long long)((double)ms * 1e6 / (double)(m->frames_timed - 1));
     }
+    m->stats.wire_ns = m->stats_wire_ns;
     *out = m->stats;
     return RT_OK;
 }
@@ -669,6 +711,8 @@ int rt_mg_reset_stats(rt_mg* m)
 {
     if (!m) return RT_ERR_ARG;
     memset(&m->stats, 0, sizeof(m->stats));
+    m->stats_wire_ns = 0;
+    memset(m->hp.ns, 0, sizeof(m->hp.ns)); memset(m->hp.calls, 0, sizeof(m->hp.calls));
     m->frames_timed = 0;
     return RT_OK;
 }
@@ -720,15 +764,37 @@ static int post(rt_mg* m, std::vector<Exchange>&& xs)
     }
     if (is_rccl(m))
     {
-        const bool self = m->transport == RT_MG_TRANSPORT_RCCL_SELF;
+        const bool self = is_self(m);
+        const bool wire = m->transport == RT_MG_TRANSPORT_WIRE_MODEL;
         const bool on_main = m->comm_on_main && (m->n_itr == 0 || m->two_lanes); /* one lane with interior rows: they follow the boundary rows on the main stream */
         hipStream_t cs = on_main ? ms : m->comm;
         m->pending_on_main = on_main;
         if (!on_main)
         {
-            MG_HIP(m, hipEventRecord(m->ev_packed, ms));
-            MG_HIP(m, hipStreamWaitEvent(cs, m->ev_packed, 0));
+            { HP(m, HP_EVENT); MG_HIP(m, hipEventRecord(m->ev_packed, ms)); }
+            { HP(m, HP_EVENT); MG_HIP(m, hipStreamWaitEvent(cs, m->ev_packed, 0)); }
         }
+        unsigned long long wire_ns = 0;
+        if (wire)
+        {
+            /* the data of this exchange is ready when stream `cs` gets here: note the GPU clock (rt_wire_delay runs on the
+             * context's current stream) */
+            size_t most = 0;
+            for (auto& x : m->pending_x)
+            {
+                size_t out = 0, in = 0;
+                for (auto& p : x.parts) { out += p.send_bytes; in += p.recv_bytes; }
+                most = std::max(most, std::max(out, in)); /* one full-duplex link per neighbour */
+            }
+            wire_ns = (unsigned long long)((double)most / m->wire_gbs + m->wire_lat_us * 1e3);
+            m->stats_wire_ns += wire_ns;
+            if (cs != ms) MG_RT(m, rt_set_stream(m->ctx, cs));
+            int wrc; { HP(m, HP_PACK); wrc = rt_wire_delay(m->ctx, 0, m->wire_slot, 0); }
+            if (cs != ms) rt_set_stream(m->ctx, ms);
+            if (wrc != RT_OK) MG_FAIL(m, wrc, "rt_wire_delay: %s", rt_last_error(m->ctx));
+        }
+        {
+        HP(m, HP_RCCL);
         MG_NCCL(m, g_rccl.GroupStart());
         for (auto& x : m->pending_x)
             for (auto& p : x.parts)
@@ -738,6 +804,15 @@ static int post(rt_mg* m, std::vector<Exchange>&& xs)
                 MG_NCCL(m, g_rccl.Recv(p.recv, p.recv_bytes, ncclUint8, self ? 0 : x.peer, m->nccl, cs));
             }
         MG_NCCL(m, g_rccl.GroupEnd());
+        }
+        if (wire)
+        {
+            if (cs != ms) MG_RT(m, rt_set_stream(m->ctx, cs));
+            int wrc; { HP(m, HP_PACK); wrc = rt_wire_delay(m->ctx, 1, m->wire_slot, wire_ns); }
+            if (cs != ms) rt_set_stream(m->ctx, ms);
+            if (wrc != RT_OK) MG_FAIL(m, wrc, "rt_wire_delay: %s", rt_last_error(m->ctx));
+            m->wire_slot = (m->wire_slot + 1) & 7;
+        }
         if (!on_main) MG_HIP(m, hipEventRecord(m->ev_arrived, cs));
         return RT_OK;
     }
@@ -748,7 +823,7 @@ static int post(rt_mg* m, std::vector<Exchange>&& xs)
         for (auto& p : x.parts) msg->parts.push_back({p.send, p.send_bytes});
         MG_HIP(m, hipEventCreateWithFlags(&msg->ready, hipEventDisableTiming));
         MG_HIP(m, hipEventCreateWithFlags(&msg->consumed, hipEventDisableTiming));
-        MG_HIP(m, hipEventRecord(msg->ready, ms));
+        { HP(m, HP_EVENT); MG_HIP(m, hipEventRecord(msg->ready, ms)); }
         m->hub->box[{m->rank, x.peer}].push_back(msg);
         m->pending_local.push_back(msg);
     }
@@ -816,7 +891,7 @@ static int complete(rt_mg* m)
         auto msg = q.front();
         q.pop_front();
         if (msg->parts.size() != x.parts.size()) MG_FAIL(m, RT_ERR_STATE, "LOCAL transport: message shape mismatch between ranks %d and %d", x.peer, m->rank);
-        MG_HIP(m, hipStreamWaitEvent(ms, msg->ready, 0));
+        { HP(m, HP_EVENT); MG_HIP(m, hipStreamWaitEvent(ms, msg->ready, 0)); }
         if (x.parts.size() > 8) MG_FAIL(m, RT_ERR_STATE, "LOCAL transport: more than 8 parts in a message");
         const void* src[8];
         void* dst[8];
@@ -828,7 +903,7 @@ static int complete(rt_mg* m)
             src[i] = msg->parts[i].first; dst[i] = x.parts[i].recv; nb[i] = x.parts[i].recv_bytes;
         }
         MG_RT(m, rt_copy_parts(m->ctx, (int)x.parts.size(), src, dst, nb));
-        MG_HIP(m, hipEventRecord(msg->consumed, ms));
+        { HP(m, HP_EVENT); MG_HIP(m, hipEventRecord(msg->consumed, ms)); }
         msg->consumed_recorded = true;
     }
     return RT_OK;
@@ -841,6 +916,7 @@ static size_t list_bytes(uint32_t count) { return (size_t)(count > 0 ? count : 1
 static int fetch_counts(rt_mg* m, int slot, hipStream_t st)
 {
     const size_t rows = (size_t)m->max_passes * 2 * m->sides.size();
+    HP(m, HP_COUNTS);
     MG_HIP(m, hipMemcpy2DAsync(m->cnt_all[slot], 4, m->bm_arena[slot], m->bm_stride * 4, 4, rows, hipMemcpyDeviceToHost, st));
     return RT_OK;
 }
@@ -856,6 +932,7 @@ static int mark_plan(rt_mg* m, int frame, int slot, hipStream_t writer)
         if (m->transport == RT_MG_TRANSPORT_LOCAL) { int rc = local_guard(m, s.last_bm[slot], writer); if (rc != RT_OK) return rc; }
         bm[s.side] = s.need_bm[slot];
     }
+    HP(m, HP_MARK);
     MG_RT(m, rt_halo_mark_sides(m->ctx, frame, 0, m->passes, bm[0], bm[1]));
     return RT_OK;
 }
@@ -877,6 +954,7 @@ static void add_bitmap_parts(rt_mg* m, int slot, std::vector<Exchange>& xs)
 static int run_rows(rt_mg* m, int stage, int part, const int (*ranges)[2], int n, bool second_lane)
 {
     if (n <= 0) return RT_OK;
+    HP(m, HP_LAUNCH);
     MG_RT(m, rt_frame_stage_run_ranges(m->ctx, m->frame, stage, part, n, &ranges[0][0], second_lane ? 1 : 0));
     return RT_OK;
 }
@@ -903,6 +981,7 @@ static int post_halo(rt_mg* m, int stage, int buf, bool with_plan)
             bms[i] = s.give_bm[slot] + (size_t)k * s.bm_words;
             dsts[i] = s.send_buf[k & 1];
         }
+        HP(m, HP_PACK);
         MG_RT(m, rt_halo_pack_sparse_ranges(m->ctx, buf, (int)m->sides.size(), row0, nrows, bms, dsts));
     }
     for (size_t i = 0; i < m->sides.size(); ++i)
@@ -958,17 +1037,25 @@ static int finish_halo(rt_mg* m)
             bms[i] = s.need_bm[slot] + (size_t)k * s.bm_words;
             srcs[i] = s.recv_buf;
         }
+        HP(m, HP_PACK);
         MG_RT(m, rt_halo_unpack_sparse_ranges(m->ctx, m->pending_buf, (int)m->sides.size(), row0, nrows, bms, srcs));
     }
     if (carried)
     {
-        /* the plan of frame + 1 is complete on the device: its counts travel to the host behind it, on the prep
-         * stream (the spatial passes of this frame do not wait for that copy) */
-        MG_HIP(m, hipEventRecord(m->ev_carried, ms));
-        MG_HIP(m, hipStreamWaitEvent(m->prep, m->ev_carried, 0));
-        rc = fetch_counts(m, nslot, m->prep);
+        /* the plan of frame + 1 is complete on the device: its counts travel to the host behind it, on the prep (= tail) stream
+         * (the spatial passes of this frame do not wait for that copy). There the copy queues behind the previous frame's resolve and
+         * the marks of frame + 2, so the host — which cannot size the messages of frame + 1 without the counts — wakes up late, and
+         * with it the look-ahead stage 0 of frame + 2 it enqueues. r05 A/B, RT_MG_COUNTS_ON_COMM=1 (the idle communication stream:
+         * counts 400 us earlier at 4K): SLOWER, 0.868 -> 1.19 ms at 4K and 0.293 -> 0.365 at 1080p (rank 4 of 8, MIRROR) — with
+         * stage 0 of frame + 2 started that early, generate and resolve hold the wavefront slots and the main stream's chain of
+         * small launches (pack, exchange, boundary pass, ...) crawls behind them: 205 us for the pack that takes 13 alone
+         * (profiles/r05_strip_timelines.txt). The late counts are the throttle that keeps the chain fed. */
+        hipStream_t cs = m->counts_on_comm ? m->comm : m->prep;
+        { HP(m, HP_EVENT); MG_HIP(m, hipEventRecord(m->ev_carried, ms)); }
+        { HP(m, HP_EVENT); MG_HIP(m, hipStreamWaitEvent(cs, m->ev_carried, 0)); }
+        rc = fetch_counts(m, nslot, cs);
         if (rc != RT_OK) return rc;
-        MG_HIP(m, hipEventRecord(m->ev_plan[nslot], m->prep));
+        { HP(m, HP_EVENT); MG_HIP(m, hipEventRecord(m->ev_plan[nslot], cs)); }
         m->plan_frame[nslot] = (long long)m->frame + 1;
         rt_state_epoch(m->ctx, &m->plan_epoch[nslot]);
         m->plan_passes = m->passes;
@@ -1006,7 +1093,7 @@ int rt_mg_frame_begin(rt_mg* m, int frame, int clear_first)
         }
     }
     m->seg = rt_mg::SEG_RAYCAST;
-    MG_HIP(m, hipEventRecord(m->frames_timed == 0 ? m->ev_t0 : m->ev_t1, main_stream(m)));
+    { HP(m, HP_EVENT); MG_HIP(m, hipEventRecord(m->frames_timed == 0 ? m->ev_t0 : m->ev_t1, main_stream(m))); }
     m->frames_timed += 1;
     m->stats.frames += 1;
     if (m->use_sparse && !m->warm) m->stats.cold_frames += 1;
@@ -1037,9 +1124,9 @@ static int frame_step(rt_mg* m, int* more)
         case rt_mg::SEG_IDLE: MG_FAIL(m, RT_ERR_STATE, "rt_mg_frame_begin first");
         case rt_mg::SEG_RAYCAST:
         {
-            MG_RT(m, rt_frame_stage_begin(m->ctx, m->frame, 0, m->clear_first));
+            { HP(m, HP_STAGE); MG_RT(m, rt_frame_stage_begin(m->ctx, m->frame, 0, m->clear_first)); }
             /* [clear,] raycast of all owned rows: the marks and the second lane need the G-buffer */
-            MG_RT(m, rt_frame_stage_run_part(m->ctx, m->frame, 0, 1, m->a, m->b));
+            { HP(m, HP_LAUNCH); MG_RT(m, rt_frame_stage_run_part(m->ctx, m->frame, 0, 1, m->a, m->b)); }
             if (!m->use_sparse || m->warm) { m->seg = rt_mg::SEG_GENERATE; return frame_step(m, more); }
             uint64_t epoch = 0;
             rt_state_epoch(m->ctx, &epoch);
@@ -1076,8 +1163,10 @@ static int frame_step(rt_mg* m, int* more)
             /* cold frame, 2: what I will gather from each neighbour in every pass of THIS frame. A plan the previous
              * frame carried for this slot may still be on its way to the host on the prep stream (counts copy into
              * cnt_all[slot], reading bm_arena[slot]): the main stream waits for it before it re-marks the slot. */
-            MG_HIP(m, hipStreamWaitEvent(ms, m->ev_plan[slot], 0));
-            MG_HIP(m, hipStreamWaitEvent(ms, m->ev_marked[slot], 0)); /* a stale mark of this slot (other epoch) on the prep stream */
+            { HP(m, HP_EVENT); MG_HIP(m, hipStreamWaitEvent(ms, m->ev_plan[slot], 0)); }
+            /* stale look-ahead marks (other epoch) still queued on the prep stream: of this slot — they write its bitmaps — and of
+             * the other slots too: every mark may rebuild the context's shaded-bit rows, which the mark below reads */
+            for (auto& e : m->ev_marked) MG_HIP(m, hipStreamWaitEvent(ms, e, 0));
             m->marked_frame[slot] = -1;
             rc = mark_plan(m, m->frame, slot, ms);
             if (rc != RT_OK) return rc;
@@ -1098,7 +1187,7 @@ static int frame_step(rt_mg* m, int* more)
             rc = fetch_counts(m, slot, ms);
             if (rc != RT_OK) return rc;
             /* the one host wait of a cold frame: message sizes */
-            MG_HIP(m, hipEventRecord(m->ev_arrived2, ms));
+            { HP(m, HP_EVENT); MG_HIP(m, hipEventRecord(m->ev_arrived2, ms)); }
             rc = wait_event_deadline(m, m->ev_arrived2, "the cold frame's bitmap exchange");
             if (rc != RT_OK) return rc;
             m->plan_frame[slot] = m->frame;
@@ -1112,7 +1201,7 @@ static int frame_step(rt_mg* m, int* more)
             const bool lanes = m->two_lanes && exchanges && m->n_itr > 0;
             if (lanes)
             {
-                MG_RT(m, rt_frame_stage_fork(m->ctx)); /* the second lane starts behind the raycast */
+                { HP(m, HP_STAGE); MG_RT(m, rt_frame_stage_fork(m->ctx)); /* the second lane starts behind the raycast */ }
                 rc = run_rows(m, 0, 2, m->itr, m->n_itr, true);
                 if (rc != RT_OK) return rc;
             }
@@ -1123,8 +1212,8 @@ static int frame_step(rt_mg* m, int* more)
                  * frame: then the first exchange below waits for that mark, once). */
                 uint64_t epoch = 0;
                 rt_state_epoch(m->ctx, &epoch);
-                MG_HIP(m, hipEventRecord(m->ev_gbuf, ms));
-                MG_HIP(m, hipStreamWaitEvent(m->prep, m->ev_gbuf, 0));
+                { HP(m, HP_EVENT); MG_HIP(m, hipEventRecord(m->ev_gbuf, ms)); }
+                { HP(m, HP_EVENT); MG_HIP(m, hipStreamWaitEvent(m->prep, m->ev_gbuf, 0)); }
                 MG_RT(m, rt_set_stream(m->ctx, m->prep));
                 for (int ahead = 1; ahead <= 2 && rc == RT_OK; ++ahead)
                 {
@@ -1155,9 +1244,9 @@ static int frame_step(rt_mg* m, int* more)
                 if (carry) MG_HIP(m, hipStreamWaitEvent(ms, m->ev_marked[nslot], 0)); /* marked during the previous frame: long done */
                 rc = post_halo(m, 0, RT_RES_PHYS + buf, carry);
                 if (rc != RT_OK) return rc;
-                MG_RT(m, rt_frame_stage_end(m->ctx, 0));
+                { HP(m, HP_STAGE); MG_RT(m, rt_frame_stage_end(m->ctx, 0)); }
             }
-            else MG_RT(m, rt_frame_stage_end(m->ctx, 0));
+            else { HP(m, HP_STAGE); MG_RT(m, rt_frame_stage_end(m->ctx, 0)); }
             m->stage = 1;
             m->seg = P > 0 ? rt_mg::SEG_PASS : rt_mg::SEG_FINAL;
             return exchanges ? RT_OK : frame_step(m, more);
@@ -1166,7 +1255,7 @@ static int frame_step(rt_mg* m, int* more)
         {
             const int s = m->stage; /* spatial pass s - 1 */
             const bool lanes = m->two_lanes && exchanges && m->n_itr > 0;
-            MG_RT(m, rt_frame_stage_begin(m->ctx, m->frame, s, 0));
+            { HP(m, HP_STAGE); MG_RT(m, rt_frame_stage_begin(m->ctx, m->frame, s, 0)); }
             /* interior rows on the second lane: beside the exchange in flight (default: on real links they hide the wire), or —
              * RT_MG_INTERIOR_LATE=1 — only once the exchange has completed: its kernel then does not queue for wavefront slots
              * behind them (A/B on the stand-in transports, profiles/r04_strip_interior_late.txt) */
@@ -1174,7 +1263,7 @@ static int frame_step(rt_mg* m, int* more)
             if (exchanges) { rc = finish_halo(m); if (rc != RT_OK) return rc; }
             if (lanes && m->interior_late)
             {
-                MG_RT(m, rt_frame_stage_fork(m->ctx)); /* the lane starts behind the completed exchange */
+                { HP(m, HP_STAGE); MG_RT(m, rt_frame_stage_fork(m->ctx)); /* the lane starts behind the completed exchange */ }
                 rc = run_rows(m, s, 0, m->itr, m->n_itr, true);
                 if (rc != RT_OK) return rc;
             }
@@ -1195,7 +1284,7 @@ static int frame_step(rt_mg* m, int* more)
                         f.send_list[sd.side] = sd.send_buf[s & 1];
                     }
                 }
-                MG_RT(m, rt_halo_fuse_set(m->ctx, &f));
+                { HP(m, HP_PACK); MG_RT(m, rt_halo_fuse_set(m->ctx, &f)); }
             }
             if (exchanges)
             {
@@ -1213,16 +1302,16 @@ static int frame_step(rt_mg* m, int* more)
                 if (rc != RT_OK) return rc;
                 posted = true;
             }
-            MG_RT(m, rt_frame_stage_end(m->ctx, s));
+            { HP(m, HP_STAGE); MG_RT(m, rt_frame_stage_end(m->ctx, s)); }
             m->stage = s + 1;
             if (s == P) m->seg = rt_mg::SEG_FINAL;
             return posted ? RT_OK : frame_step(m, more);
         }
         case rt_mg::SEG_FINAL:
         {
-            MG_RT(m, rt_frame_stage_begin(m->ctx, m->frame, P + 1, 0));
-            MG_RT(m, rt_frame_stage_run(m->ctx, m->frame, P + 1, m->a, m->b));
-            MG_RT(m, rt_frame_stage_end(m->ctx, P + 1));
+            { HP(m, HP_STAGE); MG_RT(m, rt_frame_stage_begin(m->ctx, m->frame, P + 1, 0)); }
+            { HP(m, HP_LAUNCH); MG_RT(m, rt_frame_stage_run(m->ctx, m->frame, P + 1, m->a, m->b)); }
+            { HP(m, HP_STAGE); MG_RT(m, rt_frame_stage_end(m->ctx, P + 1)); }
             m->seg = rt_mg::SEG_IDLE;
             *more = 0;
             return RT_OK;

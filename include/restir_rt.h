@@ -231,6 +231,9 @@ int rt_side_stream(rt_ctx* ctx, int which, void** hip_stream); /* which = 0: the
 /* n <= 8 device-to-device copies in ONE launch on the context's current stream: what the strip driver's stand-in transports
  * (LOCAL, MIRROR) move the parts of an exchange with, as one grouped ncclSend/ncclRecv is one launch */
 int rt_copy_parts(rt_ctx* ctx, int n, const void* const* src, void* const* dst, const size_t* bytes);
+/* RT_MG_TRANSPORT_WIRE_MODEL: a dependent delay on the context's current stream. phase 0 notes the GPU wall clock when the stream
+ * reaches it; phase 1 holds the stream until `ns` after that note (slot 0..7). No host sleep, one sleeping wavefront. */
+int rt_wire_delay(rt_ctx* ctx, int phase, int slot, unsigned long long ns);
 int rt_geometry(rt_ctx* ctx, int* width, int* height, int* row_begin, int* row_end, int* halo);
 /* device addresses of n_rows storage rows of a reservoir buffer: 64-B records and 16-B radiance side
  * records; dense halos travel from / into the buffers themselves */
@@ -255,7 +258,12 @@ enum { RT_MG_TRANSPORT_RCCL = 0, RT_MG_TRANSPORT_LOCAL = 1, RT_MG_TRANSPORT_MIRR
        RT_MG_TRANSPORT_RCCL_SELF = 4 /* MIRROR with the real thing on the chain (r04): one rank alone, a ONE-rank RCCL communicator, every
                                   exchange = the grouped ncclSend/ncclRecv of the RCCL transport with the true per-side message sizes, on the
                                   stream the RCCL transport uses, addressed to the rank itself — so overhead measurements on a 1-GPU box
-                                  contain RCCL's launch and copy kernel (no xGMI wire time: bytes / link rate is added separately) */ };
+                                  contain RCCL's launch and copy kernel (no xGMI wire time) */,
+       RT_MG_TRANSPORT_WIRE_MODEL = 5 /* RCCL_SELF + the xGMI wire (r05): an exchange completes no earlier than
+                                  max over the two neighbours (bytes to / from that neighbour) / RT_MG_WIRE_GBS (default 153 GB/s, one
+                                  link per neighbour) + RT_MG_WIRE_LAT_US (default 5 us) after its data was ready on the stream — a
+                                  dependent delay on the exchange's stream (rt_wire_delay), not a host sleep. What tools/strip_overhead.py
+                                  reports as THE bound of an N-strip frame on one-GPU boxes. */ };
 enum { RT_MG_DENSE = 1 /* whole 87-row bands, sent from the buffers in place */, RT_MG_ONE_LANE = 2 /* no second stream */,
        RT_MG_SEPARATE_PACK = 4 /* sparse halos packed / unpacked by launches of their own (r02) instead of by the spatial passes */ };
 typedef struct
@@ -265,6 +273,7 @@ typedef struct
     unsigned long long plan_wait_ns;        /* host time waiting for the next frame's plan counts (0 in a steady loop) */
     unsigned long long bytes_sent, messages, records_sent;
     unsigned long long gpu_ns_per_frame;    /* HIP-event time between the starts of the first and the latest frame / (frames - 1) */
+    unsigned long long wire_ns;             /* WIRE_MODEL: modelled link time of all exchanges (sum of the dependent delays asked for) */
 } rt_mg_stats;
 /* strips of >= halo rows; row_cost NULL: near-equal heights; else minimise the most expensive strip
  * (row_cost[r] = e.g. shaded pixels of storage row r). bounds: world + 1 entries. */
@@ -424,7 +433,13 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
  * key 20 (r05): 1 (default) = the resolve kernel of rt_frame / rt_frame_stage tone-maps the pixel it has just accumulated
  * (tone_mapping reads nothing but the pixel's own accumulation value, common/kernels/common.cu:30-74): no k_tone_mapping
  * launch, no second read of the accumulation buffer. 0 = two launches as the reference. rt_resolve / rt_tone_mapping, the
- * per-kernel entry points, are always the reference's two kernels. Same pixels. */
+ * per-kernel entry points, are always the reference's two kernels. Same pixels.
+ * key 21 (r05): 1 (default) = the shaded-bit rows rt_halo_mark reads (key 19) are built once per camera / scene / option epoch
+ * instead of in front of every mark. 0 = every time (r04). Same marks.
+ * key 22 (r05): -1 (default) = for strips, 1 = always: the pipelined stage 0 (key 14) of frame f+1 waits neither for the main stream (when frame f took
+ * its own stage 0 from the look-ahead stream: its inputs were written there) nor for resolve(f-1): a third G-buffer set and a
+ * fifth reservoir buffer make resolve(f-2) the last reader of what it overwrites. 0 = as r04 (behind the main stream and
+ * behind resolve(f-1)). Same results. */
 int rt_tuning(rt_ctx* ctx, int key, int value);
 /* the value a key holds now (measurement records name the builder / variants that were really used) */
 int rt_tuning_get(rt_ctx* ctx, int key, int* value);

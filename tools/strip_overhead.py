@@ -5,6 +5,9 @@ csrc/strip_mg.cpp) with one rank ALONE on the GPU, its neighbours replaced by a 
   --transport rccl_self   the real grouped ncclSend/ncclRecv of the RCCL transport, true message sizes, to the rank itself on
                           a one-rank communicator (r04): RCCL's launch + copy kernel are on the chain; the xGMI wire is not
                           (xgmi_wire_us_per_frame = bytes per frame and side / 153 GB/s: a stated addend)
+  --transport wire_model  rccl_self + the wire ON the chain (r05): every exchange completes no earlier than
+                          max over the neighbours (bytes to / from it) / RT_MG_WIRE_GBS (153) + RT_MG_WIRE_LAT_US (5) after its
+                          data was ready on the stream (a dependent delay on the GPU, csrc/strip_mg.cpp post()). THE bound.
 
 Same launches, same pack/unpack work and message sizes as a real exchange; the peers' skew is missing. Every measurement
 runs in a PROCESS OF ITS OWN (HIP maps streams onto hardware queues by creation history: a process that has created and
@@ -36,7 +39,7 @@ def measure(W, H, N, flags, tris, frames=40, warm=6, rank=None, bounds=None, tra
     from cedec_2024_rt_amd import api, scenes
     from cedec_2024_rt_amd.types import bench_options
 
-    T = {"mirror": api.RT_MG_TRANSPORT_MIRROR, "rccl_self": api.RT_MG_TRANSPORT_RCCL_SELF}[transport]
+    T = {"mirror": api.RT_MG_TRANSPORT_MIRROR, "rccl_self": api.RT_MG_TRANSPORT_RCCL_SELF, "wire_model": api.RT_MG_TRANSPORT_WIRE_MODEL}[transport]
     bounds = bounds or api.mg_partition(H, N)
     rank = N // 2 if rank is None else rank
     a, b = bounds[rank]
@@ -62,7 +65,10 @@ def measure(W, H, N, flags, tris, frames=40, warm=6, rank=None, bounds=None, tra
     out = dict(rows=b - a, ms_per_frame=round(wall / frames * 1e3, 4), gpu_event_ms_per_frame=round(st["gpu_ns_per_frame"] / 1e6, 4), host_us=round(st["host_ns"] / frames / 1e3, 1),
                host_loop_us=round(t_host / frames * 1e6, 1), plan_wait_us=round(st["plan_wait_ns"] / frames / 1e3, 1),
                cold_frames=st["cold_frames"], MB_sent_per_frame=round(st["bytes_sent"] / frames / 1e6, 3),
-               messages_per_frame=st["messages"] / frames, transport=transport)
+               messages_per_frame=st["messages"] / frames, transport=transport,
+               wire_model_us_per_frame=round(st["wire_ns"] / frames / 1e3, 1))
+    if transport == "wire_model":
+        out["wire_model"] = dict(GBs=float(os.environ.get("RT_MG_WIRE_GBS", "153")), latency_us=float(os.environ.get("RT_MG_WIRE_LAT_US", "5")))
     sides = (1 if rank in (0, N - 1) else 2) if N > 1 else 0
     out["xgmi_wire_us_per_frame"] = round(st["bytes_sent"] / frames / max(sides, 1) / (XGMI_GBS * 1e9) * 1e6, 1) if sides else 0.0
     mg.close()
@@ -88,7 +94,7 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--only", default=None, help="WxH:N:sparse|dense|onelane|separate[:rank] — one case in this process")
     ap.add_argument("--bounds", default=None, help="strip edges for --only: 0,a,b,...,H")
-    ap.add_argument("--transport", default="mirror", choices=("mirror", "rccl_self"))
+    ap.add_argument("--transport", default="mirror", choices=("mirror", "rccl_self", "wire_model"))
     ap.add_argument("--sizes", default="1920x1080,3840x2160")
     ap.add_argument("--ns", default="2,4,8")
     ap.add_argument("--rounds", type=int, default=4, help="balance rounds for N = 8 (0: equal rows only)")
@@ -135,13 +141,14 @@ def main():
                 row = dict(rows=[b - a for a, b in bounds], ms=t, max_ms=max(t), speedup_bound=round(single / max(t), 2),
                            MB_sent_per_frame=max(rk[0]["MB_sent_per_frame"] for rk in runs),
                            xgmi_wire_us_per_frame=max(rk[0]["xgmi_wire_us_per_frame"] for rk in runs),
-                           host_us=max(rk[0]["host_us"] for rk in runs))
+                           host_us=max(rk[0]["host_us"] for rk in runs),
+                           wire_model_us_per_frame=max(rk[0].get("wire_model_us_per_frame", 0.0) for rk in runs))
                 name = "equal rows" if it == 0 else ("rows cut by measured cost" if final else f"balance round {it}")
                 res[f"{W}x{H} N={N} all ranks, {name}"] = row
                 print(json.dumps({f"{W}x{H} N={N} all ranks, {name}": row}), flush=True)
                 if final:
                     if rounds:
-                        cuts[f"{W}x{H}:{N}:{sha}"] = dict(bounds=[bounds[0][0]] + [e for _, e in bounds], transport=T, max_ms=max(t),
+                        cuts[f"{W}x{H}:{N}:{sha}"] = dict(bounds=[bounds[0][0]] + [e for _, e in bounds], transport=T, max_ms=max(t), build_id=api.build_id(),
                                                           equal_rows_max_ms=res[f"{W}x{H} N={N} all ranks, equal rows"]["max_ms"])
                     break
                 cost = np.zeros(H)
