@@ -43,15 +43,18 @@ class RtError(RuntimeError):
     pass
 
 
-_lib = None
+EXP_LIB_PATH = os.path.join(HERE, "librestir_rt_exp.so")
+_libs = {}
 
 
-def load_library():
-    """Load librestir_rt.so and declare prototypes. Raises if the library was not built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = os.environ.get("RT_LIB_PATH", LIB_PATH)  # A/B builds of the same HIP library (tools/experiments)
+def load_library(exp=False):
+    """Load librestir_rt.so (exp=True: librestir_rt_exp.so, the same sources built with -DRT_EXPERIMENTS = the product plus the A/B
+    forms that were measured and left off; the variant tests and the A/B tools use it) and declare prototypes. Raises if the
+    library was not built."""
+    exp = bool(exp)
+    if exp in _libs:
+        return _libs[exp]
+    path = os.environ.get("RT_LIB_PATH", EXP_LIB_PATH if exp else LIB_PATH)  # A/B builds of the same HIP library (tools/experiments)
     if not os.path.exists(path):
         raise RtError(f"{path} not built: run __graft_entry__.build() (make -C cedec_2024_rt_amd/csrc)")
     # One HIP runtime per process: the torch wheel bundles its own libamdhip64 (same SONAME as
@@ -169,7 +172,7 @@ def load_library():
     L.rt_mg_get_stats.argtypes = [vp, vp]
     L.rt_mg_reset_stats.argtypes = [vp]
     L.rt_mg_selftest_rccl.argtypes = [C.c_size_t]
-    _lib = L
+    _libs[exp] = L
     return L
 
 
@@ -318,8 +321,8 @@ _BUF_DTYPE = {
 class Renderer:
     """One HIP context = one GPU = one row strip of the image (the whole image by default)."""
 
-    def __init__(self, width, height, device=0, rows=None, halo=0, stream=None):
-        self.L = load_library()
+    def __init__(self, width, height, device=0, rows=None, halo=0, stream=None, exp=False):
+        self.L = load_library(exp or bool(os.environ.get("RT_EXPERIMENTS")))  # exp: the library with the A/B forms (rt_tuning's experiment keys)
         self.W, self.H = int(width), int(height)
         r0, r1 = rows if rows is not None else (0, self.H)
         self.rows = (int(r0), int(r1))

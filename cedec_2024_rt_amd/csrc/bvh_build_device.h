@@ -144,10 +144,11 @@ __global__ void k_tri_extents(const float* __restrict__ tris, int n, float* __re
     }
 }
 
-/* ------------------------------------------------------------------ 3. PLOC */
 #ifndef RT_PLOC_RADIUS
 #define RT_PLOC_RADIUS 16
 #endif
+#ifdef RT_EXPERIMENTS /* builder 2 (PLOC + host SAH over the top, r02): A/B only since the device SAH builder (3) */
+/* ------------------------------------------------------------------ 3. PLOC */
 struct PlocState
 {
     unsigned int m;        /* clusters left */
@@ -235,6 +236,7 @@ __global__ void k_ploc_init(int n, const uint32_t* __restrict__ ids /* sorted po
     const float* b = prim_boxes + 6 * (size_t)ids[i];
     for (int k = 0; k < 6; ++k) cbox[6 * (size_t)i + k] = b[k];
 }
+#endif /* RT_EXPERIMENTS */
 /* parent links of the cluster roots under the host-built top of the tree */
 __global__ void k_scatter_int(int n, const int* __restrict__ idx, const int* __restrict__ val, int* __restrict__ dst)
 {

@@ -240,6 +240,7 @@ static int collapse_wide(const std::vector<BvhNode>& bin, const rt_triangle* tri
     return height;
 }
 
+#ifdef RT_EXPERIMENTS /* builder 1: the host reference of the device SAH builder (3), A/B and tests only */
 /* ---- high-quality build (the reference asks HIPRT for hiprtBuildFlagBitPreferHighQualityBuild,
  * common/loader.hpp:98-99): top-down binned-SAH binary tree over the references on the host, in
  * the same BvhNode format the device LBVH emits (so both traversals and the wide collapse work
@@ -362,4 +363,4 @@ struct SahBuilder
         }
     }
 };
-
+#endif /* RT_EXPERIMENTS */

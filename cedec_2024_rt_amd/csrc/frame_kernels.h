@@ -657,6 +657,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : (SHADOWED 
     }
 }
 
+#ifdef RT_EXPERIMENTS /* rt_tuning key 11: A/B form, librestir_rt_exp.so only */
 /* the deferred visibility-reuse rays of k_generate_candidate<.., DEFER>: a compact list of pixels, walked by full
  * wavefronts. Persistent-style grid: a lane takes queue entries blockIdx*64+lane, +gridDim*64, ... (the host sizes
  * the grid from the previous frame's count, so that is normally one entry per lane). Sets the visibility bit of the
@@ -686,6 +687,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_RESOLVE_WAVES_FWD) void k_candidate
     }
 }
 
+#endif /* RT_EXPERIMENTS */
 /* -------------------------------------------------------- temporal_resampling */
 /* examples/10_restir_di/10_restir_di.cu:137-237 (stand-alone entry point) */
 template <bool SHADOWED>
@@ -1062,6 +1064,7 @@ template <int WAVES> RT_DEV void occupancy_bound()
     if (WAVES == 5) asm volatile("; occupancy: 96 VGPRs -> 5 wavefronts per SIMD" ::: "v95");
     if (WAVES == 6) asm volatile("; occupancy: 80 VGPRs -> 6 wavefronts per SIMD" ::: "v79");
 }
+#ifdef RT_EXPERIMENTS /* rt_tuning key 8 = 0: the per-lane gather form of the pass (r01), A/B only */
 template <int WAVES>
 __global__ __launch_bounds__(BLOCK) void k_spatial_gather(
     SceneView S, FrameParams P, HaloFuse F, const float4* __restrict__ g0, const float4* __restrict__ g1, const float4* __restrict__ in_rec,
@@ -1073,6 +1076,7 @@ __global__ __launch_bounds__(BLOCK) void k_spatial_gather(
     spatial_pixel<false, BLOCK>(S, P, F, nullptr, x, row, g0, g1, in_rec, in_rad, out_rec, out_rad);
 }
 
+#endif /* RT_EXPERIMENTS */
 /* LDS-staged variant of the same pass (north star: "LDS-staged neighbour reservoirs"; rt_tuning key 8 = 1).
  * What can be staged: a 32x8 tile's +-87-pixel neighbour window holds (32+174) x (8+174) = 37 492 records = 2.4 MB
  * against 160 KB of LDS, and each pixel consumes 5 of them, so the RECORDS cannot be staged. What serialises the
@@ -1094,6 +1098,7 @@ __global__ void k_shaded_bitmap(int W, int rows, const float4* __restrict__ g1, 
     if (lane == 0 && w0 < words) bits[(size_t)row * words + w0] = (uint32_t)m;
     if (lane == 32 && w0 + 1 < words) bits[(size_t)row * words + w0 + 1] = (uint32_t)(m >> 32);
 }
+#ifdef RT_EXPERIMENTS /* rt_tuning key 8 = 1: LDS-staged shaded-bit window (r02), A/B only */
 template <int WAVES>
 __global__ __launch_bounds__(BLOCK) void k_spatial_lds(
     FrameParams P, const uint32_t* __restrict__ bits, const float4* __restrict__ g0, const float4* __restrict__ g1,
@@ -1202,6 +1207,7 @@ __global__ __launch_bounds__(BLOCK) void k_spatial_lds(
 }
 
 
+#endif /* RT_EXPERIMENTS */
 /* Cooperative gather variant of the same pass (rt_tuning key 8 = 2). What bounds k_spatial_gather is not bytes but
  * address-processing slots of the CU's vector L1: a per-lane gather of a 64-B record is 4 dwordx4 wave-instructions that
  * each touch 64 different cache lines (TCP_TOTAL_CACHE_ACCESSES = 1 521 per wavefront, 0.47 per cycle and CU). Here the
@@ -1299,18 +1305,23 @@ RT_DEV void wave_scatter_records(float4* __restrict__ rec, const int idx, float4
         if (to[j] >= 0) store_stream<STREAM ? 1 : 0>(reinterpret_cast<float4*>(base + ((uint32_t)to[j] * 64u + part16)), s_wave[64 * j + lane]);
     RT_WAVE_LDS_FENCE();
 }
-/* FUSED: halo records live in the exchange lists (HaloFuse, multi-GPU strips); otherwise every record is in in_rec */
-template <int WAVES, bool FUSED>
-__global__ __launch_bounds__(BLOCK) void k_spatial_coop(
-    SceneView S, FrameParams P, HaloFuse F, const float4* __restrict__ g0, const float4* __restrict__ g1, const float4* __restrict__ in_rec,
-    const float4* __restrict__ in_rad, float4* __restrict__ out_rec, float4* __restrict__ out_rad)
+/* The pass for one wavefront of pixels (8 x 8 tile): everything of k_spatial_coop up to the stores. TB = threads of the
+ * workgroup's tile (BLOCK: four wavefronts, TRACE_BLOCK: one). s_wave: the wavefront's 4-KB record image.
+ * FUSED: halo records live in the exchange lists (HaloFuse, multi-GPU strips); otherwise every record is in in_rec */
+struct SpatialOut
 {
-    occupancy_bound<WAVES>();
-    __shared__ __attribute__((aligned(16))) float4 s_img[BLOCK / 64][256];
-    const int lane = threadIdx.x & 63;
-    float4* s_wave = s_img[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))]; /* a scalar: the LDS-DMA base (M0) without per-load lane reads */
+    Res r;
+    float4 G0, G1;
+    size_t li;
+    int x, row;
+    bool in_image, active;
+};
+template <int TB, bool FUSED>
+RT_DEV void spatial_coop_wave(const FrameParams& P, const HaloFuse& F, const float4* __restrict__ g0, const float4* __restrict__ g1,
+                              const float4* __restrict__ in_rec, const float4* __restrict__ in_rad, float4* s_wave, const int lane, SpatialOut& o)
+{
     int x = 0, row = P.lrow0;
-    const bool in_image = tile_pixel<BLOCK>(P, x, row);
+    const bool in_image = tile_pixel<TB>(P, x, row);
     const int yi = P.H - 1 - row;
     const size_t li = in_image ? (size_t)x + (size_t)(row - P.lrow0) * P.W : 0; /* out of the image: names record 0, stores nothing */
     float4 G0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), G1 = G0;
@@ -1397,15 +1408,37 @@ __global__ __launch_bounds__(BLOCK) void k_spatial_coop(
     }
     else
         r = res_zero(); /* the reference stores nothing here (:275-287); we keep the shaded bit valid */
-    const uint32_t mbits = ((uint32_t)r.M & RES_M_MASK) | (r.vis ? RES_VIS_BIT : 0u) | (active ? RES_SHADED_BIT : 0u);
-    wave_scatter_records(out_rec, in_image ? (int)li : -1, s_wave, lane, make_float4(r.hit_p.x, r.hit_p.y, r.hit_p.z, r.ucw),
+    o.r = r; o.G0 = G0; o.G1 = G1; o.li = li; o.x = x; o.row = row; o.in_image = in_image; o.active = active;
+}
+/* the stores of the pass: the 64-B record through the wavefront's image, the radiance side record, the halo lists (FUSED) */
+template <bool FUSED>
+RT_DEV void spatial_coop_store(const FrameParams& P, const HaloFuse& F, float4* s_wave, const int lane, const SpatialOut& o,
+                               float4* __restrict__ out_rec, float4* __restrict__ out_rad)
+{
+    const Res& r = o.r;
+    const uint32_t mbits = ((uint32_t)r.M & RES_M_MASK) | (r.vis ? RES_VIS_BIT : 0u) | (o.active ? RES_SHADED_BIT : 0u);
+    wave_scatter_records(out_rec, o.in_image ? (int)o.li : -1, s_wave, lane, make_float4(r.hit_p.x, r.hit_p.y, r.hit_p.z, r.ucw),
                          make_float4(r.hit_n.x, r.hit_n.y, r.hit_n.z, as_float(mbits)), make_float4(r.org_p.x, r.org_p.y, r.org_p.z, r.lum),
                          make_float4(r.org_n.x, r.org_n.y, r.org_n.z, r.w_sum));
-    if (!in_image) return;
-    store_stream<2>(out_rad + li, make_float4(r.rad.x, r.rad.y, r.rad.z, as_float(r.ownv)));
-    if (FUSED) res_give(F, P.W, li, x, row, r, active);
+    if (!o.in_image) return;
+    store_stream<2>(out_rad + o.li, make_float4(r.rad.x, r.rad.y, r.rad.z, as_float(r.ownv)));
+    if (FUSED) res_give(F, P.W, o.li, o.x, o.row, r, o.active);
+}
+template <int WAVES, bool FUSED>
+__global__ __launch_bounds__(BLOCK) void k_spatial_coop(
+    SceneView S, FrameParams P, HaloFuse F, const float4* __restrict__ g0, const float4* __restrict__ g1, const float4* __restrict__ in_rec,
+    const float4* __restrict__ in_rad, float4* __restrict__ out_rec, float4* __restrict__ out_rad)
+{
+    occupancy_bound<WAVES>();
+    __shared__ __attribute__((aligned(16))) float4 s_img[BLOCK / 64][256];
+    const int lane = threadIdx.x & 63;
+    float4* s_wave = s_img[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))]; /* a scalar: the LDS-DMA base (M0) without per-load lane reads */
+    SpatialOut o;
+    spatial_coop_wave<BLOCK, FUSED>(P, F, g0, g1, in_rec, in_rad, s_wave, lane, o);
+    spatial_coop_store<FUSED>(P, F, s_wave, lane, o, out_rec, out_rad);
 }
 
+#ifdef RT_EXPERIMENTS /* rt_tuning key 8 = 3: software-pipelined pass (r04: slower), A/B only */
 /* Software-pipelined form of k_spatial_coop (rt_tuning key 8 = 3, r04). k_spatial_coop's neighbour loop is
  * draw -> fetch -> s_waitcnt vmcnt(0) -> merge, five times in series: 55 % of its wave cycles wait for memory with nothing in
  * flight during a merge. What serialises it is the reference's RNG protocol (the merge draw of neighbour k is consumed only if
@@ -1587,6 +1620,7 @@ __global__ __launch_bounds__(BLOCK) void k_spatial_pipe(
     store_stream<2>(out_rad + li, make_float4(r.rad.x, r.rad.y, r.rad.z, as_float(r.ownv)));
 }
 
+#endif /* RT_EXPERIMENTS */
 /* SURVEY.md §8(d) ALGORITHMIC bytes of one spatial_resampling launch, counted with the
  * reference's record sizes (Visibility 16 B, Reservoir 76 B): per pixel 16; per shaded pixel
  * +76 in +76 out; per neighbour that passed the on-screen / not-self tests +16, and +76 more if
@@ -2054,6 +2088,70 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_RESOLVE_WAVES) void k_resolve(Scene
 }
 
 
+#ifdef RT_EXPERIMENTS /* rt_tuning keys 23 (last pass + resolve fused, r05: slower) and 15 (resolve as a stream, r02: slower), A/B only */
+/* The LAST spatial pass and resolve in one kernel (r05, rt_tuning key 23). The reference launches spatial_resampling for the
+ * last time (10_restir_di.cu:256-388) and then resolve (:390-459), which reads of that pass's output only the pixel's own
+ * reservoir — and nothing else reads it (10_restir_di.cpp:355-379; the temporal history was saved before the passes, :314-321).
+ * Here the wavefront that has merged a pixel's neighbours shades the pixel at once: the kernel-wide barrier between the two
+ * becomes a per-pixel dependency, wavefronts waiting for gathered records (the pass: vector-L1 miss path) run beside wavefronts
+ * walking shadow rays (resolve: issue), and the record's trip through HBM — 80 B written, 80 + 32 B read back per pixel — is
+ * not on the path. STORE: the pass's output is written as the reference's kernel does (rt_download(RT_BUF_RES_*), the halo
+ * lists of strips, the per-kernel sequence: identical buffers); without it the records stay in registers.
+ * One-wavefront workgroups on 8 x 8 tiles; the 4-KB record image of the gathers is the LDS stack of the walk afterwards. */
+#ifndef RT_SPATIAL_RESOLVE_WAVES
+#define RT_SPATIAL_RESOLVE_WAVES 6
+#endif
+template <bool FUSED, bool STORE>
+__global__ __launch_bounds__(TRACE_BLOCK, RT_SPATIAL_RESOLVE_WAVES) void k_spatial_resolve(
+    SceneView S, FrameParams P, HaloFuse F, const float4* __restrict__ g0, const float4* __restrict__ g1, const float4* __restrict__ in_rec,
+    const float4* __restrict__ in_rad, float4* __restrict__ out_rec, float4* __restrict__ out_rad, float4* __restrict__ accum,
+    uint32_t* __restrict__ pixels)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_ROWS * TRACE_BLOCK];
+    static_assert(sizeof(s_stack) >= 4096, "the record image needs 64 x 64 B");
+    float4* s_wave = reinterpret_cast<float4*>(s_stack);
+    const int lane = threadIdx.x & 63;
+    SpatialOut o;
+    spatial_coop_wave<TRACE_BLOCK, FUSED>(P, F, g0, g1, in_rec, in_rad, s_wave, lane, o);
+    if (STORE) spatial_coop_store<FUSED>(P, F, s_wave, lane, o, out_rec, out_rad);
+    /* resolve (10_restir_di.cu:390-459) of the same pixel, from the registers */
+    const int tri = as_int(o.G0.w);
+    const bool shade = o.active; /* shaded surface: neither sky nor emissive */
+    if (o.in_image && !shade)
+    {
+        float4 a = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+        if (tri >= 0) { const float4 ke = S.trimat[2 * (size_t)tri + 1]; a = make_float4(ke.x, ke.y, ke.z, 1.0f); }
+        accum[o.li] = a;
+        if (pixels) pixels[o.li] = tone_map_rgba8(a);
+    }
+    const f3 sp = F3(o.G0.x, o.G0.y, o.G0.z), sn = F3(o.G1.x, o.G1.y, o.G1.z);
+    const Res& r = o.r;
+    const uint32_t ownv = ownv_trusted(P.ownv_tag, r.ownv);
+    const bool known = (ownv & OWNV_KNOWN) != 0u;
+    const bool need = shade && !known;
+    if (P.stats && shade)
+    {
+        const bool self = self_occluded(S.bvh.tv, tri, sp + 0.001f * sn, r.hit_p - sp, sn, !known);
+        count_walk_flags(P.stats + 4 * WALK_RESOLVE, true, !known && !self, !known && self, known);
+    }
+    RT_WAVE_LDS_FENCE(); /* the image becomes the stack */
+    const bool walked = check_visibility_wide<TRACE_BLOCK, true>(S.wide, s_stack, sp, sn, r.hit_p, need, S.bvh.tv, shade ? tri : -1);
+    if (!shade) return;
+    const float4 kd = S.trimat[2 * (size_t)tri];
+    const f3 brdf = (1.0f / kPI) * F3(kd.x, kd.y, kd.z);
+    const float G = geometry_term(sp, sn, r.hit_p, r.hit_n);
+    const float V = (known ? (ownv & OWNV_VISIBLE) != 0u : walked) ? 1.0f : 0.0f;
+    const f3 radiance = brdf * G * V * r.rad * r.ucw;
+    float4 a = make_float4(radiance.x, radiance.y, radiance.z, 1.0f);
+    if (P.accumulate)
+    {
+        const float4 p = accum[o.li];
+        a = make_float4(p.x + radiance.x, p.y + radiance.y, p.z + radiance.z, p.w + 1.0f);
+    }
+    accum[o.li] = a;
+    if (pixels) pixels[o.li] = tone_map_rgba8(a);
+}
+
 /* resolve as a stream (bvh.h occluded_stream; rt_tuning key 15, evaluated and off by default): persistent one-wavefront
  * workgroups walk the launch's tiles round-robin (workgroup w: tiles w, w + gridDim.x, ...: the XCD band of tile rows
  * the other tracing kernels give it) and keep their lanes supplied with new pixels. Sky / emissive pixels are written
@@ -2138,6 +2236,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_RESOLVE_STREAM_WAVES) void k_resolv
     occluded_stream<TRACE_BLOCK>(S.wide, s_stack, next_job, fetch, finish);
 }
 
+#endif /* RT_EXPERIMENTS */
 /* ------------------------------------------------------- configs #2 / #3: path tracers */
 /* shadow rays of 08_nee / 09_ris through the work-sharing walk (bvh.h occluded_ws) */
 #ifndef RT_PT_WS
@@ -2651,6 +2750,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_stats(SceneView S, const float*
     stats[2 * (size_t)i + 1] = st[1];
 }
 
+#ifdef RT_EXPERIMENTS /* rt_trace_* mode: persistent-wavefront queue (r01), A/B only */
 /* Persistent wavefront tracing over a ray queue with LANE refill: a lane whose ray is finished
  * pulls the next ray index while the other lanes keep traversing (ballot of idle lanes -> one
  * aggregated atomic -> prefix popcount), instead of idling until the slowest lane of its wave is
@@ -2798,6 +2898,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_queue(WideView wide, const floa
     }
 }
 
+#endif /* RT_EXPERIMENTS */
 __global__ void k_math_eval(int fn, const float* __restrict__ in, int n, float* __restrict__ out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -165,6 +165,8 @@ struct rt_ctx
     int tune_mark_window = 1; /* rt_tuning key 19 (r04): k_halo_mark collects a workgroup's marks in LDS first */
     unsigned long long* d_wire = nullptr; /* rt_wire_delay: GPU clock stamps */
     int wall_khz = 100000;
+    int tune_fuse_final = -1; /* rt_tuning key 23 (r05): last spatial pass + resolve in one kernel: -1 auto, 0 never, 1 always, 2 = A/B without the pass's stores */
+    bool final_fused = false; /* the running frame's last pass has resolved its rows */
     int tune_spec_free = -1; /* rt_tuning key 22 (r05): the look-ahead stage 0 free of the main stream and of the latest resolve: -1 auto = strips */
     int tune_mark_cache = 1; /* rt_tuning key 21 (r05): the shaded-bit rows of the halo marks are built once per epoch */
     uint64_t mark_bits_epoch = 0, gbuf_epoch = 0; /* epoch d_mark_bits was built under (0: not cached) / the current G-buffer was traced under */
@@ -493,6 +495,7 @@ static int build_bvh_device(rt_ctx* c, int n_tris)
     const float pad = 4e-5f * (ext > 1.0f ? ext : 1.0f); /* as the host path: hits lie within rounding distance of the triangle */
     const float3 slo = make_float3(lo[0], lo[1], lo[2]);
     const float3 sext = make_float3(fmaxf(hi[0] - lo[0], 1e-20f), fmaxf(hi[1] - lo[1], 1e-20f), fmaxf(hi[2] - lo[2], 1e-20f));
+    (void)slo; (void)sext; /* Morton keys: builder 2 (experiments build) */
     /* 2. early split clipping: count, scan, emit */
     uint32_t* d_cnt = (uint32_t*)dalloc((size_t)n_tris * 4); BD_PTR(d_cnt);
     uint32_t* d_off = (uint32_t*)dalloc((size_t)n_tris * 4); BD_PTR(d_off);
@@ -586,6 +589,7 @@ static int build_bvh_device(rt_ctx* c, int n_tris)
         BD_HIP(hipGetLastError());
         d_leaf_ids = d_final;
     }
+#ifdef RT_EXPERIMENTS
     else
     {
     /* 3. Morton order */
@@ -743,6 +747,9 @@ static int build_bvh_device(rt_ctx* c, int n_tris)
     }
     d_leaf_ids = d_ids2;
     } /* builder 2 */
+#else
+    else BD_FAIL(RT_ERR_UNSUPPORTED, "BVH builder %d is an A/B form of librestir_rt_exp.so", c->bvh_builder);
+#endif
     int* d_height = (int*)dalloc(4); BD_PTR(d_height);
     BD_HIP(hipMemsetAsync(d_height, 0, 4, st));
     k_bvh_height<<<grid, 256, 0, st>>>(n, d_children, d_parent, d_height);
@@ -838,6 +845,7 @@ static int build_bvh(rt_ctx* c, const rt_triangle* tris, int n_tris)
     }
     const int n = (int)refs.size();
     c->n_refs = n;
+#ifdef RT_EXPERIMENTS
     if (c->bvh_builder == 1 && n >= 2)
     {
         SahBuilder sb(refs);
@@ -854,6 +862,7 @@ static int build_bvh(rt_ctx* c, const rt_triangle* tris, int n_tris)
         RT_HIP(c, hipStreamSynchronize(st));
         return build_wide(c, tris, n);
     }
+#endif
     std::vector<float> h_boxes((size_t)n * 6);
     std::vector<int> h_ref_tri((size_t)n);
     for (int i = 0; i < n; ++i)
@@ -1429,6 +1438,7 @@ static int launch_generate(rt_ctx* c, int frame, int dst_phys, int prev_phys, bo
     c->rec_gserial[dst_phys] = c->gbuf_serial;
     const float4 *prec = fuse ? c->d_rec[prev_phys] : nullptr, *prad = fuse ? c->d_rad[prev_phys] : nullptr;
     const int g = trace_grid(c);
+#ifdef RT_EXPERIMENTS
     if (fuse && !sh && c->tune_defer_vis)
     {
         /* fused + unshadowed: the visibility-reuse rays that survive the temporal merge go through a queue */
@@ -1463,8 +1473,11 @@ static int launch_generate(rt_ctx* c, int frame, int dst_phys, int prev_phys, bo
         RT_HIP(c, hipMemcpyAsync(c->h_visq_count + lane, c->d_visq_count + lane, 4, hipMemcpyDeviceToHost, c->stream));
         return RT_OK;
     }
+#endif
     if (fuse && sh) k_generate_candidate<true, true><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
+#ifdef RT_EXPERIMENTS
     else if (fuse && c->tune_ris_pipe) k_generate_candidate<true, false, false, true><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
+#endif
     else if (fuse && use_ws(c, g)) k_generate_candidate<true, false, false, false, true><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
     else if (fuse) k_generate_candidate<true, false><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
     else if (sh) k_generate_candidate<false, true><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
@@ -1532,6 +1545,9 @@ static int halo_rows_needed(const rt_options& o)
     if (!o.use_spatial_resampling || o.spatial_resampling_sample_count <= 0) return 0;
     return (int)ceilf(o.spatial_resampling_radius / 1.96f * 5.6471f);
 }
+#ifndef RT_FUSE_FINAL_AUTO
+#define RT_FUSE_FINAL_AUTO 0 /* what rt_tuning key 23 = -1 means for a whole-frame context, until measured */
+#endif
 #ifndef RT_SHADOWED_SPATIAL_LDS
 #define RT_SHADOWED_SPATIAL_LDS 0 /* the walk's own LDS stack already limits the shadowed variant to 6 workgroups per CU */
 #endif
@@ -1566,7 +1582,19 @@ static int refresh_shaded_bits(rt_ctx* c)
 #ifndef RT_SPATIAL_PIPE_AUTO_WAVES
 #define RT_SPATIAL_PIPE_AUTO_WAVES 5 /* 16 more registers in flight than k_spatial_coop (the staged record parts) */
 #endif
-static int launch_spatial(rt_ctx* c, int frame, int pass, int in_phys, int out_phys)
+/* r05, rt_tuning key 23: the frame's last spatial pass shades its pixels itself (k_spatial_resolve). auto = whole-frame contexts;
+ * the unshadowed cooperative kernel only (the shadowed pass spends its time in its own rays). */
+static bool use_fused_final(const rt_ctx* c)
+{
+#ifndef RT_EXPERIMENTS
+    return false; /* k_spatial_resolve: measured slower (profiles/r05_fused_tail_ab.txt), experiments build only */
+#endif
+    const bool whole = c->row_begin == 0 && c->row_end == c->H;
+    const int want = c->tune_fuse_final < 0 ? (whole ? RT_FUSE_FINAL_AUTO : 0) : c->tune_fuse_final;
+    return want != 0 && !c->opt.use_shadowed_target_function && c->opt.use_spatial_resampling && c->tune_spatial_variant == 2 && !c->tune_stream &&
+           c->opt.spatial_resampling_passes >= 1;
+}
+static int launch_spatial(rt_ctx* c, int frame, int pass, int in_phys, int out_phys, bool fuse_final = false)
 {
     const int need = halo_rows_needed(c->opt);
     if ((c->row_begin > 0 && c->row_begin - c->lrow0 < (need < c->row_begin ? need : c->row_begin)) ||
@@ -1576,6 +1604,7 @@ static int launch_spatial(rt_ctx* c, int frame, int pass, int in_phys, int out_p
     const SceneView S = make_scene(c);
     const FrameParams P = make_params(c, frame, pass, K_SPATIAL);
     const bool lds_variant = use_lds_spatial(c);
+    (void)lds_variant; /* the product build has no LDS-staged form */
     c->rec_gserial[out_phys] = c->gbuf_serial;
     if (c->opt.use_shadowed_target_function)
     {
@@ -1585,6 +1614,7 @@ static int launch_spatial(rt_ctx* c, int frame, int pass, int in_phys, int out_p
         else
             k_spatial<true, false><<<trace_grid(c), TRACE_BLOCK, (size_t)(RT_SHADOWED_SPATIAL_LDS), c->stream>>>(S, P, c->fuse, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys]);
     }
+#ifdef RT_EXPERIMENTS
     else if (lds_variant && c->tune_spatial_variant == 3)
     {
         /* software-pipelined cooperative kernel (r04): staged shaded bits + the next neighbour's record in flight */
@@ -1602,21 +1632,44 @@ static int launch_spatial(rt_ctx* c, int frame, int pass, int in_phys, int out_p
         switch (c->tune_spatial_waves) { case 4: RT_SPL(4); break; case 5: RT_SPL(5); break; case 6: RT_SPL(6); break; default: RT_SPL(0); break; }
 #undef RT_SPL
     }
+#endif
+#ifdef RT_EXPERIMENTS
+    else if (fuse_final)
+    {
+        /* the last pass + resolve (+ tone mapping) of the staged frame in one launch of one-wavefront workgroups */
+        const bool fused = c->fuse.recv[0] || c->fuse.recv[1] || c->fuse.send[0] || c->fuse.send[1];
+        const bool store = c->tune_fuse_final != 2; /* 2: A/B only, the pass's output buffer is NOT written */
+        uint32_t* px = c->tune_fuse_tonemap ? (uint32_t*)c->d_pixels : nullptr;
+#define RT_SPR(FU, ST) k_spatial_resolve<FU, ST><<<trace_grid(c), TRACE_BLOCK, 0, c->stream>>>(S, P, c->fuse, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys], c->d_accum, px)
+        if (fused) { if (store) RT_SPR(true, true); else RT_SPR(true, false); }
+        else { if (store) RT_SPR(false, true); else RT_SPR(false, false); }
+#undef RT_SPR
+        c->final_fused = true;
+    }
+#endif
     else if (c->tune_spatial_variant == 2 || c->tune_spatial_variant == 3) /* 3 where the pipelined kernel does not apply (strips, radius > 30, > 5 neighbours) */
     {
 #define RT_SPC2(WV, FU) k_spatial_coop<WV, FU><<<launch_grid(c), BLOCK, (size_t)c->tune_spatial_lds, c->stream>>>(S, P, c->fuse, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys])
 #define RT_SPC(WV) do { if (fused) RT_SPC2(WV, true); else RT_SPC2(WV, false); } while (0)
         const bool fused = c->fuse.recv[0] || c->fuse.recv[1] || c->fuse.send[0] || c->fuse.send[1];
+#ifdef RT_EXPERIMENTS
         switch (c->tune_spatial_waves < 0 ? RT_SPATIAL_GATHER_AUTO_WAVES : c->tune_spatial_waves) { case 4: RT_SPC(4); break; case 5: RT_SPC(5); break; case 6: RT_SPC(6); break; default: RT_SPC(0); break; }
+#else
+        RT_SPC(RT_SPATIAL_GATHER_AUTO_WAVES); /* the product library carries the one register budget it uses (rt_tuning key 9: experiments build) */
+#endif
 #undef RT_SPC2
 #undef RT_SPC
     }
+#ifdef RT_EXPERIMENTS
     else
     {
 #define RT_SPG(WV) k_spatial_gather<WV><<<launch_grid(c), BLOCK, (size_t)c->tune_spatial_lds, c->stream>>>(S, P, c->fuse, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys])
         switch (c->tune_spatial_waves < 0 ? RT_SPATIAL_GATHER_AUTO_WAVES : c->tune_spatial_waves) { case 4: RT_SPG(4); break; case 5: RT_SPG(5); break; case 6: RT_SPG(6); break; default: RT_SPG(0); break; }
 #undef RT_SPG
     }
+#else
+    else RT_FAIL(c, RT_ERR_UNSUPPORTED, "spatial variant %d is an A/B form of librestir_rt_exp.so", c->tune_spatial_variant);
+#endif
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }
@@ -1653,6 +1706,7 @@ int rt_spatial_resampling(rt_ctx* c, int frame, int pass, int in, int out)
 static int launch_resolve(rt_ctx* c, int phys, uint32_t* pixels = nullptr)
 {
     const int g = trace_grid(c);
+#ifdef RT_EXPERIMENTS
     if (c->tune_stream)
     {
         /* persistent wavefronts, tiles dealt out round-robin (no job counter) */
@@ -1660,7 +1714,9 @@ static int launch_resolve(rt_ctx* c, int phys, uint32_t* pixels = nullptr)
         const int wgs = g < resident ? g : resident;
         k_resolve_stream<<<wgs, TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RESOLVE), c->d_g0, c->d_g1, c->d_rec[phys], c->d_rad[phys], c->d_accum, g);
     }
-    else if (use_ws(c, g)) k_resolve<true><<<g, TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RESOLVE), c->d_g0, c->d_g1, c->d_rec[phys], c->d_rad[phys], c->d_accum, pixels);
+    else
+#endif
+    if (use_ws(c, g)) k_resolve<true><<<g, TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RESOLVE), c->d_g0, c->d_g1, c->d_rec[phys], c->d_rad[phys], c->d_accum, pixels);
     else k_resolve<false><<<g, TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RESOLVE), c->d_g0, c->d_g1, c->d_rec[phys], c->d_rad[phys], c->d_accum, pixels);
     RT_HIP(c, hipGetLastError());
     return RT_OK;
@@ -1790,6 +1846,7 @@ int rt_frame_stage_begin(rt_ctx* c, int frame, int stage, int clear_first)
         c->f_clear = clear_first != 0;
         c->f_stage = 0;
         c->gen_taken = false;
+        c->final_fused = false;
         c->f_frame = frame;
         c->frame_tag = next_ownv_tag(c);
         return RT_OK;
@@ -1871,7 +1928,12 @@ static int stage_run_ranges(rt_ctx* c, int frame, int stage, int part, int row0,
     {
         const int k = stage - 1;
         rc = join_tail_for(c, c->f_out); /* the pass's output buffer can be the one the previous frame's resolve reads */
-        if (rc == RT_OK) rc = launch_spatial(c, frame, k, c->f_in, c->f_out);
+        if (rc == RT_OK && k == passes - 1 && use_fused_final(c))
+        {
+            rc = join_tail(c); /* the kernel writes the accumulation buffer and the pixels the previous frame's tail writes */
+            if (rc == RT_OK) rc = launch_spatial(c, frame, k, c->f_in, c->f_out, true);
+        }
+        else if (rc == RT_OK) rc = launch_spatial(c, frame, k, c->f_in, c->f_out);
         if (k < 3) mark(4 + k);
     }
     else
@@ -1883,6 +1945,17 @@ static int stage_run_ranges(rt_ctx* c, int frame, int stage, int part, int row0,
          * (rt_frame_stage_end keeps the logical names on the reference's buffers), so the result is the
          * reference's, stale data included. */
         const int final_phys = passes > 0 ? c->f_out : c->fZ;
+        if (c->final_fused)
+        {
+            /* the last pass has shaded (and, key 20, tone-mapped) these rows already */
+            mark(7);
+            if (!c->tune_fuse_tonemap) rc = launch_tone_mapping(c);
+            mark(8);
+            c->sub0 = c->sub1 = -1;
+            c->subb0 = c->subb1 = 0;
+            c->cur_tag = 0u;
+            return rc;
+        }
         const bool tail = whole && use_tail(c);
         hipStream_t ms = c->stream;
         if (tail)
@@ -2697,6 +2770,7 @@ int rt_trace_closest(rt_ctx* c, const float* rays, uint32_t n, float* hits)
     RT_HIP(c, hipEventCreate(&e0));
     RT_HIP(c, hipEventCreate(&e1));
     RT_HIP(c, hipEventRecord(e0, c->stream));
+#ifdef RT_EXPERIMENTS
     if (c->trace_mode == 2 || c->trace_mode == 3)
     {
         unsigned int* d_head = (unsigned int*)c->d_counter;
@@ -2705,11 +2779,15 @@ int rt_trace_closest(rt_ctx* c, const float* rays, uint32_t n, float* hits)
         if (c->trace_mode == 2) k_trace_queue<false><<<grid, BLOCK, 0, c->stream>>>(make_scene(c).wide, d_r, (int)n, d_h, d_head);
         else k_trace_queue<true><<<grid, BLOCK, 0, c->stream>>>(make_scene(c).wide, d_r, (int)n, d_h, d_head);
     }
-    else if (c->trace_mode == 0) k_trace_closest<0><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_h);
+    else
+#endif
+    if (c->trace_mode == 0) k_trace_closest<0><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_h);
     else if (c->trace_mode == 4) k_trace_closest<0, true><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_h);
     else if (c->trace_mode == 5) k_trace_anyhit<true><<<(n + TRACE_BLOCK - 1) / TRACE_BLOCK, TRACE_BLOCK, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_h);
     else if (c->trace_mode == 6) k_trace_anyhit<false><<<(n + TRACE_BLOCK - 1) / TRACE_BLOCK, TRACE_BLOCK, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_h);
+#ifdef RT_EXPERIMENTS
     else k_trace_closest<1><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_h);
+#endif
     RT_HIP(c, hipGetLastError());
     RT_HIP(c, hipEventRecord(e1, c->stream));
     RT_HIP(c, hipMemcpyAsync(hits, d_h, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
@@ -2741,7 +2819,9 @@ int rt_trace_stats(rt_ctx* c, const float* rays, uint32_t n, uint32_t* stats)
     if (c->trace_mode == 5) k_trace_stats_ws<<<(n + TRACE_BLOCK - 1) / TRACE_BLOCK, TRACE_BLOCK, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_s);
     else if (c->trace_mode == 0) k_trace_stats<0><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_s);
     else if (c->trace_mode == 4) k_trace_stats<0, true><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_s);
+#ifdef RT_EXPERIMENTS
     else k_trace_stats<1><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_s);
+#endif
     RT_HIP(c, hipGetLastError());
     RT_HIP(c, hipMemcpyAsync(stats, d_s, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
@@ -2760,9 +2840,31 @@ int rt_bvh_config(rt_ctx* c, float split_factor)
 /* performance knobs (results never depend on them): keys 0..3 = tile order of raycast /
  * generate_candidate(+temporal) / spatial_resampling / resolve (0 row-major, 1 column-major inside
  * each XCD band); key 4 = extra LDS bytes per spatial workgroup (limits resident workgroups per CU). */
+/* keys / values that select code the product library does not carry (A/B forms measured and left off; csrc/Makefile builds
+ * them into librestir_rt_exp.so with -DRT_EXPERIMENTS, which the variant tests and tools load) */
+static bool experiment_only(int key, int value)
+{
+#ifdef RT_EXPERIMENTS
+    (void)key; (void)value;
+    return false;
+#else
+    switch (key)
+    {
+        case 5: return value != 3;                 /* BVH builders 0 (LBVH), 1 (host SAH), 2 (PLOC + host top): the default is 3 */
+        case 8: return value != 2;                 /* spatial pass forms: gather, LDS-staged bits, software-pipelined */
+        case 9: return value != -1 && value != RT_SPATIAL_GATHER_AUTO_WAVES; /* other register budgets of the pass */
+        case 10: return true;                      /* PLOC search radius (builder 2) */
+        case 11: case 12: case 15: return value != 0; /* deferred visibility queue, pipelined RIS loop form, resolve as a stream */
+        case 23: return value > 0;                 /* last pass + resolve in one kernel */
+        default: return false;
+    }
+#endif
+}
 int rt_tuning(rt_ctx* c, int key, int value)
 {
     RT_CHECK_CTX(c);
+    if (experiment_only(key, value))
+        RT_FAIL(c, RT_ERR_UNSUPPORTED, "rt_tuning %d = %d selects an A/B form that only librestir_rt_exp.so (built with -DRT_EXPERIMENTS) carries", key, value);
     if (key >= 0 && key <= 3 && (value == 0 || value == 1 || value == -1)) c->tune_tile_mode[key] = value;
     else if (key == 4 && value >= 0 && value <= 160 * 1024) c->tune_spatial_lds = value;
     else if (key == 5 && value >= 0 && value <= 3) c->bvh_builder = value; /* before rt_scene_set */
@@ -2782,6 +2884,7 @@ int rt_tuning(rt_ctx* c, int key, int value)
     else if (key == 19 && (value == 0 || value == 1)) c->tune_mark_window = value;
     else if (key == 20 && (value == 0 || value == 1)) c->tune_fuse_tonemap = value;
     else if (key == 21 && (value == 0 || value == 1)) { c->tune_mark_cache = value; c->mark_bits_epoch = 0; }
+    else if (key == 23 && value >= -1 && value <= 2) c->tune_fuse_final = value;
     else if (key == 22 && value >= -1 && value <= 1) { c->tune_spec_free = value; c->spec_valid = false; c->spec_gen_valid = false; }
     else RT_FAIL(c, RT_ERR_ARG, "bad tuning key/value %d/%d", key, value);
     return RT_OK;
@@ -2812,6 +2915,7 @@ int rt_tuning_get(rt_ctx* c, int key, int* value)
         case 20: *value = c->tune_fuse_tonemap; break;
         case 21: *value = c->tune_mark_cache; break;
         case 22: *value = c->tune_spec_free; break;
+        case 23: *value = c->tune_fuse_final; break;
         default: RT_FAIL(c, RT_ERR_ARG, "bad tuning key %d", key);
     }
     return RT_OK;
@@ -2826,6 +2930,9 @@ int rt_trace_mode(rt_ctx* c, int mode)
 {
     RT_CHECK_CTX(c);
     if (mode < 0 || mode > 6) RT_FAIL(c, RT_ERR_ARG, "mode must be 0..6");
+#ifndef RT_EXPERIMENTS
+    if (mode >= 1 && mode <= 3) RT_FAIL(c, RT_ERR_UNSUPPORTED, "trace mode %d (binary stackless walk / ray queue) is an A/B form of librestir_rt_exp.so", mode);
+#endif
     c->trace_mode = mode;
     return RT_OK;
 }

@@ -357,89 +357,63 @@ int rt_build_ms(rt_ctx* ctx, float* ms); /* wall time of the last rt_scene_set (
  * (6); rays with tmax < 0 are lanes without a ray. rt_trace_time: device ms of the last call's kernel. */
 int rt_trace_mode(rt_ctx* ctx, int mode);
 int rt_trace_time(rt_ctx* ctx, float* ms);
-/* performance knobs; results never depend on them. keys 0..3: workgroup->tile order inside an XCD
- * band for raycast / generate_candidate / spatial_resampling / resolve (0 row-major, 1 column-major);
- * key 4: extra LDS bytes per unshadowed spatial_resampling workgroup (round 1's occupancy throttle, kept for
- * A/B runs; the kernel carries an explicit register budget instead, key 9: 6 wavefronts per SIMD by default). Defaults: {-1,0,-1,0}, 0;
- * -1 (r04) = auto: column-major for whole-frame contexts, row-major for strip contexts (an XCD's band of a strip is a few tile
- * rows: row-major is 6 % of a 135-row strip's frame, 3 % of a 270-row strip's; whole frames lose 4 % with it).
- * key 5 (before rt_scene_set): builder (default 3). 0 = device LBVH (Morton codes + Karras) with host pre-split and host
- * collapse (round 1), 1 = host binned SAH (the reference requests HIPRT's high-quality build,
- * common/loader.hpp:98-99), 2 = on the device: pre-split, Morton sort, PLOC hierarchy, wide collapse; only the boxes
- * of the last <= 8 192 clusters visit the host, which builds the top of the tree over them by an exact SAH sweep
- * (12 ms for 212 k triangles, frame +1.2 % against builder 1), 3 (default since r03) = builder 1's algorithm on the device:
- * pre-split, top-down binned SAH (32 centroid bins per axis, level by level over the large nodes, one wavefront per
- * subtree of <= 64 references), wide collapse — the same tree as builder 1 (380 779 records, 15 levels on the benchmark
- * scene) in 11 ms instead of 230; the host reads back counters only. All feed the same traversals; results never depend on
- * the builder.
- * key 6: rt_path_trace as 0 = one launch per frame (the reference's shape), 1 = wavefront (one launch
- * per bounce over the list of live paths, compacted with wave ballots), 2 = auto (default: wavefront
- * for 09_ris, whose per-bounce RIS makes compaction pay; one launch for 07_pt). Same results.
- * key 7 (before rt_scene_set): number of wide-BVH records emitted breadth-first before the
- * collapse switches to depth-first order (record order only; no measurable effect, default 2048).
- * key 8: unshadowed spatial_resampling as 2 (default) = the wavefront fetches the 64 neighbour records of a round together,
- * four lanes per 64-B record, as LDS-DMA loads that land transposed in LDS, and writes its 64 records the same way (a
- * quarter of the L1 address slots and L2 write requests of 0); 0 = one dependent per-lane record gather per neighbour;
- * 1 = LDS-staged variant: the tile's +-87-pixel window of shaded bits staged in LDS, neighbour addresses derived from LDS
- * alone, the record of neighbour k+1 in flight while neighbour k is merged (whole-frame contexts, radius <= 30, <= 5
- * neighbours; kernel 0 otherwise). Per pass at 1920x1080: 0.150 / 0.183 / 0.184 ms (2 / 0 / 1).
- * key 9: register budget of the unshadowed spatial pass, in wavefronts per SIMD (4, 5, 6; 0 = unbounded = 7; -1 = auto,
- * default: 6 for the gather kernel, none for the LDS-staged kernel).
- * key 10 (before rt_scene_set): PLOC search radius of builder 2 (places in Morton order, default 16).
- * key 11: rt_frame's fused generate_candidate + temporal_resampling (unshadowed target) walks the visibility-reuse ray
- * of 10_restir_di.cu:127-131 1 = only for candidates that survive the temporal merge — the ray's answer is
- * unobservable otherwise — through a compacted queue, 0 (default: 75 % survive in the bench scene, no gain) = for
- * every candidate as the reference does. Same results.
- * key 12: 1 = software-pipelined RIS loop in the fused candidate kernel (A/B only, default 0).
- * key 13: shadow rays of generate_candidate / resolve walked with the work-sharing any-hit traversal (idle lanes of a
- * wavefront take over half of a busy lane's LDS stack): -1 (default) = for launches of at most ~one round of
- * wavefronts (strips of the multi-GPU frame), 0 = never, 1 (default) = always. Same results.
- * key 14: rt_frame / rt_frame_stage run the NEXT frame's stage 0 on a stream of its own behind stage 0 of the current frame,
- * beside the spatial passes, the halo exchanges and resolve. 1 = its primary rays (they depend on the camera only), into a
- * second G-buffer set; 2 (r03) = its generate_candidate + temporal_resampling as well, into a fourth reservoir buffer: the
- * reference saves the temporal history right after temporal_resampling, before the spatial passes (10_restir_di.cpp:314-321),
- * so frame f+1's candidates depend on frame f only through a buffer that is final when frame f's stage 0 ends. The next frame
- * takes the results if it is the next frame number and camera, scene, options (rt_state_epoch) and the reservoir buffers
- * (uploads, per-kernel calls) are unchanged, and runs its own stage 0 otherwise. 0 = never; -1 (default) = level 2, except
- * that a whole-frame context with rt_timing enabled keeps its kernels back to back on one stream (per-kernel times stay
- * meaningful); strips: 1080p in 8 strips 0.47 -> 0.44 ms per frame, 4K 1.24 -> 1.15; a whole 1080p frame 1.86 -> 1.81 ms
- * (DESIGN.md sections 6-7). With rt_timing enabled level 2 behaves as level 1. rt_sync waits for that stream too; in a
- * steady loop every frame's launches run exactly once. Same results.
- * key 15: 1 = resolve as a STREAM: persistent wavefronts keep pulling pixels, a lane whose shadow ray is settled shades
- * its pixel and fetches the next one while the other lanes keep walking (csrc/bvh.h occluded_stream). Evaluated and
- * left off (default 0): same instruction count as the work-sharing kernel but 0.48 against 0.36 ms — a wavefront
- * holding rays of several tiles and ages sends 1.5x the requests to L2 and misses 2.6x as often, see DESIGN.md
- * section 5.2 and profiles/r02_stream_resolve_ab.txt. Same results.
- * key 16: -1 (default, r04) = for launches of at most about one generation of wavefronts (strips), 0 = never, 1 = primary rays with the work-sharing CLOSEST-hit walk (csrc/bvh.h closest_ws: pieces of a ray walked by
- * several lanes, merged by a 64-bit LDS min on (t, index)). Evaluated and left off (default 0): raycast 0.311 -> 0.318 ms
- * at 1080p, 0.997 -> 1.029 at 4K — primary rays of an 8x8 tile are coherent (31.8 passes per wavefront for 23.1 steps
- * per ray) and the walk needs 88 registers instead of 70. Same results.
- * key 17 (r03): resolve + tone_mapping of a staged frame on a stream of their own ("tail"): they read only the frame's final
- * reservoirs and G-buffer, so the main stream goes on with the next frame's first halo exchange meanwhile; whatever could
- * overwrite what they read (the next frame's first spatial pass, the pipelined stage 0 after next, any call outside the
- * staged frame, downloads) waits for them. -1 (default) = 1 = on (a whole 1080p frame 1.68 -> 1.63 ms, 8 strips 0.44 -> 0.37 ms),
- * 0 = never. Off while rt_timing is enabled. Same results.
- * key 18 (r03): 1 (default) = rt_halo_mark lets rows more than 40 rows from a neighbour's region test the pass's first draws
- * against a bound on the neighbour distance (radius = sqrt(-2 log rv0) <= the rows to go) before replaying log / sqrt / sincos
- * for every neighbour: nine passes in ten are skipped there. 0 = full replay everywhere. Same marks (tested bit for bit).
- * key 8 = 3 (r04): the cooperative spatial kernel software-pipelined over the staged shaded-bit window (all draws and neighbour
- * addresses first, the record of neighbour k+1 in flight while neighbour k is merged; whole-frame contexts, radius <= 30, <= 5
- * neighbours, else kernel 2). Evaluated and left off: 0.152 against 0.1435 ms per pass at 1920x1080 (5 instead of 6 wavefronts
- * per SIMD for the 16 staged registers, a barrier for the window). Same results.
- * key 19 (r04): 1 (default) = rt_halo_mark collects the marks of a workgroup's tile in an LDS bitmap of its +-87-pixel window
- * and sends only the non-zero words to the global bitmaps (image widths that are multiples of 32, reach <= 87 px, <= 3 passes
- * per call; the direct form otherwise): the direct form's one global atomicOr per marked neighbour, many to one word, made the
- * kernel 84 us for a 135-row strip at 1920 px and 310 us for a 270-row strip at 3840 px. 0 = direct. Same marks.
- * key 20 (r05): 1 (default) = the resolve kernel of rt_frame / rt_frame_stage tone-maps the pixel it has just accumulated
- * (tone_mapping reads nothing but the pixel's own accumulation value, common/kernels/common.cu:30-74): no k_tone_mapping
- * launch, no second read of the accumulation buffer. 0 = two launches as the reference. rt_resolve / rt_tone_mapping, the
- * per-kernel entry points, are always the reference's two kernels. Same pixels.
- * key 21 (r05): 1 (default) = the shaded-bit rows rt_halo_mark reads (key 19) are built once per camera / scene / option epoch
- * instead of in front of every mark. 0 = every time (r04). Same marks.
- * key 22 (r05): -1 (default) = for strips, 1 = always: the pipelined stage 0 (key 14) of frame f+1 waits neither for the main stream (when frame f took
- * its own stage 0 from the look-ahead stream: its inputs were written there) nor for resolve(f-1): a third G-buffer set and a
- * fifth reservoir buffer make resolve(f-2) the last reader of what it overwrites. 0 = as r04 (behind the main stream and
- * behind resolve(f-1)). Same results. */
+/* Performance knobs; RESULTS NEVER DEPEND ON THEM (every key / value is tested bit for bit against the default). rt_tuning_get
+ * returns the value a key holds, -1 meaning "auto" where a key has one. Keys marked [exp] select A/B forms that were measured and
+ * left off: they are compiled only into librestir_rt_exp.so (csrc/Makefile, -DRT_EXPERIMENTS); the product library answers
+ * RT_ERR_UNSUPPORTED for them. History and numbers of every key: docs/MEASUREMENT_LOG_*.md.
+ *
+ * Launch geometry
+ *  0..3  tile order inside an XCD band of raycast / generate_candidate / spatial_resampling / resolve: 0 row-major, 1 column-major,
+ *        -1 auto (keys 0 and 2; default): column-major for whole-frame contexts, row-major for a strip's primary rays and for the
+ *        spatial pass of strips under 200 rows. Defaults {-1, 0, -1, 0}.
+ *  4     extra LDS bytes per unshadowed spatial workgroup (round 1's occupancy throttle; default 0).
+ *  9     register budget of the unshadowed spatial pass in wavefronts per SIMD: -1 auto = 6 (default). [exp] 4, 5, 0 (= unbounded, 7).
+ *  13    shadow rays of generate_candidate / resolve through the work-sharing any-hit walk: 1 always (default), 0 never, -1 only
+ *        for launches of about one generation of wavefronts.
+ *  16    primary rays through the work-sharing closest-hit walk: -1 auto = launches of about one generation of wavefronts, i.e.
+ *        strips (default), 0 never, 1 always (a whole frame's coherent 8 x 8 tiles gain nothing: 0.311 -> 0.318 ms).
+ * Scene (before rt_scene_set)
+ *  5     BVH builder: 3 = on the device: pre-split, top-down binned SAH, 4-wide collapse; the host reads counters (default;
+ *        11 ms for 212 k triangles). [exp] 0 = device LBVH + host collapse (r01), 1 = host binned SAH (the tree builder 3
+ *        reproduces; 230 ms), 2 = device PLOC + host SAH over the top 8 192 clusters. All feed the same walk.
+ *  7     wide-BVH records emitted breadth-first before the collapse goes depth-first (default 2048; no measurable effect).
+ *  10    [exp] PLOC search radius of builder 2 (default 16).
+ * Frame structure
+ *  6     rt_path_trace: 0 one launch per frame (the reference's shape), 1 one launch per bounce over the compacted list of live
+ *        paths, 2 auto (default: per bounce for 09_ris).
+ *  14    the NEXT frame's stage 0 on a stream of its own beside this frame's passes, exchanges and resolve: 0 never, 1 its
+ *        primary rays (second / third G-buffer set), 2 its generate_candidate + temporal_resampling too (the reference saves the
+ *        history before the passes, 10_restir_di.cpp:314-321), -1 auto = 2 (default; level 1 while rt_timing is enabled on a
+ *        whole-frame context). The next frame takes the results if frame number, camera, scene, options (rt_state_epoch) and
+ *        reservoir buffers are unchanged, and runs its own stage 0 otherwise. rt_sync waits for that stream too.
+ *  17    resolve + tone_mapping of a staged frame on a "tail" stream of their own: -1 auto = 1 on (default), 0 off. Off while
+ *        rt_timing is enabled.
+ *  20    the staged frame's resolve kernel tone-maps the pixel it has just accumulated (common/kernels/common.cu:30-74 reads
+ *        nothing else): 1 (default), 0 = two launches as the reference. rt_resolve / rt_tone_mapping are always the two kernels.
+ *  22    (r05) the look-ahead stage 0 (key 14) of frame f+1 waits neither for the main stream (frame f took its own stage 0 from
+ *        the look-ahead stream) nor for resolve(f-1): with three G-buffer sets and five reservoir buffers resolve(f-2) is the
+ *        last reader of what it overwrites. -1 auto = strips (default: rank 4 of 8 at 1080p 0.306 -> 0.287 ms), 0 never (r04's
+ *        dependencies), 1 always (a whole 1080p frame: 1.277 -> 1.296 ms).
+ * Spatial pass
+ *  8     2 = the wavefront fetches the 64 records of a round together, four lanes per 64-B record, as LDS-DMA loads that land
+ *        transposed in LDS, and writes its 64 records the same way (default, the only product form). [exp] 0 = one per-lane
+ *        gather per neighbour (r01), 1 = the tile's +-87-px window of shaded bits staged in LDS (r02), 3 = form 2 software-
+ *        pipelined over that window (r04: 0.152 against 0.1435 ms).
+ *  23    [exp] (r05) the LAST spatial pass + resolve in one kernel (k_spatial_resolve): 1 = with the pass's own stores, 2 = records
+ *        kept in registers (the pass's output buffer is NOT written), 0 / -1 = two kernels (default). Measured slower:
+ *        profiles/r05_fused_tail_ab.txt.
+ * Candidates / resolve A/B forms
+ *  11    [exp] visibility-reuse rays of the fused candidate kernel only for candidates that survive the temporal merge, through a
+ *        compacted queue (75 % survive in the bench scene: no gain). Default 0.
+ *  12    [exp] software-pipelined RIS loop form. Default 0.
+ *  15    [exp] resolve as a stream of persistent wavefronts (0.48 against 0.36 ms, r02). Default 0.
+ * Strips (multi-GPU)
+ *  18    rt_halo_mark: rows more than 40 rows from a neighbour's region test the pass's first draws against a bound on the
+ *        neighbour distance before replaying log / sqrt / sincos: 1 (default), 0 = full replay.
+ *  19    rt_halo_mark collects a workgroup's marks in an LDS bitmap of its +-87-pixel window, one global atomic per non-zero
+ *        word: 1 (default; widths that are multiples of 32, reach <= 87 px, <= 3 passes per call), 0 = one atomic per mark.
+ *  21    (r05) the shaded-bit rows key 19 reads are built once per camera / scene / option epoch: 1 (default), 0 = in front of
+ *        every mark (r04). */
 int rt_tuning(rt_ctx* ctx, int key, int value);
 /* the value a key holds now (measurement records name the builder / variants that were really used) */
 int rt_tuning_get(rt_ctx* ctx, int key, int* value);

@@ -26,6 +26,28 @@ def test_library_exports_every_declared_symbol():
     assert sorted(api.EXPORTS) == names
 
 
+def test_product_library_carries_no_experiment_kernels():
+    """the A/B forms (per-lane gather / LDS-staged / software-pipelined spatial pass, fused last pass + resolve,
+    resolve as a stream, ray queue, PLOC builder ...) are code objects of librestir_rt_exp.so only; both libraries export the
+    same C-ABI."""
+    import subprocess
+
+    from cedec_2024_rt_amd import api
+
+    exp = api.load_library(exp=True)
+    assert not [n for n in _declared() if not hasattr(exp, n)]
+    assert exp.rt_build_id().decode().endswith("-exp") and not api.build_id().endswith("-exp")
+    A_B_ONLY = ("k_spatial_gather", "k_spatial_lds", "k_spatial_pipe", "k_spatial_resolve", "k_resolve_stream", "k_trace_queue",
+                "k_candidate_visibility", "k_ploc_nn")
+
+    def kernels(path):
+        out = subprocess.run(["strings", "-a", path], capture_output=True, text=True, check=True).stdout
+        return {k for k in A_B_ONLY if k in out}
+
+    assert kernels(api.LIB_PATH) == set(), "A/B-only kernels in the product library"
+    assert kernels(api.EXP_LIB_PATH) == set(A_B_ONLY)
+
+
 def test_pod_sizes_match_reference():
     from cedec_2024_rt_amd import types
 

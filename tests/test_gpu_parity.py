@@ -132,7 +132,7 @@ def test_lbvh_equals_brute_force(api, oracle, scenes, golden_scenes):
         sc = oracle.Scene(tris, use_bvh=False)
         ref = sc.trace_closest(rays, force_brute=True)
         for builder in (0, 1, 2, 3):  # 0: device LBVH (Morton + Karras), 1: host binned SAH, 2: device PLOC, 3: device binned SAH
-            r = api.Renderer(8, 8)
+            r = api.Renderer(8, 8, exp=True)  # builders 0-2 and walk modes 1-3: librestir_rt_exp.so
             r.tuning(5, builder)
             r.set_scene(tris)
             # 0: 4-wide quantised BVH + LDS stack (production), 1: binary tree + stackless trail,
@@ -189,7 +189,7 @@ def test_deep_traversal_stack_spills_past_lds(api, oracle):
     ref = sc.trace_closest(rays, force_brute=True)
     assert (ref[:, 3].view(np.int32) >= 0).mean() > 0.5
     for builder in (0, 1, 2, 3):
-        r = api.Renderer(8, 8)
+        r = api.Renderer(8, 8, exp=True)  # builders 0-2 and walk modes 1-3: librestir_rt_exp.so
         r.tuning(5, builder)
         r.set_scene(tris)
         assert 3 * (r.bvh_info()["wide_height"] - 1) >= 24 + 6, r.bvh_info()
@@ -215,7 +215,7 @@ def test_lbvh_blocks_scene_vs_oracle_bvh(api, oracle, scenes):
     sc = oracle.Scene(tris, use_bvh=True)
     ref = sc.trace_closest(rays)
     for builder in (0, 1, 2, 3):
-        r = api.Renderer(8, 8)
+        r = api.Renderer(8, 8, exp=True)  # builders 0-2 and walk modes 1-3: librestir_rt_exp.so
         r.tuning(5, builder)
         r.set_scene(tris)
         info = r.scene_info()
@@ -701,8 +701,8 @@ def test_round3_entry_points(api, scenes):
     the tail stream, rt_halo_fuse_set refuses to be called outside a spatial stage or for a side without a neighbour."""
     import ctypes as C
 
-    L = api.load_library()
-    r = api.Renderer(64, 48)
+    L = api.load_library(exp=True)
+    r = api.Renderer(64, 48, exp=True)
     if not os.environ.get("RT_TUNING"):  # the defaults (soak runs force other settings through the environment)
         assert r.tuning_get(5) == 3 and "SAH" in r.bvh_builder()      # default builder: the device SAH build
         assert r.tuning_get(14) == -1 and r.tuning_get(17) == -1 and r.tuning_get(13) == 1
@@ -714,6 +714,18 @@ def test_round3_entry_points(api, scenes):
         r.tuning(5, 4)
     with pytest.raises(api.RtError):
         r.tuning_get(99)
+    # the PRODUCT library carries none of the A/B forms and says so
+    if not os.environ.get("RT_LIB_PATH") and not os.environ.get("RT_EXPERIMENTS"):
+        prod = api.Renderer(64, 48)
+        for key, val in ((5, 0), (5, 1), (5, 2), (8, 0), (8, 1), (8, 3), (9, 4), (9, 5), (10, 8), (11, 1), (12, 1), (15, 1), (23, 1)):
+            with pytest.raises(api.RtError, match="librestir_rt_exp"):
+                prod.tuning(key, val)
+        for key, val in ((5, 3), (8, 2), (9, -1), (9, 6), (11, 0), (13, 0), (14, 1), (16, 1), (20, 0), (21, 0), (22, 1), (23, 0)):
+            prod.tuning(key, val)
+        for mode in (1, 2, 3):
+            with pytest.raises(api.RtError, match="librestir_rt_exp"):
+                prod.trace_mode(mode)
+        prod.close()
     assert len(api.build_id()) == 16
     s = C.c_void_p()
     assert L.rt_side_stream(r.h, 0, C.byref(s)) == 0 and s.value
@@ -805,7 +817,7 @@ def test_lds_staged_spatial_variant_is_bit_identical(api, scenes, W, H, optkw):
     eye, at = (scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT) if W == 1920 else ((0.5, 2.5, 6.0), (0.0, 1.5, -1.0))
     rs = []
     for variant in (0, 1, 2, 3):  # 3 (r04): the cooperative fetch software-pipelined over the staged shaded-bit window
-        r = api.Renderer(W, H)
+        r = api.Renderer(W, H, exp=True)
         r.set_scene(tris)
         r.lookat(eye, at)
         r.set_options(bench_options(**optkw))
@@ -831,7 +843,7 @@ def test_candidate_kernel_variants_are_bit_identical(api, scenes):
     W, H = 320, 180
     rs = []
     for k11, k12 in ((0, 0), (1, 0), (0, 1), (1, 1)):
-        r = api.Renderer(W, H)
+        r = api.Renderer(W, H, exp=True)
         r.set_scene(tris)
         r.lookat((0.5, 2.5, 6.0), (0.0, 1.5, -1.0))
         r.set_options(bench_options())
@@ -911,7 +923,7 @@ def test_resolve_as_a_stream_is_bit_identical(api, scenes):
     for rows, halo, acc in ((None, 0, 0), (None, 0, 1), ((90, 200), 70, 0)):
         rs = []
         for stream in (0, 1):
-            r = api.Renderer(W, H, rows=rows, halo=halo)
+            r = api.Renderer(W, H, rows=rows, halo=halo, exp=True)
             r.set_scene(tris)
             r.lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)
             r.set_options(bench_options(accumulate=acc, spatial_resampling_radius=20.0))

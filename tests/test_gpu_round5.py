@@ -1,0 +1,255 @@
+"""Round-5 GPU tests: every new launch form against the ORACLE (not against another setting of the product) on the frames
+bench.py times, plus form-against-form checks of buffers the oracle has no opinion on.
+
+* rt_tuning 20: resolve tone-maps its own pixel (common/kernels/common.cu:30-74 behind 10_restir_di.cu:451-458);
+* rt_tuning 23: the LAST spatial pass + resolve in one kernel (10_restir_di.cu:256-459 for one pixel), with and without the
+  pass's own stores, whole frames and three LOCAL strips;
+* rt_tuning 22: the look-ahead stage 0 free of the main stream and of the latest resolve (three G-buffer sets, five reservoir
+  buffers), forced on a whole-frame context (strips have it by default: tests/test_mg_native.py, test_gpu_round4.py);
+* rt_tuning 21: the halo marks with and without the cached shaded-bit rows: same bitmaps, also across a camera move;
+* RT_MG_TRANSPORT_WIRE_MODEL moves what MIRROR moves and holds the stream for the modelled time.
+"""
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FOVY = np.float32(np.pi) / np.float32(4)
+
+
+def _eq_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
+
+
+def _res_bad(a, b, mask):
+    bad = []
+    for f in a.dtype.names:
+        if f == "pad":
+            continue
+        if not _eq_bits(np.ascontiguousarray(a[f][mask]), np.ascontiguousarray(b[f][mask])):
+            bad.append(f)
+    return bad
+
+
+@pytest.fixture(scope="module")
+def api():
+    from cedec_2024_rt_amd import api as _api
+
+    return _api
+
+
+@pytest.fixture(scope="module")
+def scenes():
+    from cedec_2024_rt_amd import scenes as s
+
+    return s
+
+
+def _oracle_frames(oracle, tris, W, H, eye, at, frames, **optkw):
+    oracle.set_math_mode(oracle.MATH_PORTABLE)
+    sc = oracle.Scene(tris, use_bvh=True)
+    rg = oracle.raygen_lookat(eye, at, (0, 1, 0), FOVY, W, H)
+    st = oracle.new_state(W, H)
+    opt = oracle.bench_options(**optkw)
+    eyev = np.asarray(eye, np.float32)
+    for f in range(1, frames + 1):
+        sc.frame(W, H, f, rg, eyev, opt, st, None)
+    shaded = (st["vis"]["index"] >= 0) & ~np.isin(st["vis"]["index"], sc.lights)
+    return st, shaded
+
+
+@pytest.mark.parametrize("W,H,frames,tuning,optkw", [
+    (480, 270, 12, {23: 1}, {}),                  # last pass + resolve fused, the pass's records stored
+    (480, 270, 12, {23: 2}, {}),                  # ... records kept in registers (A/B form)
+    (480, 270, 12, {23: 1, 20: 0}, {}),           # ... with the reference's separate tone_mapping launch
+    (480, 270, 12, {23: 1, 14: 0, 17: 0}, {}),    # ... frames back to back on one stream (the headline's form)
+    (480, 270, 7, {23: 1}, {"accumulate": 1}),    # ... accumulating (resolve reads the buffer it adds to)
+    (480, 270, 5, {23: 1}, {"spatial_resampling_passes": 1}),
+    (480, 270, 5, {23: 1}, {"spatial_resampling_passes": 2}),
+    (480, 270, 12, {22: 1}, {}),                  # free-running look-ahead on a whole frame
+    (480, 270, 12, {22: 1, 23: 1}, {}),
+    (480, 270, 12, {20: 0}, {}),                  # the reference's two tail launches
+    (1920, 1080, 6, {23: 1, 22: 1}, {}),          # the benchmark's own size
+])
+def test_new_launch_forms_vs_oracle(api, oracle, scenes, W, H, frames, tuning, optkw):
+    """blocks_restir, bench options, frames enqueued back to back with no sync in between; accumulation, pixels and the temporal
+    history of the last frame == the oracle's"""
+    from cedec_2024_rt_amd.types import bench_options
+
+    tris = scenes.make_blocks_restir()
+    eye, at = scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT
+    r = api.Renderer(W, H, exp=23 in tuning)  # rt_tuning 23 is an A/B form: librestir_rt_exp.so
+    for k, v in tuning.items():
+        r.tuning(k, v)
+    r.set_scene(tris)
+    r.lookat(eye, at)
+    r.set_options(bench_options(**optkw))
+    for f in range(1, frames + 1):
+        r.frame(f)
+    st, shaded = _oracle_frames(oracle, tris, W, H, eye, at, frames, **optkw)
+    acc = r.download(api.RT_BUF_ACCUMULATION)
+    ref = st["accum"].reshape(acc.shape)
+    nbad = int((acc.view(np.uint32) != ref.view(np.uint32)).any(axis=1).sum())
+    assert nbad == 0, f"frame {frames}: {nbad} pixels differ from the oracle"
+    assert np.array_equal(r.download(api.RT_BUF_PIXELS).reshape(H, W, 4), st["pixels"])
+    bad = _res_bad(r.download(api.RT_BUF_RES_TEMPORAL), st["temporal"], shaded)
+    assert not bad, f"temporal history after frame {frames}: {bad}"
+    r.close()
+
+
+def test_fused_final_pass_writes_the_reference_buffers(api, scenes):
+    """rt_tuning 23 = 1 keeps every buffer a caller can download identical to the two-kernel form: the final reservoirs the last
+    pass writes (RT_BUF_RES_0 / RT_BUF_RES_1 after rt_frame), frame after frame"""
+    from cedec_2024_rt_amd.types import bench_options
+
+    W, H = 320, 200
+    tris = scenes.make_blocks_restir()
+    rs = []
+    for fused in (0, 1):
+        r = api.Renderer(W, H, exp=True)
+        r.tuning(23, fused)
+        r.set_scene(tris)
+        r.lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)
+        r.set_options(bench_options())
+        rs.append(r)
+    for f in range(1, 6):
+        finals = [r.frame(f) for r in rs]
+        assert finals[0] == finals[1]
+        for buf in (api.RT_BUF_RES_0, api.RT_BUF_RES_1, api.RT_BUF_RES_TEMPORAL, api.RT_BUF_ACCUMULATION, api.RT_BUF_PIXELS):
+            a, b = rs[0].download(buf), rs[1].download(buf)
+            if a.dtype.names:
+                sh = rs[0].download(api.RT_BUF_RES_TEMPORAL)["M"] > 0
+                assert not _res_bad(a, b, sh), (f, buf)
+            else:
+                assert _eq_bits(a, b), (f, buf)
+    for r in rs:
+        r.close()
+
+
+def test_fused_final_pass_on_three_local_strips_vs_oracle(api, oracle, scenes):
+    """rt_tuning 23 = 1 on strip contexts: the last pass (boundary rows on the main stream, interior rows on the second lane,
+    halo records from the exchange lists) resolves its own rows"""
+    from cedec_2024_rt_amd.types import bench_options
+
+    W, H, frames = 480, 270, 8
+    tris = scenes.make_blocks_restir()
+    eye, at = scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT
+    bounds = api.mg_partition(H, 3)
+    ctxs = []
+    for b in bounds:
+        c = api.Renderer(W, H, rows=b, halo=87, exp=True)
+        c.tuning(23, 1)
+        c.set_scene(tris)
+        c.lookat(eye, at)
+        c.set_options(bench_options())
+        ctxs.append(c)
+    hub = api.MgHub(3)
+    mgs = [api.MultiGpu(c, k, bounds, transport=api.RT_MG_TRANSPORT_LOCAL, hub=hub) for k, c in enumerate(ctxs)]
+    for f in range(1, frames + 1):
+        api.mg_frame_lockstep(mgs, f)
+    st, _ = _oracle_frames(oracle, tris, W, H, eye, at, frames)
+    ref = st["accum"].reshape(H, W, 4)
+    for c, (a, b) in zip(ctxs, bounds):
+        acc = c.download(api.RT_BUF_ACCUMULATION).reshape(c.local_rows, W, 4)[a - c.local_row0: b - c.local_row0]
+        assert _eq_bits(acc, ref[a:b]), f"rows {a}:{b}: {int((acc != ref[a:b]).any(axis=2).sum())} pixels differ from the oracle"
+        px = c.download(api.RT_BUF_PIXELS).reshape(c.local_rows, W, 4)[a - c.local_row0: b - c.local_row0]
+        assert np.array_equal(px, st["pixels"][a:b])
+    for m in mgs:
+        m.close()
+    hub.close()
+    for c in ctxs:
+        c.close()
+
+
+def test_cached_mark_rows_give_the_same_plans(api, scenes):
+    """rt_tuning 21: the shaded-bit rows of rt_halo_mark_sides built once per epoch == rebuilt in front of every mark, for several
+    frames and across a camera move (the cache must not survive the epoch)"""
+    import torch
+
+    from cedec_2024_rt_amd.types import bench_options
+
+    W, H = 480, 270
+    tris = scenes.make_blocks_restir()
+    bounds = api.mg_partition(H, 3)
+    rank = 1
+    out = []
+    for cache in (1, 0):
+        c = api.Renderer(W, H, rows=bounds[rank], halo=87)
+        c.tuning(21, cache)
+        c.set_scene(tris)
+        c.lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)
+        c.set_options(bench_options())
+        words = c.halo_bitmap_words(87)
+        fb = c.halo_flags_bytes(87)
+        got = []
+        for move in range(2):
+            if move:
+                c.orbit(40.0, -15.0)
+            c.raycast()
+            # the neighbours' flags: this rank's own boundary rows stand in for them (any deterministic content will do)
+            flags = torch.zeros(fb, dtype=torch.uint8, device="cuda")
+            for side, (src, dst) in enumerate(((bounds[rank][0], bounds[rank][0] - 87), (bounds[rank][1] - 87, bounds[rank][1]))):
+                c.halo_flags_pack(src, 87, flags.data_ptr())
+                c.sync()
+                c.halo_flags_unpack(dst, 87, flags.data_ptr())
+            for frame in (3, 4, 5):
+                bm = torch.zeros((2, 3, words), dtype=torch.int32, device="cuda")
+                c._ck(c.L.rt_halo_mark_sides(c.h, frame, 0, 3, bm[0].data_ptr(), bm[1].data_ptr()))
+                c.sync()
+                got.append(bm.cpu().numpy().copy())
+        out.append(got)
+        c.close()
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+    assert any(int(a[:, :, 0].sum()) > 0 for a in out[0])  # something was marked at all
+
+
+def test_wire_model_transport_moves_what_mirror_moves_and_takes_its_time(api, scenes):
+    """RT_MG_TRANSPORT_WIRE_MODEL = RCCL_SELF + a dependent delay per exchange: same images as MIRROR (a rank receives what it
+    sent), the modelled wire time is reported, and with a slow modelled link the frames really take that long"""
+    import os
+
+    from cedec_2024_rt_amd.types import bench_options
+
+    W, H = 480, 270
+    tris = scenes.make_blocks_restir()
+    bounds = api.mg_partition(H, 3)
+    imgs, stats, wall = {}, {}, {}
+    for name, T, env in (("mirror", api.RT_MG_TRANSPORT_MIRROR, {}), ("wire", api.RT_MG_TRANSPORT_WIRE_MODEL, {}),
+                         ("slow", api.RT_MG_TRANSPORT_WIRE_MODEL, {"RT_MG_WIRE_GBS": "0.5", "RT_MG_WIRE_LAT_US": "200"})):
+        old = {k: os.environ.get(k) for k in ("RT_MG_WIRE_GBS", "RT_MG_WIRE_LAT_US")}
+        os.environ.update(env)
+        try:
+            c = api.Renderer(W, H, rows=bounds[1], halo=87)
+            c.set_scene(tris)
+            c.lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)
+            c.set_options(bench_options())
+            mg = api.MultiGpu(c, 1, bounds, transport=T)
+            for f in range(1, 4):
+                mg.frame(f)
+            c.sync()
+            mg.reset_stats()
+            t0 = time.perf_counter()
+            for f in range(4, 10):
+                mg.frame(f)
+            c.sync()
+            wall[name] = (time.perf_counter() - t0) / 6
+            stats[name] = mg.stats()
+            imgs[name] = c.download(api.RT_BUF_ACCUMULATION)
+            mg.close()
+            c.close()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    assert _eq_bits(imgs["mirror"], imgs["wire"]) and _eq_bits(imgs["mirror"], imgs["slow"])
+    assert stats["mirror"]["wire_ns"] == 0 and stats["wire"]["wire_ns"] > 0
+    assert stats["wire"]["bytes_sent"] == stats["mirror"]["bytes_sent"]
+    # three exchanges per frame, each held for >= 200 us + bytes / 0.5 GB/s: the stream cannot be faster than the model
+    per_frame_model = stats["slow"]["wire_ns"] / 6 * 1e-9
+    assert per_frame_model > 3 * 200e-6
+    assert wall["slow"] >= 0.95 * per_frame_model, (wall, per_frame_model)

@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 from cedec_2024_rt_amd import api, scenes  # noqa: E402
 
 builder = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-r = api.Renderer(64, 64)
+r = api.Renderer(64, 64, exp=True)  # builders 0-2: librestir_rt_exp.so
 r.tuning(5, builder)
 tris = scenes.make_blocks_restir()
 for _ in range(5):

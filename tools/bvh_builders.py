@@ -19,7 +19,7 @@ names = {0: "device LBVH (Karras) + host pre-split/collapse", 1: "host binned SA
          3: "device: pre-split, top-down binned SAH (32 bins), collapse"}
 CASES = [(1, None), (3, None), (0, None), (2, 16)] if not os.environ.get("BVH_PLOC_SWEEP") else [(2, rad) for rad in (8, 16, 32, 64, 128)]
 for builder, rad in CASES:
-    r = api.Renderer(W, H)
+    r = api.Renderer(W, H, exp=True)  # the A/B forms live in librestir_rt_exp.so
     r.tuning(5, builder)
     if rad is not None:
         r.tuning(10, rad)

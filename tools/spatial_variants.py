@@ -28,7 +28,7 @@ elif not only:
 for name, key4, key8, key9 in CASES:
     if only and only != name:
         continue
-    r = api.Renderer(W, H)
+    r = api.Renderer(W, H, exp=True)  # the A/B forms live in librestir_rt_exp.so
     r.set_scene(tris)
     r.lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)
     r.set_options(bench_options())

@@ -10,7 +10,7 @@ key, values = int(sys.argv[1]), [int(v) for v in sys.argv[2:]]
 tris = scenes.make_blocks_restir()
 out = {}
 for W, H in ((1920, 1080), (3840, 2160)):
-    r = api.Renderer(W, H)
+    r = api.Renderer(W, H, exp=True)  # the A/B forms live in librestir_rt_exp.so
     r.set_scene(tris); r.lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT); r.set_options(bench_options())
     for v in values * 2:
         r.tuning(key, v)
