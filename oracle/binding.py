@@ -163,6 +163,7 @@ FN = dict(warp_unit_triangle=(0, 2, 2), sample_hemisphere=(1, 3, 3), sample_2d_g
           geometry_term=(3, 12, 1), intersect_ray_triangle=(4, 17, 4), luminance=(5, 3, 1),
           normal_rejection=(6, 6, 1), depth_rejection=(7, 9, 1), triangle_props=(8, 9, 7), aces=(9, 1, 1),
           surface_ray=(10, 16, 6), tangent_world=(11, 15, 3),
+          resolve_arithmetic=(12, 25, 4),  # 10_restir_di.cu:433-458 with the shadow ray's answer V as an input
           logf=(20, 1, 1), cosf=(21, 1, 1), sinf=(22, 1, 1), expf=(23, 1, 1), pow8=(24, 1, 1),
           pow_gamma=(25, 1, 1), div=(26, 2, 1), sqrt=(27, 1, 1),
           sincos_sin=(28, 1, 1), sincos_cos=(29, 1, 1))  # portable_math.h pm_sincosf (always the portable form)

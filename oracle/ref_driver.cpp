@@ -21,8 +21,9 @@
  *   - generate_candidate with use_visibility_reuse = use_shadowed_target_function = false
  *   - temporal_resampling / spatial_resampling with use_shadowed_target_function = false
  *   - save_temporal_reservoir, clear, tone_mapping.
- * raycast, resolve and the visibility-reuse ray of generate_candidate stay unpinned by
- * the reference (DESIGN.md "Oracle").
+ * raycast, the ray of resolve and the visibility-reuse ray of generate_candidate stay unpinned by
+ * the reference (DESIGN.md "Oracle"); resolve's ARITHMETIC is pinned through the reference's own functions with the ray's
+ * answer V as an input (cmd_fn id 12, ref::resolve_arithmetic below).
  *
  * Kernel parameters of type TypedBuffer<T> are declared by value in the reference; the
  * type has a deleted copy constructor, so the Itanium C++ ABI passes it by invisible
@@ -61,6 +62,27 @@ namespace ref
 {
 #include "examples/10_restir_di/10_restir_di.cu"
 }
+namespace ref
+{
+/* The ARITHMETIC of the reference's resolve kernel (examples/10_restir_di/10_restir_di.cu:433-458) on given operands, through
+ * the reference's own functions, constants and vector operators, statement for statement and operand for operand in the kernel's
+ * order (`1.0f / PI * color`, `brdf * G * V * radiance * ucw`, the float4 `+=` / `=` of the accumulation). The kernel itself
+ * cannot run here: its V = check_visibility(...) reaches raytrace(), i.e. HIPRT, a missing binary — so V is an INPUT. This is what
+ * pins the expression order of the oracle's o_resolve. */
+static float4 resolve_arithmetic(float3 color, float3 surf_p, float3 surf_n, float3 hit_position, float3 hit_normal, float3 sample_radiance,
+                                 float ucw, float V, bool accumulate, float4 accumulation)
+{
+    float3 radiance;
+    {
+        const float3 brdf = 1.0f / PI * color;
+        const float G = geometry_term(surf_p, surf_n, hit_position, hit_normal);
+        radiance = brdf * G * V * sample_radiance * ucw;
+    }
+    if (accumulate) { accumulation += {radiance.x, radiance.y, radiance.z, 1.0f}; }
+    else { accumulation = {radiance.x, radiance.y, radiance.z, 1.0f}; }
+    return accumulation;
+}
+}  // namespace ref
 namespace ref_ao
 {
 /* 04_ao.cu re-includes the same pragma-once headers; only its two functions are new */
@@ -226,6 +248,12 @@ static void cmd_fn(Blobs& b, FILE* out)
                 ref::TangentBasis b = ref::make_tangent_basis(f3(a + 9), 0, tb);
                 float3 w = ref::local_to_world(f3(a + 12), b);
                 o.push_back(w.x); o.push_back(w.y); o.push_back(w.z);
+                break; }
+            case 12: { /* resolve's arithmetic, 10_restir_di.cu:433-458: in 25 (Kd3 p3 n3 hit_p3 hit_n3 Le3 ucw V accumulate prev4) -> out 4 */
+                const float* a = in + 25 * i;
+                const float4 r = ref::resolve_arithmetic(f3(a), f3(a + 3), f3(a + 6), f3(a + 9), f3(a + 12), f3(a + 15), a[18], a[19], a[20] != 0.0f,
+                                                         make_float4(a[21], a[22], a[23], a[24]));
+                o.push_back(r.x); o.push_back(r.y); o.push_back(r.z); o.push_back(r.w);
                 break; }
             default: o.push_back(0.0f);
         }

@@ -862,6 +862,29 @@ static inline float ucw_of(const OReservoir* r, float p_hat)
 }
 
 /* Function-level exports for pinning against oracle/_ref (bulk, n items each). */
+/* the arithmetic of resolve, examples/10_restir_di/10_restir_di.cu:433-458, V (the shadow ray's answer, :443-444) given:
+ * brdf = 1/PI * Kd (:437); G (:439-441); radiance = brdf * G * V * sample.radiance * ucw, left to right (:447);
+ * accumulation += / = {radiance, 1} (:451-458). Used by o_resolve and, for the check against the reference's own functions
+ * (oracle/ref_driver.cpp cmd_fn id 12), by o_fn_bulk. */
+static inline v4 resolve_arithmetic(v3 color, v3 surf_p, v3 surf_n, v3 hit_position, v3 hit_normal, v3 sample_radiance, float ucw, float V,
+                                    int accumulate, v4 accumulation)
+{
+    const v3 brdf = muls(color, 1.0f / O_PI);
+    const float G = geometry_term(surf_p, surf_n, hit_position, hit_normal);
+    const v3 radiance = muls(mulv(muls(muls(brdf, G), V), sample_radiance), ucw);
+    if (accumulate)
+    {
+        accumulation.x += radiance.x; accumulation.y += radiance.y;
+        accumulation.z += radiance.z; accumulation.w += 1.0f;
+    }
+    else
+    {
+        const v4 o = {radiance.x, radiance.y, radiance.z, 1.0f};
+        accumulation = o;
+    }
+    return accumulation;
+}
+
 ORACLE_API void o_fn_bulk(int fn, const float* in, float* out, int n)
 {
     for (int i = 0; i < n; ++i)
@@ -921,6 +944,14 @@ ORACLE_API void o_fn_bulk(int fn, const float* in, float* out, int n)
                 const v3 w = tangent_to_world(&t, V3(a[9], a[10], a[11]), V3(a[12], a[13], a[14]));
                 float* o = out + 3 * i;
                 o[0] = w.x; o[1] = w.y; o[2] = w.z;
+                break; }
+            case 12: { /* resolve's arithmetic, 10_restir_di.cu:433-458: in 25 (Kd3 p3 n3 hit_p3 hit_n3 Le3 ucw V accumulate prev4) -> out 4 */
+                const float* a = in + 25 * i;
+                const v4 prev = {a[21], a[22], a[23], a[24]};
+                const v4 r = resolve_arithmetic(V3(a[0], a[1], a[2]), V3(a[3], a[4], a[5]), V3(a[6], a[7], a[8]), V3(a[9], a[10], a[11]),
+                                                V3(a[12], a[13], a[14]), V3(a[15], a[16], a[17]), a[18], a[19], a[20] != 0.0f, prev);
+                float* o = out + 4 * i;
+                o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w;
                 break; }
             /* raw math functions in the current mode: in 1 -> out 1 */
             case 20: out[i] = m_log(in[i]); break;
@@ -1205,21 +1236,10 @@ ORACLE_API void o_resolve(const OScene* s, v4* accum, int W, int H, const OVisib
             }
             const Surf surf = make_surface_info_eye(&v, s->tris, eye);
             const OReservoir* r = &res[pixel_idx];
-            const v3 brdf = muls(tri->color, 1.0f / O_PI);
-            const float G = geometry_term(surf.p, surf.n, r->sample.hit_position, r->sample.hit_normal);
             const float V = check_visibility(s, surf.p, surf.n, r->sample.hit_position);
             ++rays;
-            const v3 radiance = muls(mulv(muls(muls(brdf, G), V), r->sample.radiance), r->ucw);
-            if (opt->accumulate)
-            {
-                accum[pixel_idx].x += radiance.x; accum[pixel_idx].y += radiance.y;
-                accum[pixel_idx].z += radiance.z; accum[pixel_idx].w += 1.0f;
-            }
-            else
-            {
-                const v4 o = {radiance.x, radiance.y, radiance.z, 1.0f};
-                accum[pixel_idx] = o;
-            }
+            accum[pixel_idx] = resolve_arithmetic(tri->color, surf.p, surf.n, r->sample.hit_position, r->sample.hit_normal, r->sample.radiance,
+                                                  r->ucw, V, opt->accumulate, accum[pixel_idx]);
         }
     }
     if (cnt) cnt->rays += rays;

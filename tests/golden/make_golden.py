@@ -36,6 +36,31 @@ from oracle import binding as ob  # noqa: E402
 REF = "/root/reference"
 
 
+def resolve_inputs(rng, n):
+    """operands of resolve's arithmetic (10_restir_di.cu:433-458) as a frame has them: Kd in [0,1], surface / light positions a few
+    units apart, unit normals, radiance up to 120 (assets/blocks_restir.mtl Ke), ucw from tiny to large, V in {0, 1} (and a few other
+    values: the expression multiplies by it), both accumulate settings, previous accumulation values, plus zeros / coincident points"""
+    x = np.zeros((n, 25), np.float32)
+    x[:, 0:3] = rng.random((n, 3), dtype=np.float32)
+    x[:, 3:6] = (rng.random((n, 3), dtype=np.float32) * 40 - 20).astype(np.float32)
+    nn = rng.standard_normal((n, 3)).astype(np.float32)
+    x[:, 6:9] = nn / np.linalg.norm(nn, axis=1, keepdims=True).astype(np.float32)
+    x[:, 9:12] = x[:, 3:6] + (rng.standard_normal((n, 3)) * np.float32(6)).astype(np.float32)
+    nn = rng.standard_normal((n, 3)).astype(np.float32)
+    x[:, 12:15] = nn / np.linalg.norm(nn, axis=1, keepdims=True).astype(np.float32)
+    x[:, 15:18] = (rng.random((n, 3), dtype=np.float32) * np.float32(120)).astype(np.float32)
+    x[:, 18] = np.exp(rng.random(n) * 30 - 20).astype(np.float32)
+    x[:, 19] = (rng.random(n) < 0.7).astype(np.float32)
+    x[::17, 19] = rng.random(len(x[::17]), dtype=np.float32)
+    x[:, 20] = (rng.random(n) < 0.5).astype(np.float32)
+    x[:, 21:24] = (rng.random((n, 3), dtype=np.float32) * np.float32(50)).astype(np.float32)
+    x[:, 24] = np.floor(rng.random(n) * 64).astype(np.float32)
+    x[::29, 9:12] = x[::29, 3:6]      # light sample on the surface point: G = 0/0
+    x[::31, 18] = 0.0                 # ucw = 0 (p_hat = 0)
+    x[::37, 15:18] = 0.0
+    return x
+
+
 def main():
     assert ob.have_ref(), "oracle/_ref/ref_kernels missing: make -C oracle"
     c1 = scenes.load_obj(os.path.join(REF, "assets/cornellbox1.obj"))
@@ -51,6 +76,11 @@ def main():
     for name, (fid, nin, nout) in ob.FN.items():
         if fid >= 20:
             continue
+        if name == "resolve_arithmetic":  # (r05) a generator of its own: the fixtures of rounds 1-4 keep their random streams
+            x = resolve_inputs(np.random.default_rng(20251003), 4000)
+            fn[name + "_in"] = x
+            fn[name + "_out"] = ob.ref_fn(name, x)
+            continue
         x = rng.random((2000, nin), dtype=np.float32)
         if name == "intersect_ray_triangle":
             x = (x * 2 - 1).astype(np.float32)
@@ -63,6 +93,8 @@ def main():
         fn[name + "_in"] = x
         fn[name + "_out"] = ob.ref_fn(name, x)
     np.savez_compressed(os.path.join(HERE, "ref_functions.npz"), **fn)
+    if "--only-functions" in sys.argv:
+        return
 
     # kernels on cornellbox1, default camera (common/misc.hpp:217-218), 48x27
     W, H = 48, 27

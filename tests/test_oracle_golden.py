@@ -30,7 +30,10 @@ def _libm(oracle):
 
 
 FNS = ["warp_unit_triangle", "sample_hemisphere", "sample_2d_gaussian", "geometry_term", "intersect_ray_triangle",
-       "luminance", "normal_rejection", "depth_rejection", "triangle_props", "aces", "surface_ray", "tangent_world"]
+       "luminance", "normal_rejection", "depth_rejection", "triangle_props", "aces", "surface_ray", "tangent_world",
+       # the arithmetic of resolve (10_restir_di.cu:433-458) through the reference's own functions and operators, the shadow ray's
+       # answer V given (the kernel itself needs HIPRT): pins the expression order of the oracle's o_resolve
+       "resolve_arithmetic"]
 
 
 @pytest.mark.parametrize("name", FNS)
@@ -53,6 +56,13 @@ def test_functions_vs_reference_live(oracle, name):
         x = rng.random((3000, nin), dtype=np.float32)
     if name == "aces":
         x = np.abs(x)
+    if name == "resolve_arithmetic":
+        import importlib.util
+
+        spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
+        mg = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mg)
+        x = mg.resolve_inputs(rng, 3000)
     got, want = oracle.fn_bulk(name, x), oracle.ref_fn(name, x)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
