@@ -260,6 +260,38 @@ RT_DEV float target_function(const SceneView& S, uint32_t* s_stack, f3 op, f3 on
     return target_unshadowed(op, on, hp, hn, lum);
 }
 
+/* One RIS candidate's weight = evaluate_target_function(...) / light_sample.pdf (10_restir_di.cu:98-105: p_hat = (1/PI) G lum,
+ * common/reservoir.hpp:42-59, unshadowed always, :104) as ONE guarded expression (r05): the shared-reciprocal forms of rt_device.h
+ * (normalize, / sqr_dist, / pdf) each sit behind a range test on their operands; nested, that is three data-dependent branches per
+ * candidate around 60 instructions. Here the three forms run unconditionally — plain arithmetic, no traps, garbage in = garbage out —
+ * and ONE test of all their operand ranges afterwards decides whether the result stands; if not (zero / subnormal / huge operands:
+ * never on the bench scene) the candidate is evaluated again by the nested-guard functions. Same operations on the same operands in
+ * the same order as target_unshadowed + div_pdf when every guard passes, and those functions themselves otherwise. */
+#ifndef RT_RIS_ONE_GUARD
+#define RT_RIS_ONE_GUARD 1
+#endif
+RT_DEV float div_pdf(float p_hat, float pdf, float r1);
+RT_DEV float ris_weight(f3 sp, f3 sn, f3 lp, f3 ln, float lum, float pdf, float r1_pdf)
+{
+#if RT_FAST_DIV && RT_RIS_ONE_GUARD
+    const f3 v = lp - sp;
+    const float sqr_dist = dot(v, v);
+    const float len = sqrt_in_range(sqr_dist);
+    const float rl = rcp_refined(len);
+    const f3 vh = F3(div_by(v.x, len, rl), div_by(v.y, len, rl), div_by(v.z, len, rl));
+    const float num = fabsf(dot(vh, sn)) * fabsf(dot(-vh, ln));
+    const float G = div_by(num, sqr_dist, rcp_refined(sqr_dist));
+    const float brdf = 1.0f / kPI;
+    const float p_hat = brdf * G * lum;
+    const float w = div_by(p_hat, pdf, r1_pdf);
+    /* `&`, not `&&`: ONE condition from five compare masks (with `&&` the compiler rebuilds the nested branches and sinks the
+     * arithmetic back into them) */
+    const unsigned ok = (unsigned)div_den_ok(sqr_dist) & (unsigned)(__builtin_fminf(__builtin_fminf(fabsf(v.x), fabsf(v.y)), fabsf(v.z)) >= kDivNumLo) &
+                        (unsigned)div_num_ok(num) & (unsigned)(r1_pdf == r1_pdf) & (unsigned)div_num_ok(p_hat);
+    if (ok) return w;
+#endif
+    return div_pdf(target_unshadowed(sp, sn, lp, ln, lum), pdf, r1_pdf);
+}
 /* weight = p_hat / pdf (10_restir_di.cu:98-105) with the pdf's refined reciprocal from the light table (k_light_table) */
 RT_DEV float div_pdf(float p_hat, float pdf, float r1)
 {
@@ -313,7 +345,7 @@ RT_DEV bool temporal_merge(const FrameParams& P, int x, int yi, f3 sp, f3 sn, Re
     r.w_sum += weight;
     r.M += pr.M;
     float V = V_cur;
-    if (u < weight / r.w_sum)
+    if (reservoir_accept(u, weight, r.w_sum))
     {
         res_take_sample(r, pr);
         V = V_prev;
@@ -442,11 +474,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : (SHADOWED 
                 warp_unit_triangle(bx, by);
                 const f3 lp = (1.0f - bx - by) * v0 + bx * v1 + by * v2;
                 const f3 ln = F3(L3n.x, L3n.y, L3n.z);
-                const float p_hat = target_unshadowed(sp, sn, lp, ln, L2.y); /* unshadowed always (:104) */
-                const float weight = div_pdf(p_hat, L2.z, L3n.w);           /* 1/L * 1/area (:98-99) */
+                const float weight = ris_weight(sp, sn, lp, ln, L2.y, L2.z, L3n.w); /* p_hat (unshadowed always, :104) / pdf = 1/L * 1/area (:98-99) */
                 r.w_sum += weight;
                 r.M += 1;
-                if (u < weight / r.w_sum)
+                if (reservoir_accept(u, weight, r.w_sum))
                 {
                     sel = (int)nth; sel_bx = bx; sel_by = by;
                 }
@@ -478,7 +509,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : (SHADOWED 
                 const float u = rng.uniformf();
                 r.w_sum += weight;
                 r.M += 1;
-                if (u < weight / r.w_sum)
+                if (reservoir_accept(u, weight, r.w_sum))
                 {
                     sel = (int)nth; sel_bx = bx; sel_by = by;
                 }
@@ -530,7 +561,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : (SHADOWED 
             const float weight = div_pdf(p_hat, C2.z, C3.w);
             r.w_sum += weight;
             r.M += 1;
-            if (u < weight / r.w_sum)
+            if (reservoir_accept(u, weight, r.w_sum))
             {
                 sel = (int)nth; sel_bx = bx; sel_by = by;
             }
@@ -568,7 +599,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : (SHADOWED 
         r.M += 1;
         /* only what identifies the winner is carried through the loop (3 registers instead of the
          * 8 of position, normal, luminance): its sample is rebuilt once below, bit for bit */
-        if (u < weight / r.w_sum)
+        if (reservoir_accept(u, weight, r.w_sum))
         {
             sel = (int)nth; sel_bx = bx; sel_by = by;
         }
@@ -828,7 +859,7 @@ RT_DEV void spatial_pixel(const SceneView& S, const FrameParams& P, const HaloFu
                 const float weight = p_hat_y * nr.ucw * (float)nr.M;
                 r.w_sum += weight;
                 r.M += nr.M;
-                if (ud[k] < weight / r.w_sum)
+                if (reservoir_accept(ud[k], weight, r.w_sum))
                 {
                     res_take_sample(r, nr);
                     rad_from = prad[k];
@@ -875,7 +906,7 @@ RT_DEV void spatial_pixel(const SceneView& S, const FrameParams& P, const HaloFu
             const float u = rng.uniformf();
             r.w_sum += weight;
             r.M += nr.M;
-            if (u < weight / r.w_sum)
+            if (reservoir_accept(u, weight, r.w_sum))
             {
                 res_take_sample(r, nr);
                 rad_from = nrad;
@@ -1001,7 +1032,7 @@ RT_DEV void spatial_wave_shadowed(const SceneView& S, const FrameParams& P, cons
                 const float weight = p_hat_y * nr.ucw * (float)nr.M;
                 r.w_sum += weight;
                 r.M += nr.M;
-                if (ud[k] < weight / r.w_sum)
+                if (reservoir_accept(ud[k], weight, r.w_sum))
                 {
                     res_take_sample(r, nr);
                     rad_from = halo_code_radiance(F, in_rec, in_rad, pcode[k]);
@@ -1190,7 +1221,7 @@ __global__ __launch_bounds__(BLOCK) void k_spatial_lds(
                 const float weight = p_hat_y * nr.ucw * (float)nr.M;
                 r.w_sum += weight;
                 r.M += nr.M;
-                if (ud[k] < weight / r.w_sum)
+                if (reservoir_accept(ud[k], weight, r.w_sum))
                 {
                     res_take_sample(r, nr);
                     rad_from = (size_t)pid[k];
@@ -1388,7 +1419,7 @@ RT_DEV void spatial_coop_wave(const FrameParams& P, const HaloFuse& F, const flo
                 const float u = rng.uniformf();
                 r.w_sum += weight;
                 r.M += nr.M;
-                if (u < weight / r.w_sum)
+                if (reservoir_accept(u, weight, r.w_sum))
                 {
                     res_take_sample(r, nr);
                     d0 = d1;
@@ -1590,7 +1621,7 @@ __global__ __launch_bounds__(BLOCK) void k_spatial_pipe(
                 const float weight = p_hat_y * nr.ucw * (float)nr.M;
                 r.w_sum += weight;
                 r.M += nr.M;
-                if (ud[k] < weight / r.w_sum)
+                if (reservoir_accept(ud[k], weight, r.w_sum))
                 {
                     res_take_sample(r, nr);
                     d0 = d1;
@@ -2381,7 +2412,7 @@ RT_DEV bool path_bounce(const SceneView& S, uint32_t* s_stack, const FrameParams
                     const float weight = p_hat / L2.z;
                     r.w_sum += weight;
                     r.M += 1;
-                    if (uuv[j] < weight / r.w_sum)
+                    if (reservoir_accept(uuv[j], weight, r.w_sum))
                     {
                         r.hit_p = tgt[j]; r.hit_n = ln; r.lum = L2.y;
                         const float4 ke = S.light_ke[nthv[j]];
@@ -2423,7 +2454,7 @@ RT_DEV bool path_bounce(const SceneView& S, uint32_t* s_stack, const FrameParams
             const float uu = st.rng.uniformf();
             r.w_sum += weight;
             r.M += 1;
-            if (uu < weight / r.w_sum)
+            if (reservoir_accept(uu, weight, r.w_sum))
             {
                 r.hit_p = lp; r.hit_n = ln; r.lum = L2.y;
                 const float4 ke = S.light_ke[nth];

