@@ -542,11 +542,16 @@ def _main():
     r, mg, frame, total_rays, elapsed = R["r"], R["mg"], R["frame"], R["rays"], R["dt"]
     info = r.scene_info()
     pipelined_dt = None
-    if world == 1:
+    # profiling runs (tools/profile_round.sh: RT_TUNING=14=0,17=0) keep every kernel of the process un-overlapped: no pipelined region
+    no_pipelined = bool(os.environ.get("BENCH_NO_PIPELINED")) or any(kv.split("=")[0] in ("14", "17") for kv in filter(None, os.environ.get("RT_TUNING", "").split(",")))
+    if world == 1 and not no_pipelined:
         r.tuning(14, -1)
         r.tuning(17, -1)
         frame, _, pipelined_dt = timed(r, None, r.frame, frame, width, height, K, Wm)
+        r.tuning(14, 0)  # the per-kernel event loop, the PCIe-inclusive loop and the walk counters below: un-overlapped frames again
+        r.tuning(17, 0)
 
+    single_ref = None
     spatial_ms = per_kernel = algo_bytes = pcie_ms = event_median = None
     verified = mg_stats = walks = verified_seq = None
     if world == 1:
@@ -647,6 +652,36 @@ def _main():
                 ref = full.download(api.RT_BUF_ACCUMULATION).reshape(height, width, 4)
                 verified = bool(np.array_equal(np.concatenate(parts, axis=0).view(np.uint32), ref.view(np.uint32)))
                 full.close()
+        # The single-GPU frame of THIS node, measured in this very run on rank 0's GPU while the other ranks wait (outside the timed
+        # region): the N = 1 line's `value` is the un-pipelined frame of SURVEY 8(d) and an N > 1 `value` is the strip driver's
+        # pipelined throughput, so a ratio of the two lines flatters the strips by the pipelining gain (~11 %). The line therefore
+        # carries both single-GPU frame times and the two ratios itself. BENCH_NO_SINGLE=1 skips it.
+        if not os.environ.get("BENCH_NO_SINGLE") and (dev_shm or not dev_mirror):
+            wd.tick("single-GPU reference frames on rank 0", 600)
+            single = None
+            if rank == 0:
+                one = api.Renderer(width, height, device=local_rank)
+                one.set_scene(tris)
+                one.lookat(eye, center)
+                one.set_options(opt)
+                res1 = {}
+                for name, t14, t17 in (("unpipelined", 0, 0), ("pipelined", -1, -1)):
+                    one.tuning(14, t14)
+                    one.tuning(17, t17)
+                    for f in range(1, Wm + 3):
+                        one.frame(f)
+                    one.sync()
+                    t1 = time.perf_counter()
+                    for f in range(Wm + 3, Wm + 3 + max(K, 20)):
+                        one.frame(f)
+                    one.sync()
+                    res1[name] = (time.perf_counter() - t1) / max(K, 20) * 1e3
+                one.close()
+                single = res1
+            dist.barrier()
+            single_ref = single
+        else:
+            single_ref = None
     if mg is not None:
         mg.close()
     r.close()
@@ -709,6 +744,12 @@ def _main():
         if world > 1:
             out["value_definition"] = ("throughput of the native strip driver's pipelined frames; the N = 1 line's `value` is un-pipelined "
                                        "frames (SURVEY 8d) and its `value_pipelined` is the figure this one is comparable with")
+            if single_ref is not None:
+                out["single_gpu_on_this_node"] = {
+                    "ms_per_frame_unpipelined": single_ref["unpipelined"], "ms_per_frame_pipelined": single_ref["pipelined"],
+                    "speedup_vs_unpipelined": single_ref["unpipelined"] / ms, "speedup_vs_pipelined": single_ref["pipelined"] / ms,
+                    "note": "a whole-frame context on rank 0's GPU, timed in this run while the other ranks waited: the N = 1 line's `value` "
+                            "is the un-pipelined frame, this line's `value` is pipelined throughput — compare like with like"}
             out["config"]["strips"] = [list(b) for b in R["bounds"]]
             out["strip_driver"] = mg_stats
             if verified is not None:
@@ -748,10 +789,10 @@ def _main():
             out["value_gpu_event_median"] = {"value": total_rays / event_median / 1e3, "unit": "Mray/s", "ms_per_frame": event_median,
                                              "note": "rays / GPU-event median of frames run back to back on one stream with per-kernel events (SURVEY 8d's "
                                                      "definition of the frame time); `value` is the same frames without the events, wall clock over K frames"}
-            out["value_pipelined"] = {"value": total_rays * K / pipelined_dt / 1e6, "unit": "Mray/s", "ms_per_step": pipelined_dt / K * 1e3,
-                                      "steps": K, "warmup": Wm,
-                                      "note": "throughput of pipelined frames (stage 0 of frame f+1 beside the passes of frame f; every kernel still runs "
-                                              "once per frame): the headline of rounds 1-4, and what the N > 1 lines are comparable with"}
+            out["value_pipelined"] = None if pipelined_dt is None else {
+                "value": total_rays * K / pipelined_dt / 1e6, "unit": "Mray/s", "ms_per_step": pipelined_dt / K * 1e3, "steps": K, "warmup": Wm,
+                "note": "throughput of pipelined frames (stage 0 of frame f+1 beside the passes of frame f; every kernel still runs "
+                        "once per frame): the headline of rounds 1-4, and what the N > 1 lines are comparable with"}
             if walks is not None:
                 out["bvh_walks_per_frame"] = walks
                 out["Mwalk_per_s"] = walks["walked"] / ms / 1e3

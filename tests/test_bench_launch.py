@@ -72,6 +72,8 @@ def test_plain_launch_two_ranks_shm_is_verified():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0 and d["scaling"] == "strong"
     assert d["verified_vs_single_context"] is True, d
     assert len(d["config"]["strips"]) == 2 and "dev_shm" in d
+    one = d["single_gpu_on_this_node"]  # the like-with-like reference the line carries itself
+    assert one["ms_per_frame_unpipelined"] > 0 and one["ms_per_frame_pipelined"] > 0 and one["speedup_vs_pipelined"] > 0
     assert "fresh child processes" in d["launched_by"]
 
 

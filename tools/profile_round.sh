@@ -11,9 +11,9 @@ rm -rf $OUT; mkdir -p $OUT
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 export BENCH_VERIFY=0
 # per-kernel profiles are of frames whose kernels run back to back on one stream (RT_TUNING=14=0: without the pipelined stage 0
-# the kernels of consecutive frames do not overlap, so a kernel's duration and counters are its own; the bench line records
+# the kernels of consecutive frames do not overlap (17=0: resolve on the main stream too), so a kernel's duration and counters are its own; the bench line records
 # rt_tuning_env). The headline bench.json above is the default (pipelined) run.
-export RT_TUNING=14=0
+export RT_TUNING=14=0,17=0
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o st -- python3 bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c -d $OUT/pmc_$c -o pmc -- python3 bench.py --no-cpu-baseline --steps 16 --warmup 2 > $OUT/pmc_$c.log 2>&1
