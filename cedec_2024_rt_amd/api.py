@@ -670,7 +670,7 @@ class Renderer:
 
     def math_eval(self, fn, x):
         x = np.ascontiguousarray(x, dtype=np.float32)
-        n = x.size // {26: 2, 33: 2, 35: 2, 31: 12, 32: 12}.get(fn, 1)
+        n = x.size // {26: 2, 33: 2, 35: 2, 31: 12, 32: 12, 36: 3, 37: 3, 38: 14}.get(fn, 1)
         out = np.zeros(n, dtype=np.float32)
         self._ck(self.L.rt_math_eval(self.h, int(fn), _p(x), n, _p(out)))
         return out

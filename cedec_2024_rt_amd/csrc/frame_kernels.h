@@ -2972,6 +2972,27 @@ __global__ void k_math_eval(int fn, const float* __restrict__ in, int n, float* 
         }
         case 34: r = div_den_ok(in[i]) ? as_float(as_uint(sqrt_in_range(in[i])) ^ as_uint(sqrtf(in[i]))) : as_float(0xffffffffu); break;
         case 35: r = div_pdf(in[2 * (size_t)i], in[2 * (size_t)i + 1], div_den_ok(in[2 * (size_t)i + 1]) ? rcp_refined(in[2 * (size_t)i + 1]) : as_float(0x7fc00000u)); break;
+        /* r05 device self-checks. 36: reservoir_accept(u, W, S) as 1 / 0, and +2 when the decision came from the division-free path
+         * (coverage); 37: the same comparison with the plain division (what the host recomputes in IEEE binary32 too) */
+        case 36:
+        {
+            const float u = in[3 * (size_t)i], W = in[3 * (size_t)i + 1], S = in[3 * (size_t)i + 2];
+            const float t = u * S, d = W - t;
+            const float margin = __builtin_fmaf(fabsf(W), 9.5367431640625e-07f, 7.52316384526264e-37f);
+            r = (reservoir_accept(u, W, S) ? 1.0f : 0.0f) + ((fabsf(d) > margin && t > 0.0f) ? 2.0f : 0.0f);
+            break;
+        }
+        case 37: r = (in[3 * (size_t)i] < in[3 * (size_t)i + 1] / in[3 * (size_t)i + 2]) ? 1.0f : 0.0f; break;
+        /* 38: ris_weight against the nested-guard functions it replaces: XOR of the two results' bits; in: sp3 sn3 lp3 ln3 lum pdf (14) */
+        case 38:
+        {
+            const float* q = in + 14 * (size_t)i;
+            const f3 sp = F3(q[0], q[1], q[2]), sn = F3(q[3], q[4], q[5]), lp = F3(q[6], q[7], q[8]), ln = F3(q[9], q[10], q[11]);
+            const float lum = q[12], pdf = q[13];
+            const float r1 = div_den_ok(pdf) ? rcp_refined(pdf) : as_float(0x7fc00000u); /* as k_light_table stores it */
+            r = as_float(as_uint(ris_weight(sp, sn, lp, ln, lum, pdf, r1)) ^ as_uint(target_unshadowed(sp, sn, lp, ln, lum) / pdf));
+            break;
+        }
         default: break;
     }
     out[i] = r;

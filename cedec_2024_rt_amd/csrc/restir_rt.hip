@@ -2941,7 +2941,7 @@ int rt_math_eval(rt_ctx* c, int fn, const float* in, uint32_t n, float* out)
 {
     RT_CHECK_CTX(c);
     if (n == 0) return RT_OK;
-    const size_t nin = (fn == 26 || fn == 33 || fn == 35) ? 2 : ((fn == 31 || fn == 32) ? 12 : 1); /* floats per item */
+    const size_t nin = (fn == 26 || fn == 33 || fn == 35) ? 2 : ((fn == 31 || fn == 32) ? 12 : ((fn == 36 || fn == 37) ? 3 : (fn == 38 ? 14 : 1))); /* floats per item */
     float *d_i = nullptr, *d_o = nullptr;
     RT_HIP(c, hipMalloc(&d_i, (size_t)n * 4 * nin));
     RT_HIP(c, hipMalloc(&d_o, (size_t)n * 4));

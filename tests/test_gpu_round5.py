@@ -253,3 +253,101 @@ def test_wire_model_transport_moves_what_mirror_moves_and_takes_its_time(api, sc
     per_frame_model = stats["slow"]["wire_ns"] / 6 * 1e-9
     assert per_frame_model > 3 * 200e-6
     assert wall["slow"] >= 0.95 * per_frame_model, (wall, per_frame_model)
+
+
+def _log_uniform(rng, n, e_lo, e_hi, signed=False):
+    """float32 values with exponents uniform in [e_lo, e_hi) and random mantissas, a quarter of them extreme"""
+    e = rng.integers(e_lo + 127, e_hi + 127, size=n, dtype=np.uint32)
+    m = rng.integers(0, 1 << 23, size=n, dtype=np.uint32)
+    k = n // 4
+    m[:k // 3] = 0
+    m[k // 3: 2 * k // 3] = (1 << 23) - 1
+    m[2 * k // 3: k] = 1 << rng.integers(0, 23, size=k - 2 * k // 3, dtype=np.uint32)
+    bits = (e << 23) | m
+    if signed:
+        bits |= rng.integers(0, 2, size=n, dtype=np.uint32) << 31
+    return bits.view(np.float32)
+
+
+def test_division_free_accept_is_the_division(api):
+    """reservoir_accept (rt_device.h, r05) == `u < weight / w_sum` (common/reservoir.hpp:22-37) for EVERY operand triple: decided
+    from u * w_sum against weight where the two are more than 2^-20 |weight| apart, by the division itself otherwise. Device
+    self-check against IEEE binary32 division recomputed on the host (numpy) and on the device, over: triples as the RIS loop has
+    them (w_sum >= weight > 0, u in [0, 1)), triples built to land within a few ulps of equality (the only place the two forms
+    could differ), u = 0, zeros, subnormals, huge and tiny magnitudes, infinities, NaNs, negative weights and sums."""
+    r = api.Renderer(8, 8)
+    rng = np.random.default_rng(505)
+    fast_total = 0
+    for batch in range(5):
+        n = 3_000_000
+        u = ((rng.integers(0, 1 << 23, size=n, dtype=np.uint32) | np.uint32(0x3F800000)).view(np.float32) - np.float32(1.0)).astype(np.float32)  # PCG::uniformf's grid
+        W = _log_uniform(rng, n, -40, 40)
+        S = (W * (np.float32(1.0) + _log_uniform(rng, n, -10, 12))).astype(np.float32)  # w_sum = weight + earlier weights
+        if batch == 1:  # near equality: S = W / u up to a few ulps, so that u * S is within rounding distance of W
+            with np.errstate(all="ignore"):
+                S = (W / np.maximum(u, np.float32(2.0 ** -23))).astype(np.float32)
+            S = (S.view(np.uint32) + rng.integers(-3, 4, size=n).astype(np.uint32)).view(np.float32)
+        if batch == 2:  # arbitrary magnitudes and signs, u anywhere in [0, 1)
+            W = _log_uniform(rng, n, -126, 120, signed=True)
+            S = _log_uniform(rng, n, -126, 120, signed=True)
+        if batch == 3:  # special values in every position
+            sp = np.float32([0.0, -0.0, 1e-45, -1e-45, 1e-38, 1.0, np.inf, -np.inf, np.nan, 3.4e38, 2.0 ** -120, 2.0 ** -100])
+            k = len(sp)
+            g = np.array(np.meshgrid(np.float32([0.0, 2.0 ** -23, 0.25, 0.5, 1.0 - 2.0 ** -23]), sp, sp)).reshape(3, -1)
+            u[: g.shape[1]], W[: g.shape[1]], S[: g.shape[1]] = g[0], g[1], g[2]
+            u[g.shape[1]: g.shape[1] + 200000] = 0.0  # u = 0: "is the quotient non-zero", incl. quotients that underflow
+            W[g.shape[1]: g.shape[1] + 100000] = _log_uniform(rng, 100000, -126, -60)
+            S[g.shape[1]: g.shape[1] + 100000] = _log_uniform(rng, 100000, 20, 120)
+        if batch == 4:  # equality exactly and one ulp around it
+            S = _log_uniform(rng, n, -30, 30)
+            W = (u * S).astype(np.float32)
+            W = (W.view(np.uint32) + rng.integers(-2, 3, size=n).astype(np.uint32)).view(np.float32)
+        x = np.stack([u, W, S], axis=1).astype(np.float32)
+        got = r.math_eval(36, x)
+        dev = r.math_eval(37, x)
+        with np.errstate(all="ignore"):
+            want = (x[:, 0] < (x[:, 1] / x[:, 2]).astype(np.float32))
+        assert np.array_equal(dev != 0, want), "device IEEE division differs from the host's"  # the yardstick itself
+        acc = (got.astype(np.int32) & 1) != 0
+        bad = acc != want
+        assert not bad.any(), f"batch {batch}: reservoir_accept differs from the division for {int(bad.sum())} triples, e.g. {x[bad][:4]}"
+        fast = got >= 2.0
+        fast_total += int(fast.sum())
+        if batch == 0:
+            assert fast.mean() > 0.99  # the RIS loop's operands: the division is the rare path
+        if batch in (1, 4):
+            assert (~fast).mean() > 0.2  # and the near-equality batches really reach it
+    assert fast_total > 5_000_000
+    r.close()
+
+
+def test_single_guard_ris_weight_is_the_nested_form(api):
+    """ris_weight (frame_kernels.h, r05: the three shared-reciprocal forms of a RIS candidate behind ONE range test) ==
+    target_unshadowed(...) / pdf with the compiler's divisions, bit for bit: surface / light pairs as a frame has them and pairs
+    built to leave every range (coincident and nearly coincident points, axis-aligned offsets, huge coordinates, zero / tiny /
+    huge luminance and pdf)."""
+    r = api.Renderer(8, 8)
+    rng = np.random.default_rng(606)
+    n = 3_000_000
+    sp = (rng.random((n, 3), dtype=np.float32) * 60 - 30).astype(np.float32)
+    lp = (rng.random((n, 3), dtype=np.float32) * 60 - 30).astype(np.float32)
+    k = n // 10
+    lp[:k, 0] = sp[:k, 0]
+    lp[k:2 * k] = sp[k:2 * k] + (rng.random((k, 3), dtype=np.float32) * np.float32(1e-4)).astype(np.float32)
+    lp[2 * k:3 * k] = sp[2 * k:3 * k]
+    lp[3 * k:4 * k, 1] = (sp[3 * k:4 * k, 1] + np.float32(1e-30)).astype(np.float32)
+    sp[4 * k:5 * k] *= np.float32(1e18)
+    nrm = rng.normal(size=(2, n, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=2, keepdims=True)
+    lum = _log_uniform(rng, n, -20, 10)
+    pdf = _log_uniform(rng, n, -20, 20)
+    lum[5 * k:6 * k] = _log_uniform(rng, k, -126, 100)
+    pdf[6 * k:7 * k] = _log_uniform(rng, k, -100, 100)
+    lum[7 * k:7 * k + 1000] = 0.0
+    x = np.concatenate([sp, nrm[0], lp, nrm[1], lum[:, None], pdf[:, None]], axis=1).astype(np.float32)
+    out = r.math_eval(38, x).view(np.uint32)
+    both_nan = (sp == lp).all(axis=1) | ~np.isfinite(sp).all(axis=1)
+    bad = (out != 0) & ~both_nan
+    # a NaN on both sides may differ in payload only
+    assert not bad.any(), f"ris_weight: {int(bad.sum())} of {n} differ from the nested-guard form, e.g. {x[bad][:2]}"
+    r.close()
