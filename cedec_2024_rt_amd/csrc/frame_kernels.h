@@ -233,6 +233,35 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_RAYCAST_WS_WAVES : RT_RAYCAST_
     gbuffer_write(S, P, g0, g1, li, h.u, h.v, h.prim);
 }
 
+#ifdef RT_EXPERIMENTS /* rt_tuning key 24 (r05): a prototype for launches of less than one generation of wavefronts */
+/* HALF-DENSITY raycast: a wavefront carries 32 primary rays (the upper or lower 8 x 4 half of an 8 x 8 tile) in lanes 0-31 and 32
+ * rayless lanes that only ever HELP — the work-sharing walk hands them parts of the busy lanes' stacks (a rayless lane enters with
+ * tmin > tmax: its root culls everything, it is idle at the first sharing check). Twice the wavefronts, each with half the rays and
+ * twice the hands per ray: a 135-row strip's raycast is 4 050 wavefronts on a GPU that holds 8 192, lasts as long as its slowest
+ * wavefront, and keeps the vector ALUs 40 % busy — the idle half of the machine can work on the same rays. Same rays, same hits. */
+__global__ __launch_bounds__(TRACE_BLOCK, RT_RAYCAST_WS_WAVES) void k_raycast_half(SceneView S, FrameParams P, float4* __restrict__ vis,
+                                                                                float4* __restrict__ g0, float4* __restrict__ g1)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[WIDE_LDS_ROWS_CLOSEST * TRACE_BLOCK];
+    const int t = (int)threadIdx.x, tile = (int)(blockIdx.x >> 1), half = (int)(blockIdx.x & 1);
+    int x = 0, row = P.row0;
+    const bool has = t < 32 && tile_pixel_at<TRACE_BLOCK>(P, tile, t + 32 * half, x, row);
+    const int yi = P.H - 1 - row;
+    const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
+    if (P.stats && has) count_walk_flags(P.stats + 4 * WALK_RAYCAST, true, true, false, false);
+    const float u = (float)x / (float)P.W, v = (float)yi / (float)P.H;
+    const f3 forward = normalize(cross(P.rg_up, P.rg_right));
+    const f3 to = P.rg_origin + forward + mix(-P.rg_right, P.rg_right, u) + mix(P.rg_up, -P.rg_up, v);
+    const f3 rd = normalize(to - P.rg_origin);
+    Hit h;
+    h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.prim = -1;
+    closest_ws<TRACE_BLOCK>(S.wide, S.bvh.tv, s_stack, P.rg_origin, has ? rd : F3(0.0f, 0.0f, 1.0f), has ? 0.0f : 1.0f, has ? kFltMax : 0.0f, h);
+    if (!has) return;
+    vis[li] = make_float4(h.u, h.v, as_float(h.prim), as_float(0));
+    gbuffer_write(S, P, g0, g1, li, h.u, h.v, h.prim);
+}
+#endif /* RT_EXPERIMENTS */
+
 /* rebuild the G-buffer from an uploaded Visibility buffer */
 __global__ __launch_bounds__(BLOCK) void k_gbuffer_from_vis(SceneView S, FrameParams P,
                                                              const float4* __restrict__ vis,

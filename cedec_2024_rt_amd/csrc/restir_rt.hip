@@ -165,6 +165,7 @@ struct rt_ctx
     int tune_mark_window = 1; /* rt_tuning key 19 (r04): k_halo_mark collects a workgroup's marks in LDS first */
     unsigned long long* d_wire = nullptr; /* rt_wire_delay: GPU clock stamps */
     int wall_khz = 100000;
+    int tune_half_raycast = 0; /* rt_tuning key 24 (r05, experiments build): half-density raycast with helper lanes */
     int tune_fuse_final = -1; /* rt_tuning key 23 (r05): last spatial pass + resolve in one kernel: -1 auto, 0 never, 1 always, 2 = A/B without the pass's stores */
     bool final_fused = false; /* the running frame's last pass has resolved its rows */
     int tune_spec_free = -1; /* rt_tuning key 22 (r05): the look-ahead stage 0 free of the main stream and of the latest resolve: -1 auto = strips */
@@ -1262,14 +1263,22 @@ int rt_clear(rt_ctx* c)
     return RT_OK;
 }
 
+/* the raycast launch of the context's tuning, on `st`, into the given G-buffer set */
+static void launch_raycast(rt_ctx* c, hipStream_t st, float4* vis, float4* g0, float4* g1)
+{
+#ifdef RT_EXPERIMENTS
+    if (c->tune_half_raycast) { k_raycast_half<<<2 * trace_grid(c), TRACE_BLOCK, 0, st>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), vis, g0, g1); return; }
+#endif
+    if (use_ws_primary(c, trace_grid(c))) k_raycast<true><<<trace_grid(c), TRACE_BLOCK, 0, st>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), vis, g0, g1);
+    else k_raycast<false><<<trace_grid(c), TRACE_BLOCK, 0, st>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), vis, g0, g1);
+}
 int rt_raycast(rt_ctx* c)
 {
     RT_CHECK_CTX(c);
     JOIN_TAIL(c);
     JOIN_SPEC(c);
     NEED_SCENE(c);
-    if (use_ws_primary(c, trace_grid(c))) k_raycast<true><<<trace_grid(c), TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_vis, c->d_g0, c->d_g1);
-    else k_raycast<false><<<trace_grid(c), TRACE_BLOCK, 0, c->stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_vis, c->d_g0, c->d_g1);
+    launch_raycast(c, c->stream, c->d_vis, c->d_g0, c->d_g1);
     RT_HIP(c, hipGetLastError());
     c->has_gbuffer = true;
     ++c->gbuf_serial;
@@ -1335,8 +1344,7 @@ static int launch_next_raycast(rt_ctx* c, int frame)
     const int s0 = c->sub0, s1 = c->sub1, b0 = c->subb0, b1 = c->subb1;
     c->sub0 = c->sub1 = -1; c->subb0 = c->subb1 = 0; /* all owned rows */
     if (c->timing) hipEventRecord(c->ev_spec_t[o][0], c->spec_stream);
-    if (use_ws_primary(c, trace_grid(c))) k_raycast<true><<<trace_grid(c), TRACE_BLOCK, 0, c->spec_stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_gset[o][0], c->d_gset[o][1], c->d_gset[o][2]);
-    else k_raycast<false><<<trace_grid(c), TRACE_BLOCK, 0, c->spec_stream>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), c->d_gset[o][0], c->d_gset[o][1], c->d_gset[o][2]);
+    launch_raycast(c, c->spec_stream, c->d_gset[o][0], c->d_gset[o][1], c->d_gset[o][2]);
     RT_HIP(c, hipGetLastError());
     if (c->timing) hipEventRecord(c->ev_spec_t[o][1], c->spec_stream);
     c->spec_timed[o] = c->timing;
@@ -2856,6 +2864,7 @@ static bool experiment_only(int key, int value)
         case 10: return true;                      /* PLOC search radius (builder 2) */
         case 11: case 12: case 15: return value != 0; /* deferred visibility queue, pipelined RIS loop form, resolve as a stream */
         case 23: return value > 0;                 /* last pass + resolve in one kernel */
+        case 24: return value != 0;                /* half-density raycast with helper lanes */
         default: return false;
     }
 #endif
@@ -2885,6 +2894,7 @@ int rt_tuning(rt_ctx* c, int key, int value)
     else if (key == 20 && (value == 0 || value == 1)) c->tune_fuse_tonemap = value;
     else if (key == 21 && (value == 0 || value == 1)) { c->tune_mark_cache = value; c->mark_bits_epoch = 0; }
     else if (key == 23 && value >= -1 && value <= 2) c->tune_fuse_final = value;
+    else if (key == 24 && (value == 0 || value == 1)) c->tune_half_raycast = value;
     else if (key == 22 && value >= -1 && value <= 1) { c->tune_spec_free = value; c->spec_valid = false; c->spec_gen_valid = false; }
     else RT_FAIL(c, RT_ERR_ARG, "bad tuning key/value %d/%d", key, value);
     return RT_OK;
@@ -2916,6 +2926,7 @@ int rt_tuning_get(rt_ctx* c, int key, int* value)
         case 21: *value = c->tune_mark_cache; break;
         case 22: *value = c->tune_spec_free; break;
         case 23: *value = c->tune_fuse_final; break;
+        case 24: *value = c->tune_half_raycast; break;
         default: RT_FAIL(c, RT_ERR_ARG, "bad tuning key %d", key);
     }
     return RT_OK;

@@ -372,6 +372,9 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
  *        for launches of about one generation of wavefronts.
  *  16    primary rays through the work-sharing closest-hit walk: -1 auto = launches of about one generation of wavefronts, i.e.
  *        strips (default), 0 never, 1 always (a whole frame's coherent 8 x 8 tiles gain nothing: 0.311 -> 0.318 ms).
+ *  24    [exp] (r05) raycast at half density: a wavefront carries 32 primary rays and 32 rayless lanes that only take work from
+ *        the others' stacks, twice the wavefronts (would a strip's one-generation launch finish sooner with two lanes per ray?
+ *        No: 80 -> 94 us for 135 rows, 269 -> 449 us for a whole frame; profiles/r05_half_raycast_ab.txt). Default 0.
  * Scene (before rt_scene_set)
  *  5     BVH builder: 3 = on the device: pre-split, top-down binned SAH, 4-wide collapse; the host reads counters (default;
  *        11 ms for 212 k triangles). [exp] 0 = device LBVH + host collapse (r01), 1 = host binned SAH (the tree builder 3

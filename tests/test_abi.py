@@ -37,7 +37,7 @@ def test_product_library_carries_no_experiment_kernels():
     exp = api.load_library(exp=True)
     assert not [n for n in _declared() if not hasattr(exp, n)]
     assert exp.rt_build_id().decode().endswith("-exp") and not api.build_id().endswith("-exp")
-    A_B_ONLY = ("k_spatial_gather", "k_spatial_lds", "k_spatial_pipe", "k_spatial_resolve", "k_resolve_stream", "k_trace_queue",
+    A_B_ONLY = ("k_spatial_gather", "k_spatial_lds", "k_spatial_pipe", "k_spatial_resolve", "k_resolve_stream", "k_trace_queue", "k_raycast_half",
                 "k_candidate_visibility", "k_ploc_nn")
 
     def kernels(path):

@@ -7,6 +7,7 @@ bench.py times, plus form-against-form checks of buffers the oracle has no opini
 * rt_tuning 22: the look-ahead stage 0 free of the main stream and of the latest resolve (three G-buffer sets, five reservoir
   buffers), forced on a whole-frame context (strips have it by default: tests/test_mg_native.py, test_gpu_round4.py);
 * rt_tuning 21: the halo marks with and without the cached shaded-bit rows: same bitmaps, also across a camera move;
+* rt_tuning 24: raycast at half density — 32 primary rays and 32 rayless helper lanes per wavefront (10_restir_di.cu:9-34);
 * RT_MG_TRANSPORT_WIRE_MODEL moves what MIRROR moves and holds the stream for the modelled time.
 """
 import time
@@ -72,6 +73,8 @@ def _oracle_frames(oracle, tris, W, H, eye, at, frames, **optkw):
     (480, 270, 12, {22: 1, 23: 1}, {}),
     (480, 270, 12, {20: 0}, {}),                  # the reference's two tail launches
     (1920, 1080, 6, {23: 1, 22: 1}, {}),          # the benchmark's own size
+    (480, 270, 6, {24: 1}, {}),                   # half-density raycast (32 rays + 32 helper lanes per wavefront)
+    (1920, 1080, 3, {24: 1, 22: 1}, {}),
 ])
 def test_new_launch_forms_vs_oracle(api, oracle, scenes, W, H, frames, tuning, optkw):
     """blocks_restir, bench options, frames enqueued back to back with no sync in between; accumulation, pixels and the temporal
@@ -80,7 +83,7 @@ def test_new_launch_forms_vs_oracle(api, oracle, scenes, W, H, frames, tuning, o
 
     tris = scenes.make_blocks_restir()
     eye, at = scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT
-    r = api.Renderer(W, H, exp=23 in tuning)  # rt_tuning 23 is an A/B form: librestir_rt_exp.so
+    r = api.Renderer(W, H, exp=bool({23, 24} & set(tuning)))  # rt_tuning 23 and 24 are A/B forms: librestir_rt_exp.so
     for k, v in tuning.items():
         r.tuning(k, v)
     r.set_scene(tris)
