@@ -29,13 +29,45 @@ struct FrameParams
     /* options (common/options.hpp) */
     int accumulate, ris_sample_count, use_temporal, use_spatial, spatial_count, vis_reuse;
     float spatial_radius;
-    int tile_mode; /* workgroup -> tile order inside an XCD's band: 0 row-major, 1 column-major */
+    int tile_mode; /* workgroup -> tile order inside an XCD's band: 0 row-major, 1 column-major; 2 / 3: tile rows interleaved over the XCDs, row- / column-major */
     uint32_t ownv_tag; /* own-visibility flags are written / trusted under this tag only (rt_device.h); 0 = never */
     /* rt_walk_stats (measurement, off = nullptr: one wave-uniform test per kernel): 4 counters per kernel slot
      * {rays the reference traces here, walked through the BVH, settled by the one-triangle self-occlusion test, not evaluated
      * (answer known from the own-visibility flags, or unobservable)}; slots WALK_RAYCAST .. WALK_RESOLVE */
     unsigned long long* stats;
+#ifdef RT_EXPERIMENTS
+    /* rt_exp_wave_clock (measurement, experiments library only): two words per wavefront of the chosen kernel — the constant
+     * 100-MHz clock when it started, and when its last lane left | hardware id << 40 (XCD, SE, CU, SIMD) */
+    unsigned long long* wave_clock;
+#endif
 };
+#ifdef RT_EXPERIMENTS
+struct WaveClock
+{
+    unsigned long long* out;
+    unsigned long long t0;
+    RT_DEV explicit WaveClock(const FrameParams& P) : out(P.wave_clock), t0(0)
+    {
+        if (out) t0 = wall_clock64();
+    }
+    RT_DEV ~WaveClock()
+    {
+        if (!out) return;
+        /* lanes leave a kernel at different returns: the first lane of every leaving group notes the time, the latest stands */
+        const unsigned long long act = __ballot(true);
+        if ((int)(threadIdx.x & 63) != __ffsll((long long)act) - 1) return;
+        const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+        /* HW_ID: simd [5:4], cu [11:8], sh [12], se [15:13] */
+        const unsigned long long id = ((unsigned long long)(xcc & 15u) << 12) | (((hw >> 13) & 7u) << 9) | (((hw >> 12) & 1u) << 8) | (((hw >> 8) & 15u) << 4) | (((hw >> 4) & 3u) << 2);
+        const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        out[2 * w] = t0;
+        atomicMax(&out[2 * w + 1], (wall_clock64() & 0xffffffffffull) | (id << 40));
+    }
+};
+#define RT_WAVE_CLOCK(P) WaveClock wave_clock_(P)
+#else
+#define RT_WAVE_CLOCK(P)
+#endif
 enum { WALK_RAYCAST = 0, WALK_GENERATE = 1, WALK_SPATIAL = 2, WALK_RESOLVE = 3 };
 /* one ray per lane at most; works under any exec mask (ballots count the active lanes) */
 RT_DEV void count_walk_flags(unsigned long long* __restrict__ st, bool ref, bool walked, bool self, bool skipped)
@@ -123,6 +155,39 @@ RT_DEV bool tile_pixel_at(const FrameParams& P, const int b, const int t, int& x
         ty = (b & 7) * band_rows + (slot - tx * band_rows);
         if (tx >= tiles_x || ty >= tiles_y) return false;
     }
+    else if (P.tile_mode >= 4)
+    {
+        /* workgroup b = tile b: neighbouring tiles on different XCDs; 4: row by row, 5: in stripes 32 tiles wide */
+        if (P.tile_mode == 4) { ty = b / tiles_x; tx = b - ty * tiles_x; }
+        else if (P.tile_mode >= 6)
+        {
+            /* row-major in runs of R tiles: run r on XCD r % 8 (6: R = 4, 7: R = 16) */
+            const int R = P.tile_mode == 6 ? 4 : 16, slot = b >> 3;
+            const int tile = ((slot / R) * 8 + (b & 7)) * R + slot % R;
+            ty = tile / tiles_x; tx = tile - ty * tiles_x;
+        }
+        else
+        {
+            const int per_stripe = 32 * tiles_y, s = b / per_stripe, r = b - s * per_stripe;
+            const int w = tiles_x - 32 * s < 32 ? tiles_x - 32 * s : 32; /* the last stripe may be narrower */
+            if (w <= 0) return false;
+            ty = r / w; tx = 32 * s + (r - ty * w);
+        }
+        if (tx >= tiles_x || ty >= tiles_y) return false;
+    }
+    else if (P.tile_mode >= 2)
+    {
+        /* r05: INTERLEAVED tile rows — XCD k takes tile rows k, k + 8, k + 16, ... (every XCD sees a sample of the whole image: the
+         * eight bands of modes 0 / 1 cost what their part of the scene costs, and the launch ends with the dearest band's XCD),
+         * walked row by row (2) or column by column (3) */
+        const int band_rows = (tiles_y + 7) / 8;
+        const int slot = b >> 3;
+        int j;
+        if (P.tile_mode == 2) { j = slot / tiles_x; tx = slot - j * tiles_x; }
+        else { tx = slot / band_rows; j = slot - tx * band_rows; }
+        ty = 8 * j + (b & 7);
+        if (tx >= tiles_x || ty >= tiles_y) return false;
+    }
     else
     {
         const int n_tiles = tiles_x * tiles_y;
@@ -166,9 +231,9 @@ RT_DEV bool tile_pixel(const FrameParams& P, int& x, int& row)
 }
 static inline int tile_grid(int W, int rows, int tile_w = TILE_W, int tile_h = TILE_H, int rows_b = 0)
 {
-    /* covers both orders: mode 1 needs 8 * ceil(tiles_y/8) * tiles_x workgroups */
+    /* covers every order: modes 1-3 need 8 * ceil(tiles_y/8) * tiles_x workgroups */
     const int tx = (W + tile_w - 1) / tile_w, ty = (rows + tile_h - 1) / tile_h + (rows_b > 0 ? (rows_b + tile_h - 1) / tile_h : 0);
-    const int a = ((tx * ty + 7) / 8) * 8, b = 8 * ((ty + 7) / 8) * tx;
+    const int a = ((tx * ty + 127) / 128) * 128 /* whole runs of 16 tiles on 8 XCDs (mode 7) */, b = 8 * ((ty + 7) / 8) * tx;
     return a > b ? a : b;
 }
 
@@ -214,6 +279,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_RAYCAST_WS_WAVES : RT_RAYCAST_
                                                     float4* __restrict__ g0, float4* __restrict__ g1)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_stack[(WS ? WIDE_LDS_ROWS_CLOSEST : WIDE_LDS_STACK) * TRACE_BLOCK];
+    RT_WAVE_CLOCK(P);
     int x, row;
     if (!tile_pixel<TRACE_BLOCK>(P, x, row)) return;
     const int yi = P.H - 1 - row;
@@ -430,6 +496,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : (SHADOWED 
     float4* __restrict__ out_rad, uint32_t* __restrict__ vis_queue = nullptr, unsigned int* __restrict__ vis_count = nullptr)
 {
     static_assert(!DEFER || (FUSE_TEMPORAL && !SHADOWED), "deferred visibility: fused unshadowed kernel only");
+    RT_WAVE_CLOCK(P);
     constexpr bool LATE = WS && FUSE_TEMPORAL && !SHADOWED && !DEFER; /* the visibility-reuse ray after the temporal merge */
     /* shadowed target: every lane stays through the RIS loop, so that the wavefront can fetch its light records together */
     constexpr bool STAY = SHADOWED && !DEFER && !PIPE && RT_SHADOWED_RIS_COOP && RT_RIS_COOP && RT_LIGHT_STRIDE == 4;
@@ -1484,17 +1551,19 @@ RT_DEV void spatial_coop_store(const FrameParams& P, const HaloFuse& F, float4* 
     store_stream<2>(out_rad + o.li, make_float4(r.rad.x, r.rad.y, r.rad.z, as_float(r.ownv)));
     if (FUSED) res_give(F, P.W, o.li, o.x, o.row, r, o.active);
 }
-template <int WAVES, bool FUSED>
-__global__ __launch_bounds__(BLOCK) void k_spatial_coop(
+/* TB: 256 threads on a 32 x 8 tile, or (r05, rt_tuning key 8 = 4) one wavefront on an 8 x 8 tile */
+template <int WAVES, bool FUSED, int TB = BLOCK>
+__global__ __launch_bounds__(TB) void k_spatial_coop(
     SceneView S, FrameParams P, HaloFuse F, const float4* __restrict__ g0, const float4* __restrict__ g1, const float4* __restrict__ in_rec,
     const float4* __restrict__ in_rad, float4* __restrict__ out_rec, float4* __restrict__ out_rad)
 {
     occupancy_bound<WAVES>();
-    __shared__ __attribute__((aligned(16))) float4 s_img[BLOCK / 64][256];
+    __shared__ __attribute__((aligned(16))) float4 s_img[TB / 64][256];
+    RT_WAVE_CLOCK(P);
     const int lane = threadIdx.x & 63;
     float4* s_wave = s_img[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))]; /* a scalar: the LDS-DMA base (M0) without per-load lane reads */
     SpatialOut o;
-    spatial_coop_wave<BLOCK, FUSED>(P, F, g0, g1, in_rec, in_rad, s_wave, lane, o);
+    spatial_coop_wave<TB, FUSED>(P, F, g0, g1, in_rec, in_rad, s_wave, lane, o);
     spatial_coop_store<FUSED>(P, F, s_wave, lane, o, out_rec, out_rad);
 }
 
@@ -2098,6 +2167,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, RT_RESOLVE_WAVES) void k_resolve(Scene
      * buffer again (one launch and a 16-B read per pixel less). NULL for the per-kernel entry point rt_resolve: the reference's
      * resolve (10_restir_di.cu:390-459) does not touch the pixel buffer. */
     __shared__ __attribute__((aligned(16))) uint32_t s_stack[(WS ? WIDE_LDS_ROWS : WIDE_LDS_STACK) * TRACE_BLOCK];
+    RT_WAVE_CLOCK(P);
     int x, row;
     if (!tile_pixel<TRACE_BLOCK>(P, x, row)) return;
     const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;

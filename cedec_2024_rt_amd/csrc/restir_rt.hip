@@ -88,9 +88,10 @@ struct rt_ctx
     int n_tris = 0, n_lights = 0, bvh_height = 0, n_refs = 0;
     /* rt_tuning: tile order per kernel {raycast, generate, spatial, resolve, other} and the spatial
      * pass's occupancy limiter (extra dynamic LDS). Defaults from the sweep in DESIGN.md §5. */
-    int tune_tile_mode[5] = {-1, 0, -1, 0, 0}; /* -1 = auto: column-major for whole-frame contexts, row-major for strips (r04: a strip's
-                                                  band of an XCD is a few tile rows; row-major is 6 % of a 135-row strip's frame and 3 % of a
-                                                  270-row one's, profiles/r04_strip_tile_modes.txt; whole frames lose 4 % with it) */
+    int tune_tile_mode[5] = {-1, -1, -1, -1, 0}; /* -1 = auto (make_params): r05 — the tracing kernels take their tiles INTERLEAVED over
+                                                    the XCDs (whole frames: tile rows k, k + 8, ...; strips: tile b on XCD b % 8), the
+                                                    spatial pass keeps an XCD's band of tile rows, column by column (its +-87-px
+                                                    neighbour window must stay in that XCD's L2); profiles/r05_tile_interleave_ab.txt */
     int tune_spatial_lds = 0;     /* rt_tuning key 4: extra dynamic LDS per unshadowed spatial workgroup (A/B of the old throttle) */
     int tune_spatial_variant = 2; /* rt_tuning key 8: 2 = k_spatial_coop (default: four lanes per record, LDS-DMA gathers, transposed
                                      stores), 0 = k_spatial_gather (one per-lane gather per neighbour), 1 = k_spatial_lds (staged
@@ -165,6 +166,9 @@ struct rt_ctx
     int tune_mark_window = 1; /* rt_tuning key 19 (r04): k_halo_mark collects a workgroup's marks in LDS first */
     unsigned long long* d_wire = nullptr; /* rt_wire_delay: GPU clock stamps */
     int wall_khz = 100000;
+    unsigned long long* d_wave_clock = nullptr; /* rt_exp_wave_clock (experiments library): two words per wavefront of one kernel */
+    size_t wave_clock_words = 0;
+    int wave_clock_kernel = -1, wave_clock_pass = 0;
     int tune_half_raycast = 0; /* rt_tuning key 24 (r05, experiments build): half-density raycast with helper lanes */
     int tune_fuse_final = -1; /* rt_tuning key 23 (r05): last spatial pass + resolve in one kernel: -1 auto, 0 never, 1 always, 2 = A/B without the pass's stores */
     bool final_fused = false; /* the running frame's last pass has resolved its rows */
@@ -260,15 +264,25 @@ static FrameParams make_params(const rt_ctx* c, int frame, int pass, int kernel 
     P.spatial_count = c->opt.spatial_resampling_sample_count; P.vis_reuse = c->opt.use_visibility_reuse;
     P.spatial_radius = c->opt.spatial_resampling_radius;
     {
-        /* auto (r04, profiles/r04_strip_tile_modes.txt): whole frames column-major; strips trace their primary rays row-major, and
-         * run the spatial pass row-major too when they are short (a 135-row strip: -6 % of its frame; a 270-row strip keeps
-         * column-major: its neighbour window would not stay in the XCD's L2 otherwise) */
+        /* auto. r01-r04 gave XCD k ONE band of tile rows in every kernel (order inside the band: r04, profiles/r04_strip_tile_modes.txt).
+         * The tracing kernels' cost per tile follows the scene (sky rows, brick rows ...), so the launch ended with the dearest
+         * band's XCD while the others idled: r05 interleaves their tiles over the XCDs — whole frames by tile rows (2), strips
+         * tile by tile (4: balanced for any height) — raycast -14 %, generate_candidate -9 %, resolve -12 % of a whole frame; an
+         * 8-rank 4K strip -7 % with its spatial launches interleaved too (a 1080p one +-0). The whole frame's spatial pass keeps
+         * its bands: its neighbour window has to stay in one XCD's L2 (interleaved: 0.132 -> 0.199 ms), and cutting the bands by
+         * cost instead of height gains nothing (profiles/r05_spatial_band_cuts.txt). */
         const bool whole = c->row_begin == 0 && c->row_end == c->H;
-        const int autom = whole ? 1 : (kernel == K_SPATIAL && c->row_end - c->row_begin >= 200 ? 1 : 0);
+        /* the shadowed-target pass traces up to six rays per pixel: a tracing kernel first (runs of 16 tiles per XCD: 4.67 -> 3.83 ms
+         * per frame; interleaved tile rows 3.91) */
+        const int spatial = c->opt.use_shadowed_target_function ? 7 : (whole || c->row_end - c->row_begin >= 400 ? 1 : 4);
+        const int autom = kernel == K_SPATIAL ? spatial : (kernel == K_OTHER ? 0 : (whole ? 2 : 4));
         P.tile_mode = c->tune_tile_mode[kernel] >= 0 ? c->tune_tile_mode[kernel] : autom;
     }
     P.ownv_tag = c->cur_tag;
     P.stats = c->walk_on ? c->d_walk : nullptr;
+#ifdef RT_EXPERIMENTS
+    P.wave_clock = c->d_wave_clock && kernel == c->wave_clock_kernel && (kernel != K_SPATIAL || pass == c->wave_clock_pass) ? c->d_wave_clock : nullptr;
+#endif
     return P;
 }
 static uint32_t next_ownv_tag(rt_ctx* c)
@@ -395,7 +409,7 @@ int rt_destroy(rt_ctx* c)
     hipFree(c->d_shaded_bits); hipFree(c->d_mark_bits);
     hipFree(c->d_visq[0]); hipFree(c->d_visq[1]); hipFree(c->d_visq_count);
     if (c->h_visq_count) hipHostFree(c->h_visq_count);
-    hipFree(c->d_walk); hipFree(c->d_wire);
+    hipFree(c->d_walk); hipFree(c->d_wire); hipFree(c->d_wave_clock);
     hipFree(c->d_counter); hipFree(c->d_stage); hipFree(c->d_paths[0]); hipFree(c->d_paths[1]); hipFree(c->d_pt_counters);
     if (c->ev_created) for (auto& e : c->ev) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -1655,6 +1669,18 @@ static int launch_spatial(rt_ctx* c, int frame, int pass, int in_phys, int out_p
         c->final_fused = true;
     }
 #endif
+#ifdef RT_EXPERIMENTS
+    else if (c->tune_spatial_variant == 4)
+    {
+        /* r05, A/B only: k_spatial_coop as one-wavefront workgroups on 8 x 8 tiles (a finished wavefront's slot is refilled at once; a
+         * 256-thread workgroup's four slots wait for four free slots on one CU: 5 400 of 6 144 slots filled on average). More
+         * wavefronts in flight (5 750), each slower (25.9 -> 27.9 us): the pass is bound by its misses in flight, +1.3 % */
+        const bool fused = c->fuse.recv[0] || c->fuse.recv[1] || c->fuse.send[0] || c->fuse.send[1];
+#define RT_SPC1(FU) k_spatial_coop<RT_SPATIAL_GATHER_AUTO_WAVES, FU, TRACE_BLOCK><<<trace_grid(c), TRACE_BLOCK, (size_t)c->tune_spatial_lds, c->stream>>>(S, P, c->fuse, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys])
+        if (fused) RT_SPC1(true); else RT_SPC1(false);
+#undef RT_SPC1
+    }
+#endif
     else if (c->tune_spatial_variant == 2 || c->tune_spatial_variant == 3) /* 3 where the pipelined kernel does not apply (strips, radius > 30, > 5 neighbours) */
     {
 #define RT_SPC2(WV, FU) k_spatial_coop<WV, FU><<<launch_grid(c), BLOCK, (size_t)c->tune_spatial_lds, c->stream>>>(S, P, c->fuse, c->d_g0, c->d_g1, c->d_rec[in_phys], c->d_rad[in_phys], c->d_rec[out_phys], c->d_rad[out_phys])
@@ -2703,6 +2729,36 @@ int rt_walk_stats_enable(rt_ctx* c, int on)
     c->spec_valid = false; c->spec_gen_valid = false;
     return RT_OK;
 }
+#ifdef RT_EXPERIMENTS
+/* Experiments library only (not in include/restir_rt.h; tools/wave_timeline.py binds it by name). Arms the per-wavefront clock of
+ * ONE kernel of the frame — 0 raycast, 1 generate_candidate, 2 spatial_resampling pass `pass`, 3 resolve, -1 off — or, with
+ * `out` non-null, reads the 2 x n words the launches since then left (synchronises). Results never depend on it. */
+int rt_exp_wave_clock(rt_ctx* c, int kernel, int pass, uint64_t* out, size_t n_words)
+{
+    RT_CHECK_CTX(c);
+    int rc = rt_sync(c);
+    if (rc != RT_OK) return rc;
+    if (out)
+    {
+        if (!c->d_wave_clock || n_words > c->wave_clock_words) RT_FAIL(c, RT_ERR_STATE, "rt_exp_wave_clock: arm first");
+        RT_HIP(c, hipMemcpy(out, c->d_wave_clock, n_words * 8, hipMemcpyDeviceToHost));
+        return RT_OK;
+    }
+    /* one-wavefront workgroups over 8 x 8 tiles at most: every order's grid fits in twice the tile count */
+    const size_t words = 4 * ((size_t)trace_grid(c) + 1024) + 8 * (size_t)launch_grid(c);
+    if (kernel >= 0 && words > c->wave_clock_words)
+    {
+        if (c->d_wave_clock) hipFree(c->d_wave_clock);
+        c->d_wave_clock = nullptr;
+        RT_HIP(c, hipMalloc(&c->d_wave_clock, words * 8));
+        c->wave_clock_words = words;
+    }
+    if (c->d_wave_clock) RT_HIP(c, hipMemset(c->d_wave_clock, 0, c->wave_clock_words * 8));
+    c->wave_clock_kernel = kernel; c->wave_clock_pass = pass;
+    c->spec_valid = false; c->spec_gen_valid = false;
+    return RT_OK;
+}
+#endif
 int rt_walk_stats(rt_ctx* c, uint64_t out[16])
 {
     RT_CHECK_CTX(c);
@@ -2874,12 +2930,12 @@ int rt_tuning(rt_ctx* c, int key, int value)
     RT_CHECK_CTX(c);
     if (experiment_only(key, value))
         RT_FAIL(c, RT_ERR_UNSUPPORTED, "rt_tuning %d = %d selects an A/B form that only librestir_rt_exp.so (built with -DRT_EXPERIMENTS) carries", key, value);
-    if (key >= 0 && key <= 3 && (value == 0 || value == 1 || value == -1)) c->tune_tile_mode[key] = value;
+    if (key >= 0 && key <= 3 && value >= -1 && value <= 7) c->tune_tile_mode[key] = value;
     else if (key == 4 && value >= 0 && value <= 160 * 1024) c->tune_spatial_lds = value;
     else if (key == 5 && value >= 0 && value <= 3) c->bvh_builder = value; /* before rt_scene_set */
     else if (key == 6 && value >= 0 && value <= 2) c->pt_wavefront = value;
     else if (key == 7 && value >= 0) c->bvh_bfs_records = value; /* before rt_scene_set */
-    else if (key == 8 && value >= 0 && value <= 3) { c->tune_spatial_variant = value; c->shaded_bits_stale = true; }
+    else if (key == 8 && value >= 0 && value <= 4) { c->tune_spatial_variant = value; c->shaded_bits_stale = true; }
     else if (key == 9 && (value == 0 || value == -1 || (value >= 4 && value <= 6))) c->tune_spatial_waves = value;
     else if (key == 10 && value >= 1 && value <= 256) c->ploc_radius = value; /* before rt_scene_set */
     else if (key == 11 && (value == 0 || value == 1)) c->tune_defer_vis = value;

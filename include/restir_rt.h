@@ -363,9 +363,14 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
  * RT_ERR_UNSUPPORTED for them. History and numbers of every key: docs/MEASUREMENT_LOG_*.md.
  *
  * Launch geometry
- *  0..3  tile order inside an XCD band of raycast / generate_candidate / spatial_resampling / resolve: 0 row-major, 1 column-major,
- *        -1 auto (keys 0 and 2; default): column-major for whole-frame contexts, row-major for a strip's primary rays and for the
- *        spatial pass of strips under 200 rows. Defaults {-1, 0, -1, 0}.
+ *  0..3  workgroup -> tile order of raycast (and rt_path_trace) / generate_candidate / spatial_resampling / resolve. Workgroup b runs
+ *        on XCD b % 8. 0, 1: XCD k takes ONE band of tile rows, row by row / column by column (r01-r04). r05, the XCDs
+ *        interleaved: 2, 3 = XCD k takes tile rows k, k + 8, ... (row by row / column by column), 4 = tile b (row-major) on XCD
+ *        b % 8, 5 = the same in stripes 32 tiles wide, 6, 7 = row-major runs of 4 / 16 tiles per XCD. -1 auto (default for all
+ *        four): tracing kernels 2 on whole frames, 4 on strips (a band costs what its part of the scene costs: raycast -14 %,
+ *        generate_candidate -9 %, resolve -12 %, an 8-rank 4K strip -7 %); the spatial pass 1 on whole frames and strips of
+ *        400 rows or more (its +-87-px neighbour window must stay in one XCD's L2), 4 on shorter strips, 7 with the shadowed
+ *        target function (4.67 -> 3.83 ms per frame). profiles/r05_tile_interleave_ab.txt.
  *  4     extra LDS bytes per unshadowed spatial workgroup (round 1's occupancy throttle; default 0).
  *  9     register budget of the unshadowed spatial pass in wavefronts per SIMD: -1 auto = 6 (default). [exp] 4, 5, 0 (= unbounded, 7).
  *  13    shadow rays of generate_candidate / resolve through the work-sharing any-hit walk: 1 always (default), 0 never, -1 only
@@ -401,7 +406,8 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
  *  8     2 = the wavefront fetches the 64 records of a round together, four lanes per 64-B record, as LDS-DMA loads that land
  *        transposed in LDS, and writes its 64 records the same way (default, the only product form). [exp] 0 = one per-lane
  *        gather per neighbour (r01), 1 = the tile's +-87-px window of shaded bits staged in LDS (r02), 3 = form 2 software-
- *        pipelined over that window (r04: 0.152 against 0.1435 ms).
+ *        pipelined over that window (r04: 0.152 against 0.1435 ms), 4 = form 2 as one-wavefront workgroups on 8 x 8 tiles (r05:
+ *        more wavefronts in flight, each slower: +1.3 %).
  *  23    [exp] (r05) the LAST spatial pass + resolve in one kernel (k_spatial_resolve): 1 = with the pass's own stores, 2 = records
  *        kept in registers (the pass's output buffer is NOT written), 0 / -1 = two kernels (default). Measured slower:
  *        profiles/r05_fused_tail_ab.txt.

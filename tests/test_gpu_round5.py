@@ -7,6 +7,8 @@ bench.py times, plus form-against-form checks of buffers the oracle has no opini
 * rt_tuning 22: the look-ahead stage 0 free of the main stream and of the latest resolve (three G-buffer sets, five reservoir
   buffers), forced on a whole-frame context (strips have it by default: tests/test_mg_native.py, test_gpu_round4.py);
 * rt_tuning 21: the halo marks with and without the cached shaded-bit rows: same bitmaps, also across a camera move;
+* rt_tuning 0-3 = 2 ... 7: the tile orders that interleave the XCDs (results never depend on the order); 8 = 4: the pass in
+  one-wavefront workgroups;
 * rt_tuning 24: raycast at half density — 32 primary rays and 32 rayless helper lanes per wavefront (10_restir_di.cu:9-34);
 * RT_MG_TRANSPORT_WIRE_MODEL moves what MIRROR moves and holds the stream for the modelled time.
 """
@@ -75,6 +77,14 @@ def _oracle_frames(oracle, tris, W, H, eye, at, frames, **optkw):
     (1920, 1080, 6, {23: 1, 22: 1}, {}),          # the benchmark's own size
     (480, 270, 6, {24: 1}, {}),                   # half-density raycast (32 rays + 32 helper lanes per wavefront)
     (1920, 1080, 3, {24: 1, 22: 1}, {}),
+    (480, 270, 5, {0: 2, 1: 3, 2: 2, 3: 3}, {}),  # r05 tile orders: tile rows interleaved over the XCDs, row- / column-major
+    (480, 270, 5, {0: 4, 1: 5, 2: 4, 3: 5}, {}),  # ... tile b on XCD b % 8, row by row / in stripes of 32 tiles
+    (480, 270, 5, {0: 6, 1: 7, 2: 6, 3: 7}, {}),  # ... runs of 4 / 16 tiles per XCD
+    (500, 277, 4, {0: 5, 1: 6, 2: 7, 3: 2}, {}),  # ... on an image whose sides are no multiple of the tile
+    (480, 270, 5, {0: 0, 1: 1, 2: 0, 3: 1}, {}),  # the band orders of r01-r04
+    (480, 270, 4, {2: 7}, {"use_shadowed_target_function": 1}),
+    (480, 270, 5, {8: 4}, {}),                    # the pass as one-wavefront workgroups on 8 x 8 tiles (A/B form)
+    (1920, 1080, 3, {0: 7, 1: 4, 2: 5, 3: 6}, {}),
 ])
 def test_new_launch_forms_vs_oracle(api, oracle, scenes, W, H, frames, tuning, optkw):
     """blocks_restir, bench options, frames enqueued back to back with no sync in between; accumulation, pixels and the temporal
@@ -83,7 +93,7 @@ def test_new_launch_forms_vs_oracle(api, oracle, scenes, W, H, frames, tuning, o
 
     tris = scenes.make_blocks_restir()
     eye, at = scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT
-    r = api.Renderer(W, H, exp=bool({23, 24} & set(tuning)))  # rt_tuning 23 and 24 are A/B forms: librestir_rt_exp.so
+    r = api.Renderer(W, H, exp=bool({23, 24} & set(tuning)) or tuning.get(8) == 4)  # A/B forms: librestir_rt_exp.so
     for k, v in tuning.items():
         r.tuning(k, v)
     r.set_scene(tris)

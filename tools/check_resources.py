@@ -21,8 +21,8 @@ BUDGET = [
     (r"^k_generate_candidate<true, false, false, false, false>", 0, 5),       # the whole frame's fused candidates + temporal
     (r"^k_generate_candidate<true, false, false, false, true>", 0, 6),        # strips (work-sharing walk)
     (r"^k_generate_candidate<false, false, false, false, false>", 0, 6),      # rt_generate_candidate
-    (r"^k_spatial_coop<6, false>", 0, 6),                                     # the roofline kernel
-    (r"^k_spatial_coop<6, true>", 0, 5),                                      # strips: halo lists read / written in the pass
+    (r"^k_spatial_coop<6, false, 256>", 0, 6),                                # the roofline kernel
+    (r"^k_spatial_coop<6, true, 256>", 0, 5),                                 # strips: halo lists read / written in the pass
     (r"^k_resolve<", 0, 8),
     (r"^k_spatial<true, true>", 80, 7),
     (r"^k_tone_mapping", 0, 8),
