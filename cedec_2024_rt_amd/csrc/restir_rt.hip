@@ -275,7 +275,11 @@ static FrameParams make_params(const rt_ctx* c, int frame, int pass, int kernel 
         /* the shadowed-target pass traces up to six rays per pixel: a tracing kernel first (runs of 16 tiles per XCD: 4.67 -> 3.83 ms
          * per frame; interleaved tile rows 3.91) */
         const int spatial = c->opt.use_shadowed_target_function ? 7 : (whole || c->row_end - c->row_begin >= 400 ? 1 : 4);
-        const int autom = kernel == K_SPATIAL ? spatial : (kernel == K_OTHER ? 0 : (whole ? 2 : 4));
+        /* interleaved tile rows give an XCD ceil(tile rows / 8) of them: within 2 % of an eighth for 1080p (135) and 4K (270), not
+         * for 1280 x 720 (90 tile rows: 12 against 11.25) — runs of 16 tiles then (balanced for any shape; equal at 1080p) */
+        const int tile_rows = (c->row_end - c->row_begin + 7) / 8;
+        const int traced = !whole ? 4 : (50 * ((tile_rows + 7) / 8) * 8 <= 51 * tile_rows ? 2 : 7);
+        const int autom = kernel == K_SPATIAL ? spatial : (kernel == K_OTHER ? 0 : traced);
         P.tile_mode = c->tune_tile_mode[kernel] >= 0 ? c->tune_tile_mode[kernel] : autom;
     }
     P.ownv_tag = c->cur_tag;
@@ -1786,12 +1790,16 @@ int rt_path_trace(rt_ctx* c, int example, int frame)
     if (example != 7 && example != 8 && example != 9) RT_FAIL(c, RT_ERR_ARG, "example must be 7 (07_pt), 8 (08_nee) or 9 (09_ris)");
     if (example != 7 && c->n_lights == 0) RT_FAIL(c, RT_ERR_STATE, "08_nee / 09_ris need at least one emissive triangle");
     const SceneView S = make_scene(c);
-    const FrameParams P = make_params(c, frame, 0, K_RAYCAST);
+    FrameParams P = make_params(c, frame, 0, K_RAYCAST);
     const f3 sky = F3(c->opt.sky_color[0], c->opt.sky_color[1], c->opt.sky_color[2]);
     const int g = trace_grid(c);
     const int md = c->opt.max_depth;
     const bool sh = c->opt.use_shadowed_target_function != 0;
     const bool wavefront = c->pt_wavefront == 1 || (c->pt_wavefront == 2 && example == 9);
+    /* one launch per bounce: the first launch's tile order is the order of the path list every later bounce walks — an XCD's
+     * band of the image keeps neighbouring paths on one XCD (interleaved: +2 %); one launch per frame gains 5-10 % interleaved
+     * like the frame's tracing kernels (profiles/r05_tile_interleave_ab.txt) */
+    if (wavefront && c->tune_tile_mode[K_RAYCAST] < 0) P.tile_mode = 1;
     if (wavefront && md > 0 && md <= 60)
     {
         /* one launch per bounce over the compacted list of live paths */
@@ -2740,8 +2748,8 @@ int rt_exp_wave_clock(rt_ctx* c, int kernel, int pass, uint64_t* out, size_t n_w
     if (rc != RT_OK) return rc;
     if (out)
     {
-        if (!c->d_wave_clock || n_words > c->wave_clock_words) RT_FAIL(c, RT_ERR_STATE, "rt_exp_wave_clock: arm first");
-        RT_HIP(c, hipMemcpy(out, c->d_wave_clock, n_words * 8, hipMemcpyDeviceToHost));
+        if (!c->d_wave_clock) RT_FAIL(c, RT_ERR_STATE, "rt_exp_wave_clock: arm first");
+        RT_HIP(c, hipMemcpy(out, c->d_wave_clock, std::min(n_words, c->wave_clock_words) * 8, hipMemcpyDeviceToHost)); /* the rest stays as the caller left it */
         return RT_OK;
     }
     /* one-wavefront workgroups over 8 x 8 tiles at most: every order's grid fits in twice the tile count */

@@ -4,7 +4,7 @@ launch of raycast / generate_candidate / spatial_resampling / resolve (frames ba
 span, wavefront-time / span = mean wavefronts in flight, the in-flight count over 20 slices of the span, when each XCD ran out of
 work, and the span a perfectly packed launch would need (wavefront-time / peak in flight).
 
-  python tools/wave_timeline.py [WxH] [rt_tuning k=v ...]     e.g.  python tools/wave_timeline.py 1920x1080 0=0 1=0 3=0
+  python tools/wave_timeline.py [WxH] [rows=A:B] [rt_tuning k=v ...]     e.g.  python tools/wave_timeline.py 1920x1080 0=0 1=0 3=0
 """
 import ctypes as C
 import os
@@ -19,7 +19,11 @@ from cedec_2024_rt_amd.types import bench_options  # noqa: E402
 
 args = sys.argv[1:]
 W, H = (int(v) for v in args.pop(0).split("x")) if args and "x" in args[0] else (1920, 1080)
-r = api.Renderer(W, H, exp=True)
+rows = None
+if args and args[0].startswith("rows="):  # a strip (87 halo rows that nobody fills: timing only)
+    a, b = args.pop(0)[5:].split(":")
+    rows = (int(a), int(b))
+r = api.Renderer(W, H, rows=rows, halo=87 if rows else 0, exp=True)
 r.set_scene(scenes.make_blocks_restir())
 r.lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)
 r.set_options(bench_options())
@@ -31,13 +35,21 @@ for kv in args:
 fn = r.L.rt_exp_wave_clock
 fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
 fn.restype = C.c_int
+def frame(f):
+    if rows:  # the staged frame of a strip, its halo rows never filled (timing only)
+        for stage in range(5):
+            r.frame_stage(f, stage)
+    else:
+        r.frame(f)
+
+
 for f in range(1, 12):
-    r.frame(f)
+    frame(f)
 r.sync()
-print("%dx%d, rt_tuning %s" % (W, H, " ".join(args) or "defaults"))
+print("%dx%d%s, rt_tuning %s" % (W, H, " rows %d:%d" % rows if rows else "", " ".join(args) or "defaults"))
 for name, kernel, pas in (("raycast", 0, 0), ("generate_candidate", 1, 0), ("spatial_resampling pass 1", 2, 1), ("resolve", 3, 0)):
     assert fn(r.h, kernel, pas, None, 0) == 0
-    r.frame(12)
+    frame(12)
     r.sync()
     n = 4 * (W // 8 + 2) * (H // 8 + 2) + 4096
     buf = np.zeros(n, np.uint64)
