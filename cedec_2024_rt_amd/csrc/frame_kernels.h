@@ -249,20 +249,35 @@ RT_DEV void surface_info(const BvhView& bvh, int tri, float u, float v, f3 eye, 
 }
 
 /* G-buffer entry from a Visibility record */
-RT_DEV void gbuffer_write(const SceneView& S, const FrameParams& P, float4* __restrict__ g0,
-                          float4* __restrict__ g1, size_t li, float u, float v, int index)
+RT_DEV void gbuffer_make(const SceneView& S, const FrameParams& P, float u, float v, int index, float4& G0, float4& G1)
 {
     if (index < 0)
     {
-        g0[li] = make_float4(0.0f, 0.0f, 0.0f, as_float(-1));
-        g1[li] = make_float4(0.0f, 0.0f, 0.0f, as_float(0u));
+        G0 = make_float4(0.0f, 0.0f, 0.0f, as_float(-1));
+        G1 = make_float4(0.0f, 0.0f, 0.0f, as_float(0u));
         return;
     }
     const bool emissive = as_uint(S.trimat[2 * (size_t)index].w) != 0u;
     f3 p, n;
     surface_info(S.bvh, index, u, v, P.eye, p, n);
-    g0[li] = make_float4(p.x, p.y, p.z, as_float(index));
-    g1[li] = make_float4(n.x, n.y, n.z, as_float(emissive ? GB_EMISSIVE : GB_SHADED));
+    G0 = make_float4(p.x, p.y, p.z, as_float(index));
+    G1 = make_float4(n.x, n.y, n.z, as_float(emissive ? GB_EMISSIVE : GB_SHADED));
+}
+RT_DEV void gbuffer_write(const SceneView& S, const FrameParams& P, float4* __restrict__ g0,
+                          float4* __restrict__ g1, size_t li, float u, float v, int index)
+{
+    float4 G0, G1;
+    gbuffer_make(S, P, u, v, index, G0, G1);
+    g0[li] = G0;
+    g1[li] = G1;
+}
+/* common/camera.hpp:27-35 shoot(xi / W, yi / H): no jitter, no + 0.5 (10_restir_di.cu:17-24) */
+RT_DEV f3 primary_direction(const FrameParams& P, int x, int yi)
+{
+    const float u = (float)x / (float)P.W, v = (float)yi / (float)P.H;
+    const f3 forward = normalize(cross(P.rg_up, P.rg_right));
+    const f3 to = P.rg_origin + forward + mix(-P.rg_right, P.rg_right, u) + mix(P.rg_up, -P.rg_up, v);
+    return normalize(to - P.rg_origin);
 }
 
 /* -------------------------------------------------------------------- raycast */
@@ -286,10 +301,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_RAYCAST_WS_WAVES : RT_RAYCAST_
     const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
     if (P.stats) count_walk_flags(P.stats + 4 * WALK_RAYCAST, true, true, false, false); /* every primary ray is walked */
 
-    const float u = (float)x / (float)P.W, v = (float)yi / (float)P.H;
-    const f3 forward = normalize(cross(P.rg_up, P.rg_right));
-    const f3 to = P.rg_origin + forward + mix(-P.rg_right, P.rg_right, u) + mix(P.rg_up, -P.rg_up, v);
-    const f3 rd = normalize(to - P.rg_origin);
+    const f3 rd = primary_direction(P, x, yi);
 
     Hit h;
     h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.prim = -1;
@@ -489,13 +501,18 @@ RT_DEV void wave_gather_records(const float4* q, float4* s_wave, const int lane,
 #ifndef RT_RIS_COOP
 #define RT_RIS_COOP 1 /* 0: per-lane light record gathers in the work-sharing generate kernel too (A/B) */
 #endif
-template <bool FUSE_TEMPORAL, bool SHADOWED, bool DEFER = false, bool PIPE = false, bool WS = false>
+/* RAYCAST (r05, rt_tuning key 25): the kernel traces the pixel's primary ray first (raycast, 10_restir_di.cu:9-34) and writes the
+ * Visibility record and the G-buffer (`vis_w`, `g0_w`, `g1_w`; `g0` / `g1` are not read) — generate_candidate needs the raycast of its
+ * OWN pixel only, and as two launches the second waits until the first has drained (its last wavefront starts at 216 of 257 us). */
+template <bool FUSE_TEMPORAL, bool SHADOWED, bool DEFER = false, bool PIPE = false, bool WS = false, bool RAYCAST = false>
 __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : (SHADOWED ? RT_GENERATE_SH_WAVES : RT_TRACE_WAVES)) void k_generate_candidate(
     SceneView S, FrameParams P, const float4* __restrict__ g0, const float4* __restrict__ g1,
     const float4* __restrict__ prev_rec, const float4* __restrict__ prev_rad, float4* __restrict__ out_rec,
-    float4* __restrict__ out_rad, uint32_t* __restrict__ vis_queue = nullptr, unsigned int* __restrict__ vis_count = nullptr)
+    float4* __restrict__ out_rad, uint32_t* __restrict__ vis_queue = nullptr, unsigned int* __restrict__ vis_count = nullptr,
+    float4* __restrict__ vis_w = nullptr, float4* __restrict__ g0_w = nullptr, float4* __restrict__ g1_w = nullptr)
 {
     static_assert(!DEFER || (FUSE_TEMPORAL && !SHADOWED), "deferred visibility: fused unshadowed kernel only");
+    static_assert(!RAYCAST || (WS && FUSE_TEMPORAL && !SHADOWED && !DEFER && !PIPE), "primary rays in the product's fused kernel only");
     RT_WAVE_CLOCK(P);
     constexpr bool LATE = WS && FUSE_TEMPORAL && !SHADOWED && !DEFER; /* the visibility-reuse ray after the temporal merge */
     /* shadowed target: every lane stays through the RIS loop, so that the wavefront can fetch its light records together */
@@ -511,7 +528,21 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : (SHADOWED 
     f3 late_sp = F3(0.0f, 0.0f, 0.0f), late_sn = F3(0.0f, 1.0f, 0.0f);
     Res r = res_zero();
     float4 G0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), G1 = G0;
-    if (in_image) { G0 = g0[li]; G1 = g1[li]; }
+    if constexpr (RAYCAST)
+    {
+        if (in_image)
+        {
+            if (P.stats) count_walk_flags(P.stats + 4 * WALK_RAYCAST, true, true, false, false);
+            Hit h;
+            h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.prim = -1;
+            trace_wide<false, false, TRACE_BLOCK>(S.wide, s_stack, P.rg_origin, primary_direction(P, x, yi), 0.0f, kFltMax, h);
+            vis_w[li] = make_float4(h.u, h.v, as_float(h.prim), as_float(0));
+            gbuffer_make(S, P, h.u, h.v, h.prim, G0, G1);
+            g0_w[li] = G0;
+            g1_w[li] = G1;
+        }
+    }
+    else if (in_image) { G0 = g0[li]; G1 = g1[li]; }
     const uint32_t flags = as_uint(G1.w);
     if (in_image && !(flags & GB_SHADED))
     {

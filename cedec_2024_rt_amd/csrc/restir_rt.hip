@@ -169,6 +169,7 @@ struct rt_ctx
     unsigned long long* d_wave_clock = nullptr; /* rt_exp_wave_clock (experiments library): two words per wavefront of one kernel */
     size_t wave_clock_words = 0;
     int wave_clock_kernel = -1, wave_clock_pass = 0;
+    int tune_fuse_raycast = -1; /* rt_tuning key 25 (r05): stage 0 as ONE launch (primary ray, then candidates + temporal merge): -1 auto */
     int tune_half_raycast = 0; /* rt_tuning key 24 (r05, experiments build): half-density raycast with helper lanes */
     int tune_fuse_final = -1; /* rt_tuning key 23 (r05): last spatial pass + resolve in one kernel: -1 auto, 0 never, 1 always, 2 = A/B without the pass's stores */
     bool final_fused = false; /* the running frame's last pass has resolved its rows */
@@ -1328,7 +1329,22 @@ static bool use_next_generate(const rt_ctx* c)
  * is running several of them side by side (rank 4 of 8: 1080p 0.306 -> 0.287 ms, 4K 0.889 -> 0.870, profiles/r05_spec_free_ab.txt);
  * a whole frame's kernels fill the GPU alone and only take slots from each other (pipelined 1080p frame 1.277 -> 1.296 ms) */
 static bool spec_free(const rt_ctx* c) { return c->tune_spec_free < 0 ? (c->row_begin != 0 || c->row_end != c->H) : c->tune_spec_free != 0; }
-static int launch_generate(rt_ctx* c, int frame, int dst_phys, int prev_phys, bool fuse);
+static int launch_generate(rt_ctx* c, int frame, int dst_phys, int prev_phys, bool fuse, float4* raycast_vis = nullptr);
+/* r05, rt_tuning key 25: raycast + generate_candidate (+ temporal merge) of a frame in ONE launch — the candidates need the primary ray
+ * of their own pixel only, and two launches on a stream cost the first one's ramp-down (its last wavefront starts at 216 of 257 us).
+ * The product's fused candidate kernel only (temporal merge on, unshadowed, work-sharing shadow walk), whole owned rows, and not while
+ * rt_timing brackets the two kernels with events. auto = whole-frame contexts (a strip's marks wait for the G-buffer alone). */
+static bool use_fused_stage0(const rt_ctx* c)
+{
+    const bool whole = c->row_begin == 0 && c->row_end == c->H;
+    const int want = c->tune_fuse_raycast < 0 ? (whole ? 1 : 0) : c->tune_fuse_raycast;
+    if (!want || c->timing) return false;
+#ifdef RT_EXPERIMENTS
+    if (c->tune_half_raycast || c->tune_defer_vis || c->tune_ris_pipe) return false;
+#endif
+    const int g = trace_grid(c);
+    return c->opt.use_temporal_resampling && !c->opt.use_shadowed_target_function && c->n_lights > 0 && use_ws(c, g) && !use_ws_primary(c, g);
+}
 /* the next frame's primary rays, behind everything enqueued on the main stream so far, on the stream of their own */
 static int launch_next_raycast(rt_ctx* c, int frame)
 {
@@ -1362,7 +1378,8 @@ static int launch_next_raycast(rt_ctx* c, int frame)
     const int s0 = c->sub0, s1 = c->sub1, b0 = c->subb0, b1 = c->subb1;
     c->sub0 = c->sub1 = -1; c->subb0 = c->subb1 = 0; /* all owned rows */
     if (c->timing) hipEventRecord(c->ev_spec_t[o][0], c->spec_stream);
-    launch_raycast(c, c->spec_stream, c->d_gset[o][0], c->d_gset[o][1], c->d_gset[o][2]);
+    const bool one_launch = use_next_generate(c) && use_fused_stage0(c); /* the candidates' launch below traces the primary rays too */
+    if (!one_launch) launch_raycast(c, c->spec_stream, c->d_gset[o][0], c->d_gset[o][1], c->d_gset[o][2]);
     RT_HIP(c, hipGetLastError());
     if (c->timing) hipEventRecord(c->ev_spec_t[o][1], c->spec_stream);
     c->spec_timed[o] = c->timing;
@@ -1385,7 +1402,7 @@ static int launch_next_raycast(rt_ctx* c, int frame)
         const uint32_t tag_now = c->cur_tag;
         c->spec_gen_tag = next_ownv_tag(c); /* the frame that takes these candidates continues under their tag */
         c->cur_tag = c->spec_gen_tag;
-        rc = launch_generate(c, frame + 1, c->spare, c->fY, c->opt.use_temporal_resampling != 0);
+        rc = launch_generate(c, frame + 1, c->spare, c->fY, c->opt.use_temporal_resampling != 0, one_launch ? c->d_gset[o][0] : nullptr);
         c->cur_tag = tag_now;
         c->stream = ms; c->d_g0 = g0; c->d_g1 = g1;
         if (rc == RT_OK)
@@ -1405,7 +1422,7 @@ static int launch_next_raycast(rt_ctx* c, int frame)
     return RT_OK;
 }
 /* stage 0's raycast over all owned rows: the G-buffer traced beside the previous frame if it is still the right one */
-static int raycast_or_take(rt_ctx* c, bool whole, int frame)
+static int raycast_or_take(rt_ctx* c, bool whole, int frame, bool may_defer = false, bool* deferred = nullptr)
 {
     c->timed_spec_set = -1;
     c->gen_taken = false;
@@ -1450,10 +1467,22 @@ static int raycast_or_take(rt_ctx* c, bool whole, int frame)
     }
     c->spec_valid = false;
     c->spec_gen_valid = false;
+    if (may_defer)
+    {
+        /* rt_raycast without its launch: the candidates' kernel of this stage traces the primary rays (use_fused_stage0) */
+        JOIN_TAIL(c);
+        JOIN_SPEC(c);
+        c->has_gbuffer = true;
+        ++c->gbuf_serial;
+        c->gbuf_epoch = c->epoch;
+        c->shaded_bits_stale = true;
+        *deferred = true;
+        return RT_OK;
+    }
     return rt_raycast(c);
 }
 
-static int launch_generate(rt_ctx* c, int frame, int dst_phys, int prev_phys, bool fuse)
+static int launch_generate(rt_ctx* c, int frame, int dst_phys, int prev_phys, bool fuse, float4* raycast_vis)
 {
     if (c->n_lights == 0 && c->opt.ris_sample_count > 0)
         RT_FAIL(c, RT_ERR_STATE, "scene has no emissive triangle (the reference divides by zero here)");
@@ -1504,6 +1533,9 @@ static int launch_generate(rt_ctx* c, int frame, int dst_phys, int prev_phys, bo
 #ifdef RT_EXPERIMENTS
     else if (fuse && c->tune_ris_pipe) k_generate_candidate<true, false, false, true><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
 #endif
+    else if (fuse && use_ws(c, g) && raycast_vis)
+        k_generate_candidate<true, false, false, false, true, true><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, nullptr, nullptr, prec, prad, orec, orad, nullptr, nullptr, raycast_vis, c->d_g0, c->d_g1);
+    else if (raycast_vis) RT_FAIL(c, RT_ERR_STATE, "the one-launch stage 0 needs the product's fused candidate kernel");
     else if (fuse && use_ws(c, g)) k_generate_candidate<true, false, false, false, true><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
     else if (fuse) k_generate_candidate<true, false><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
     else if (sh) k_generate_candidate<false, true><<<g, TRACE_BLOCK, 0, c->stream>>>(S, P, c->d_g0, c->d_g1, prec, prad, orec, orad);
@@ -1956,14 +1988,16 @@ static int stage_run_ranges(rt_ctx* c, int frame, int stage, int part, int row0,
         mark(0);
         if (part != 2 && c->f_clear) rc = rt_clear(c);
         mark(1);
-        if (part != 2 && rc == RT_OK) rc = raycast_or_take(c, row0 == c->row_begin && row1 == c->row_end && rowb0 >= rowb1, frame);
-        if (part != 2 && rc == RT_OK && row0 == c->row_begin && row1 == c->row_end) rc = refresh_shaded_bits(c);
+        bool deferred = false; /* the primary rays are traced by the candidates' launch */
+        if (part != 2 && rc == RT_OK) rc = raycast_or_take(c, whole, frame, part == 0 && whole && use_fused_stage0(c), &deferred);
+        if (part != 2 && rc == RT_OK && row0 == c->row_begin && row1 == c->row_end && !deferred) rc = refresh_shaded_bits(c);
         mark(2);
         if (part != 1 && rc == RT_OK && !c->gen_taken)
         {
             rc = join_tail_for(c, c->fY); /* this frame's candidates may go where the previous frame's resolve still reads */
-            if (rc == RT_OK) rc = launch_generate(c, frame, c->fY, c->fX, c->opt.use_temporal_resampling != 0);
+            if (rc == RT_OK) rc = launch_generate(c, frame, c->fY, c->fX, c->opt.use_temporal_resampling != 0, deferred ? c->d_vis : nullptr);
         }
+        if (deferred && rc == RT_OK) rc = refresh_shaded_bits(c);
         mark(3);
     }
     else if (stage <= passes)
@@ -2959,6 +2993,7 @@ int rt_tuning(rt_ctx* c, int key, int value)
     else if (key == 21 && (value == 0 || value == 1)) { c->tune_mark_cache = value; c->mark_bits_epoch = 0; }
     else if (key == 23 && value >= -1 && value <= 2) c->tune_fuse_final = value;
     else if (key == 24 && (value == 0 || value == 1)) c->tune_half_raycast = value;
+    else if (key == 25 && value >= -1 && value <= 1) c->tune_fuse_raycast = value;
     else if (key == 22 && value >= -1 && value <= 1) { c->tune_spec_free = value; c->spec_valid = false; c->spec_gen_valid = false; }
     else RT_FAIL(c, RT_ERR_ARG, "bad tuning key/value %d/%d", key, value);
     return RT_OK;
@@ -2991,6 +3026,7 @@ int rt_tuning_get(rt_ctx* c, int key, int* value)
         case 22: *value = c->tune_spec_free; break;
         case 23: *value = c->tune_fuse_final; break;
         case 24: *value = c->tune_half_raycast; break;
+        case 25: *value = c->tune_fuse_raycast; break;
         default: RT_FAIL(c, RT_ERR_ARG, "bad tuning key %d", key);
     }
     return RT_OK;

@@ -396,6 +396,11 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
  *        reservoir buffers are unchanged, and runs its own stage 0 otherwise. rt_sync waits for that stream too.
  *  17    resolve + tone_mapping of a staged frame on a "tail" stream of their own: -1 auto = 1 on (default), 0 off. Off while
  *        rt_timing is enabled.
+ *  25    (r05) stage 0 of the staged frame as ONE launch: the candidates' kernel traces the primary ray of its pixel first
+ *        (raycast needs nothing else, generate_candidate nothing but it; as two launches the second waits for the first one's
+ *        ramp-down): -1 auto = whole-frame contexts (default), 0 two launches, 1 also on strips. Applies to the product's fused
+ *        candidate kernel (temporal merge on, unshadowed target), not while rt_timing brackets the kernels; rt_raycast /
+ *        rt_generate_candidate are always the two kernels.
  *  20    the staged frame's resolve kernel tone-maps the pixel it has just accumulated (common/kernels/common.cu:30-74 reads
  *        nothing else): 1 (default), 0 = two launches as the reference. rt_resolve / rt_tone_mapping are always the two kernels.
  *  22    (r05) the look-ahead stage 0 (key 14) of frame f+1 waits neither for the main stream (frame f took its own stage 0 from

@@ -720,7 +720,7 @@ def test_round3_entry_points(api, scenes):
         for key, val in ((5, 0), (5, 1), (5, 2), (8, 0), (8, 1), (8, 3), (8, 4), (9, 4), (9, 5), (10, 8), (11, 1), (12, 1), (15, 1), (23, 1), (24, 1)):
             with pytest.raises(api.RtError, match="librestir_rt_exp"):
                 prod.tuning(key, val)
-        for key, val in ((5, 3), (8, 2), (9, -1), (9, 6), (11, 0), (13, 0), (14, 1), (16, 1), (20, 0), (21, 0), (22, 1), (23, 0), (24, 0)):
+        for key, val in ((5, 3), (8, 2), (9, -1), (9, 6), (11, 0), (13, 0), (14, 1), (16, 1), (20, 0), (21, 0), (22, 1), (23, 0), (24, 0), (25, 0), (25, 1)):
             prod.tuning(key, val)
         for mode in (1, 2, 3):
             with pytest.raises(api.RtError, match="librestir_rt_exp"):

@@ -9,6 +9,7 @@ bench.py times, plus form-against-form checks of buffers the oracle has no opini
 * rt_tuning 21: the halo marks with and without the cached shaded-bit rows: same bitmaps, also across a camera move;
 * rt_tuning 0-3 = 2 ... 7: the tile orders that interleave the XCDs (results never depend on the order); 8 = 4: the pass in
   one-wavefront workgroups;
+* rt_tuning 25: stage 0 of the staged frame as ONE launch (raycast inside the candidates' kernel, 10_restir_di.cu:9-135);
 * rt_tuning 24: raycast at half density — 32 primary rays and 32 rayless helper lanes per wavefront (10_restir_di.cu:9-34);
 * RT_MG_TRANSPORT_WIRE_MODEL moves what MIRROR moves and holds the stream for the modelled time.
 """
@@ -85,6 +86,14 @@ def _oracle_frames(oracle, tris, W, H, eye, at, frames, **optkw):
     (480, 270, 4, {2: 7}, {"use_shadowed_target_function": 1}),
     (480, 270, 5, {8: 4}, {}),                    # the pass as one-wavefront workgroups on 8 x 8 tiles (A/B form)
     (1920, 1080, 3, {0: 7, 1: 4, 2: 5, 3: 6}, {}),
+    (480, 270, 8, {25: 0}, {}),                   # stage 0 as two launches (r01-r04) ...
+    (480, 270, 8, {25: 1}, {}),                   # ... and as one: primary ray, then candidates + temporal merge (the default)
+    (480, 270, 8, {25: 1, 14: 0, 17: 0}, {}),     # ... frames back to back on one stream (the headline's form)
+    (500, 277, 5, {25: 1, 22: 1}, {}),
+    (480, 270, 6, {25: 1}, {"accumulate": 1}),
+    (480, 270, 4, {25: 1}, {"use_temporal_resampling": 0}),   # no temporal merge: the one-launch form does not apply, two launches run
+    (480, 270, 3, {25: 1}, {"use_shadowed_target_function": 1}),
+    (1920, 1080, 4, {25: 1}, {}),
 ])
 def test_new_launch_forms_vs_oracle(api, oracle, scenes, W, H, frames, tuning, optkw):
     """blocks_restir, bench options, frames enqueued back to back with no sync in between; accumulation, pixels and the temporal
@@ -169,6 +178,41 @@ def test_fused_final_pass_on_three_local_strips_vs_oracle(api, oracle, scenes):
         assert _eq_bits(acc, ref[a:b]), f"rows {a}:{b}: {int((acc != ref[a:b]).any(axis=2).sum())} pixels differ from the oracle"
         px = c.download(api.RT_BUF_PIXELS).reshape(c.local_rows, W, 4)[a - c.local_row0: b - c.local_row0]
         assert np.array_equal(px, st["pixels"][a:b])
+    for m in mgs:
+        m.close()
+    hub.close()
+    for c in ctxs:
+        c.close()
+
+
+def test_one_launch_stage0_on_three_local_strips_vs_oracle(api, oracle, scenes):
+    """rt_tuning 25 = 1 forced on strip contexts (auto: whole frames only): the look-ahead's stage 0 of every strip is one launch; the
+    marks of the halo plans then read a G-buffer the candidates' kernel wrote"""
+    from cedec_2024_rt_amd.types import bench_options
+
+    W, H, frames = 480, 270, 9
+    tris = scenes.make_blocks_restir()
+    eye, at = scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT
+    bounds = api.mg_partition(H, 3)
+    ctxs = []
+    for b in bounds:
+        c = api.Renderer(W, H, rows=b, halo=87)
+        c.tuning(25, 1)
+        c.set_scene(tris)
+        c.lookat(eye, at)
+        c.set_options(bench_options())
+        ctxs.append(c)
+    hub = api.MgHub(3)
+    mgs = [api.MultiGpu(c, k, bounds, transport=api.RT_MG_TRANSPORT_LOCAL, hub=hub) for k, c in enumerate(ctxs)]
+    for f in range(1, frames + 1):
+        api.mg_frame_lockstep(mgs, f)
+    st, _ = _oracle_frames(oracle, tris, W, H, eye, at, frames)
+    ref = st["accum"].reshape(H, W, 4)
+    for c, (a, b) in zip(ctxs, bounds):
+        acc = c.download(api.RT_BUF_ACCUMULATION).reshape(c.local_rows, W, 4)[a - c.local_row0: b - c.local_row0]
+        assert _eq_bits(acc, ref[a:b]), f"rows {a}:{b}: {int((acc != ref[a:b]).any(axis=2).sum())} pixels differ from the oracle"
+        vis = c.download(api.RT_BUF_VISIBILITY).reshape(c.local_rows, W)[a - c.local_row0: b - c.local_row0]
+        assert np.array_equal(vis["index"], st["vis"]["index"].reshape(H, W)[a:b])
     for m in mgs:
         m.close()
     hub.close()

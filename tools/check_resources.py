@@ -18,9 +18,10 @@ import sys
 BUDGET = [
     (r"^k_raycast<false>", 0, 8),
     (r"^k_raycast<true>", 0, 7),                                              # strips: work-sharing closest-hit walk
-    (r"^k_generate_candidate<true, false, false, false, false>", 0, 5),       # the whole frame's fused candidates + temporal
-    (r"^k_generate_candidate<true, false, false, false, true>", 0, 6),        # strips (work-sharing walk)
-    (r"^k_generate_candidate<false, false, false, false, false>", 0, 6),      # rt_generate_candidate
+    (r"^k_generate_candidate<true, false, false, false, true, true>", 0, 6),   # the whole frame's stage 0: primary ray + candidates + temporal
+    (r"^k_generate_candidate<true, false, false, false, true, false>", 0, 6),  # candidates + temporal (strips, rt_timing)
+    (r"^k_generate_candidate<true, false, false, false, false, false>", 0, 5), # ... without the work-sharing walk (rt_tuning 13 = 0)
+    (r"^k_generate_candidate<false, false, false, false, false, false>", 0, 6), # rt_generate_candidate
     (r"^k_spatial_coop<6, false, 256>", 0, 6),                                # the roofline kernel
     (r"^k_spatial_coop<6, true, 256>", 0, 5),                                 # strips: halo lists read / written in the pass
     (r"^k_resolve<", 0, 8),
