@@ -309,7 +309,7 @@ def test_wire_model_transport_moves_what_mirror_moves_and_takes_its_time(api, sc
     # three exchanges per frame, each held for >= 200 us + bytes / 0.5 GB/s: the stream cannot be faster than the model
     per_frame_model = stats["slow"]["wire_ns"] / 6 * 1e-9
     assert per_frame_model > 3 * 200e-6
-    assert wall["slow"] >= 0.95 * per_frame_model, (wall, per_frame_model)
+    assert wall["slow"] >= 0.8 * per_frame_model, (wall, per_frame_model)  # a sanity bound, not a measurement: the host clock against the GPU's
 
 
 def _log_uniform(rng, n, e_lo, e_hi, signed=False):
