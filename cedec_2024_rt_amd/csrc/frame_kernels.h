@@ -39,6 +39,9 @@ struct FrameParams
     /* rt_exp_wave_clock (measurement, experiments library only): two words per wavefront of the chosen kernel — the constant
      * 100-MHz clock when it started, and when its last lane left | hardware id << 40 (XCD, SE, CU, SIMD) */
     unsigned long long* wave_clock;
+    /* rt_exp_tile_perm (measurement): workgroup b of the chosen kernel takes the place of workgroup tile_perm[b] in the launch's tile
+     * order (a permutation that keeps b % 8, i.e. the XCD): what would longest-first dispatch gain? */
+    const uint32_t* tile_perm;
 #endif
 };
 #ifdef RT_EXPERIMENTS
@@ -140,9 +143,12 @@ template <> struct TileShape<64> { static constexpr int W = 8, H = 8; };
 
 /* workgroup index b, thread index t (the persistent kernels walk a job counter instead of blockIdx / threadIdx) */
 template <int TB = BLOCK>
-RT_DEV bool tile_pixel_at(const FrameParams& P, const int b, const int t, int& x, int& row)
+RT_DEV bool tile_pixel_at(const FrameParams& P, int b, const int t, int& x, int& row)
 {
     constexpr int TILE_W = TileShape<TB>::W, TILE_H = TileShape<TB>::H;
+#ifdef RT_EXPERIMENTS
+    if (TB == TRACE_BLOCK && P.tile_perm) b = (int)P.tile_perm[b];
+#endif
     const int tiles_x = (P.W + TILE_W - 1) / TILE_W;
     const int tiles_ya = (P.row1 - P.row0 + TILE_H - 1) / TILE_H;
     const int tiles_y = tiles_ya + (P.rowb1 > P.rowb0 ? (P.rowb1 - P.rowb0 + TILE_H - 1) / TILE_H : 0);

@@ -166,6 +166,8 @@ struct rt_ctx
     int tune_mark_window = 1; /* rt_tuning key 19 (r04): k_halo_mark collects a workgroup's marks in LDS first */
     unsigned long long* d_wire = nullptr; /* rt_wire_delay: GPU clock stamps */
     int wall_khz = 100000;
+    uint32_t* d_tile_perm[4] = {nullptr, nullptr, nullptr, nullptr}; /* rt_exp_tile_perm (experiments library): dispatch order of a tracing kernel */
+    size_t tile_perm_n[4] = {0, 0, 0, 0};
     unsigned long long* d_wave_clock = nullptr; /* rt_exp_wave_clock (experiments library): two words per wavefront of one kernel */
     size_t wave_clock_words = 0;
     int wave_clock_kernel = -1, wave_clock_pass = 0;
@@ -287,6 +289,9 @@ static FrameParams make_params(const rt_ctx* c, int frame, int pass, int kernel 
     P.stats = c->walk_on ? c->d_walk : nullptr;
 #ifdef RT_EXPERIMENTS
     P.wave_clock = c->d_wave_clock && kernel == c->wave_clock_kernel && (kernel != K_SPATIAL || pass == c->wave_clock_pass) ? c->d_wave_clock : nullptr;
+    /* whole launches over the context's own rows only (the grid the permutation was checked against) */
+    const bool own_rows = c->sub0 < 0 || (c->sub0 == c->row_begin && c->sub1 == c->row_end && c->subb1 <= c->subb0);
+    P.tile_perm = (kernel == K_RAYCAST || kernel == K_GENERATE || kernel == K_RESOLVE) && own_rows ? c->d_tile_perm[kernel] : nullptr;
 #endif
     return P;
 }
@@ -415,6 +420,7 @@ int rt_destroy(rt_ctx* c)
     hipFree(c->d_visq[0]); hipFree(c->d_visq[1]); hipFree(c->d_visq_count);
     if (c->h_visq_count) hipHostFree(c->h_visq_count);
     hipFree(c->d_walk); hipFree(c->d_wire); hipFree(c->d_wave_clock);
+    for (auto& p : c->d_tile_perm) hipFree(p);
     hipFree(c->d_counter); hipFree(c->d_stage); hipFree(c->d_paths[0]); hipFree(c->d_paths[1]); hipFree(c->d_pt_counters);
     if (c->ev_created) for (auto& e : c->ev) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -2798,6 +2804,32 @@ int rt_exp_wave_clock(rt_ctx* c, int kernel, int pass, uint64_t* out, size_t n_w
     if (c->d_wave_clock) RT_HIP(c, hipMemset(c->d_wave_clock, 0, c->wave_clock_words * 8));
     c->wave_clock_kernel = kernel; c->wave_clock_pass = pass;
     c->spec_valid = false; c->spec_gen_valid = false;
+    return RT_OK;
+}
+#endif
+#ifdef RT_EXPERIMENTS
+/* Experiments library only (tools/tile_lpt.py). Workgroup b of kernel 0 raycast / 1 generate_candidate (the one-launch stage 0 too) /
+ * 3 resolve takes the tile workgroup perm[b] would have taken; perm must be a permutation of 0 .. n-1 that keeps b % 8 (checked), n =
+ * the kernel's grid for the context's own rows; n = 0 removes it. Results never depend on it (every tile still runs exactly once). */
+int rt_exp_tile_perm(rt_ctx* c, int kernel, const uint32_t* perm, size_t n)
+{
+    RT_CHECK_CTX(c);
+    if (kernel != K_RAYCAST && kernel != K_GENERATE && kernel != K_RESOLVE) RT_FAIL(c, RT_ERR_ARG, "kernel 0, 1 or 3");
+    int rc = rt_sync(c);
+    if (rc != RT_OK) return rc;
+    if (c->d_tile_perm[kernel]) { hipFree(c->d_tile_perm[kernel]); c->d_tile_perm[kernel] = nullptr; c->tile_perm_n[kernel] = 0; }
+    c->spec_valid = false; c->spec_gen_valid = false;
+    if (n == 0) return RT_OK;
+    if (!perm || n != (size_t)trace_grid(c)) RT_FAIL(c, RT_ERR_ARG, "the permutation must cover the kernel's %d workgroups", trace_grid(c));
+    std::vector<uint8_t> seen(n, 0);
+    for (size_t b = 0; b < n; ++b)
+    {
+        if (perm[b] >= n || seen[perm[b]] || (perm[b] & 7u) != (b & 7u)) RT_FAIL(c, RT_ERR_ARG, "not an XCD-keeping permutation at %zu", b);
+        seen[perm[b]] = 1;
+    }
+    RT_HIP(c, hipMalloc(&c->d_tile_perm[kernel], n * 4));
+    RT_HIP(c, hipMemcpy(c->d_tile_perm[kernel], perm, n * 4, hipMemcpyHostToDevice));
+    c->tile_perm_n[kernel] = n;
     return RT_OK;
 }
 #endif

@@ -220,6 +220,50 @@ def test_one_launch_stage0_on_three_local_strips_vs_oracle(api, oracle, scenes):
         c.close()
 
 
+def test_permuted_dispatch_order_vs_oracle(api, oracle, scenes):
+    """rt_exp_tile_perm (experiments library, tools/tile_lpt.py): the workgroups of stage 0 and of resolve in a random XCD-keeping order
+    — every tile still runs once, the frames are the oracle's; a permutation that moves a workgroup to another XCD is refused"""
+    import ctypes as C
+
+    from cedec_2024_rt_amd.types import bench_options
+
+    W, H, frames = 480, 270, 6
+    tris = scenes.make_blocks_restir()
+    eye, at = scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT
+    r = api.Renderer(W, H, exp=True)
+    fn = r.L.rt_exp_tile_perm
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    fn.restype = C.c_int
+    tx, ty = (W + 7) // 8, (H + 7) // 8
+    grid = max((tx * ty + 127) // 128 * 128, 8 * ((ty + 7) // 8) * tx)
+    rng = np.random.default_rng(5)
+    for kernel in (0, 1, 3):
+        perm = np.arange(grid, dtype=np.uint32)
+        for x in range(8):
+            idx = np.arange(x, grid, 8)
+            perm[idx] = rng.permutation(idx)
+        assert fn(r.h, kernel, perm.ctypes.data, grid) == 0
+    bad = np.arange(grid, dtype=np.uint32)
+    bad[[0, 1]] = bad[[1, 0]]
+    assert fn(r.h, 2, bad.ctypes.data, grid) != 0 and fn(r.h, 1, bad.ctypes.data, grid) != 0  # the spatial pass has no such hook; XCD changed
+    for kernel in (1,):  # the refused call removed kernel 1's order: set it again
+        perm = np.arange(grid, dtype=np.uint32)
+        for x in range(8):
+            idx = np.arange(x, grid, 8)
+            perm[idx] = rng.permutation(idx)
+        assert fn(r.h, kernel, perm.ctypes.data, grid) == 0
+    r.set_scene(tris)
+    r.lookat(eye, at)
+    r.set_options(bench_options())
+    for f in range(1, frames + 1):
+        r.frame(f)
+    st, shaded = _oracle_frames(oracle, tris, W, H, eye, at, frames)
+    acc = r.download(api.RT_BUF_ACCUMULATION)
+    assert _eq_bits(acc, st["accum"].reshape(acc.shape))
+    assert not _res_bad(r.download(api.RT_BUF_RES_TEMPORAL), st["temporal"], shaded)
+    r.close()
+
+
 def test_cached_mark_rows_give_the_same_plans(api, scenes):
     """rt_tuning 21: the shaded-bit rows of rt_halo_mark_sides built once per epoch == rebuilt in front of every mark, for several
     frames and across a camera move (the cache must not survive the epoch)"""
