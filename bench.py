@@ -415,7 +415,11 @@ def _main():
             cached = None
         if cached and not os.environ.get("BENCH_REBALANCE") and not os.environ.get("BENCH_EQUAL_STRIPS"):
             e = cached["bounds"]
-            if len(e) == world + 1 and e[0] == 0 and e[-1] == h and all(e[i + 1] - e[i] >= HALO for i in range(world)):
+            worse = cached.get("equal_rows_max_ms", 0.0) > 0.0 and cached.get("max_ms", 0.0) >= cached["equal_rows_max_ms"]
+            if worse:
+                # the measured cut did not beat equal rows (differences of 1-2 % are the boxes' spread): equal rows, and say so
+                part = "equal rows (the cut cached in profiles/strip_cuts.json measured %.3f ms against %.3f for equal rows)" % (cached["max_ms"], cached["equal_rows_max_ms"])
+            elif len(e) == world + 1 and e[0] == 0 and e[-1] == h and all(e[i + 1] - e[i] >= HALO for i in range(world)):
                 bounds = [(int(e[i]), int(e[i + 1])) for i in range(world)]
                 # the cut is a load-balance heuristic measured with one library build: it stays usable with another, but never silently
                 same = cached.get("build_id") == api.build_id()
