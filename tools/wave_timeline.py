@@ -57,6 +57,9 @@ for name, kernel, pas in (("raycast", 0, 0), ("generate_candidate", 1, 0), ("spa
     assert fn(r.h, -1, 0, None, 0) == 0
     t0, e = buf[0::2], buf[1::2]
     ok = t0 > 0
+    if not ok.any():
+        print("\n%s: no launch of its own in this frame (whole frames trace the primary rays inside generate_candidate: rt_tuning 25)" % name)
+        continue
     t0, e = t0[ok].astype(np.int64), e[ok]
     t1 = (e & np.uint64(0xFFFFFFFFFF)).astype(np.int64)
     hw = (e >> np.uint64(40)).astype(np.int64)
