@@ -1,7 +1,9 @@
 /*
  * restir_main.cpp — headless C++ host of the hot path: the frame loop of the reference's
  * examples/10_restir_di/10_restir_di.cpp:23-416 without GLFW/OpenGL/Orochi/HIPRT, written
- * against the C-ABI (include/restir_rt.h) only.
+ * against the C-ABI only: include/restir_rt.h for everything the example's frame loop does; restir_rt_internal.h
+ * supplies what its measurement switches add (--mirror / --shm stand-in transports, --cost-strips' rt_row_shaded,
+ * the path tracers' ray counter).
  *
  *   restir_app [--obj scene.obj | --tris scene.tris] [--size W H] [--frames N]
  *              [--eye x y z] [--lookat x y z] [--temporal 0|1] [--spatial 0|1]
@@ -50,6 +52,7 @@
 #include <unistd.h>
 
 #include "../include/restir_rt.h"
+#include "../include/restir_rt_internal.h" /* --mirror, --shm, --cost-strips, rt_path_trace_rays */
 #include "../cedec_2024_rt_amd/csrc/host_path.h"
 
 /* RGB8 PNG, top row first, as saveScreenshot writes it (common/misc.hpp:226-245 via stbi_write_png);
@@ -267,7 +270,7 @@ static int rank_main(int rank, int ranks, bool mirror, bool shm, bool equal_stri
         }
     }
     rt_mg* mg = nullptr;
-    rc = rt_mg_create(ctx, rank, ranks, bounds.data(), shm ? RT_MG_TRANSPORT_SHM : (mirror ? RT_MG_TRANSPORT_MIRROR : RT_MG_TRANSPORT_RCCL),
+    rc = rt_mg_create(ctx, rank, ranks, bounds.data(), shm ? (int)RT_MG_TRANSPORT_SHM : (mirror ? (int)RT_MG_TRANSPORT_MIRROR : (int)RT_MG_TRANSPORT_RCCL),
                       mirror ? nullptr : sh->uid, 0, &mg);
     if (rc != RT_OK) { fprintf(stderr, "rank %d: rt_mg_create failed (%d): %s\n", rank, rc, mg ? rt_mg_last_error(mg) : ""); return 1; }
     CK(rt_clear(ctx));

@@ -86,7 +86,9 @@ def lib_sha256():
     from cedec_2024_rt_amd import api
 
     h = hashlib.sha256()
-    with open(api.LIB_PATH, "rb") as f:
+    # the file the contexts of this process run (RT_EXPERIMENTS=1 / RT_LIB_PATH select another one)
+    path = os.environ.get("RT_LIB_PATH", api.EXP_LIB_PATH if os.environ.get("RT_EXPERIMENTS") else api.LIB_PATH)
+    with open(path, "rb") as f:
         h.update(f.read())
     return h.hexdigest()
 
@@ -200,8 +202,12 @@ def launch_ranks(args, argv):
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    import tempfile
+
+    rdv_dir = tempfile.mkdtemp(prefix="bench_rdv_")  # the children's file store lives here (no port race); removed below
     base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), BENCH_LAUNCHED_BY_PARENT="1")
+                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), BENCH_LAUNCHED_BY_PARENT="1",
+                BENCH_RENDEZVOUS_FILE=os.path.join(rdv_dir, "store"))
     me = os.path.abspath(__file__)
     procs = []
     for r in range(n):
@@ -244,6 +250,9 @@ def launch_ranks(args, argv):
     for p in procs:
         p.wait()
     th.join(timeout=10.0)
+    import shutil
+
+    shutil.rmtree(rdv_dir, ignore_errors=True)
     rcs = [p.returncode for p in procs]
     out = None
     for ln in lines:
@@ -345,10 +354,14 @@ def _main():
     if world > 1:
         import torch.distributed as dist
 
+        # ranks started by bench.py itself rendezvous through a file of the parent's private directory (a port picked by
+        # bind(0) + close can be taken by someone else before rank 0 binds it); under torch.distributed.run the launcher's TCP store
+        rdv = os.environ.get("BENCH_RENDEZVOUS_FILE")
+        kw = dict(init_method="file://" + rdv, rank=rank, world_size=world) if rdv else {}
         if dev_mirror:
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo", **kw)
         else:
-            dist.init_process_group(backend="nccl", device_id=dev)  # RCCL; only barriers, the id broadcast and reductions
+            dist.init_process_group(backend="nccl", device_id=dev, **kw)  # RCCL; only barriers, the id broadcast and reductions
 
     width, height = args.width, args.height
     scene_desc = {"generator": "scenes.make_blocks_restir (seed 2024)", "stand_in": True}
@@ -422,7 +435,7 @@ def _main():
             elif len(e) == world + 1 and e[0] == 0 and e[-1] == h and all(e[i + 1] - e[i] >= HALO for i in range(world)):
                 bounds = [(int(e[i]), int(e[i + 1])) for i in range(world)]
                 # the cut is a load-balance heuristic measured with one library build: it stays usable with another, but never silently
-                same = cached.get("build_id") == api.build_id()
+                same = cached.get("build_id") == api.build_id()  # exp=None: the library this process's contexts load
                 part = "rows cut by measured cost per strip (cached: profiles/strip_cuts.json, slowest strip alone %.3f -> %.3f ms, measured with %s)" % (
                     cached.get("equal_rows_max_ms", 0.0), cached.get("max_ms", 0.0),
                     "this library build" if same else "ANOTHER library build %s: BENCH_REBALANCE=1 re-measures" % cached.get("build_id", "(unrecorded)"))
@@ -490,6 +503,10 @@ def _main():
             if any(errs):
                 if mg is not None:
                     mg.close()
+                if rank == 0:  # every rank's own failure: WHICH RCCL call failed, its code and ncclGetLastError's text (strip_mg.cpp MG_NCCL)
+                    for e in errs:
+                        if e:
+                            sys.stderr.write("native RCCL strip driver: %s\n" % e)
                 mg = python_strips(next(e for e in errs if e))
                 part += ", FALLBACK: Python StripFrame over torch.distributed (native RCCL driver failed to initialise)"
         return r, mg, bounds, build_ms, part
@@ -556,7 +573,7 @@ def _main():
         r.tuning(17, 0)
 
     single_ref = None
-    spatial_ms = per_kernel = algo_bytes = pcie_ms = event_median = None
+    spatial_ms = per_kernel = algo_bytes = pcie_ms = event_median = two_launch = None
     verified = mg_stats = walks = verified_seq = None
     if world == 1:
         # algorithmic bytes of the three spatial launches of one timed frame (RNG replay, untimed): pass k of
@@ -567,16 +584,41 @@ def _main():
         # roofline kernel, and the GPU-event median of the frame (SURVEY §8d's definition of the frame time)
         names = ("clear", "raycast", "generate_candidate", "spatial0", "spatial1", "spatial2", "resolve", "tone_mapping", "frame")
         r.timing_enable(True)
-        rows = []
-        for _ in range(max(K, 50)):
-            frame += 1
-            r.frame(frame)
-            t = r.timing()
-            rows.append([t[k] for k in names])
-        rows = np.array(rows)
-        per_kernel = dict(zip(names, (round(float(x), 4) for x in rows.mean(axis=0))))
+
+        def timed_rows(n):
+            nonlocal frame
+            rows_, one = [], True
+            for _ in range(n):
+                frame += 1
+                r.frame(frame)
+                t = r.timing()
+                one = one and r.stage0_one_launch()
+                rows_.append([t[k] for k in names])
+            return np.array(rows_), one
+
+        # r06: the events bracket the launches the HEADLINE frames run — stage 0 as ONE launch (rt_tuning 25)
+        # is one entry, `stage0` (the bracket where the raycast launch would be is empty and is added to it, so that the entries
+        # sum to `frame`); the two kernels of rt_raycast / rt_generate_candidate are timed right after it (`kernel_ms_two_launch_stage0`)
+        rows, one_launch = timed_rows(max(K, 50))
+        mean = rows.mean(axis=0)
+        if one_launch:
+            per_kernel = {"clear": round(float(mean[0]), 4), "stage0": round(float(mean[1] + mean[2]), 4)}
+        else:
+            per_kernel = {"clear": round(float(mean[0]), 4), "raycast": round(float(mean[1]), 4), "generate_candidate": round(float(mean[2]), 4)}
+        per_kernel.update({k: round(float(x), 4) for k, x in zip(names[3:], mean[3:])})
+        per_kernel["stage0_form"] = ("one launch: primary ray + candidates + temporal merge (k_generate_candidate<..., RAYCAST>), as in the frames `value` times"
+                                     if one_launch else "two launches: k_raycast, k_generate_candidate")
+        per_kernel["sum_over_frame"] = round(float(sum(mean[:8]) / mean[8]), 4)
         spatial_ms = float(rows[:, 3:6].mean())
         event_median = float(np.median(rows[:, 8]))
+        two_launch = None
+        if one_launch:
+            r.tuning(25, 0)
+            rows2, _ = timed_rows(max(K // 2, 20))
+            r.tuning(25, -1)
+            m2 = rows2.mean(axis=0)
+            two_launch = {"raycast": round(float(m2[1]), 4), "generate_candidate": round(float(m2[2]), 4), "frame": round(float(m2[8]), 4),
+                          "note": "rt_tuning 25 = 0: the reference's two kernels back to back, what rt_raycast / rt_generate_candidate launch"}
         # PCIe-inclusive variant (never `value`): the reference copies the RGBA8 image to the host and
         # synchronises every frame (10_restir_di.cpp:386-389)
         r.timing_enable(False)
@@ -686,6 +728,7 @@ def _main():
             single_ref = single
         else:
             single_ref = None
+    lib_build_id = r.build_id()  # of the library this context runs
     if mg is not None:
         mg.close()
     r.close()
@@ -762,7 +805,7 @@ def _main():
             out["also_3840x2160"] = also_4k
         if world == 1:
             sha = lib_sha256()
-            pmc = committed_pmc(sha, api.build_id())
+            pmc = committed_pmc(sha, lib_build_id)
             contract_ach = algo_bytes / (spatial_ms * 1e-3) / 1e9
             traffic = pmc["traffic"]
             measured_ach = (traffic / (spatial_ms * 1e-3) / 1e9) if traffic else None
@@ -786,8 +829,12 @@ def _main():
                 "valu_issue_frac_weighted": pmc["valu"],
             }
             out["lib_sha256"] = sha
-            out["build_id"] = api.build_id()
+            out["build_id"] = lib_build_id
             out["kernel_ms"] = per_kernel
+            if two_launch is not None:
+                out["kernel_ms_two_launch_stage0"] = two_launch
+            out["value_definition"] = ("un-pipelined frames of SURVEY 8(d): K frames back to back on one stream, wall clock; since round 5. Rounds 1-4 "
+                                       "reported the pipelined throughput here: compare across rounds through `value_pipelined`")
             out["gpu_event_median_ms"] = event_median
             # SURVEY 8(d)'s frame time = GPU-event median of >= 50 un-overlapped frames
             out["value_gpu_event_median"] = {"value": total_rays / event_median / 1e3, "unit": "Mray/s", "ms_per_frame": event_median,

@@ -1,4 +1,4 @@
-"""ctypes mirror of include/restir_rt.h (librestir_rt.so).
+"""ctypes mirror of include/restir_rt.h + include/restir_rt_internal.h (librestir_rt.so).
 
 `Renderer` keeps the reference example's host API — camera, options, accumulation, one call per
 kernel with the reference's kernel names (examples/10_restir_di/10_restir_di.cpp:231-383) — on
@@ -19,21 +19,30 @@ RT_RES_0, RT_RES_1, RT_RES_TEMPORAL = 0, 1, 2
 RT_RES_PHYS = 16
 RT_BUF_VISIBILITY, RT_BUF_RES_0, RT_BUF_RES_1, RT_BUF_RES_TEMPORAL, RT_BUF_ACCUMULATION, RT_BUF_PIXELS = range(6)
 
-EXPORTS = [
-    "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_set_stream_own", "rt_sync", "rt_scene_set", "rt_scene_info",
-    "rt_camera_lookat", "rt_camera_set", "rt_camera_get", "rt_camera_orbit", "rt_camera_zoom", "rt_camera_pan",
-    "rt_camera_updated", "rt_camera_pose", "rt_options_set", "rt_options_get", "rt_clear",
-    "rt_raycast", "rt_generate_candidate", "rt_temporal_resampling", "rt_save_temporal_reservoir",
-    "rt_spatial_resampling", "rt_resolve", "rt_tone_mapping", "rt_frame", "rt_frame_stage", "rt_frame_stage_input", "rt_frame_stage_begin", "rt_frame_stage_run", "rt_frame_stage_end", "rt_frame_stage_output", "rt_frame_stage_run_part", "rt_frame_stage_fork", "rt_frame_stage_run_async", "rt_frame_stage_run_ranges", "rt_halo_bitmap_words", "rt_halo_flags_bytes",
-    "rt_halo_flags_pack", "rt_halo_flags_unpack", "rt_halo_mark", "rt_halo_scan", "rt_halo_pack_sparse", "rt_halo_unpack_sparse", "rt_halo_mark_sides", "rt_halo_pack_sparse_ranges", "rt_halo_unpack_sparse_ranges", "rt_path_trace", "rt_path_trace_rays", "rt_local_rows", "rt_download",
-    "rt_upload", "rt_halo_bytes", "rt_halo_pack", "rt_halo_unpack", "rt_ray_count", "rt_timing_enable",
-    "rt_timing", "rt_spatial_bytes", "rt_trace_closest", "rt_trace_stats", "rt_bvh_config", "rt_bvh_info", "rt_build_ms", "rt_trace_mode", "rt_trace_time", "rt_tuning", "rt_math_eval",
-    "rt_row_shaded", "rt_visibility_rays_walked", "rt_state_epoch", "rt_get_stream", "rt_geometry", "rt_res_region", "rt_lane",
-    "rt_mg_partition", "rt_mg_bands", "rt_mg_unique_id", "rt_mg_load_error", "rt_mg_hub_create", "rt_mg_hub_destroy", "rt_mg_create",
-    "rt_mg_destroy", "rt_mg_last_error", "rt_mg_frame", "rt_mg_frame_begin", "rt_mg_frame_step", "rt_mg_get_stats", "rt_mg_reset_stats",
-    "rt_mg_selftest_rccl", "rt_tuning_get", "rt_build_id", "rt_halo_fuse_set", "rt_side_stream", "rt_copy_parts",
-    "rt_walk_stats_enable", "rt_walk_stats", "rt_wire_delay",
+# include/restir_rt.h: the reference-facing boundary (what the stub of INTEGRATION.md section 2 binds)
+PUBLIC_EXPORTS = [
+    "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_sync", "rt_scene_set", "rt_scene_info", "rt_camera_lookat",
+    "rt_camera_set", "rt_camera_get", "rt_camera_orbit", "rt_camera_zoom", "rt_camera_pan", "rt_camera_updated",
+    "rt_options_set", "rt_options_get", "rt_clear", "rt_raycast", "rt_generate_candidate", "rt_temporal_resampling",
+    "rt_save_temporal_reservoir", "rt_spatial_resampling", "rt_resolve", "rt_tone_mapping", "rt_path_trace", "rt_frame",
+    "rt_local_rows", "rt_download", "rt_upload", "rt_mg_partition", "rt_mg_unique_id", "rt_mg_create", "rt_mg_destroy",
+    "rt_mg_last_error", "rt_mg_frame", "rt_mg_get_stats", "rt_ray_count", "rt_timing_enable", "rt_timing", "rt_build_id",
 ]
+# include/restir_rt_internal.h: what the strip driver, the measurement tools and the parity tests use beyond it
+INTERNAL_EXPORTS = [
+    "rt_set_stream_own", "rt_camera_pose", "rt_path_trace_rays", "rt_frame_stage", "rt_frame_stage_input",
+    "rt_frame_stage_begin", "rt_frame_stage_run", "rt_frame_stage_run_part", "rt_frame_stage_fork", "rt_frame_stage_run_async",
+    "rt_frame_stage_run_ranges", "rt_frame_stage_end", "rt_frame_stage_output", "rt_halo_bytes", "rt_halo_pack",
+    "rt_halo_unpack", "rt_halo_bitmap_words", "rt_halo_flags_bytes", "rt_halo_flags_pack", "rt_halo_flags_unpack",
+    "rt_halo_mark", "rt_halo_scan", "rt_halo_pack_sparse", "rt_halo_unpack_sparse", "rt_halo_mark_sides",
+    "rt_halo_pack_sparse_ranges", "rt_halo_unpack_sparse_ranges", "rt_halo_fuse_set", "rt_state_epoch", "rt_get_stream",
+    "rt_side_stream", "rt_copy_parts", "rt_wire_delay", "rt_geometry", "rt_res_region", "rt_lane", "rt_mg_bands",
+    "rt_mg_load_error", "rt_mg_hub_create", "rt_mg_hub_destroy", "rt_mg_frame_begin", "rt_mg_frame_step", "rt_mg_reset_stats",
+    "rt_mg_selftest_rccl", "rt_visibility_rays_walked", "rt_walk_stats_enable", "rt_walk_stats", "rt_stage0_one_launch",
+    "rt_row_shaded", "rt_spatial_bytes", "rt_trace_closest", "rt_trace_stats", "rt_bvh_config", "rt_bvh_info", "rt_build_ms",
+    "rt_trace_mode", "rt_trace_time", "rt_tuning", "rt_tuning_get", "rt_math_eval",
+]
+EXPORTS = PUBLIC_EXPORTS + INTERNAL_EXPORTS
 
 RT_MG_TRANSPORT_RCCL, RT_MG_TRANSPORT_LOCAL, RT_MG_TRANSPORT_MIRROR, RT_MG_TRANSPORT_SHM, RT_MG_TRANSPORT_RCCL_SELF, RT_MG_TRANSPORT_WIRE_MODEL = 0, 1, 2, 3, 4, 5
 RT_MG_DENSE, RT_MG_ONE_LANE, RT_MG_SEPARATE_PACK = 1, 2, 4
@@ -150,6 +159,7 @@ def load_library(exp=False):
     L.rt_build_id.argtypes = []
     L.rt_build_id.restype = C.c_char_p
     L.rt_row_shaded.argtypes = [vp, vp]
+    L.rt_stage0_one_launch.argtypes = [vp, vp]
     L.rt_visibility_rays_walked.argtypes = [vp, vp]
     L.rt_state_epoch.argtypes = [vp, vp]
     L.rt_get_stream.argtypes = [vp, vp]
@@ -176,15 +186,22 @@ def load_library(exp=False):
     return L
 
 
-def build_id():
-    """rt_build_id(): hash of the sources + flags the loaded library was built from"""
-    return load_library().rt_build_id().decode()
+def _exp_default(exp):
+    """exp=None: the library Renderer() would pick (RT_EXPERIMENTS=1 selects librestir_rt_exp.so for every context)"""
+    return bool(os.environ.get("RT_EXPERIMENTS")) if exp is None else bool(exp)
+
+
+def build_id(exp=None):
+    """rt_build_id(): hash of the sources + flags the library was built from. exp=None: the library a Renderer() of this
+    process loads (a context of the experiments library must not report the product's id); Renderer.build_id() is
+    the id of the library THAT context runs."""
+    return load_library(_exp_default(exp)).rt_build_id().decode()
 
 
 # ---- native multi-GPU strip driver (csrc/strip_mg.cpp) -------------------------------------------
-def mg_partition(height, world, halo=87, row_cost=None):
+def mg_partition(height, world, halo=87, row_cost=None, exp=None):
     """[(a, b)] per rank: near-equal strips, or cost-weighted if row_cost (uint32 per storage row) is given."""
-    L = load_library()
+    L = load_library(_exp_default(exp))
     b = np.zeros(world + 1, dtype=np.int32)
     rc_ptr = None
     if row_cost is not None:
@@ -197,9 +214,9 @@ def mg_partition(height, world, halo=87, row_cost=None):
     return [(int(b[i]), int(b[i + 1])) for i in range(world)]
 
 
-def mg_bands(bounds, rank, halo=87):
+def mg_bands(bounds, rank, halo=87, exp=None):
     """(boundary, interior) row ranges of a strip, as lists of (row0, row1)."""
-    L = load_library()
+    L = load_library(_exp_default(exp))
     world = len(bounds)
     flat = np.array([bounds[0][0]] + [e for _, e in bounds], dtype=np.int32)
     bl, il = np.zeros(4, np.int32), np.zeros(4, np.int32)
@@ -211,9 +228,9 @@ def mg_bands(bounds, rank, halo=87):
             [(int(il[2 * i]), int(il[2 * i + 1])) for i in range(ni.value)])
 
 
-def mg_unique_id():
+def mg_unique_id(exp=None):
     """128-byte RCCL unique id (bytes); make it on one rank and hand it to the others."""
-    L = load_library()
+    L = load_library(_exp_default(exp))
     buf = (C.c_char * 128)()
     rc = L.rt_mg_unique_id(buf)
     if rc != 0:
@@ -224,8 +241,9 @@ def mg_unique_id():
 class MgHub:
     """Mailbox of the LOCAL transport: several strip contexts of one process on one GPU (tests)."""
 
-    def __init__(self, world):
-        self.L = load_library()
+    def __init__(self, world, exp=None, renderer=None):
+        # the hub must come from the library whose rt_mg_create will receive it (ADVICE r05): pass the renderer, or exp
+        self.L = renderer.L if renderer is not None else load_library(_exp_default(exp))
         self.h = C.c_void_p()
         if self.L.rt_mg_hub_create(int(world), C.byref(self.h)) != 0:
             raise RtError("rt_mg_hub_create failed")
@@ -253,6 +271,8 @@ class MultiGpu:
                 self._id = C.create_string_buffer(bytes(unique_id), 128)
                 arg = C.cast(self._id, C.c_void_p)
             elif transport == RT_MG_TRANSPORT_LOCAL:
+                if hub.L is not self.L:
+                    raise RtError("MgHub and Renderer come from different libraries (product / experiments): MgHub(world, renderer=r)")
                 arg = hub.h
             elif transport == RT_MG_TRANSPORT_SHM:
                 self._name = C.create_string_buffer(str(shm_name).encode())
@@ -599,6 +619,17 @@ class Renderer:
         names = ["clear", "raycast", "generate_candidate", "spatial0", "spatial1", "spatial2", "resolve",
                  "tone_mapping", "frame"]
         return dict(zip(names, (float(x) for x in ms)))
+
+    def stage0_one_launch(self):
+        """whether the last frame's stage 0 ran as ONE launch on the context's stream (rt_tuning 25): timing()['generate_candidate']
+        is then that launch and timing()['raycast'] the empty event bracket in front of it"""
+        v = C.c_int()
+        self._ck(self.L.rt_stage0_one_launch(self.h, C.byref(v)))
+        return bool(v.value)
+
+    def build_id(self):
+        """rt_build_id() of the library THIS context runs (product or experiments)"""
+        return self.L.rt_build_id().decode()
 
     def spatial_bytes(self, frame, pas, src):
         a, b = C.c_uint64(), C.c_uint64()

@@ -1,23 +1,26 @@
 /*
- * bvh.h — software LBVH for gfx950 (CDNA4 has no ray-tracing hardware; replaces the
- * reference's HIPRT geometry: build common/loader.hpp:68-112, traversal
- * common/raytrace.hpp:18-52).
+ * bvh.h — software BVH walks for gfx950 (CDNA4 has no ray-tracing hardware; replaces the traversal half of the
+ * reference's HIPRT use, common/raytrace.hpp:18-52; the build half, common/loader.hpp:68-112, is bvh_build_device.h).
  *
- * Build: large triangles are first cut into box fragments ("references", host, early split
- * clipping) because a Morton-order hierarchy over mixed-size triangles overlaps badly; then on
- * the device: 63-bit Morton codes of the reference centres -> radix sort (rocPRIM) -> Karras
- * 2012 hierarchy (one thread per internal node) -> bottom-up AABB refit (one launch per tree
- * level) -> 64-byte "pair" nodes holding BOTH children's boxes. Leaves name the ORIGINAL
- * triangle, so a triangle may be reached through several leaves (harmless: same t, tie rule).
+ * WHAT THE PRODUCT WALKS: the 4-wide tree with 8-bit quantised child boxes ("wide" records, 48 B; layout below at
+ * `WideView`), built on the device by bvh_build_device.h (pre-split of large triangles, top-down binned SAH, collapse
+ * to four children per record). Every walk keeps a per-lane stack, 14 entries in LDS + 50 in scratch:
+ *   trace_wide          one lane = one ray, leaf tests deferred and batched (rt_trace_closest, the per-kernel entry points)
+ *   occluded_ws         work-sharing any-hit walk: idle lanes take halves of busy lanes' stacks (shadow rays of
+ *                       generate_candidate / resolve)
+ *   closest_ws          the same for closest hits (primary rays of strips)
+ *   closest_quad (r06)  four lanes per ray, one child box each, for launches that cannot fill the GPU with one lane per ray
+ * All of them run the reference's exact intersect_ray_triangle (common/core.hpp:91-136) at the leaves; boxes are rounded
+ * outward and the slab tests carry a margin, so the tree only prunes.
  *
- * Traversal (device, per lane): stackless. A 64-bit trail word records, per level, whether
- * the sibling subtree is still pending; backtracking follows parent/sibling links stored in
- * the node (no per-lane stack in LDS or scratch => registers only, full occupancy).
+ * Result contract (the pinned definition of raytrace()): the hit is the one a brute-force loop over ALL
+ * triangles reports: smallest t in [tmin,tmax], ties -> highest triangle index (examples/04_ao/04_ao.cu:8-29).
+ * tests/test_gpu_parity.py::test_lbvh_equals_brute_force holds every builder x walk to it.
  *
- * Result contract (the pinned definition of raytrace(), DESIGN.md "Oracle"): the hit is the
- * one a brute-force loop over ALL triangles with the reference's intersect_ray_triangle
- * (common/core.hpp:91-136) reports: smallest t in [tmin,tmax], ties -> highest triangle
- * index. Boxes are padded and the slab test is conservative, so the BVH only prunes.
+ * ALSO HERE, A/B ONLY (librestir_rt_exp.so, rt_trace_mode 1; rounds 1-2): the binary LBVH of round 1 — Morton codes,
+ * Karras 2012 hierarchy, bottom-up refit, 64-byte "pair" nodes (`BvhNode`), walked without a stack through a 64-bit
+ * trail word (`trace`). The Morton-key and refit kernels at the end of the file also serve builder 0 and the
+ * pre-split's ordering. The product library refuses that trace mode.
  */
 #pragma once
 #include "rt_device.h"

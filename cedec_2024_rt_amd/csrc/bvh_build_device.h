@@ -1,19 +1,19 @@
 /*
- * bvh_build_device.h — the BVH build entirely on the GPU (included once, by restir_rt.hip; replaces
- * the reference's hiprtBuildGeometry, common/loader.hpp:68-112; the host SAH builder of
- * bvh_build_host.h stays as the high-quality alternative).
+ * bvh_build_device.h — the BVH build entirely on the GPU (included once, by restir_rt.hip; replaces the reference's
+ * hiprtBuildGeometry, common/loader.hpp:68-112). Builder 3 (rt_tuning key 5, the default and the product's only one):
  *
- *   1. early split clipping of large triangles into box fragments ("references"): count pass,
- *      exclusive scan, emit pass (the recursion of bvh_build_host.h::split_refs with a per-thread stack);
- *   2. 63-bit Morton keys of the reference centres, radix sort (rocPRIM)            [kernels in bvh.h]
- *   3. binary hierarchy by PLOC — parallel locally-ordered clustering (Meister & Bittner 2018): every
- *      cluster looks RADIUS places left and right in Morton order for the neighbour whose union box is
- *      smallest, mutual nearest neighbours merge, the array is compacted, repeat until one cluster is
- *      left. Near-SAH quality without a top-down pass; boxes come with the merges, so there is no refit.
- *      (The Karras 2012 hierarchy + level-by-level refit of round 1 remains as builder 0.)
- *   4. collapse into the 4-wide quantised records the kernels traverse, level by level on the device.
- * No host round trip carries tree data; the host reads back a handful of counters (reference count,
- * clusters left, record count, heights).
+ *   1.  early split clipping of large triangles into box fragments ("references"): count pass, exclusive scan, emit
+ *       pass (the recursion of bvh_build_host.h::split_refs with a per-thread stack);
+ *   3b. top-down binned SAH over the references: nodes of more than SAH_MEDIUM references are binned by many
+ *       workgroups and split by one wavefront each, medium nodes are binned and split by one workgroup, small ones by one
+ *       wavefront down to the leaves — the tree the host builder (bvh_build_host.h, builder 1) makes, reproduced on the device;
+ *   4.  collapse into the 4-wide quantised 48-B records the kernels walk (bvh.h), level by level on the device.
+ * No host round trip carries tree data; the host reads back a handful of counters (reference count, record count,
+ * heights). Wall time of rt_scene_set for the 212 k-triangle bench scene: rt_build_ms / `build_ms` of the bench line
+ * (upload + light tables + this build, synchronised).
+ *
+ * A/B only (-DRT_EXPERIMENTS): section 3, PLOC — parallel locally-ordered clustering (Meister & Bittner 2018) over Morton-sorted
+ * references (builder 2, round 2) — and, through bvh.h's kernels, the Karras hierarchy + refit of round 1 (builder 0).
  */
 #pragma once
 #include <hip/hip_runtime.h>

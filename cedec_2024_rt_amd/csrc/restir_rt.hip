@@ -21,7 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 
-#include "../../include/restir_rt.h"
+#include "../../include/restir_rt_internal.h"
 #include "bvh.h"
 #include "rt_device.h"
 
@@ -171,6 +171,7 @@ struct rt_ctx
     unsigned long long* d_wave_clock = nullptr; /* rt_exp_wave_clock (experiments library): two words per wavefront of one kernel */
     size_t wave_clock_words = 0;
     int wave_clock_kernel = -1, wave_clock_pass = 0;
+    bool stage0_one_launch = false; /* the last staged frame's stage 0 on the main stream traced its primary rays in the candidates' launch */
     int tune_fuse_raycast = -1; /* rt_tuning key 25 (r05): stage 0 as ONE launch (primary ray, then candidates + temporal merge): -1 auto */
     int tune_half_raycast = 0; /* rt_tuning key 24 (r05, experiments build): half-density raycast with helper lanes */
     int tune_fuse_final = -1; /* rt_tuning key 23 (r05): last spatial pass + resolve in one kernel: -1 auto, 0 never, 1 always, 2 = A/B without the pass's stores */
@@ -1338,13 +1339,16 @@ static bool spec_free(const rt_ctx* c) { return c->tune_spec_free < 0 ? (c->row_
 static int launch_generate(rt_ctx* c, int frame, int dst_phys, int prev_phys, bool fuse, float4* raycast_vis = nullptr);
 /* r05, rt_tuning key 25: raycast + generate_candidate (+ temporal merge) of a frame in ONE launch — the candidates need the primary ray
  * of their own pixel only, and two launches on a stream cost the first one's ramp-down (its last wavefront starts at 216 of 257 us).
- * The product's fused candidate kernel only (temporal merge on, unshadowed, work-sharing shadow walk), whole owned rows, and not while
- * rt_timing brackets the two kernels with events. auto = whole-frame contexts (a strip's marks wait for the G-buffer alone). */
+ * The product's fused candidate kernel only (temporal merge on, unshadowed, work-sharing shadow walk), whole owned rows.
+ * auto = whole-frame contexts (a strip's marks wait for the G-buffer alone). */
 static bool use_fused_stage0(const rt_ctx* c)
 {
     const bool whole = c->row_begin == 0 && c->row_end == c->H;
     const int want = c->tune_fuse_raycast < 0 ? (whole ? 1 : 0) : c->tune_fuse_raycast;
-    if (!want || c->timing) return false;
+    /* r06: also while rt_timing brackets the kernels — the events then bracket the ONE launch the headline frames run
+     * (ms[1] = the empty bracket where the raycast launch would be, ms[2] = the launch; rt_stage0_one_launch says which
+     * form the timed frame ran). rt_tuning 25 = 0 times the two kernels. */
+    if (!want) return false;
 #ifdef RT_EXPERIMENTS
     if (c->tune_half_raycast || c->tune_defer_vis || c->tune_ris_pipe) return false;
 #endif
@@ -1379,8 +1383,17 @@ static int launch_next_raycast(rt_ctx* c, int frame)
     }
     /* the G-buffer set and the spare reservoir buffer written below: last read by the resolve before the latest one (the set of
      * frame f-2; the buffer that left the roles when frame f-1 was taken) — or earlier */
-    if (c->n_resolved >= 2 || (c->n_resolved >= 1 && !spec_free(c)))
+    /* With ONE resolve on record the free-running form waits for it too (that it need not rested on the main-stream
+     * wait above being forced at that point — one frame of overlap, once, buys an invariant that does not depend on it). */
+    if (c->n_resolved >= 1)
         RT_HIP(c, hipStreamWaitEvent(c->spec_stream, c->ev_resolved[(spec_free(c) && c->n_resolved >= 2) ? 1 : 0], 0));
+    /* the invariants the free-running look-ahead rests on, checked where it writes (cheap integer tests, every build): the set it
+     * overwrites is not the one the running frame reads, and the candidates' buffer has no role in the running frame nor is it
+     * what the tail in flight reads */
+    if (o == c->gcur) RT_FAIL(c, RT_ERR_STATE, "look-ahead stage 0 would overwrite the running frame's G-buffer set %d", o);
+    if (use_next_generate(c) && (c->spare == c->fX || c->spare == c->fY || c->spare == c->fZ || c->spare == c->quarantine ||
+                                 (spec_free(c) && c->tail_pending_main && c->spare == c->tail_phys))) /* r04's dependencies hand the tail's buffer over and wait for the latest resolve above */
+        RT_FAIL(c, RT_ERR_STATE, "look-ahead candidates' buffer %d is in use (X %d Y %d Z %d quarantine %d tail %d)", c->spare, c->fX, c->fY, c->fZ, c->quarantine, c->tail_pending_main ? c->tail_phys : -1);
     const int s0 = c->sub0, s1 = c->sub1, b0 = c->subb0, b1 = c->subb1;
     c->sub0 = c->sub1 = -1; c->subb0 = c->subb1 = 0; /* all owned rows */
     if (c->timing) hipEventRecord(c->ev_spec_t[o][0], c->spec_stream);
@@ -1996,6 +2009,7 @@ static int stage_run_ranges(rt_ctx* c, int frame, int stage, int part, int row0,
         mark(1);
         bool deferred = false; /* the primary rays are traced by the candidates' launch */
         if (part != 2 && rc == RT_OK) rc = raycast_or_take(c, whole, frame, part == 0 && whole && use_fused_stage0(c), &deferred);
+        if (part != 2) c->stage0_one_launch = deferred;
         if (part != 2 && rc == RT_OK && row0 == c->row_begin && row1 == c->row_end && !deferred) rc = refresh_shaded_bits(c);
         mark(2);
         if (part != 1 && rc == RT_OK && !c->gen_taken)
@@ -2217,6 +2231,14 @@ int rt_timing(rt_ctx* c, float ms[9])
         RT_HIP(c, hipEventSynchronize(c->ev_spec_t[c->timed_spec_set][1]));
         RT_HIP(c, hipEventElapsedTime(&ms[1], c->ev_spec_t[c->timed_spec_set][0], c->ev_spec_t[c->timed_spec_set][1]));
     }
+    return RT_OK;
+}
+
+int rt_stage0_one_launch(rt_ctx* c, int* one_launch)
+{
+    RT_CHECK_CTX(c);
+    if (!one_launch) return RT_ERR_ARG;
+    *one_launch = c->stage0_one_launch ? 1 : 0;
     return RT_OK;
 }
 
@@ -2635,11 +2657,16 @@ int rt_copy_parts(rt_ctx* c, int n, const void* const* src, void* const* dst, co
     return RT_OK;
 }
 /* WIRE_MODEL (strip_mg.cpp): phase 0 = stamp the GPU clock on the current stream (in front of an exchange), phase 1 = hold
- * the current stream until `ns` nanoseconds after that stamp (behind the exchange). slot: 0..7 (one per exchange in flight). */
+ * the current stream until `ns` nanoseconds after that stamp (behind the exchange). slot: 0..7. A slot's stamp and wait must be
+ * enqueued on ONE stream, and a slot must not be shared between streams: stream order is what keeps the next stamp of a slot behind
+ * the wait that still reads it (the strip driver: slots 0-3 for exchanges on the main stream, 4-7 on the communication stream). */
 int rt_wire_delay(rt_ctx* c, int phase, int slot, unsigned long long ns)
 {
     RT_CHECK_CTX(c);
     if (slot < 0 || slot > 7 || (phase != 0 && phase != 1)) RT_FAIL(c, RT_ERR_ARG, "rt_wire_delay: phase 0 / 1, slot 0..7");
+    /* one sleeping wavefront holds the stream for `ns`: a mistyped RT_MG_WIRE_GBS / RT_MG_WIRE_LAT_US must not park it until the
+     * watchdog fires. 5 ms = a 4K frame's whole dense halo at a hundredth of an xGMI link. */
+    if (ns > 5000000ull) RT_FAIL(c, RT_ERR_ARG, "rt_wire_delay: %llu ns is more than the 5 ms a modelled exchange may take (RT_MG_WIRE_GBS / RT_MG_WIRE_LAT_US?)", ns);
     if (!c->d_wire)
     {
         RT_HIP(c, hipMalloc(&c->d_wire, 8 * sizeof(unsigned long long)));

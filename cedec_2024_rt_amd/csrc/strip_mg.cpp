@@ -3,7 +3,7 @@
  * GPU, the image cut into row strips, reservoir halos exchanged with rank +-1 between the spatial
  * passes. The reference is single-GPU (examples/10_restir_di/10_restir_di.cpp:35,
  * 231-383): this file is the frame loop of :257-379 for one strip, built on the C-ABI of
- * include/restir_rt.h only (it is a client of rt_frame_stage_* / rt_halo_*), plus HIP streams/events
+ * include/restir_rt.h + restir_rt_internal.h only (it is a client of rt_frame_stage_* / rt_halo_*), plus HIP streams/events
  * and RCCL point-to-point over xGMI.
  *
  * What it adds over the Python StripFrame of round 1 (cedec_2024_rt_amd/strips.py):
@@ -42,7 +42,7 @@
 #include <unistd.h>
 #include <hip/hip_runtime.h>
 
-#include "../../include/restir_rt.h"
+#include "../../include/restir_rt_internal.h"
 
 /* ------------------------------------------------------------------ RCCL, resolved at run time */
 namespace
@@ -63,7 +63,16 @@ struct Rccl
     int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    const char* (*GetLastError)(ncclComm_t) = nullptr; /* optional (NCCL >= 2.13): the library's own text for the last failure */
     std::string err;
+    /* "<generic error string>[; RCCL says: <ncclGetLastError>]" for a failed call */
+    std::string describe(int rc, ncclComm_t comm) const
+    {
+        std::string s = GetErrorString ? GetErrorString(rc) : "?";
+        const char* last = GetLastError ? GetLastError(comm) : nullptr;
+        if (last && *last) { s += "; RCCL says: "; s += last; }
+        return s;
+    }
 
     bool load()
     {
@@ -85,6 +94,7 @@ struct Rccl
         RCCL_SYM(Recv, "ncclRecv")
         RCCL_SYM(GetErrorString, "ncclGetErrorString")
 #undef RCCL_SYM
+        GetLastError = reinterpret_cast<decltype(GetLastError)>(dlsym(lib, "ncclGetLastError"));
         return true;
     }
 };
@@ -260,7 +270,7 @@ struct HpScope
     do                                                                                                     \
     {                                                                                                      \
         int _r = (call);                                                                                   \
-        if (_r != ncclSuccess) MG_FAIL(m, RT_ERR_COMM, "%s failed: %s", #call, g_rccl.GetErrorString(_r)); \
+        if (_r != ncclSuccess) MG_FAIL(m, RT_ERR_COMM, "rank %d of %d: %s failed with code %d: %s", (m)->rank, (m)->world, #call, _r, g_rccl.describe(_r, (m)->nccl).c_str()); \
     } while (0)
 
 static bool is_self(const rt_mg* m) { return m->transport == RT_MG_TRANSPORT_RCCL_SELF || m->transport == RT_MG_TRANSPORT_WIRE_MODEL; }
@@ -789,7 +799,9 @@ static int post(rt_mg* m, std::vector<Exchange>&& xs)
             wire_ns = (unsigned long long)((double)most / m->wire_gbs + m->wire_lat_us * 1e3);
             m->stats_wire_ns += wire_ns;
             if (cs != ms) MG_RT(m, rt_set_stream(m->ctx, cs));
-            int wrc; { HP(m, HP_PACK); wrc = rt_wire_delay(m->ctx, 0, m->wire_slot, 0); }
+            /* slots per stream: in-order execution of ONE stream keeps a slot's next stamp behind the wait that reads it */
+            const int wslot = (on_main ? 0 : 4) + (m->wire_slot & 3);
+            int wrc; { HP(m, HP_PACK); wrc = rt_wire_delay(m->ctx, 0, wslot, 0); }
             if (cs != ms) rt_set_stream(m->ctx, ms);
             if (wrc != RT_OK) MG_FAIL(m, wrc, "rt_wire_delay: %s", rt_last_error(m->ctx));
         }
@@ -808,7 +820,8 @@ static int post(rt_mg* m, std::vector<Exchange>&& xs)
         if (wire)
         {
             if (cs != ms) MG_RT(m, rt_set_stream(m->ctx, cs));
-            int wrc; { HP(m, HP_PACK); wrc = rt_wire_delay(m->ctx, 1, m->wire_slot, wire_ns); }
+            const int wslot = (on_main ? 0 : 4) + (m->wire_slot & 3);
+            int wrc; { HP(m, HP_PACK); wrc = rt_wire_delay(m->ctx, 1, wslot, wire_ns); }
             if (cs != ms) rt_set_stream(m->ctx, ms);
             if (wrc != RT_OK) MG_FAIL(m, wrc, "rt_wire_delay: %s", rt_last_error(m->ctx));
             m->wire_slot = (m->wire_slot + 1) & 7;

@@ -78,6 +78,24 @@ def test_plain_launch_two_ranks_shm_is_verified():
 
 
 @pytest.mark.gpu
+def test_plain_launch_eight_ranks_shm_is_verified():
+    """VERDICT r05 item 8, first-contact insurance for the driver's N = 8 run: the documented command with EIGHT ranks — eight fresh
+    children, the file-store rendezvous, the id broadcast, eight strip contexts with two neighbours each (six of them), the
+    gather of the verification — end to end on this box's one GPU over the exact SHM transport, at a reduced size (640 x 720:
+    eight 90-row strips, the thinnest the 87-row halo allows). The assembled eight-strip frame == a single context's, bit for bit."""
+    rc, lines, err = _run_bench({"BENCH_DEV_SHM": "1", "BENCH_NO_4K": "1", "BENCH_LAUNCH_TIMEOUT_S": "800"},
+                                "--gpus", "8", "--steps", "2", "--warmup", "1", "--width", "640", "--height", "720", timeout=900)
+    assert rc == 0, err[-3000:]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["verified_vs_single_context"] is True, d
+    assert [b - a for a, b in d["config"]["strips"]] == [90] * 8
+    assert len(d["strip_driver"]) == 8 and sorted(x["rank"] for x in d["strip_driver"]) == list(range(8))
+    assert "fresh child processes" in d["launched_by"]
+
+
+@pytest.mark.gpu
 def test_plain_launch_reports_a_stalled_rank():
     """rank 1 stops in the second timed frame: its watchdog ends it, rank 0's ends rank 0 with the diagnostic line, the parent
     relays ONE null line and exits 1"""

@@ -726,7 +726,7 @@ def test_round3_entry_points(api, scenes):
             with pytest.raises(api.RtError, match="librestir_rt_exp"):
                 prod.trace_mode(mode)
         prod.close()
-    assert len(api.build_id()) == 16
+    assert len(api.build_id(exp=False)) == 16 and r.build_id().startswith(api.build_id(exp=False))
     s = C.c_void_p()
     assert L.rt_side_stream(r.h, 0, C.byref(s)) == 0 and s.value
     assert L.rt_side_stream(r.h, 1, C.byref(s)) != 0

@@ -111,7 +111,7 @@ def test_timed_path_three_local_strips_vs_oracle(api, oracle, scenes):
         c.lookat(eye, at)
         c.set_options(bench_options())
         ctxs.append(c)
-    hub = api.MgHub(3)
+    hub = api.MgHub(3, renderer=ctxs[0])
     mgs = [api.MultiGpu(c, k, bounds, transport=api.RT_MG_TRANSPORT_LOCAL, hub=hub) for k, c in enumerate(ctxs)]
     for f in range(1, frames + 1):
         api.mg_frame_lockstep(mgs, f)

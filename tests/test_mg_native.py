@@ -103,7 +103,7 @@ class _Rig:
 
         self.full = make()
         self.ctxs = [make(rows=b, halo=87) for b in self.bounds]
-        self.hub = api.MgHub(len(self.bounds))
+        self.hub = api.MgHub(len(self.bounds), renderer=self.ctxs[0])
         self.mgs = [api.MultiGpu(c, k, self.bounds, transport=api.RT_MG_TRANSPORT_LOCAL, hub=self.hub, flags=flags)
                     for k, c in enumerate(self.ctxs)]
 
