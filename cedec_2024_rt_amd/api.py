@@ -56,14 +56,19 @@ EXP_LIB_PATH = os.path.join(HERE, "librestir_rt_exp.so")
 _libs = {}
 
 
-def load_library(exp=False):
+OCML_LIB_PATH = os.path.join(HERE, "librestir_rt_ocml.so")          # measurement builds (csrc/Makefile `ocml`): device libm = ocml,
+OCML_FMA_LIB_PATH = os.path.join(HERE, "librestir_rt_ocml_fma.so")  # ... and FMA contraction as hiprtc's default
+
+
+def load_library(exp=False, path=None):
     """Load librestir_rt.so (exp=True: librestir_rt_exp.so, the same sources built with -DRT_EXPERIMENTS = the product plus the A/B
     forms that were measured and left off; the variant tests and the A/B tools use it) and declare prototypes. Raises if the
     library was not built."""
     exp = bool(exp)
-    if exp in _libs:
-        return _libs[exp]
-    path = os.environ.get("RT_LIB_PATH", EXP_LIB_PATH if exp else LIB_PATH)  # A/B builds of the same HIP library (tools/experiments)
+    key = os.path.abspath(path) if path else exp  # path: one more build of the same sources beside the two (tools/ocml_drift.py)
+    if key in _libs:
+        return _libs[key]
+    path = path or os.environ.get("RT_LIB_PATH", EXP_LIB_PATH if exp else LIB_PATH)  # A/B builds of the same HIP library (tools/experiments)
     if not os.path.exists(path):
         raise RtError(f"{path} not built: run __graft_entry__.build() (make -C cedec_2024_rt_amd/csrc)")
     # One HIP runtime per process: the torch wheel bundles its own libamdhip64 (same SONAME as
@@ -182,7 +187,7 @@ def load_library(exp=False):
     L.rt_mg_get_stats.argtypes = [vp, vp]
     L.rt_mg_reset_stats.argtypes = [vp]
     L.rt_mg_selftest_rccl.argtypes = [C.c_size_t]
-    _libs[exp] = L
+    _libs[key] = L
     return L
 
 
@@ -341,8 +346,8 @@ _BUF_DTYPE = {
 class Renderer:
     """One HIP context = one GPU = one row strip of the image (the whole image by default)."""
 
-    def __init__(self, width, height, device=0, rows=None, halo=0, stream=None, exp=False):
-        self.L = load_library(exp or bool(os.environ.get("RT_EXPERIMENTS")))  # exp: the library with the A/B forms (rt_tuning's experiment keys)
+    def __init__(self, width, height, device=0, rows=None, halo=0, stream=None, exp=False, lib_path=None):
+        self.L = load_library(exp or bool(os.environ.get("RT_EXPERIMENTS")), path=lib_path)  # exp: the library with the A/B forms (rt_tuning's experiment keys)
         self.W, self.H = int(width), int(height)
         r0, r1 = rows if rows is not None else (0, self.H)
         self.rows = (int(r0), int(r1))

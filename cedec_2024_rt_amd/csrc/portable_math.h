@@ -35,6 +35,17 @@
 #define PM_FN static inline
 #endif
 
+/* MEASUREMENT BUILD ONLY (csrc/Makefile target `ocml`, librestir_rt_ocml.so; r06): with -DRT_MATH_OCML the
+ * DEVICE side of the functions below is the device libm the reference's kernels get when hiprtc compiles them on an AMD GPU
+ * (common/shader.hpp:107-175): ocml's logf / expf / sinf / cosf / powf. Such a library is NOT bit-identical to the oracle; it
+ * exists so that tools/ocml_drift.py can measure, on the MI355X itself, how far the product's portable functions are from what
+ * "the reference as run" computes (flipped pixels, differing histories, relative L2 per frame). The product never defines it. */
+#if defined(RT_MATH_OCML) && defined(__HIP_DEVICE_COMPILE__)
+#define PM_OCML 1
+#else
+#define PM_OCML 0
+#endif
+
 PM_FN uint32_t pm_f2u(float f)
 {
     uint32_t u;
@@ -51,6 +62,9 @@ PM_FN float pm_u2f(uint32_t u)
 /* natural logarithm, binary32. log(+0) = -inf, log(x<0) = NaN. */
 PM_FN float pm_logf(float x)
 {
+#if PM_OCML
+    return ::logf(x); /* reservoir.hpp:92 `log(rv0)` on the device = __ocml_log_f32 */
+#endif
     const float ln2_hi = 6.9313812256e-01f; /* 0x3f317180 */
     const float ln2_lo = 9.0580006145e-06f; /* 0x3717f7d1 */
     const float Lg1 = 0.66666662693f;       /* 0xaaaaaa.0p-24 */
@@ -111,6 +125,9 @@ PM_FN float pm_scale2f(float y, int k)
 /* e^x, binary32. */
 PM_FN float pm_expf(float x)
 {
+#if PM_OCML
+    return ::expf(x); /* reservoir.hpp:71 */
+#endif
     const float ln2hi = 6.9314575195e-1f; /* 0x3f317200 */
     const float ln2lo = 1.4286067653e-6f; /* 0x35bfbe8e */
     const float invln2 = 1.4426950216e+0f;
@@ -171,6 +188,10 @@ PM_FN float pm_expf(float x)
  * tests/test_portable_math.py: <= 1 ulp. Contract range |x| <= 32768; beyond it the functions are defined as (0, 1). */
 PM_FN void pm_sincosf(float x, float* sn, float* cs)
 {
+#if PM_OCML
+    *sn = ::sinf(x); *cs = ::cosf(x); /* reservoir.hpp:93-94, core.hpp:84-86: two calls, as the reference makes them */
+    return;
+#endif
     const uint32_t ax = pm_f2u(x) & 0x7fffffffu;
     if (ax >= 0x7f800000u) { *sn = pm_u2f(0x7fc00000u); *cs = pm_u2f(0x7fc00000u); return; }
     if (ax > 0x47000000u) { *sn = 0.0f; *cs = 1.0f; return; } /* |x| > 32768: out of contract */
@@ -230,6 +251,9 @@ PM_FN float pm_cosf(float x)
  * (common/reservoir.hpp:61-65). */
 PM_FN float pm_pow8f(float x)
 {
+#if PM_OCML
+    return ::powf(x, 8.0f); /* reservoir.hpp:64 `powf(max(dot, 0), 8)` */
+#endif
     const float x2 = x * x;
     const float x4 = x2 * x2;
     return x4 * x4;
@@ -238,6 +262,9 @@ PM_FN float pm_pow8f(float x)
 /* general x^y for x >= 0 (tone mapping, display only): exp(y*log(x)). */
 PM_FN float pm_powf_pos(float x, float y)
 {
+#if PM_OCML
+    return ::powf(x, y); /* common/kernels/common.cu:58-61 */
+#endif
     if (x == 0.0f) return (y > 0.0f) ? 0.0f : (y == 0.0f ? 1.0f : pm_u2f(0x7f800000u));
     if (x == 1.0f || y == 0.0f) return 1.0f;
     return pm_expf(y * pm_logf(x));

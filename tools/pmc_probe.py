@@ -17,5 +17,5 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for k, c, v, g in rows:
     if short(k).startswith("k_") and g == gmin[short(k)]:
         agg[short(k)][c].append(v)
-out = {k: {c: round(sum(v) / len(v), 3) for c, v in cs.items()} for k, cs in agg.items() if k.split("<")[0] in ("k_raycast", "k_generate_candidate", "k_spatial_gather", "k_spatial_coop", "k_resolve")}
+out = {k: {c: round(sum(v) / len(v), 3) for c, v in cs.items()} for k, cs in agg.items() if k.split("<")[0] in ("k_raycast", "k_generate_candidate", "k_spatial_gather", "k_spatial_coop", "k_resolve", "k_gather", "k_raycast_quad")}
 print(json.dumps(out, indent=1))
