@@ -246,10 +246,18 @@ RT_DEV float wide_byte(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xff
 #define RT_LEAF_NUM_CLOSEST 1
 #define RT_LEAF_DEN_CLOSEST 2
 #endif
+#ifndef RT_LEAF_RANGE_TMAX
+#define RT_LEAF_RANGE_TMAX 1 /* 1 = closest-hit leaf tests range-check against the ray's tmax (r01-r05, the default); 0 = against the best hit so
+                                far (r06 A/B: same winner, no gain - see RT_NO_DEFER_BARY in frame_kernels.h) */
+#endif
 /* STRIDE = threads of the calling workgroup = row pitch of the LDS stack (entry i of thread t at word i*STRIDE + t) */
+/* tv (closest hit, r06): the ORIGINAL triangles (3 x float4 each, as closest_ws takes them). With it the walk keeps only
+ * (t, index) of the best hit and the barycentrics of the WINNER are computed once, after the walk, by the same
+ * intersect_ray_triangle on the same operands (same bits) — core.hpp:131-133's two IEEE divisions (a2 / a, a0 / a: 2 x 11
+ * instructions whenever any lane of the wavefront accepts a hit in a leaf pass) leave the loop, and two registers with them. */
 template <bool ANY, bool STATS = false, int STRIDE = BLOCK_THREADS>
 RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3 ro, f3 rd, float tmin, float tmax,
-                       Hit& hit, uint32_t* stats = nullptr)
+                       Hit& hit, uint32_t* stats = nullptr, const float4* __restrict__ tv = nullptr)
 {
     if (bvh.n_tris <= 0) return false;
     /* finite reciprocal: an exactly axis-parallel ray must still be culled by its slab */
@@ -310,11 +318,14 @@ RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3
                 const f3 v0 = F3(t0.x, t0.y, t0.z), v1 = F3(t0.w, t1.x, t1.y), v2 = F3(t1.z, t1.w, t2.x);
                 const int pi = as_int(t2.y);
                 float t, u, v;
-                if (intersect_ray_triangle(t, u, v, ro, rd, tmin, tmax, v0, v1, v2))
+                /* closest hit: a candidate beyond `best` cannot win (best == tmax until the first hit), so the range test of
+                 * core.hpp:103 runs against best and the three sub-areas are computed for fewer lanes; same winner */
+                if (intersect_ray_triangle(t, u, v, ro, rd, tmin, (ANY || RT_LEAF_RANGE_TMAX) ? tmax : best, v0, v1, v2))
                 {
                     if (prim < 0 || t < best || (t == best && pi > prim))
                     {
-                        best = t; bu = u; bv = v; prim = pi;
+                        best = t; prim = pi;
+                        if (ANY || !tv) { bu = u; bv = v; } /* with tv the divisions behind u, v are dead code here */
                         if (ANY) { hit.t = t; hit.u = u; hit.v = v; hit.prim = pi; return true; }
                     }
                 }
@@ -414,6 +425,13 @@ RT_DEV bool trace_wide(const WideView& bvh, uint32_t* __restrict__ lds_stack, f3
         }
     }
     if (prim < 0) return false;
+    if (!ANY && tv)
+    {
+        f3 v0, v1, v2;
+        load_tri(tv, prim, v0, v1, v2); /* the leaf record's vertices are these values (k_wide_leaves copies them) */
+        float t;
+        intersect_ray_triangle(t, bu, bv, ro, rd, tmin, tmax, v0, v1, v2); /* accepts again: same operands */
+    }
     hit.t = best; hit.u = bu; hit.v = bv; hit.prim = prim;
     return true;
 }
@@ -780,7 +798,7 @@ RT_DEV bool closest_ws(const WideView& bvh, const float4* __restrict__ tv, uint3
                 const f3 v0 = F3(t0.x, t0.y, t0.z), v1 = F3(t0.w, t1.x, t1.y), v2 = F3(t1.z, t1.w, t2.x);
                 const int pi = as_int(t2.y);
                 float t, u, v;
-                if (intersect_ray_triangle(t, u, v, ro, rd, tmin, tmax, v0, v1, v2) && t <= best)
+                if (intersect_ray_triangle(t, u, v, ro, rd, tmin, RT_LEAF_RANGE_TMAX ? tmax : fminf(tmax, best), v0, v1, v2) && t <= best) /* beyond best no winner */
                 {
                     /* -0.0f and +0.0f are the same distance: one key for both */
                     const unsigned long long key = ((unsigned long long)sortable(t + 0.0f) << 32) | (unsigned long long)(~(uint32_t)pi);

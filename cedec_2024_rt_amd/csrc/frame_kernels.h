@@ -102,6 +102,15 @@ RT_DEV void count_walk_counts(unsigned long long* __restrict__ st, uint32_t ref,
     }
 }
 
+/* A/B switch of the deferred barycentric divisions (trace_wide's tv, r06): -DRT_NO_DEFER_BARY=0 computes the winner's
+ * u, v once after the walk. MEASURED, NO GAIN (tools/lib_ab.py, three builds side by side in one process, profiles/r06_leaf_test_ab.txt):
+ * un-pipelined frame 1.2528 (u, v kept in the walk) / 1.2567 (deferred + range test against the best hit) / 1.2562 ms (deferred only),
+ * 3840x2160 4.660 / 4.644 / 4.683 - the divisions sit behind a branch few wavefront passes take (a hit must pass the range AND the
+ * three sub-area tests in some lane). Default: as r01-r05. */
+#ifndef RT_NO_DEFER_BARY
+#define RT_NO_DEFER_BARY 1
+#endif
+#define RT_BARY_TV(S) (RT_NO_DEFER_BARY ? nullptr : (S).bvh.tv)
 struct SceneView
 {
     BvhView bvh;   /* binary LBVH, stackless trail traversal (kept for A/B measurements) */
@@ -312,7 +321,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_RAYCAST_WS_WAVES : RT_RAYCAST_
     Hit h;
     h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.prim = -1;
     if (WS) closest_ws<TRACE_BLOCK>(S.wide, S.bvh.tv, s_stack, P.rg_origin, rd, 0.0f, kFltMax, h);
-    else trace_wide<false, false, TRACE_BLOCK>(S.wide, s_stack, P.rg_origin, rd, 0.0f, kFltMax, h);
+    else trace_wide<false, false, TRACE_BLOCK>(S.wide, s_stack, P.rg_origin, rd, 0.0f, kFltMax, h, nullptr, RT_BARY_TV(S));
     vis[li] = make_float4(h.u, h.v, as_float(h.prim), as_float(0));
     gbuffer_write(S, P, g0, g1, li, h.u, h.v, h.prim);
 }
@@ -541,7 +550,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_GENERATE_WS_WAVES : (SHADOWED 
             if (P.stats) count_walk_flags(P.stats + 4 * WALK_RAYCAST, true, true, false, false);
             Hit h;
             h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.prim = -1;
-            trace_wide<false, false, TRACE_BLOCK>(S.wide, s_stack, P.rg_origin, primary_direction(P, x, yi), 0.0f, kFltMax, h);
+            trace_wide<false, false, TRACE_BLOCK>(S.wide, s_stack, P.rg_origin, primary_direction(P, x, yi), 0.0f, kFltMax, h, nullptr, RT_BARY_TV(S));
             vis_w[li] = make_float4(h.u, h.v, as_float(h.prim), as_float(0));
             gbuffer_make(S, P, h.u, h.v, h.prim, G0, G1);
             g0_w[li] = G0;
@@ -1880,15 +1889,21 @@ struct HaloRegions
  * launch; the host falls back to the direct form otherwise. Same marks (the tests compare both with the replay). */
 constexpr int MARK_MAX_PASSES = 3;
 template <bool WINDOW>
-RT_DEV void halo_mark_pixel(const FrameParams& P, const float4* __restrict__ g1, const HaloRegions& R, int pass0, int n_pass, bool in_image, int x,
+RT_DEV void halo_mark_pixel(const FrameParams& P, const float4* __restrict__ g1, const HaloRegions& R, int pass0, int pi0, int pi1, bool in_image, int x,
                             int row, int trow0, int tw0, uint32_t* s_win, const uint32_t* s_bits);
 /* `bits` (WINDOW): shaded bit per pixel of all local rows (k_shaded_bitmap), staged for the tile's window: the replay's
  * "is the neighbour shaded" test — which decides whether the merge draw is consumed — reads LDS instead of gathering 4 bytes
  * of a 16-byte G-buffer record per neighbour (15 dependent 64-cache-line gathers per pixel were what the kernel waited for) */
+/* r06: gridDim.y = 1: a workgroup replays all n_pass passes of its tile one after the other (r02-r05); gridDim.y = n_pass: one workgroup
+ * per (tile, pass) - a strip's mark launch is half a generation of wavefronts whose every thread replays 3 x 5 neighbour draws in
+ * series (log, sqrt, sincos each): it lasts as long as one thread's chain, so a third of the chain on three times the wavefronts
+ * is a third of the launch (rt_tuning key 26). Same marks: a pass's bitmap depends on nothing of the other passes. */
 template <bool WINDOW>
 __global__ __launch_bounds__(BLOCK) void k_halo_mark(FrameParams P, const float4* __restrict__ g1, const uint32_t* __restrict__ bits, HaloRegions R, int pass0,
-                                                      int n_pass)
+                                                      int n_pass_all)
 {
+    const int pi0 = gridDim.y > 1 ? (int)blockIdx.y : 0, pi1 = gridDim.y > 1 ? pi0 + 1 : n_pass_all; /* bitmap slots [pi0, pi1) */
+    const int n_pass = pi1 - pi0;
     __shared__ uint32_t s_win[WINDOW ? MARK_MAX_PASSES * SPL_ROWS * SPL_WORDS : 1];
     __shared__ uint32_t s_bits[WINDOW ? SPL_ROWS * SPL_WORDS : 1];
     int x = 0, row = P.row0;
@@ -1911,7 +1926,7 @@ __global__ __launch_bounds__(BLOCK) void k_halo_mark(FrameParams P, const float4
         }
         __syncthreads();
     }
-    halo_mark_pixel<WINDOW>(P, g1, R, pass0, n_pass, in_image, x, row, trow0, tw0, s_win, s_bits);
+    halo_mark_pixel<WINDOW>(P, g1, R, pass0, pi0, pi1, in_image, x, row, trow0, tw0, s_win, s_bits);
     if (WINDOW)
     {
         __syncthreads();
@@ -1920,7 +1935,7 @@ __global__ __launch_bounds__(BLOCK) void k_halo_mark(FrameParams P, const float4
         {
             const uint32_t w = s_win[i];
             if (!w) continue;
-            const int pi = i / (SPL_ROWS * SPL_WORDS), rem = i - pi * (SPL_ROWS * SPL_WORDS);
+            const int pl = i / (SPL_ROWS * SPL_WORDS), rem = i - pl * (SPL_ROWS * SPL_WORDS), pi = pi0 + pl; /* window slot -> bitmap slot */
             const int r = rem / SPL_WORDS, ww = rem - r * SPL_WORDS;
             const int nrow = trow0 - SPL_HALO + r, gw = tw0 + ww;
 #pragma unroll
@@ -1931,7 +1946,7 @@ __global__ __launch_bounds__(BLOCK) void k_halo_mark(FrameParams P, const float4
     }
 }
 template <bool WINDOW>
-RT_DEV void halo_mark_pixel(const FrameParams& P, const float4* __restrict__ g1, const HaloRegions& R, int pass0, int n_pass, bool in_image, int x,
+RT_DEV void halo_mark_pixel(const FrameParams& P, const float4* __restrict__ g1, const HaloRegions& R, int pass0, int pi0, int pi1, bool in_image, int x,
                             int row, int trow0, int tw0, uint32_t* s_win, const uint32_t* s_bits)
 {
     if (!in_image) return;
@@ -1961,7 +1976,7 @@ RT_DEV void halo_mark_pixel(const FrameParams& P, const float4* __restrict__ g1,
         const float q = ((float)dmin - 1.01f) / scale;
         thr = pm_expf(-0.5f * q * q) * 1.001f;
     }
-    for (int pi = 0; pi < n_pass; ++pi) /* one bitmap per spatial pass, same launch */
+    for (int pi = pi0; pi < pi1; ++pi) /* one bitmap per spatial pass, same launch */
     {
         PCG rng = pcg_init(hashPCG4((uint32_t)x, (uint32_t)yi, (uint32_t)P.frame, (uint32_t)(2 + pass0 + pi)), 0);
         if (far_row)
@@ -1990,7 +2005,7 @@ RT_DEV void halo_mark_pixel(const FrameParams& P, const float4* __restrict__ g1,
             if (WINDOW)
             {
                 /* every row of the window, region or not: the flush keeps the region rows */
-                atomicOr(&s_win[(pi * SPL_ROWS + (nrow - (trow0 - SPL_HALO))) * SPL_WORDS + ((nx >> 5) - tw0)], 1u << (nx & 31));
+                atomicOr(&s_win[((pi - pi0) * SPL_ROWS + (nrow - (trow0 - SPL_HALO))) * SPL_WORDS + ((nx >> 5) - tw0)], 1u << (nx & 31));
             }
             else
             {
@@ -2449,7 +2464,7 @@ RT_DEV bool path_bounce(const SceneView& S, uint32_t* s_stack, const FrameParams
 {
     Hit h;
     ++nrays;
-    if (!trace_wide<false, false, STRIDE>(S.wide, s_stack, st.ro, st.rd, 0.0f, kFltMax, h))
+    if (!trace_wide<false, false, STRIDE>(S.wide, s_stack, st.ro, st.rd, 0.0f, kFltMax, h, nullptr, RT_BARY_TV(S)))
     {
         if (EXAMPLE == 7) st.radiance = st.radiance + st.throughput * sky;
         return false;

@@ -177,6 +177,10 @@ struct rt_ctx
     int tune_fuse_final = -1; /* rt_tuning key 23 (r05): last spatial pass + resolve in one kernel: -1 auto, 0 never, 1 always, 2 = A/B without the pass's stores */
     bool final_fused = false; /* the running frame's last pass has resolved its rows */
     int tune_spec_free = -1; /* rt_tuning key 22 (r05): the look-ahead stage 0 free of the main stream and of the latest resolve: -1 auto = strips */
+    int tune_mark_split = 0; /* rt_tuning key 26 (r06): k_halo_mark as one workgroup per (tile, pass) instead of per tile. Measured, no gain: rank 4 of
+                                8, WIRE_MODEL 0.3286 / 0.3314 (on) against 0.3310 / 0.3293 ms (off) at 1080p, 0.915 / 0.910 against 0.923 / 0.916 at 4K,
+                                MIRROR 0.292 / 0.288 against 0.287 / 0.283 and 0.810 / 0.816 against 0.811 / 0.808 (profiles/r06_mark_split_ab.txt):
+                                the marks are not on the frame's critical chain and their total work is the same. Default off. */
     int tune_mark_cache = 1; /* rt_tuning key 21 (r05): the shaded-bit rows of the halo marks are built once per epoch */
     uint64_t mark_bits_epoch = 0, gbuf_epoch = 0; /* epoch d_mark_bits was built under (0: not cached) / the current G-buffer was traced under */
     hipEvent_t ev_mark_bits = nullptr;
@@ -2496,9 +2500,9 @@ int rt_halo_mark_sides(rt_ctx* c, int frame, int pass, int n_pass, void* bitmaps
             c->mark_bits_rebuilt = true;
         }
         else RT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_mark_bits, 0)); /* the build (and every mark since) is in front of this one */
-        k_halo_mark<true><<<grid, BLOCK, 0, c->stream>>>(P, c->d_g1, c->d_mark_bits, R, pass, n_pass);
+        k_halo_mark<true><<<dim3(grid, c->tune_mark_split ? n_pass : 1), BLOCK, 0, c->stream>>>(P, c->d_g1, c->d_mark_bits, R, pass, n_pass);
     }
-    else k_halo_mark<false><<<grid, BLOCK, 0, c->stream>>>(P, c->d_g1, nullptr, R, pass, n_pass);
+    else k_halo_mark<false><<<dim3(grid, c->tune_mark_split ? n_pass : 1), BLOCK, 0, c->stream>>>(P, c->d_g1, nullptr, R, pass, n_pass);
     RT_HIP(c, hipGetLastError());
     if (window)
     {
@@ -3053,6 +3057,7 @@ int rt_tuning(rt_ctx* c, int key, int value)
     else if (key == 23 && value >= -1 && value <= 2) c->tune_fuse_final = value;
     else if (key == 24 && (value == 0 || value == 1)) c->tune_half_raycast = value;
     else if (key == 25 && value >= -1 && value <= 1) c->tune_fuse_raycast = value;
+    else if (key == 26 && (value == 0 || value == 1)) c->tune_mark_split = value;
     else if (key == 22 && value >= -1 && value <= 1) { c->tune_spec_free = value; c->spec_valid = false; c->spec_gen_valid = false; }
     else RT_FAIL(c, RT_ERR_ARG, "bad tuning key/value %d/%d", key, value);
     return RT_OK;
@@ -3086,6 +3091,7 @@ int rt_tuning_get(rt_ctx* c, int key, int* value)
         case 23: *value = c->tune_fuse_final; break;
         case 24: *value = c->tune_half_raycast; break;
         case 25: *value = c->tune_fuse_raycast; break;
+        case 26: *value = c->tune_mark_split; break;
         default: RT_FAIL(c, RT_ERR_ARG, "bad tuning key %d", key);
     }
     return RT_OK;

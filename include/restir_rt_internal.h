@@ -258,7 +258,11 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
  *  19    rt_halo_mark collects a workgroup's marks in an LDS bitmap of its +-87-pixel window, one global atomic per non-zero
  *        word: 1 (default; widths that are multiples of 32, reach <= 87 px, <= 3 passes per call), 0 = one atomic per mark.
  *  21    (r05) the shaded-bit rows key 19 reads are built once per camera / scene / option epoch: 1 (default), 0 = in front of
- *        every mark (r04). */
+ *        every mark (r04).
+ *  26    (r06) rt_halo_mark as one workgroup per (tile, pass) instead of one per tile that replays the passes in series: 0
+ *        (default = r02-r05), 1. A strip's mark launch is half a generation of wavefronts and lasts as long as one thread's
+ *        chain of 3 x 5 neighbour replays - but it is not on the frame's critical chain and its total work stays the same:
+ *        measured +-1 % (profiles/r06_mark_split_ab.txt). */
 int rt_tuning(rt_ctx* ctx, int key, int value);
 /* the value a key holds now (measurement records name the builder / variants that were really used) */
 int rt_tuning_get(rt_ctx* ctx, int key, int* value);

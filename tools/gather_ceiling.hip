@@ -11,7 +11,8 @@
 //     the image — ~25 integer instructions per round instead of the pass's ~350 (log, sqrt, sincos, exp, pow8, the merge);
 //   * DEPTH rounds in flight per wavefront (1 = the pass: issue, s_waitcnt vmcnt(0), read; 2, 3, 6: a ring of LDS images, the
 //     wait counts the rounds still travelling), WAVES wavefronts per SIMD (occupancy held down with dynamic LDS);
-//   * optionally (streams=1) the pass's streamed traffic too: G-buffer 32 B + side record 16 B read, 64 + 16 B written per pixel.
+//   * optionally the pass's streamed traffic too ("streams" bit mask: 1 = G-buffer 32 B + side record 16 B read per pixel, 2 = 64 + 16 B
+//     written per pixel in the pass's transposed form, 4 = written per lane, 8 = plain instead of non-temporal stores).
 // Every gathered dword is XORed into one word per lane that is stored at the end, so nothing is optimised away.
 // Output: one JSON line per configuration — ms per launch, records gathered per second, 64-B requests per cycle per CU at the
 // measured clock (wall_clock64 against s_memtime is not needed: requests / (ms x 2.4 GHz x 256) uses the nominal clock, stated).
@@ -49,10 +50,10 @@ __device__ __forceinline__ bool tile_of(int b, int& tx, int& ty)
     return true;
 }
 
-template <int DEPTH, bool STREAMS>
+template <int DEPTH, int STREAMS>
 __global__ __launch_bounds__(256) void k_gather(const float4* __restrict__ rec, const float4* __restrict__ rad, const float4* __restrict__ g0,
                                                 const float4* __restrict__ g1, float4* __restrict__ out_rec, float4* __restrict__ out_rad,
-                                                uint32_t* __restrict__ sink, uint32_t seed)
+                                                uint32_t* __restrict__ sink, uint32_t seed, int alu, int pre)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_all[]; /* [4 waves][DEPTH][256] float4, then the occupancy padding */
     int tx, ty;
@@ -64,7 +65,8 @@ __global__ __launch_bounds__(256) void k_gather(const float4* __restrict__ rec, 
     float4* s_wave = s_all + (size_t)wave * DEPTH * 256;
     uint32_t acc = 0;
     float4 G0, G1, R;
-    if (STREAMS) { G0 = g0[li]; G1 = g1[li]; R = rad[li]; }
+    G0 = G1 = R = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (STREAMS & 1) { G0 = g0[li]; G1 = g1[li]; R = rad[li]; }
 
     auto index_of = [&](int round) -> uint32_t {
         if (round == 0) return li;
@@ -120,15 +122,52 @@ __global__ __launch_bounds__(256) void k_gather(const float4* __restrict__ rec, 
         default: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
         }
         consume(r);
+        /* the round's arithmetic as dependent-on-the-data vector FMAs in four chains (the pass: ~345 vector instructions per round):
+         * `pre` of them BEFORE the next round's request can be issued (the pass today: all of them - the next neighbour's address needs
+         * the RNG state the merge leaves), the rest behind it (what travels meanwhile is hidden) */
+        auto work = [&](int n) {
+            float f0 = __uint_as_float((acc & 0x007fffffu) | 0x3f800000u), f1 = f0 + 1.0f, f2 = f0 + 2.0f, f3 = f0 + 3.0f;
+            for (int i = 0; i < n; i += 4)
+            {
+                f0 = __builtin_fmaf(f0, 0.999f, 0.001f); f1 = __builtin_fmaf(f1, 0.998f, 0.002f);
+                f2 = __builtin_fmaf(f2, 0.997f, 0.003f); f3 = __builtin_fmaf(f3, 0.996f, 0.004f);
+            }
+            acc ^= __float_as_uint(f0 + f1 + f2 + f3) & 1u;
+        };
+        if (pre > 0) work(pre);
         if (r + DEPTH < ROUNDS) issue(r + DEPTH);
+        if (alu - pre > 0) work(alu - pre);
     }
-    if (STREAMS)
+    acc ^= __float_as_uint(G0.x) ^ __float_as_uint(G1.y) ^ __float_as_uint(R.z);
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f vv = {__uint_as_float(acc), G0.y, G1.z, R.w};
+    if (STREAMS & 2)
     {
-        acc ^= __float_as_uint(G0.x) ^ __float_as_uint(G1.y) ^ __float_as_uint(R.z);
-        const float4 v = make_float4(__uint_as_float(acc), G0.y, G1.z, R.w);
-        /* the pass's stores: 64-B record (four 16-B parts per lane: the transposed form costs the same requests) + side record, non-temporal */
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        const v4f vv = {v.x, v.y, v.z, v.w};
+        /* the pass's stores (wave_scatter_records): every lane puts its 64-B record into the wavefront's image, then in round j lane
+         * l stores one 16-B part of the record of lane 16 j + l / 4 - a quad of lanes writes one whole 64-B segment: 64 write requests
+         * per wavefront instead of 256 partial ones; non-temporal (bit 3: plain stores) */
+        const uint32_t img = lds_base; /* image 0 of the ring: every gather has been consumed */
+        const int rot = (lane >> 2) & 3;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            asm volatile("ds_write_b128 %0, %1" :: "v"(img + (uint32_t)(4 * lane + (p ^ rot)) * 16u), "v"(vv) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint32_t part16 = (uint32_t)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+        char* base = reinterpret_cast<char*>(out_rec);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        {
+            const uint32_t to = (uint32_t)__shfl((int)li, 16 * j + (lane >> 2));
+            v4f q;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(q) : "v"(img + (uint32_t)(64 * j + lane) * 16u) : "memory");
+            v4f* dst = reinterpret_cast<v4f*>(base + (to * 64u + part16));
+            if (STREAMS & 8) *dst = q; else __builtin_nontemporal_store(q, dst);
+        }
+        if (STREAMS & 8) *reinterpret_cast<v4f*>(out_rad + li) = vv; else __builtin_nontemporal_store(vv, reinterpret_cast<v4f*>(out_rad + li));
+    }
+    if (STREAMS & 4)
+    {
+        /* the naive form: each lane stores the four 16-B parts of its own record: 256 partial-line write requests per wavefront */
 #pragma unroll
         for (int p = 0; p < 4; ++p) __builtin_nontemporal_store(vv, reinterpret_cast<v4f*>(out_rec + 4 * (size_t)li + p));
         __builtin_nontemporal_store(vv, reinterpret_cast<v4f*>(out_rad + li));
@@ -138,8 +177,8 @@ __global__ __launch_bounds__(256) void k_gather(const float4* __restrict__ rec, 
 
 struct Bufs { float4 *rec, *rad, *g0, *g1, *orec, *orad; uint32_t* sink; };
 
-template <int DEPTH, bool STREAMS>
-static double run(const Bufs& B, int waves_per_simd, int launches, size_t* lds_out)
+template <int DEPTH, int STREAMS>
+static double run(const Bufs& B, int waves_per_simd, int launches, size_t* lds_out, int alu, int pre)
 {
     /* LDS per workgroup = 4 waves x DEPTH x 4 KB; occupancy: waves_per_simd workgroups per CU need LDS <= 160 KB / waves_per_simd */
     size_t lds = (size_t)4 * DEPTH * 4096;
@@ -151,10 +190,10 @@ static double run(const Bufs& B, int waves_per_simd, int launches, size_t* lds_o
     const int grid = 8 * ((TILES_Y + 7) / 8) * TILES_X; /* 8 XCDs x (up to 17 tile rows) x 60 */
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) k_gather<DEPTH, STREAMS><<<grid, 256, lds>>>(B.rec, B.rad, B.g0, B.g1, B.orec, B.orad, B.sink, 1000u + i);
+    for (int i = 0; i < 3; ++i) k_gather<DEPTH, STREAMS><<<grid, 256, lds>>>(B.rec, B.rad, B.g0, B.g1, B.orec, B.orad, B.sink, 1000u + i, alu, pre);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int i = 0; i < launches; ++i) k_gather<DEPTH, STREAMS><<<grid, 256, lds>>>(B.rec, B.rad, B.g0, B.g1, B.orec, B.orad, B.sink, 7u * i);
+    for (int i = 0; i < launches; ++i) k_gather<DEPTH, STREAMS><<<grid, 256, lds>>>(B.rec, B.rad, B.g0, B.g1, B.orec, B.orad, B.sink, 7u * i, alu, pre);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms = 0;
@@ -163,11 +202,11 @@ static double run(const Bufs& B, int waves_per_simd, int launches, size_t* lds_o
     return ms / launches;
 }
 
-template <bool STREAMS>
-static void sweep(const Bufs& B, int only_depth, int only_waves, int launches)
+template <int STREAMS>
+static void sweep(const Bufs& B, int only_depth, int only_waves, int launches, int alu, int pre)
 {
     const int depths[] = {1, 2, 3, 6};
-    const int waves[] = {2, 4, 6, 8};
+    const int waves[] = {2, 3, 4, 5, 6, 8};
     for (int d : depths)
         for (int w : waves)
         {
@@ -177,16 +216,16 @@ static void sweep(const Bufs& B, int only_depth, int only_waves, int launches)
             double ms = 0;
             switch (d)
             {
-            case 1: ms = run<1, STREAMS>(B, w, launches, &lds); break;
-            case 2: ms = run<2, STREAMS>(B, w, launches, &lds); break;
-            case 3: ms = run<3, STREAMS>(B, w, launches, &lds); break;
-            default: ms = run<6, STREAMS>(B, w, launches, &lds); break;
+            case 1: ms = run<1, STREAMS>(B, w, launches, &lds, alu, pre); break;
+            case 2: ms = run<2, STREAMS>(B, w, launches, &lds, alu, pre); break;
+            case 3: ms = run<3, STREAMS>(B, w, launches, &lds, alu, pre); break;
+            default: ms = run<6, STREAMS>(B, w, launches, &lds, alu, pre); break;
             }
             const double recs = (double)W * H * ROUNDS, cyc = ms * 1e-3 * 2.4e9;
-            printf("{\"tool\": \"gather_ceiling\", \"streams\": %d, \"rounds_in_flight_per_wave\": %d, \"waves_per_simd\": %d, \"lds_bytes_per_workgroup\": %zu, "
+            printf("{\"tool\": \"gather_ceiling\", \"alu_fma_per_round\": %d, \"alu_before_next_request\": %d, \"streams\": %d, \"rounds_in_flight_per_wave\": %d, \"waves_per_simd\": %d, \"lds_bytes_per_workgroup\": %zu, "
                    "\"ms_per_launch\": %.4f, \"records_per_launch\": %.0f, \"gathered_GB_per_s\": %.1f, \"requests_per_cycle_per_cu_at_2.4GHz\": %.4f, "
                    "\"rounds_in_flight_per_cu\": %d, \"note\": \"64-B requests = records; 256 CUs\"}\n",
-                   STREAMS ? 1 : 0, d, w, lds, ms, recs, recs * 64 / (ms * 1e-3) / 1e9, recs / cyc / 256.0, d * w * 4);
+                   alu, pre, STREAMS, d, w, lds, ms, recs, recs * 64 / (ms * 1e-3) / 1e9, recs / cyc / 256.0, d * w * 4);
             fflush(stdout);
         }
 }
@@ -194,7 +233,8 @@ static void sweep(const Bufs& B, int only_depth, int only_waves, int launches)
 int main(int argc, char** argv)
 {
     /* gather_ceiling [all|one DEPTH WAVES] [launches] */
-    int only_depth = 0, only_waves = 0, launches = 40;
+    int only_depth = 0, only_waves = 0, launches = 40, alu_only = -1;
+    if (getenv("GC_ALU")) alu_only = atoi(getenv("GC_ALU"));
     if (argc >= 4 && !strcmp(argv[1], "one")) { only_depth = atoi(argv[2]); only_waves = atoi(argv[3]); if (argc >= 5) launches = atoi(argv[4]); }
     else if (argc >= 3) launches = atoi(argv[2]);
     const size_t n = (size_t)W * H;
@@ -207,7 +247,25 @@ int main(int argc, char** argv)
     for (size_t i = 0; i < h.size(); ++i) h[i] = (uint32_t)(i * 2654435761u);
     CK(hipMemcpy(B.rec, h.data(), n * 64, hipMemcpyHostToDevice));
     CK(hipMemset(B.rad, 1, n * 16)); CK(hipMemset(B.g0, 2, n * 16)); CK(hipMemset(B.g1, 3, n * 16));
-    sweep<false>(B, only_depth, only_waves, launches);
-    sweep<true>(B, only_depth, only_waves, launches);
+    /* streams: bit 0 = the pass's streamed reads (G-buffer 32 B + side record 16 B per pixel), bit 1 = its stores (64-B record through
+     * the transposed image + 16-B side record, non-temporal), bit 2 = the stores in the naive per-lane form, bit 3 = plain instead of
+     * non-temporal stores (with bit 1) */
+    /* (vector FMAs per round, of them in front of the next request): none; the pass today (all in front); the pass with the next
+     * neighbour's draws and address moved in front of the merge (~200 of 352); every address known up front (shaded bits in LDS) */
+    const int alus[][2] = {{0, 0}, {352, 352}, {352, 200}, {352, 0}, {176, 176}, {176, 0}};
+    for (auto& a : alus)
+    {
+        const int alu = a[0], pre = a[1];
+        if (alu_only >= 0 && alu != alu_only) continue;
+        sweep<3>(B, only_depth, only_waves, launches, alu, pre);
+        if (alu == 0)
+        {
+            sweep<0>(B, only_depth, only_waves, launches, alu, pre);
+            sweep<1>(B, only_depth, only_waves, launches, alu, pre);
+            sweep<2>(B, only_depth, only_waves, launches, alu, pre);
+            sweep<5>(B, only_depth, only_waves, launches, alu, pre);
+            sweep<11>(B, only_depth, only_waves, launches, alu, pre);
+        }
+    }
     return 0;
 }
