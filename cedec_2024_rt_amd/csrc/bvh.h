@@ -9,7 +9,7 @@
  *   occluded_ws         work-sharing any-hit walk: idle lanes take halves of busy lanes' stacks (shadow rays of
  *                       generate_candidate / resolve)
  *   closest_ws          the same for closest hits (primary rays of strips)
- *   closest_quad (r06)  four lanes per ray, one child box each, for launches that cannot fill the GPU with one lane per ray
+ *   closest_quad (r06)  [experiments library] four lanes per ray, one child box each: measured slower (profiles/r06_quad_walk_ab.txt)
  * All of them run the reference's exact intersect_ray_triangle (common/core.hpp:91-136) at the leaves; boxes are rounded
  * outward and the slab tests carry a margin, so the tree only prunes.
  *
@@ -881,6 +881,160 @@ RT_DEV bool closest_ws(const WideView& bvh, const float4* __restrict__ tv, uint3
     hit.t = t; hit.u = u; hit.v = v; hit.prim = prim;
     return true;
 }
+
+#ifdef RT_EXPERIMENTS /* rt_tuning key 16 = 2 / rt_trace_mode 7: measured and left off (profiles/r06_quad_walk_ab.txt), A/B only */
+/* ---- FOUR LANES PER RAY (r06): closest hit for launches that cannot fill the GPU with one lane per ray.
+ * A strip's raycast is half a generation of wavefronts and lasts as long as its slowest wavefront; what sets a wavefront's duration
+ * is the serial chain of walk steps of its longest ray (fetch a record, four slab tests, sort, push), and more wavefronts do not
+ * lengthen the launch. Here a wavefront carries 16 rays; lane 4 r + k tests child k of ray r's current record (one slab test instead
+ * of four), the quad agrees on the order by DPP (no LDS, no shuffles), and each lane can park ONE leaf of its own, so a leaf pass
+ * tests up to four triangles of a ray at once. Four times the wavefronts, each step less than half as long.
+ *   stack: inner records only, one column per ray: entry i of ray r at lds[i * 16 + r] (64 entries = 4 KB per wavefront: no scratch part);
+ *   leaves: parked in the lane that found them; a leaf pass runs when a lane would have to park a second one, when a quarter of the
+ *           live lanes hold one, or when no ray has inner work left;
+ *   result: (t, index) of the best hit, identical in the four lanes; the barycentrics come from one more intersect_ray_triangle on the
+ *           winner (the same operands: the same bits), as in closest_ws.
+ * MEASURED (profiles/r06_quad_walk_ab.txt): it LOSES. rt_raycast on a 135-row strip of 1080p 78 us (work-sharing walk) / 95 (plain) /
+ * 95 (this); 270 rows 104 / 119 / 140; a whole frame 228 / 234 / 474; rank 4 of 8 with the wire 0.325 -> 0.356 ms, at 4K 0.910 -> 1.04.
+ * The timelines say why: a 16-ray wavefront lives as long as a 64-ray one (mean 22.6 against 24.1 us) because 4 x the wavefronts issue
+ * 2.5 x the vector instructions and fill every slot (8 192 in flight for 55 % of the span: the launch becomes issue-bound), while the
+ * one-lane walk's launch is its slowest 1 % of wavefronts (p50 26, p99 71, max 100 us; work sharing: max 83) - rays with long walks, whose
+ * chain a quad halves (max 65 us) at a price the rest of the launch cannot pay.
+ * Same answer as trace_wide<false>: every leaf whose box chain the ray passes is tested by the reference's intersect_ray_triangle,
+ * the winner is the smallest t, ties to the highest index; boxes only prune. All four lanes of a quad must call it with the same
+ * ray; has_ray = false: a quad without a ray. */
+constexpr int QUAD_STACK = RT_WIDE_TOTAL_STACK;
+constexpr int QUAD_LDS_WORDS = QUAD_STACK * 16; /* per wavefront */
+template <int CTRL> RT_DEV float quad_perm_f(float v) { return as_float(__builtin_amdgcn_update_dpp(0, as_int(v), CTRL, 0xf, 0xf, false)); }
+template <int CTRL> RT_DEV int quad_perm_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+RT_DEV bool closest_quad(const WideView& bvh, const float4* __restrict__ tv, uint32_t* __restrict__ lds_generic, const f3 ro, const f3 rd,
+                         const float tmin, const float tmax, const bool has_ray, Hit& hit)
+{
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    lds_u32* __restrict__ stack = (lds_u32*)lds_generic;
+    if (bvh.n_tris <= 0) return false;
+    constexpr uint32_t NONE = 0x7fffffffu;
+    constexpr float MISS = 3.0e38f;
+    const int lane = threadIdx.x & 63, k = lane & 3, ray = lane >> 2;
+    f3 inv = F3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    inv.x = fminf(fmaxf(inv.x, -1e30f), 1e30f);
+    inv.y = fminf(fmaxf(inv.y, -1e30f), 1e30f);
+    inv.z = fminf(fmaxf(inv.z, -1e30f), 1e30f);
+    const bool px = inv.x >= 0.0f, py = inv.y >= 0.0f, pz = inv.z >= 0.0f;
+    const uint32_t sh = 8u * (uint32_t)k; /* this lane's byte of every per-child word */
+    float best = tmax;
+    int prim = -1;
+    int sp = 0;
+    uint32_t cur = has_ray ? 0u : NONE; /* the root is an inner record */
+    uint32_t pend = NONE;               /* this lane's parked leaf */
+
+    /* every lane that holds a leaf tests it; the quad then agrees on its best candidate and on the ray's best hit */
+    auto leaf_pass = [&]() {
+        float ct = MISS;
+        int cp = -1;
+        if (pend != NONE)
+        {
+            const float4* g = bvh.rec + WIDE_STRIDE * (size_t)pend;
+            const float4 t0 = g[0], t1 = g[1], t2 = g[2];
+            pend = NONE;
+            const f3 v0 = F3(t0.x, t0.y, t0.z), v1 = F3(t0.w, t1.x, t1.y), v2 = F3(t1.z, t1.w, t2.x);
+            float t, u, v;
+            if (intersect_ray_triangle(t, u, v, ro, rd, tmin, tmax, v0, v1, v2)) { ct = t; cp = as_int(t2.y); }
+        }
+        /* best of the quad: smaller t, ties to the higher index (-0 == +0 as in every other walk: IEEE compares) */
+        {
+            const float ot = quad_perm_f<0xB1>(ct); const int op = quad_perm_i<0xB1>(cp); /* lane ^ 1 */
+            if (op >= 0 && (cp < 0 || ot < ct || (ot == ct && op > cp))) { ct = ot; cp = op; }
+        }
+        {
+            const float ot = quad_perm_f<0x4E>(ct); const int op = quad_perm_i<0x4E>(cp); /* lane ^ 2 */
+            if (op >= 0 && (cp < 0 || ot < ct || (ot == ct && op > cp))) { ct = ot; cp = op; }
+        }
+        if (cp >= 0 && (prim < 0 || ct < best || (ct == best && cp > prim))) { best = ct; prim = cp; }
+    };
+
+    for (;;)
+    {
+        const bool has_inner = cur != NONE; /* the same in the four lanes of a quad */
+        const bool has_pend = pend != NONE;
+        const unsigned long long bi = __ballot(has_inner), bp = __ballot(has_pend);
+        if ((bi | bp) == 0ull) break;
+        /* live lanes: those of rays that still have anything to do (a quad with a parked leaf but no inner work counts once per lane) */
+        if (bp != 0ull && (bi == 0ull || 4 * __popcll(bp) >= __popcll(bi | bp)))
+        {
+            leaf_pass();
+            continue;
+        }
+        /* the four slab tests of the record, one per lane */
+        float tnv = MISS;
+        uint32_t child = 0u;
+        bool park = false;
+        if (has_inner)
+        {
+            const float4* g = bvh.rec + WIDE_STRIDE * (size_t)cur;
+            const float4 q0 = g[0], q1f = g[1], q2f = g[2];
+            const uint32_t e = as_uint(q0.w);
+            const uint32_t cbase = as_uint(q1f.x), meta = as_uint(q1f.y);
+            const uint32_t lx = as_uint(q1f.z), ly = as_uint(q1f.w), lz = as_uint(q2f.x);
+            const uint32_t hx = as_uint(q2f.y), hy = as_uint(q2f.z), hz = as_uint(q2f.w);
+            const float nxq = (float)(((px ? lx : hx) >> sh) & 0xffu), nyq = (float)(((py ? ly : hy) >> sh) & 0xffu), nzq = (float)(((pz ? lz : hz) >> sh) & 0xffu);
+            const float fxq = (float)(((px ? hx : lx) >> sh) & 0xffu), fyq = (float)(((py ? hy : ly) >> sh) & 0xffu), fzq = (float)(((pz ? hz : lz) >> sh) & 0xffu);
+            const float sx = as_float((e & 0xffu) << 23), sy = as_float(((e >> 8) & 0xffu) << 23), sz = as_float(((e >> 16) & 0xffu) << 23);
+            const float Ax = (q0.x - ro.x) * inv.x, Ay = (q0.y - ro.y) * inv.y, Az = (q0.z - ro.z) * inv.z;
+            const float Bx = sx * inv.x, By = sy * inv.y, Bz = sz * inv.z;
+            const uint32_t m = (meta >> sh) & 0xffu;
+            float tn = fmaxf(fmaxf(__builtin_fmaf(nxq, Bx, Ax), __builtin_fmaf(nyq, By, Ay)), __builtin_fmaf(nzq, Bz, Az));
+            float tf = fminf(fminf(__builtin_fmaf(fxq, Bx, Ax), __builtin_fmaf(fyq, By, Ay)), __builtin_fmaf(fzq, Bz, Az));
+            tn = fmaxf(tn, tmin);
+            tf = fminf(tf, best) * WIDE_SLAB_PAD; /* the same conservative test as trace_wide */
+            const bool h = (m != 0u) && (tn <= tf);
+            child = cbase + (uint32_t)k;
+            park = h && m == 2u;
+            if (h && m != 2u) tnv = tn;
+        }
+        /* a lane that must park a second leaf: everybody's parked leaves are tested first (best only shrinks: the slab results stay conservative) */
+        if (__ballot(park && has_pend) != 0ull) leaf_pass();
+        if (park) pend = child;
+        if (has_inner)
+        {
+            /* the quad's inner children in the order of their entry distances (ties: the lower slot first) */
+            const float t0 = quad_perm_f<0x00>(tnv), t1 = quad_perm_f<0x55>(tnv), t2 = quad_perm_f<0xAA>(tnv), t3 = quad_perm_f<0xFF>(tnv);
+            const int n_inner = (t0 < MISS ? 1 : 0) + (t1 < MISS ? 1 : 0) + (t2 < MISS ? 1 : 0) + (t3 < MISS ? 1 : 0);
+            if (n_inner == 0)
+            {
+                RT_WAVE_LDS_FENCE(); /* entries written by the other lanes of the quad */
+                if (sp > 0) { --sp; cur = stack[sp * 16 + ray]; }
+                else cur = NONE;
+            }
+            else
+            {
+                /* rank of this lane's child among the hit inner children; MISS never precedes a hit */
+                const int rank = ((t0 < tnv || (t0 == tnv && 0 < k)) ? 1 : 0) + ((t1 < tnv || (t1 == tnv && 1 < k)) ? 1 : 0) +
+                                 ((t2 < tnv || (t2 == tnv && 2 < k)) ? 1 : 0) + ((t3 < tnv || (t3 == tnv && 3 < k)) ? 1 : 0);
+                const bool mine = tnv < MISS;
+                /* the nearest goes next; rank 1 ends on top of the stack, the farthest at the bottom of the new entries */
+                if (mine && rank >= 1) stack[(sp + n_inner - 1 - rank) * 16 + ray] = child;
+                sp += n_inner - 1;
+                /* the nearest: every lane holds the four distances (and the record, hence cbase): no exchange */
+                int js = 0;
+                float tm = t0;
+                if (t1 < tm) { js = 1; tm = t1; }
+                if (t2 < tm) { js = 2; tm = t2; }
+                if (t3 < tm) js = 3;
+                cur = (child - (uint32_t)k) + (uint32_t)js;
+            }
+        }
+    }
+    if (prim < 0) return false;
+    f3 v0, v1, v2;
+    load_tri(tv, prim, v0, v1, v2);
+    float t, u, v;
+    intersect_ray_triangle(t, u, v, ro, rd, tmin, tmax, v0, v1, v2);
+    hit.t = t; hit.u = u; hit.v = v; hit.prim = prim;
+    return true;
+}
+
+#endif /* RT_EXPERIMENTS */
 
 /* ---- Shadow rays as a STREAM (r02). occluded_ws still starts 64 rays together and ends with the last one; the lanes
  * that are done early can only help. Here a persistent wavefront pulls jobs (pixels) from a counter: whenever at

@@ -326,6 +326,48 @@ __global__ __launch_bounds__(TRACE_BLOCK, WS ? RT_RAYCAST_WS_WAVES : RT_RAYCAST_
     gbuffer_write(S, P, g0, g1, li, h.u, h.v, h.prim);
 }
 
+#ifdef RT_EXPERIMENTS /* measured slower: profiles/r06_quad_walk_ab.txt */
+/* rt_tuning key 16 = 2 (r06): FOUR LANES PER PRIMARY RAY (bvh.h closest_quad). Workgroup 4 T + q = the 4 x 4 quadrant q of the 8 x 8 tile
+ * workgroup T of k_raycast takes; lane 4 r + k = child k of the quadrant's ray r. Four times the wavefronts of k_raycast, each with a
+ * quarter of the rays and a step less than half as long: for launches that last as long as their slowest wavefront (a strip of the
+ * multi-GPU frame: half a generation of wavefronts). Same Visibility record and G-buffer, byte for byte. */
+__global__ __launch_bounds__(TRACE_BLOCK, RT_RAYCAST_WAVES) void k_raycast_quad(SceneView S, FrameParams P, float4* __restrict__ vis,
+                                                                             float4* __restrict__ g0, float4* __restrict__ g1)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[QUAD_LDS_WORDS];
+    RT_WAVE_CLOCK(P);
+    const int t = (int)threadIdx.x, tile = (int)(blockIdx.x >> 2), q = (int)(blockIdx.x & 3), r = t >> 2;
+    const int in_tile = ((q >> 1) * 4 + (r >> 2)) * 8 + (q & 1) * 4 + (r & 3);
+    int x = 0, row = P.row0;
+    const bool has = tile_pixel_at<TRACE_BLOCK>(P, tile, in_tile, x, row);
+    const int yi = P.H - 1 - row;
+    const size_t li = (size_t)x + (size_t)(row - P.lrow0) * P.W;
+    if (P.stats) count_walk_flags(P.stats + 4 * WALK_RAYCAST, has && (t & 3) == 0, has && (t & 3) == 0, false, false);
+    const f3 rd = has ? primary_direction(P, x, yi) : F3(0.0f, 0.0f, 1.0f);
+    Hit h;
+    h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.prim = -1;
+    closest_quad(S.wide, S.bvh.tv, s_stack, P.rg_origin, rd, 0.0f, kFltMax, has, h);
+    if (!has || (t & 3) != 0) return; /* the four lanes hold the same hit: the first one writes it */
+    vis[li] = make_float4(h.u, h.v, as_float(h.prim), as_float(0));
+    gbuffer_write(S, P, g0, g1, li, h.u, h.v, h.prim);
+}
+/* rt_trace_closest mode 7: rays from a list through closest_quad, 16 per wavefront */
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest_quad(SceneView S, const float* __restrict__ rays, int n, float* __restrict__ hits)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_stack[QUAD_LDS_WORDS];
+    const int i = (int)blockIdx.x * 16 + (int)(threadIdx.x >> 2);
+    const bool has = i < n;
+    const float* r = rays + 8 * (size_t)(has ? i : 0);
+    Hit h;
+    h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.prim = -1;
+    closest_quad(S.wide, S.bvh.tv, s_stack, F3(r[0], r[1], r[2]), F3(r[3], r[4], r[5]), r[6], r[7], has, h);
+    if (!has || (threadIdx.x & 3) != 0) return;
+    float* o = hits + 4 * (size_t)i;
+    o[0] = h.t; o[1] = h.u; o[2] = h.v; o[3] = as_float(h.prim);
+}
+
+#endif /* RT_EXPERIMENTS */
+
 #ifdef RT_EXPERIMENTS /* rt_tuning key 24 (r05): a prototype for launches of less than one generation of wavefronts */
 /* HALF-DENSITY raycast: a wavefront carries 32 primary rays (the upper or lower 8 x 4 half of an 8 x 8 tile) in lanes 0-31 and 32
  * rayless lanes that only ever HELP — the work-sharing walk hands them parts of the busy lanes' stacks (a rayless lane enters with

@@ -1299,6 +1299,9 @@ static void launch_raycast(rt_ctx* c, hipStream_t st, float4* vis, float4* g0, f
 #ifdef RT_EXPERIMENTS
     if (c->tune_half_raycast) { k_raycast_half<<<2 * trace_grid(c), TRACE_BLOCK, 0, st>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), vis, g0, g1); return; }
 #endif
+#ifdef RT_EXPERIMENTS
+    if (c->tune_ws_primary == 2) { k_raycast_quad<<<4 * trace_grid(c), TRACE_BLOCK, 0, st>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), vis, g0, g1); return; }
+#endif
     if (use_ws_primary(c, trace_grid(c))) k_raycast<true><<<trace_grid(c), TRACE_BLOCK, 0, st>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), vis, g0, g1);
     else k_raycast<false><<<trace_grid(c), TRACE_BLOCK, 0, st>>>(make_scene(c), make_params(c, 0, 0, K_RAYCAST), vis, g0, g1);
 }
@@ -2824,7 +2827,7 @@ int rt_exp_wave_clock(rt_ctx* c, int kernel, int pass, uint64_t* out, size_t n_w
         return RT_OK;
     }
     /* one-wavefront workgroups over 8 x 8 tiles at most: every order's grid fits in twice the tile count */
-    const size_t words = 4 * ((size_t)trace_grid(c) + 1024) + 8 * (size_t)launch_grid(c);
+    const size_t words = 16 * ((size_t)trace_grid(c) + 1024) + 8 * (size_t)launch_grid(c); /* k_raycast_quad: four workgroups per tile */
     if (kernel >= 0 && words > c->wave_clock_words)
     {
         if (c->d_wave_clock) hipFree(c->d_wave_clock);
@@ -2955,6 +2958,7 @@ int rt_trace_closest(rt_ctx* c, const float* rays, uint32_t n, float* hits)
     else if (c->trace_mode == 5) k_trace_anyhit<true><<<(n + TRACE_BLOCK - 1) / TRACE_BLOCK, TRACE_BLOCK, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_h);
     else if (c->trace_mode == 6) k_trace_anyhit<false><<<(n + TRACE_BLOCK - 1) / TRACE_BLOCK, TRACE_BLOCK, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_h);
 #ifdef RT_EXPERIMENTS
+    else if (c->trace_mode == 7) k_trace_closest_quad<<<(n + 15) / 16, TRACE_BLOCK, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_h);
     else k_trace_closest<1><<<(n + 255) / 256, 256, 0, c->stream>>>(make_scene(c), d_r, (int)n, d_h);
 #endif
     RT_HIP(c, hipGetLastError());
@@ -3026,6 +3030,7 @@ static bool experiment_only(int key, int value)
         case 11: case 12: case 15: return value != 0; /* deferred visibility queue, pipelined RIS loop form, resolve as a stream */
         case 23: return value > 0;                 /* last pass + resolve in one kernel */
         case 24: return value != 0;                /* half-density raycast with helper lanes */
+        case 16: return value == 2;                /* four lanes per primary ray */
         default: return false;
     }
 #endif
@@ -3047,7 +3052,7 @@ int rt_tuning(rt_ctx* c, int key, int value)
     else if (key == 12 && (value == 0 || value == 1)) c->tune_ris_pipe = value;
     else if (key == 13 && value >= -1 && value <= 1) c->tune_ws = value;
     else if (key == 15 && (value == 0 || value == 1)) c->tune_stream = value;
-    else if (key == 16 && value >= -1 && value <= 1) c->tune_ws_primary = value;
+    else if (key == 16 && value >= -1 && value <= 2) c->tune_ws_primary = value;
     else if (key == 14 && value >= -1 && value <= 2) { c->tune_spec = value; if (!use_next_raycast(c)) c->spec_valid = false; if (!use_next_generate(c)) c->spec_gen_valid = false; }
     else if (key == 17 && value >= -1 && value <= 1) c->tune_tail = value;
     else if (key == 18 && (value == 0 || value == 1)) c->tune_mark_quick = value;
@@ -3105,9 +3110,9 @@ const char* rt_build_id(void) { return RT_BUILD_ID; }
 int rt_trace_mode(rt_ctx* c, int mode)
 {
     RT_CHECK_CTX(c);
-    if (mode < 0 || mode > 6) RT_FAIL(c, RT_ERR_ARG, "mode must be 0..6");
+    if (mode < 0 || mode > 7) RT_FAIL(c, RT_ERR_ARG, "mode must be 0..7");
 #ifndef RT_EXPERIMENTS
-    if (mode >= 1 && mode <= 3) RT_FAIL(c, RT_ERR_UNSUPPORTED, "trace mode %d (binary stackless walk / ray queue) is an A/B form of librestir_rt_exp.so", mode);
+    if ((mode >= 1 && mode <= 3) || mode == 7) RT_FAIL(c, RT_ERR_UNSUPPORTED, "trace mode %d (binary stackless walk / ray queue / four lanes per ray) is an A/B form of librestir_rt_exp.so", mode);
 #endif
     c->trace_mode = mode;
     return RT_OK;

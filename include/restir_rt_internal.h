@@ -185,7 +185,8 @@ int rt_build_ms(rt_ctx* ctx, float* ms); /* wall time of the last rt_scene_set (
  * 2/3 = persistent lane-refill queue (closest / any hit), 4 = mode 0 with any-hit (shadow-ray)
  * semantics: hits[i].index >= 0 iff occluded; 5 / 6 = shadow rays in one-wavefront workgroups as the frame kernels
  * walk them, with the work-sharing walk (5; rt_trace_stats then returns its pass / steal counters) or one lane per ray
- * (6); rays with tmax < 0 are lanes without a ray. rt_trace_time: device ms of the last call's kernel. */
+ * (6); rays with tmax < 0 are lanes without a ray; [exp] 7 (r06) = closest hit with FOUR LANES PER RAY, 16 rays per wavefront
+ * (closest_quad: what rt_tuning key 16 = 2 gives the primary rays). rt_trace_time: device ms of the last call's kernel. */
 int rt_trace_mode(rt_ctx* ctx, int mode);
 int rt_trace_time(rt_ctx* ctx, float* ms);
 /* Performance knobs; RESULTS NEVER DEPEND ON THEM (every key / value is tested bit for bit against the default). rt_tuning_get
@@ -207,7 +208,9 @@ int rt_trace_time(rt_ctx* ctx, float* ms);
  *  13    shadow rays of generate_candidate / resolve through the work-sharing any-hit walk: 1 always (default), 0 never, -1 only
  *        for launches of about one generation of wavefronts.
  *  16    primary rays through the work-sharing closest-hit walk: -1 auto = launches of about one generation of wavefronts, i.e.
- *        strips (default), 0 never, 1 always (a whole frame's coherent 8 x 8 tiles gain nothing: 0.311 -> 0.318 ms).
+ *        strips (default), 0 never, 1 always (a whole frame's coherent 8 x 8 tiles gain nothing: 0.311 -> 0.318 ms); [exp] 2 (r06) =
+ *        four lanes per primary ray (k_raycast_quad: 16 rays per wavefront, each lane one child box of the 4-wide record, four
+ *        times the wavefronts: 78 -> 95 us for 135 rows, 228 -> 474 us for a whole frame; profiles/r06_quad_walk_ab.txt).
  *  24    [exp] (r05) raycast at half density: a wavefront carries 32 primary rays and 32 rayless lanes that only take work from
  *        the others' stacks, twice the wavefronts (would a strip's one-generation launch finish sooner with two lanes per ray?
  *        No: 80 -> 94 us for 135 rows, 269 -> 449 us for a whole frame; profiles/r05_half_raycast_ab.txt). Default 0.

@@ -60,7 +60,7 @@ def test_product_library_carries_no_experiment_kernels():
     assert not [n for n in _declared() if not hasattr(exp, n)]
     assert exp.rt_build_id().decode().endswith("-exp") and not api.build_id(exp=False).endswith("-exp")
     A_B_ONLY = ("k_spatial_gather", "k_spatial_lds", "k_spatial_pipe", "k_spatial_resolve", "k_resolve_stream", "k_trace_queue", "k_raycast_half",
-                "k_candidate_visibility", "k_ploc_nn")
+                "k_candidate_visibility", "k_ploc_nn", "k_raycast_quad")
 
     def kernels(path):
         out = subprocess.run(["strings", "-a", path], capture_output=True, text=True, check=True).stdout

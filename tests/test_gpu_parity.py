@@ -136,8 +136,8 @@ def test_lbvh_equals_brute_force(api, oracle, scenes, golden_scenes):
             r.tuning(5, builder)
             r.set_scene(tris)
             # 0: 4-wide quantised BVH + LDS stack (production), 1: binary tree + stackless trail,
-            # 2: persistent ray queue with lane refill (closest hit)
-            for mode in (0, 1, 2):
+            # 2: persistent ray queue with lane refill (closest hit), 7 (r06): four lanes per ray, one child box each (closest_quad)
+            for mode in (0, 1, 2, 7):
                 r.trace_mode(mode)
                 dev = r.trace_closest(rays)
                 assert _eq_bits(dev, ref), f"{name} builder {builder} mode {mode}: {(dev.view(np.uint32) != ref.view(np.uint32)).any(axis=1).sum()} rays differ"
@@ -193,7 +193,7 @@ def test_deep_traversal_stack_spills_past_lds(api, oracle):
         r.tuning(5, builder)
         r.set_scene(tris)
         assert 3 * (r.bvh_info()["wide_height"] - 1) >= 24 + 6, r.bvh_info()
-        for mode in (0, 2):
+        for mode in (0, 2, 7):  # 7: closest_quad keeps its whole (inner-records-only) stack in LDS
             r.trace_mode(mode)
             dev = r.trace_closest(rays)
             assert _eq_bits(dev, ref), f"builder {builder} mode {mode}"
@@ -221,7 +221,7 @@ def test_lbvh_blocks_scene_vs_oracle_bvh(api, oracle, scenes):
         info = r.scene_info()
         print(f"builder {builder}: rt_scene_set {r.build_ms():.1f} ms, {r.bvh_info()}, binary height {info['bvh_height']}")
         assert info["triangles"] == len(tris) and info["lights"] == len(scenes.light_indices(tris))
-        for mode in (0, 1, 2):
+        for mode in (0, 1, 2, 7):
             r.trace_mode(mode)
             dev = r.trace_closest(rays)
             assert _eq_bits(dev, ref), f"builder {builder} mode {mode}: {(dev.view(np.uint32) != ref.view(np.uint32)).any(axis=1).sum()} rays differ"
@@ -717,12 +717,12 @@ def test_round3_entry_points(api, scenes):
     # the PRODUCT library carries none of the A/B forms and says so
     if not os.environ.get("RT_LIB_PATH") and not os.environ.get("RT_EXPERIMENTS"):
         prod = api.Renderer(64, 48)
-        for key, val in ((5, 0), (5, 1), (5, 2), (8, 0), (8, 1), (8, 3), (8, 4), (9, 4), (9, 5), (10, 8), (11, 1), (12, 1), (15, 1), (23, 1), (24, 1)):
+        for key, val in ((5, 0), (5, 1), (5, 2), (8, 0), (8, 1), (8, 3), (8, 4), (9, 4), (9, 5), (10, 8), (11, 1), (12, 1), (15, 1), (16, 2), (23, 1), (24, 1)):
             with pytest.raises(api.RtError, match="librestir_rt_exp"):
                 prod.tuning(key, val)
         for key, val in ((5, 3), (8, 2), (9, -1), (9, 6), (11, 0), (13, 0), (14, 1), (16, 1), (20, 0), (21, 0), (22, 1), (23, 0), (24, 0), (25, 0), (25, 1)):
             prod.tuning(key, val)
-        for mode in (1, 2, 3):
+        for mode in (1, 2, 3, 7):
             with pytest.raises(api.RtError, match="librestir_rt_exp"):
                 prod.trace_mode(mode)
         prod.close()

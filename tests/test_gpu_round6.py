@@ -152,3 +152,54 @@ def test_halo_marks_one_workgroup_per_tile_and_pass_give_the_same_plans(api, sce
     for key, got in out.items():
         for a, b in zip(ref, got):
             assert np.array_equal(a, b), key
+
+
+def test_four_lanes_per_primary_ray_writes_the_same_gbuffer(api, oracle, scenes):
+    """rt_tuning 16 = 2 (k_raycast_quad, bvh.h closest_quad): rt_raycast with 16 rays per wavefront, each lane one child box of the
+    4-wide record == the one-lane-per-ray walks, Visibility records byte for byte (whole image, a strip with a ragged width, a tiny
+    image), and whole strip frames through rt_frame_stage against the oracle (10_restir_di.cu:9-34 behind common/raytrace.hpp:18-43)"""
+    from cedec_2024_rt_amd.types import bench_options
+
+    tris = scenes.make_blocks_restir()
+    eye, at = scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT
+    for W, H, rows in ((480, 270, None), (1918, 1080, (405, 540)), (37, 19, None)):
+        vis = {}
+        for mode in (0, 1, 2):
+            r = api.Renderer(W, H, rows=rows, halo=87 if rows else 0, exp=True)  # 16 = 2: librestir_rt_exp.so
+            r.tuning(16, mode)
+            r.set_scene(tris)
+            r.lookat(eye, at)
+            r.set_options(bench_options())
+            r.raycast()
+            v = r.download(api.RT_BUF_VISIBILITY)
+            if rows:
+                v = v.reshape(r.local_rows, W)[rows[0] - r.local_row0: rows[1] - r.local_row0]
+            vis[mode] = np.ascontiguousarray(v).copy()
+            r.close()
+        assert _eq_bits(vis[2], vis[0]) and _eq_bits(vis[1], vis[0]), (W, H, rows)
+        assert (vis[0]["index"] >= 0).mean() > 0.5
+    # whole frames: three LOCAL strips, every strip's primary rays through the quad walk, against the oracle
+    W, H, frames = 480, 270, 5
+    bounds = api.mg_partition(H, 3)
+    ctxs = []
+    for b in bounds:
+        c = api.Renderer(W, H, rows=b, halo=87, exp=True)
+        c.tuning(16, 2)
+        c.set_scene(tris)
+        c.lookat(eye, at)
+        c.set_options(bench_options())
+        ctxs.append(c)
+    hub = api.MgHub(3, renderer=ctxs[0])
+    mgs = [api.MultiGpu(c, k, bounds, transport=api.RT_MG_TRANSPORT_LOCAL, hub=hub) for k, c in enumerate(ctxs)]
+    for f in range(1, frames + 1):
+        api.mg_frame_lockstep(mgs, f)
+    st = _oracle_frames(oracle, tris, W, H, eye, at, frames)
+    ref = st["accum"].reshape(H, W, 4)
+    for c, (a, b) in zip(ctxs, bounds):
+        acc = c.download(api.RT_BUF_ACCUMULATION).reshape(c.local_rows, W, 4)[a - c.local_row0: b - c.local_row0]
+        assert _eq_bits(acc, ref[a:b]), f"rows {a}:{b}: {int((acc != ref[a:b]).any(axis=2).sum())} pixels differ from the oracle"
+    for m in mgs:
+        m.close()
+    hub.close()
+    for c in ctxs:
+        c.close()

@@ -51,7 +51,7 @@ for name, kernel, pas in (("raycast", 0, 0), ("generate_candidate", 1, 0), ("spa
     assert fn(r.h, kernel, pas, None, 0) == 0
     frame(12)
     r.sync()
-    n = 4 * (W // 8 + 2) * (H // 8 + 2) + 4096
+    n = 16 * (W // 8 + 2) * (H // 8 + 2) + 4096  # k_raycast_quad: four workgroups per 8 x 8 tile
     buf = np.zeros(n, np.uint64)
     assert fn(r.h, kernel, pas, buf.ctypes.data, n) == 0
     assert fn(r.h, -1, 0, None, 0) == 0
