@@ -825,7 +825,12 @@ def _main():
                 "contract_achieved": contract_ach, "contract_frac": contract_ach / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_launch": algo_bytes, "ms_per_launch": spatial_ms,
                 "traffic_source": pmc["source"],
-                "limiter": "vector-ALU issue and memory latency, not HBM bandwidth (counters: valu_issue_frac_weighted, DESIGN.md section 5.1)",
+                "limiter": "the CU's gather path plus vector-ALU issue, not HBM bandwidth: tools/gather_ceiling.hip runs the pass's access shape without "
+                           "the pass (profiles/r06_gather_ceiling.jsonl) — the gathers alone 0.057 ms, with the pass's streamed reads and stores 0.079, "
+                           "with the pass's arithmetic as 352 vector FMAs per round 0.127-0.129 ms = this kernel, in every issue order incl. 2-3 rounds "
+                           "in flight (DESIGN.md section 5)",
+                "ceiling_microbenchmark_ms": {"gathers_only": 0.057, "gathers_and_streams": 0.079, "with_the_pass_arithmetic": 0.129,
+                                              "source": "profiles/r06_gather_ceiling.jsonl (tools/gather_ceiling.hip, one MI355X box of this pool)"},
                 "valu_issue_frac_weighted": pmc["valu"],
             }
             out["lib_sha256"] = sha

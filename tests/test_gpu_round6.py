@@ -203,3 +203,53 @@ def test_four_lanes_per_primary_ray_writes_the_same_gbuffer(api, oracle, scenes)
     hub.close()
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_look_ahead_soak_camera_moves_key22_toggles_and_per_kernel_calls_between_strip_frames(api, scenes, seed):
+    """the free-running look-ahead (rt_tuning 22, the strips' default) rests on invariants about which G-buffer set and
+    which reservoir buffer stage 0 of frame f+1 may overwrite; rt_frame_stage now checks them where it writes. This soak drives three
+    LOCAL strips and a single context through 24 frames with, at random between frames: camera moves, frame-number jumps, key 22
+    toggled (on / off / auto) on every context, key 14 toggled, and per-kernel entry points called on every context (raycast alone;
+    raycast + generate_candidate into a named buffer; resolve + tone_mapping of the last frame again) — every call that must make a
+    queued look-ahead stale. Every frame of every strip == the single context, accumulation, pixels and temporal history."""
+    import test_mg_native as tm
+
+    rng = np.random.default_rng(2200 + seed)
+    tris = scenes.make_quad_room()
+    W, H, n = 96, 330, 3
+    rig = tm._Rig(api, tris, W, H, n, (0.5, 2.5, 6.0), (0.0, 1.5, -1.0), dict(), 0)
+    frame = 0
+    for step in range(24):
+        frame += 1 if rng.integers(0, 6) else int(rng.integers(2, 5))  # now and then a jump: the plan and the look-ahead are for another frame
+        clear = False
+        ev = int(rng.integers(0, 8))
+        if ev == 0:
+            dx, dy = float(rng.uniform(-40, 40)), float(rng.uniform(-15, 15))
+            for r in rig.everyone():
+                r.orbit(dx, dy)
+            clear = True
+        elif ev == 1:
+            v = int(rng.choice([-1, 0, 1]))
+            for r in rig.everyone():
+                r.tuning(22, v)
+        elif ev == 2:
+            v = int(rng.choice([-1, 0, 1, 2]))
+            for r in rig.everyone():
+                r.tuning(14, v)
+        elif ev == 3:
+            for r in rig.everyone():
+                r.raycast()
+        elif ev == 4 and frame > 1:
+            for r in rig.everyone():
+                r.raycast()
+                r.generate_candidate(frame, api.RT_RES_1)  # a reservoir buffer changes outside the staged frame
+        elif ev == 5 and frame > 1:
+            for r in rig.everyone():
+                r.resolve(api.RT_RES_1)
+                r.tone_mapping()
+        rig.frame(frame, clear)
+        what = f"seed {seed} step {step} frame {frame} event {ev}"
+        rig.check(what)
+        rig.check_history(what)
+    rig.close()
