@@ -60,6 +60,8 @@ def test_timed_frames_run_the_one_launch_stage0_and_match_the_oracle(api, oracle
     r.lookat(eye, at)
     r.set_options(bench_options())
     r.tuning(16, 0)  # a 480 x 270 launch is "about one generation of wavefronts": auto would give its primary rays the strips' work-sharing walk, two launches
+    r.tuning(13, 1)  # the defaults this test is about, whatever RT_TUNING (soak runs) has set on the context
+    r.tuning(25, -1)
     r.timing_enable(True)
     forms = []
     for f in range(1, frames + 1):

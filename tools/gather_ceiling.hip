@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -53,11 +54,14 @@ __device__ __forceinline__ bool tile_of(int b, int& tx, int& ty)
 template <int DEPTH, int STREAMS>
 __global__ __launch_bounds__(256) void k_gather(const float4* __restrict__ rec, const float4* __restrict__ rad, const float4* __restrict__ g0,
                                                 const float4* __restrict__ g1, float4* __restrict__ out_rec, float4* __restrict__ out_rad,
-                                                uint32_t* __restrict__ sink, uint32_t seed, int alu, int pre)
+                                                uint32_t* __restrict__ sink, uint32_t seed, int alu, int pre, unsigned long long* __restrict__ clk)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_all[]; /* [4 waves][DEPTH][256] float4, then the occupancy padding */
     int tx, ty;
     if (!tile_of((int)blockIdx.x, tx, ty)) return;
+    /* in-kernel shader clock (MI355X_MICROARCH.md, DVFS item 6): shader cycles (s_memtime) over constant 100-MHz ticks (s_memrealtime)
+     * across the workgroup's life, first lane; to a buffer nothing else reads */
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     /* a wavefront = an 8 x 8 sub-tile of the 32 x 8 tile (as TileShape<256>) */
     const int x = tx * TW + wave * 8 + (lane & 7), y = ty * TH + (lane >> 3);
@@ -66,6 +70,30 @@ __global__ __launch_bounds__(256) void k_gather(const float4* __restrict__ rec, 
     uint32_t acc = 0;
     float4 G0, G1, R;
     G0 = G1 = R = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    /* pre == -1, the SPLIT experiment: can the gather path and the vector ALUs work side by side at all? Workgroups alternate roles
+     * (by rounds of 256 workgroups, so that every CU hosts both): the odd ones do NO memory work and twice the arithmetic, the even ones no
+     * arithmetic and the memory work twice - the same totals as the combined kernel, but never both in one wavefront. */
+    const int role = pre == -1 ? 1 + (int)((blockIdx.x >> 8) & 1) : 0; /* by rounds of 256 workgroups: b -> XCD b % 8, CU (b / 8) % 32, so parity of b / 8 would give every CU ONE role */ /* 0 combined, 1 memory x 2, 2 arithmetic x 2 */
+    if (role == 2)
+    {
+        float f0 = (float)li, f1 = f0 + 1.0f, f2 = f0 + 2.0f, f3 = f0 + 3.0f;
+        for (int i = 0; i < 2 * ROUNDS * alu; i += 4)
+        {
+            f0 = __builtin_fmaf(f0, 0.999f, 0.001f); f1 = __builtin_fmaf(f1, 0.998f, 0.002f);
+            f2 = __builtin_fmaf(f2, 0.997f, 0.003f); f3 = __builtin_fmaf(f3, 0.996f, 0.004f);
+        }
+        sink[li] = __float_as_uint(f0 + f1 + f2 + f3);
+        if (clk && threadIdx.x == 0)
+        {
+            clk[2 * (size_t)blockIdx.x] = __builtin_amdgcn_s_memtime() - c0;
+            clk[2 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+        }
+        return;
+    }
+    if (role == 1) { alu = 0; pre = 0; }
+  for (int rep = 0; rep < (role == 1 ? 2 : 1); ++rep)
+  {
+    seed += 77u * (uint32_t)rep;
     if (STREAMS & 1) { G0 = g0[li]; G1 = g1[li]; R = rad[li]; }
 
     auto index_of = [&](int round) -> uint32_t {
@@ -172,13 +200,19 @@ __global__ __launch_bounds__(256) void k_gather(const float4* __restrict__ rec, 
         for (int p = 0; p < 4; ++p) __builtin_nontemporal_store(vv, reinterpret_cast<v4f*>(out_rec + 4 * (size_t)li + p));
         __builtin_nontemporal_store(vv, reinterpret_cast<v4f*>(out_rad + li));
     }
+  }
     sink[li] = acc;
+    if (clk && threadIdx.x == 0)
+    {
+        clk[2 * (size_t)blockIdx.x] = __builtin_amdgcn_s_memtime() - c0;
+        clk[2 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
 }
 
-struct Bufs { float4 *rec, *rad, *g0, *g1, *orec, *orad; uint32_t* sink; };
+struct Bufs { float4 *rec, *rad, *g0, *g1, *orec, *orad; uint32_t* sink; unsigned long long* clk; };
 
 template <int DEPTH, int STREAMS>
-static double run(const Bufs& B, int waves_per_simd, int launches, size_t* lds_out, int alu, int pre)
+static double run(const Bufs& B, int waves_per_simd, int launches, size_t* lds_out, int alu, int pre, double* ghz)
 {
     /* LDS per workgroup = 4 waves x DEPTH x 4 KB; occupancy: waves_per_simd workgroups per CU need LDS <= 160 KB / waves_per_simd */
     size_t lds = (size_t)4 * DEPTH * 4096;
@@ -190,15 +224,27 @@ static double run(const Bufs& B, int waves_per_simd, int launches, size_t* lds_o
     const int grid = 8 * ((TILES_Y + 7) / 8) * TILES_X; /* 8 XCDs x (up to 17 tile rows) x 60 */
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) k_gather<DEPTH, STREAMS><<<grid, 256, lds>>>(B.rec, B.rad, B.g0, B.g1, B.orec, B.orad, B.sink, 1000u + i, alu, pre);
+    for (int i = 0; i < 3; ++i) k_gather<DEPTH, STREAMS><<<grid, 256, lds>>>(B.rec, B.rad, B.g0, B.g1, B.orec, B.orad, B.sink, 1000u + i, alu, pre, nullptr);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int i = 0; i < launches; ++i) k_gather<DEPTH, STREAMS><<<grid, 256, lds>>>(B.rec, B.rad, B.g0, B.g1, B.orec, B.orad, B.sink, 7u * i, alu, pre);
+    for (int i = 0; i < launches; ++i) k_gather<DEPTH, STREAMS><<<grid, 256, lds>>>(B.rec, B.rad, B.g0, B.g1, B.orec, B.orad, B.sink, 7u * i, alu, pre, nullptr);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms = 0;
     CK(hipEventElapsedTime(&ms, e0, e1));
     CK(hipGetLastError());
+    /* the clock the chip holds under this load: 20 more launches back to back, stamped */
+    *ghz = 0.0;
+    {
+        for (int i = 0; i < 20; ++i) k_gather<DEPTH, STREAMS><<<grid, 256, lds>>>(B.rec, B.rad, B.g0, B.g1, B.orec, B.orad, B.sink, 99u + i, alu, pre, B.clk);
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> h(2 * (size_t)grid);
+        CK(hipMemcpy(h.data(), B.clk, h.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<double> q;
+        for (int b = 0; b < grid; ++b)
+            if (h[2 * b + 1] > 200) q.push_back((double)h[2 * b] / (double)h[2 * b + 1] * 0.1); /* cycles per 10-ns tick -> GHz */
+        if (!q.empty()) { std::nth_element(q.begin(), q.begin() + q.size() / 2, q.end()); *ghz = q[q.size() / 2]; }
+    }
     return ms / launches;
 }
 
@@ -213,19 +259,19 @@ static void sweep(const Bufs& B, int only_depth, int only_waves, int launches, i
             if ((only_depth && d != only_depth) || (only_waves && w != only_waves)) continue;
             if ((size_t)4 * d * 4096 * w > 160 * 1024) continue; /* the ring does not fit at this occupancy */
             size_t lds = 0;
-            double ms = 0;
+            double ms = 0, ghz = 0;
             switch (d)
             {
-            case 1: ms = run<1, STREAMS>(B, w, launches, &lds, alu, pre); break;
-            case 2: ms = run<2, STREAMS>(B, w, launches, &lds, alu, pre); break;
-            case 3: ms = run<3, STREAMS>(B, w, launches, &lds, alu, pre); break;
-            default: ms = run<6, STREAMS>(B, w, launches, &lds, alu, pre); break;
+            case 1: ms = run<1, STREAMS>(B, w, launches, &lds, alu, pre, &ghz); break;
+            case 2: ms = run<2, STREAMS>(B, w, launches, &lds, alu, pre, &ghz); break;
+            case 3: ms = run<3, STREAMS>(B, w, launches, &lds, alu, pre, &ghz); break;
+            default: ms = run<6, STREAMS>(B, w, launches, &lds, alu, pre, &ghz); break;
             }
             const double recs = (double)W * H * ROUNDS, cyc = ms * 1e-3 * 2.4e9;
             printf("{\"tool\": \"gather_ceiling\", \"alu_fma_per_round\": %d, \"alu_before_next_request\": %d, \"streams\": %d, \"rounds_in_flight_per_wave\": %d, \"waves_per_simd\": %d, \"lds_bytes_per_workgroup\": %zu, "
                    "\"ms_per_launch\": %.4f, \"records_per_launch\": %.0f, \"gathered_GB_per_s\": %.1f, \"requests_per_cycle_per_cu_at_2.4GHz\": %.4f, "
-                   "\"rounds_in_flight_per_cu\": %d, \"note\": \"64-B requests = records; 256 CUs\"}\n",
-                   alu, pre, STREAMS, d, w, lds, ms, recs, recs * 64 / (ms * 1e-3) / 1e9, recs / cyc / 256.0, d * w * 4);
+                   "\"rounds_in_flight_per_cu\": %d, \"in_kernel_clock_GHz\": %.3f, \"requests_per_cycle_per_cu_at_that_clock\": %.4f, \"note\": \"64-B requests = records; 256 CUs\"}\n",
+                   alu, pre, STREAMS, d, w, lds, ms, recs, recs * 64 / (ms * 1e-3) / 1e9, recs / cyc / 256.0, d * w * 4, ghz, ghz > 0 ? recs / (ms * 1e-3 * ghz * 1e9) / 256.0 : 0.0);
             fflush(stdout);
         }
 }
@@ -243,6 +289,8 @@ int main(int argc, char** argv)
     CK(hipMalloc(&B.rad, n * 16)); CK(hipMalloc(&B.orad, n * 16));
     CK(hipMalloc(&B.g0, n * 16)); CK(hipMalloc(&B.g1, n * 16));
     CK(hipMalloc(&B.sink, n * 4));
+    CK(hipMalloc(&B.clk, 2 * 8 * 8192 * 2));
+    CK(hipMemset(B.clk, 0, 2 * 8 * 8192 * 2));
     std::vector<uint32_t> h(n * 16);
     for (size_t i = 0; i < h.size(); ++i) h[i] = (uint32_t)(i * 2654435761u);
     CK(hipMemcpy(B.rec, h.data(), n * 64, hipMemcpyHostToDevice));
@@ -252,7 +300,7 @@ int main(int argc, char** argv)
      * non-temporal stores (with bit 1) */
     /* (vector FMAs per round, of them in front of the next request): none; the pass today (all in front); the pass with the next
      * neighbour's draws and address moved in front of the merge (~200 of 352); every address known up front (shaded bits in LDS) */
-    const int alus[][2] = {{0, 0}, {352, 352}, {352, 200}, {352, 0}, {176, 176}, {176, 0}};
+    const int alus[][2] = {{0, 0}, {352, 352}, {352, 200}, {352, 0}, {352, -1}, {176, 176}, {176, 0}, {176, -1}};
     for (auto& a : alus)
     {
         const int alu = a[0], pre = a[1];
