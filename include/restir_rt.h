@@ -206,7 +206,11 @@ int rt_ray_count(rt_ctx* ctx, uint64_t* rays, uint64_t* shaded_pixels);
 /* time spent by the last `rt_frame` per kernel, HIP events on the context's stream.
  * ms[0..7] = clear, raycast, generate(+temporal), spatial pass 0,1,2, resolve, tone_mapping;
  * ms[8] = whole frame. Enabled by rt_timing_enable(ctx, 1). With more than 3 spatial passes the
- * passes beyond the third are attributed to ms[6] (resolve); ms[8] stays the whole frame. */
+ * passes beyond the third are attributed to ms[6] (resolve); ms[8] stays the whole frame.
+ * rt_frame runs raycast and generate_candidate (+ temporal_resampling) of a whole image as ONE launch
+ * by default: ms[2] is then that launch and ms[1] the empty bracket in front of it, and resolve tone-maps
+ * its own pixel (ms[7] = an empty bracket). The per-kernel entry points above are always the reference's
+ * kernels; restir_rt_internal.h (rt_tuning keys 25 and 20, rt_stage0_one_launch) has the switches. */
 int rt_timing_enable(rt_ctx* ctx, int on);
 int rt_timing(rt_ctx* ctx, float ms[9]);
 
