@@ -45,6 +45,7 @@ INTERNAL_EXPORTS = [
 EXPORTS = PUBLIC_EXPORTS + INTERNAL_EXPORTS
 
 RT_MG_TRANSPORT_RCCL, RT_MG_TRANSPORT_LOCAL, RT_MG_TRANSPORT_MIRROR, RT_MG_TRANSPORT_SHM, RT_MG_TRANSPORT_RCCL_SELF, RT_MG_TRANSPORT_WIRE_MODEL = 0, 1, 2, 3, 4, 5
+RT_MG_TRANSPORT_MIRROR_WIRE = 6
 RT_MG_DENSE, RT_MG_ONE_LANE, RT_MG_SEPARATE_PACK = 1, 2, 4
 
 

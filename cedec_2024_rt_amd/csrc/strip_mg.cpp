@@ -175,6 +175,8 @@ struct rt_mg
     bool interior_late = false; /* RT_MG_INTERIOR_LATE=1 */
     double wire_gbs = 153.0, wire_lat_us = 5.0; /* WIRE_MODEL: one xGMI link per neighbour (bytes per ns = GB/s), fixed latency */
     int wire_slot = 0;
+    unsigned long long mirror_wire_ns = 0; /* MIRROR_WIRE: the exchange in flight */
+    int mirror_wire_slot = 0;
     unsigned long long stats_wire_ns = 0; /* modelled wire time of all exchanges since rt_mg_reset_stats */
     bool counts_on_comm = false; /* RT_MG_COUNTS_ON_COMM=1 (A/B) */
     bool fuse_halos = true; /* sparse halos packed / unpacked by the spatial passes themselves (rt_halo_fuse_set, r03) */
@@ -647,6 +649,13 @@ int rt_mg_create(rt_ctx* ctx, int rank, int world, const int* bounds, int transp
         MG_NCCL(m, g_rccl.GetUniqueId(&id));
         MG_NCCL(m, g_rccl.CommInitRank(&m->nccl, 1, id, 0));
     }
+    else if (world > 1 && transport == RT_MG_TRANSPORT_MIRROR_WIRE)
+    {
+        const char* g = getenv("RT_MG_WIRE_GBS");
+        const char* l = getenv("RT_MG_WIRE_LAT_US");
+        if (g && atof(g) > 0.0) m->wire_gbs = atof(g);
+        if (l && atof(l) >= 0.0) m->wire_lat_us = atof(l);
+    }
     else if (world > 1 && transport != RT_MG_TRANSPORT_MIRROR) MG_FAIL(m, RT_ERR_ARG, "unknown transport %d", transport);
     return RT_OK;
 }
@@ -747,6 +756,25 @@ static int post(rt_mg* m, std::vector<Exchange>&& xs)
     for (auto& x : m->pending_x)
         for (auto& p : x.parts) { m->stats.bytes_sent += p.send_bytes; m->stats.messages += 1; }
     if (m->transport == RT_MG_TRANSPORT_MIRROR) return RT_OK;
+    if (m->transport == RT_MG_TRANSPORT_MIRROR_WIRE)
+    {
+        /* the data is ready HERE (the send would be posted now): note the GPU clock; the copy and the wait for the modelled link
+         * follow where the exchange completes, so that whatever runs in between hides the wire as it would on real links */
+        size_t most = 0;
+        for (auto& x : m->pending_x)
+        {
+            size_t out = 0, in = 0;
+            for (auto& p : x.parts) { out += p.send_bytes; in += p.recv_bytes; }
+            most = std::max(most, std::max(out, in));
+        }
+        m->mirror_wire_ns = (unsigned long long)((double)most / m->wire_gbs + m->wire_lat_us * 1e3);
+        m->stats_wire_ns += m->mirror_wire_ns;
+        m->mirror_wire_slot = m->wire_slot & 3; /* main stream: slots 0-3 */
+        m->wire_slot = (m->wire_slot + 1) & 7;
+        int wrc; { HP(m, HP_PACK); wrc = rt_wire_delay(m->ctx, 0, m->mirror_wire_slot, 0); }
+        if (wrc != RT_OK) MG_FAIL(m, wrc, "rt_wire_delay: %s", rt_last_error(m->ctx));
+        return RT_OK;
+    }
     if (m->transport == RT_MG_TRANSPORT_SHM)
     {
         MG_HIP(m, hipStreamSynchronize(ms)); /* what the parts hold must be final before the host copies it */
@@ -878,7 +906,7 @@ static int complete(rt_mg* m)
         }
         return RT_OK;
     }
-    if (m->transport == RT_MG_TRANSPORT_MIRROR)
+    if (m->transport == RT_MG_TRANSPORT_MIRROR || m->transport == RT_MG_TRANSPORT_MIRROR_WIRE)
     {
         /* every rank receives what it sent (a neighbour that mirrors it): same launches and bytes as a
          * real exchange with no peer to wait for — the overhead measurements of tools/strip_overhead.py */
@@ -895,6 +923,11 @@ static int complete(rt_mg* m)
                 src[n] = p.send; dst[n] = p.recv; nb[n] = p.recv_bytes; ++n;
             }
         MG_RT(m, rt_copy_parts(m->ctx, n, src, dst, nb));
+        if (m->transport == RT_MG_TRANSPORT_MIRROR_WIRE)
+        {
+            int wrc; { HP(m, HP_PACK); wrc = rt_wire_delay(m->ctx, 1, m->mirror_wire_slot, m->mirror_wire_ns); }
+            if (wrc != RT_OK) MG_FAIL(m, wrc, "rt_wire_delay: %s", rt_last_error(m->ctx));
+        }
         return RT_OK;
     }
     for (auto& x : m->pending_x)

@@ -127,7 +127,11 @@ enum { RT_MG_TRANSPORT_LOCAL = 1, RT_MG_TRANSPORT_MIRROR = 2 /* a rank receives 
                                   max over the two neighbours (bytes to / from that neighbour) / RT_MG_WIRE_GBS (default 153 GB/s, one
                                   link per neighbour) + RT_MG_WIRE_LAT_US (default 5 us) after its data was ready on the stream — a
                                   dependent delay on the exchange's stream (rt_wire_delay), not a host sleep. What tools/strip_overhead.py
-                                  reports as THE bound of an N-strip frame on one-GPU boxes. */ };
+                                  reports as THE bound of an N-strip frame on one-GPU boxes. */,
+       RT_MG_TRANSPORT_MIRROR_WIRE = 6 /* (r06) MIRROR + the same dependent delay: a copy launch per exchange, and the exchange completes no
+                                  earlier than the modelled link allows after its data was ready. The other bracket of the bound: RCCL's
+                                  one-rank self-send moves a 4K exchange at ~85 GB/s — slower than the 153-GB/s link it stands in for —
+                                  so WIRE_MODEL charges a real peer transfer's time twice over; this transport charges the wire alone. */ };
 const char* rt_mg_load_error(void);
 int rt_mg_hub_create(int world, void** hub); /* LOCAL transport: mailbox of `world` contexts in ONE process (tests) */
 int rt_mg_hub_destroy(void* hub);

@@ -255,3 +255,53 @@ def test_look_ahead_soak_camera_moves_key22_toggles_and_per_kernel_calls_between
         rig.check(what)
         rig.check_history(what)
     rig.close()
+
+
+def test_mirror_wire_transport_moves_what_mirror_moves_and_takes_the_wires_time(api, scenes):
+    """RT_MG_TRANSPORT_MIRROR_WIRE (r06) = MIRROR + the modelled link as a dependent delay: the same images and bytes as MIRROR, the same
+    modelled time as WIRE_MODEL asks for (it charges the wire without RCCL's self-send in front of it), and with a slow modelled link
+    the frames really take that long"""
+    import time
+
+    from cedec_2024_rt_amd.types import bench_options
+
+    W, H = 480, 270
+    tris = scenes.make_blocks_restir()
+    bounds = api.mg_partition(H, 3)
+    imgs, stats, wall = {}, {}, {}
+    for name, T, env in (("mirror", api.RT_MG_TRANSPORT_MIRROR, {}), ("wire_model", api.RT_MG_TRANSPORT_WIRE_MODEL, {}),
+                         ("mirror_wire", api.RT_MG_TRANSPORT_MIRROR_WIRE, {}),
+                         ("slow", api.RT_MG_TRANSPORT_MIRROR_WIRE, {"RT_MG_WIRE_GBS": "0.5", "RT_MG_WIRE_LAT_US": "200"})):
+        old = {k: os.environ.get(k) for k in ("RT_MG_WIRE_GBS", "RT_MG_WIRE_LAT_US")}
+        os.environ.update(env)
+        try:
+            c = api.Renderer(W, H, rows=bounds[1], halo=87)
+            c.set_scene(tris)
+            c.lookat(scenes.BLOCKS_RESTIR_EYE, scenes.BLOCKS_RESTIR_LOOKAT)
+            c.set_options(bench_options())
+            mg = api.MultiGpu(c, 1, bounds, transport=T)
+            for f in range(1, 4):
+                mg.frame(f)
+            c.sync()
+            mg.reset_stats()
+            t0 = time.perf_counter()
+            for f in range(4, 10):
+                mg.frame(f)
+            c.sync()
+            wall[name] = (time.perf_counter() - t0) / 6
+            stats[name] = mg.stats()
+            imgs[name] = c.download(api.RT_BUF_ACCUMULATION)
+            mg.close()
+            c.close()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    assert _eq_bits(imgs["mirror"], imgs["mirror_wire"]) and _eq_bits(imgs["mirror"], imgs["slow"])
+    assert stats["mirror"]["wire_ns"] == 0 and stats["mirror_wire"]["wire_ns"] == stats["wire_model"]["wire_ns"] > 0
+    assert stats["mirror_wire"]["bytes_sent"] == stats["mirror"]["bytes_sent"]
+    per_frame_model = stats["slow"]["wire_ns"] / 6 * 1e-9
+    assert per_frame_model > 3 * 200e-6
+    assert wall["slow"] >= 0.8 * per_frame_model, (wall, per_frame_model)  # a sanity bound: the host clock against the GPU's

@@ -9,6 +9,9 @@ csrc/strip_mg.cpp) with one rank ALONE on the GPU, its neighbours replaced by a 
                           max over the neighbours (bytes to / from it) / RT_MG_WIRE_GBS (153) + RT_MG_WIRE_LAT_US (5) after its
                           data was ready on the stream (a dependent delay on the GPU, csrc/strip_mg.cpp post()). THE bound.
 
+  --transport mirror_wire mirror + the same dependent delay (r06): the wire alone, without RCCL's one-rank self-send (which moves a 4K
+                          exchange at ~85 GB/s, slower than the link it stands in for): the other bracket of the bound
+
 Same launches, same pack/unpack work and message sizes as a real exchange; the peers' skew is missing. Every measurement
 runs in a PROCESS OF ITS OWN (HIP maps streams onto hardware queues by creation history: a process that has created and
 destroyed contexts before measures something else — 1.55 instead of 1.07 ms at 4K with RCCL's own streams in the mix,
@@ -39,7 +42,8 @@ def measure(W, H, N, flags, tris, frames=40, warm=6, rank=None, bounds=None, tra
     from cedec_2024_rt_amd import api, scenes
     from cedec_2024_rt_amd.types import bench_options
 
-    T = {"mirror": api.RT_MG_TRANSPORT_MIRROR, "rccl_self": api.RT_MG_TRANSPORT_RCCL_SELF, "wire_model": api.RT_MG_TRANSPORT_WIRE_MODEL}[transport]
+    T = {"mirror": api.RT_MG_TRANSPORT_MIRROR, "rccl_self": api.RT_MG_TRANSPORT_RCCL_SELF, "wire_model": api.RT_MG_TRANSPORT_WIRE_MODEL,
+         "mirror_wire": api.RT_MG_TRANSPORT_MIRROR_WIRE}[transport]
     bounds = bounds or api.mg_partition(H, N)
     rank = N // 2 if rank is None else rank
     a, b = bounds[rank]
@@ -94,7 +98,7 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--only", default=None, help="WxH:N:sparse|dense|onelane|separate[:rank] — one case in this process")
     ap.add_argument("--bounds", default=None, help="strip edges for --only: 0,a,b,...,H")
-    ap.add_argument("--transport", default="mirror", choices=("mirror", "rccl_self", "wire_model"))
+    ap.add_argument("--transport", default="mirror", choices=("mirror", "rccl_self", "wire_model", "mirror_wire"))
     ap.add_argument("--sizes", default="1920x1080,3840x2160")
     ap.add_argument("--ns", default="2,4,8")
     ap.add_argument("--rounds", type=int, default=4, help="balance rounds for N = 8 (0: equal rows only)")
