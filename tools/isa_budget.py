@@ -29,8 +29,9 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "cedec_2024_rt_amd", "csrc", "restir_rt.hip")
-FLAGS = ["--offload-arch=gfx950:xnack-", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-gpu-flush-denormals-to-zero",
-         "-Wno-unused-value"]
+# the product's flags (csrc/Makefile HIPFLAGS; r06: -fno-slp-vectorize had been missing here since round 4) + ISA_BUDGET_EXTRA
+FLAGS = ["--offload-arch=gfx950:xnack-", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
+         "-fno-gpu-flush-denormals-to-zero", "-Wno-unused-value"] + os.environ.get("ISA_BUDGET_EXTRA", "").split()
 
 RATES = json.load(open(os.path.join(ROOT, "profiles", "r02_valu_rates.json")))
 GHZ = 2.4
@@ -187,12 +188,19 @@ def summarise(ops):
     return cls, cyc, buckets
 
 
-KERNELS = [("k_raycast", "k_raycast<false>("), ("k_raycast<WS>", "k_raycast<true>("), ("k_generate_candidate<true,false>", "k_generate_candidate<true, false, false, false, false>("),
-           ("k_generate_candidate<true,false,WS>", "k_generate_candidate<true, false, false, false, true>("), ("k_resolve<WS>", "k_resolve<true>("), ("k_resolve_stream", "k_resolve_stream("),
-           ("k_spatial_gather", "k_spatial_gather<6>("), ("k_spatial_coop", "k_spatial_coop<6, false>("), ("k_spatial_coop<fused>", "k_spatial_coop<6, true>("), ("k_halo_mark", "k_halo_mark("), ("k_spatial_lds", "k_spatial_lds("), ("k_resolve", "k_resolve<false>("), ("k_spatial<true>", "k_spatial<true, true>("), ("k_spatial<true> per-lane records", "k_spatial<true, false>("),
+# r06: the template argument lists of the product's kernels as they are now (k_generate_candidate: <FUSE, SHADOWED, DEFER, PIPE, WS, RAYCAST>;
+# k_spatial_coop: <WAVES, FUSED, TB>); the experiments library's forms (k_spatial_gather / _lds, k_resolve_stream) are found only when the
+# tool compiles with -DRT_EXPERIMENTS (ISA_BUDGET_EXTRA="-DRT_EXPERIMENTS")
+KERNELS = [("k_raycast", "k_raycast<false>("), ("k_raycast<WS>", "k_raycast<true>("),
+           ("stage 0 as one launch: k_generate_candidate<..., WS, RAYCAST>", "k_generate_candidate<true, false, false, false, true, true>("),
+           ("k_generate_candidate<true,false,WS>", "k_generate_candidate<true, false, false, false, true, false>("),
+           ("k_generate_candidate<true,false>", "k_generate_candidate<true, false, false, false, false, false>("),
+           ("k_resolve<WS>", "k_resolve<true>("), ("k_resolve_stream", "k_resolve_stream("),
+           ("k_spatial_gather", "k_spatial_gather<6>("), ("k_spatial_coop", "k_spatial_coop<6, false, 256>("), ("k_spatial_coop<fused>", "k_spatial_coop<6, true, 256>("),
+           ("k_halo_mark", "k_halo_mark<true>("), ("k_spatial_lds", "k_spatial_lds("), ("k_resolve", "k_resolve<false>("), ("k_spatial<true>", "k_spatial<true, true>("), ("k_spatial<true> per-lane records", "k_spatial<true, false>("),
            ("k_temporal<false>", "k_temporal<false>("), ("k_tone_mapping", "k_tone_mapping("),
            ("k_path_trace<9,false>", "k_path_trace<9, false>(")]
-LOOP_KERNELS = {"k_raycast", "k_generate_candidate<true,false>", "k_spatial_gather", "k_spatial_coop", "k_halo_mark", "k_resolve", "k_spatial<true>"}
+LOOP_KERNELS = {"k_raycast", "k_generate_candidate<true,false,WS>", "stage 0 as one launch: k_generate_candidate<..., WS, RAYCAST>", "k_spatial_gather", "k_spatial_coop", "k_halo_mark", "k_resolve<WS>", "k_spatial<true>"}
 
 
 def class_costs(path):
